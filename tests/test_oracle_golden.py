@@ -1,0 +1,404 @@
+"""Pins the CPU oracle (oracle/kmx_oracle.c) against every known-answer test the
+reference holds for the hot path (tests/golden/reference_kats.json).
+Each test names the reference test it mirrors."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+
+def km(orc, s):
+    return orc.kmer_from_bytes(s.encode())
+
+
+def test_encode_binary(orc, kats):  # kmer.rs:486-503
+    L = orc.lib()
+    for ch, code in kats["encode_binary"]["codes"].items():
+        assert L.kmo_encode_binary_u8(ord(ch)) == code
+        out = C.c_uint64()
+        assert L.kmo_encode_binary(ord(ch), C.byref(out)) == orc.OK and out.value == code
+    for ch in kats["encode_binary"]["panics"]:
+        assert L.kmo_encode_binary_u8(ord(ch)) == orc.INVALID_CODE  # mod.rs:48
+        assert L.kmo_encode_binary(ord(ch), C.byref(C.c_uint64())) == orc.E_INVALID_BASE
+    # every one of the 256 byte values: only ACGTacgt are valid
+    for b in range(256):
+        assert (L.kmo_encode_binary_u8(b) != orc.INVALID_CODE) == (chr(b) in "ACGTacgt")
+
+
+def test_complement_and_valid(orc, kats):  # kmer.rs:505-527
+    L = orc.lib()
+    for a, b in kats["complement_base"]["pairs"]:
+        assert L.kmo_complement_base(a) == b
+    for v in kats["is_valid_nuc"]["valid"]:
+        assert L.kmo_is_valid_nuc(v)
+    for v in kats["is_valid_nuc"]["invalid"]:
+        assert not L.kmo_is_valid_nuc(v)
+
+
+def test_bin_repr_and_aaa(orc, kats):  # kmer.rs:433-466
+    for s, v in kats["bin_repr"]["cases"]:
+        assert km(orc, s).data == v
+    lo, hi = kats["all_a_is_zero"]["k_range"]
+    for k in range(lo, hi + 1):
+        x = km(orc, "A" * k)
+        assert x.data == 0 and x.k == k
+    L = orc.lib()
+    assert L.kmo_kmer_eq(km(orc, "aaa"), L.kmo_kmer_from_u64(0, 3))
+
+
+def test_eq_and_length(orc, kats):  # kmer.rs:468-485
+    L = orc.lib()
+    for a, b in kats["eq"]["equal"]:
+        assert L.kmo_kmer_eq(km(orc, a), km(orc, b))
+    for a, b in kats["eq"]["not_equal"]:
+        assert not L.kmo_kmer_eq(km(orc, a), km(orc, b))
+    with pytest.raises(orc.OracleError) as e:
+        km(orc, "a" * kats["length_limit"]["panics_len"])
+    assert e.value.status == orc.E_TOO_LONG
+    km(orc, "a" * kats["length_limit"]["ok_len"])
+    with pytest.raises(orc.OracleError) as e:
+        km(orc, "acgn")
+    assert e.value.status == orc.E_INVALID_BASE
+
+
+def test_rc(orc, kats):  # kmer.rs:386-424
+    L = orc.lib()
+    for s, r in kats["reverse_complement"]["cases"]:
+        assert L.kmo_kmer_eq(L.kmo_kmer_to_reverse_complement(km(orc, s)), km(orc, r)), (s, r)
+    for raw in kats["reverse_complement"]["raw"]:
+        x = orc.Kmer(raw["k"], raw["data"])
+        assert orc.kmer_to_string(L.kmo_kmer_to_reverse_complement(x)) == raw["rc_string"]
+
+
+def test_canon_ord(orc, kats):  # kmer.rs:292-322
+    L = orc.lib()
+    for s, c in kats["canonical"]["to_canonical"]:
+        assert L.kmo_kmer_eq(L.kmo_kmer_to_canonical(km(orc, s)), km(orc, c))
+    for s in kats["canonical"]["to_canonical_is_rc"]:
+        assert L.kmo_kmer_eq(L.kmo_kmer_to_canonical(km(orc, s)), L.kmo_kmer_to_reverse_complement(km(orc, s)))
+    for s, v in kats["canonical"]["is_canonical"]:
+        assert bool(L.kmo_kmer_is_canonical(km(orc, s))) == v
+    for a, b in kats["ord"]["less"]:
+        assert L.kmo_kmer_cmp(km(orc, a), km(orc, b)) < 0
+
+
+def test_append_prepend(orc, kats):  # kmer.rs:324-384
+    L = orc.lib()
+    for s, c, exp, dropped in kats["append"]["cases"]:
+        x = km(orc, s)
+        assert L.kmo_kmer_append_base_u8(C.byref(x), ord(c)) == dropped
+        assert L.kmo_kmer_eq(x, km(orc, exp))
+        x = km(orc, s)
+        assert L.kmo_kmer_append_base(C.byref(x), L.kmo_encode_binary_u8(ord(c))) == dropped
+        assert L.kmo_kmer_eq(x, km(orc, exp))
+    for s, c, exp, dropped in kats["prepend"]["cases"]:
+        x = km(orc, s)
+        assert L.kmo_kmer_prepend_base_u8(C.byref(x), ord(c)) == dropped
+        assert L.kmo_kmer_eq(x, km(orc, exp))
+        x = km(orc, s)
+        assert L.kmo_kmer_prepend_base(C.byref(x), L.kmo_encode_binary_u8(ord(c))) == dropped
+        assert L.kmo_kmer_eq(x, km(orc, exp))
+
+
+def test_str_repr_and_sub_kmer(orc, kats):  # kmer.rs:426-431, 529-542
+    L = orc.lib()
+    for s in kats["str_repr"]["cases"]:
+        assert orc.kmer_to_string(km(orc, s)) == s
+    s = kats["sub_kmer"]["seq"]
+    x = km(orc, s)
+    for i in range(len(s)):
+        for j in range(i, len(s)):
+            w = j - i
+            out = C.c_uint64()
+            assert L.kmo_sub_kmer_word(x.data, x.k, i, w, C.byref(out)) == orc.OK
+            assert L.kmo_kmer_eq(L.kmo_kmer_from_u64(out.value, w), km(orc, s[i:j]))
+
+
+def test_mask_table_quirk(orc):  # kmer.rs:584-618: entry 32 is 0
+    L = orc.lib()
+    for k in range(32):
+        assert L.kmo_mask_table(k) == (1 << (2 * k)) - 1
+    assert L.kmo_mask_table(32) == 0
+
+
+def test_quickcheck_properties(orc):  # kmer.rs:280-290, canonical_kmer.rs:216-241
+    L = orc.lib()
+    rng = random.Random(1234)
+    for _ in range(2000):
+        w = rng.getrandbits(64)
+        x = L.kmo_kmer_from_u64(w, 31)
+        assert L.kmo_kmer_eq(x, L.kmo_kmer_to_reverse_complement(L.kmo_kmer_to_reverse_complement(x)))
+        assert L.kmo_kmer_is_canonical(L.kmo_kmer_to_canonical(x))
+        a = L.kmo_ck_from_u64(w, 31)
+        b = L.kmo_ck_from_u64(w, 31)
+        L.kmo_ck_swap(C.byref(a))
+        L.kmo_ck_swap(C.byref(a))
+        assert (a.fw.data, a.rc.data) == (b.fw.data, b.rc.data)
+        # equivalency property
+        ck = L.kmo_ck_from_u64(w, 31)
+        ck2 = L.kmo_ck_from_kmer(ck.rc)
+        assert L.kmo_ck_get_word_equivalency(C.byref(ck), ck2.fw.data) == orc.TWIN_MATCH
+        L.kmo_ck_swap(C.byref(ck2))
+        assert L.kmo_ck_get_word_equivalency(C.byref(ck), ck2.fw.data) == orc.IDENTITY_MATCH
+        L.kmo_ck_append_base_u8(C.byref(ck2), ord("c"))
+        assert L.kmo_ck_get_word_equivalency(C.byref(ck), ck2.fw.data) == orc.NO_MATCH
+
+
+def test_canonical_kmer(orc, kats):  # canonical_kmer.rs:243-297
+    L = orc.lib()
+    t = kats["canonical_kmer"]
+    k0 = km(orc, t["from"]["seq"])
+    for ck in (L.kmo_ck_from_u64(k0.data, k0.k), L.kmo_ck_from_kmer(k0), orc.ck_from_bytes(t["from"]["seq"].encode())):
+        assert orc.kmer_to_string(ck.fw) == t["from"]["fw"]
+        assert orc.kmer_to_string(ck.rc) == t["from"]["rc"]
+    ck = orc.ck_from_bytes(t["from"]["seq"].encode())
+    L.kmo_ck_swap(C.byref(ck))
+    assert orc.kmer_to_string(ck.rc) == t["from"]["fw"] and orc.kmer_to_string(ck.fw) == t["from"]["rc"]
+    s = t["shift"]
+    ck = orc.ck_from_bytes(s["seq"].encode())
+    L.kmo_ck_append_base_u8(C.byref(ck), ord(s["append"]))
+    assert (orc.kmer_to_string(ck.fw), orc.kmer_to_string(ck.rc)) == (s["fw1"], s["rc1"])
+    L.kmo_ck_prepend_base_u8(C.byref(ck), ord(s["prepend"]))
+    assert (orc.kmer_to_string(ck.fw), orc.kmer_to_string(ck.rc)) == (s["fw2"], s["rc2"])
+    e = t["equivalency"]
+    a = orc.ck_from_bytes(e["a"].encode())
+    b = orc.ck_from_bytes(e["b"].encode())
+    assert L.kmo_ck_get_word_equivalency(C.byref(a), b.fw.data) == e["first"]
+    L.kmo_ck_swap(C.byref(b))
+    assert L.kmo_ck_get_word_equivalency(C.byref(a), b.fw.data) == e["after_swap"]
+    L.kmo_ck_append_base_u8(C.byref(b), ord("c"))
+    assert L.kmo_ck_get_word_equivalency(C.byref(a), b.fw.data) == e["after_append_c"]
+
+
+def test_lex_hasher(orc, kats):  # hash.rs:83-104
+    L = orc.lib()
+    t = kats["lex_hasher"]
+    for s, v in t["cases"]:
+        assert L.kmo_lex_hash_u64(km(orc, s).data, t["k"]) == v
+
+
+def _iter_case(orc, kats, case):
+    L = orc.lib()
+    r = kats["read_R"].encode()
+    if case["insert_N_at"] is not None:
+        i = case["insert_N_at"]
+        r = r[:i] + b"N" + r[i:]
+    k = kats["iterator"]["k"]
+    it = orc.Iter()
+    keep = C.create_string_buffer(r, len(r))
+    L.kmo_iter_from_u8_slice(C.byref(it), keep, len(r), k)
+    if case["inc_by"] == 1:
+        L.kmo_iter_inc(C.byref(it))
+    elif case["inc_by"]:
+        L.kmo_iter_inc_by(C.byref(it), case["inc_by"])
+    s = case["expect_window_start"]
+    fk = orc.ck_from_bytes(r[s:s + k])
+    assert (it.km.fw.data, it.km.rc.data, it.km.fw.k, it.km.rc.k) == (fk.fw.data, fk.rc.data, k, k)
+    assert it.pos == case["expect_pos"]
+
+
+def test_iterator_kats(orc, kats):  # canonical_kmer_iterator.rs:123-189
+    for case in kats["iterator"]["cases"]:
+        _iter_case(orc, kats, case)
+
+
+def test_iterator_exhaustion(orc, kats):  # canonical_kmer_iterator.rs:191-206
+    L = orc.lib()
+    r = kats["read_R"].encode()
+    e = kats["iterator"]["exhaustion"]
+    it = orc.Iter()
+    keep = C.create_string_buffer(r, len(r))
+    L.kmo_iter_from_u8_slice(C.byref(it), keep, len(r), kats["iterator"]["k"])
+    L.kmo_iter_inc_by(C.byref(it), e["first_inc_by"])
+    assert bool(L.kmo_iter_exhausted(C.byref(it))) == e["exhausted_after_first"]
+    L.kmo_iter_inc_by(C.byref(it), len(r) - e["second_inc_by_len_minus"])
+    assert bool(L.kmo_iter_exhausted(C.byref(it))) == e["exhausted_after_second"]
+    L.kmo_iter_inc(C.byref(it))
+    assert L.kmo_iter_exhausted(C.byref(it))
+
+
+def test_derived_R_values(orc, kats):  # SURVEY Appendix B derived rows
+    d = kats["derived_R_k31"]
+    r = np.frombuffer(kats["read_R"].encode(), np.uint8)
+    fw, rc, canon, flags = orc.canonical_windows(r, 1, r.size, 31)
+    assert fw.size == d["n_windows"] and flags.all()
+    for pos in (0, 1, 10, 89):
+        assert int(fw[pos]) == int(d[f"pos{pos}"]["fw"], 16)
+        assert int(rc[pos]) == int(d[f"pos{pos}"]["rc"], 16)
+    s = orc.canonical_reduce(r, 1, r.size, 31, hasher_k=31)
+    assert s.n_valid == d["n_windows"]
+    assert s.sum_canon == int(d["sum_canon"], 16)
+    assert int(canon.sum(dtype=np.uint64)) == int(d["sum_canon"], 16)
+    assert orc.lib().kmo_lex_hash_u64(int(canon[0]), 31) == int(d["lex31_canon_pos0"], 16)
+    assert orc.compute_naive(r, 31) == int(fw.sum(dtype=np.uint64)) == s.sum_fw
+
+
+# ---------------------------------------------------------------- encoding (A)
+
+def _enc_byte_from_name(name):
+    code = {ch: i for i, ch in enumerate(name)}
+    return (code["A"] << 6) | (code["C"] << 4) | (code["T"] << 2) | code["G"]
+
+
+def test_all_24_encodings(orc, kats):  # naive.rs:48-74, 167-294
+    L = orc.lib()
+    t = kats["naive_encodings"]
+    assert len(t["enc_bytes"]) == 24
+    for name, byte in t["enc_bytes"].items():
+        assert byte == _enc_byte_from_name(name), name
+        for nuc, (lo, hi) in t["rule_nuc2bits"].items():
+            field = (byte >> lo) & 3
+            for ch in (nuc, nuc.lower()):
+                assert L.kmo_naive_nuc2bits(byte, ord(ch)) == field
+            assert L.kmo_naive_bits2nuc(byte, field) == ord(nuc)
+        for a, b in t["complements"].items():
+            assert L.kmo_naive_complement(byte, L.kmo_naive_nuc2bits(byte, ord(a))) == L.kmo_naive_nuc2bits(byte, ord(b))
+
+
+def test_naive_encode_kats(orc, kats):  # naive.rs:297-445
+    t = kats["naive_encode_kats"]
+    encs = kats["naive_encodings"]["enc_bytes"]
+    for c in t["cases"]:
+        enc = encs[c["enc"]]
+        nbytes = c["B"] * c["p_bits"] // 8
+        arr = orc.naive_encode(enc, c["seq"].encode(), nbytes)
+        assert orc.words(arr, c["p_bits"]) == [int(w) for w in c["words"]], c["name"]
+        L = orc.lib()
+        p = arr.ctypes.data_as(C.POINTER(C.c_uint8))
+        assert [L.kmo_generic_get(p, nbytes, i) for i in range(c["K"])] == c["fields"]
+        assert orc.naive_decode(enc, arr) == c["decode"].encode()
+        assert orc.naive_decode(enc, orc.naive_rev_comp(enc, c["K"], arr)) == c["decode_rev_comp"].encode()
+
+
+def test_naive_encode_overflow_panics(orc, kats):  # bit_field index OOB
+    enc = kats["naive_encodings"]["enc_bytes"]["ACGT"]
+    with pytest.raises(orc.OracleError) as e:
+        orc.naive_encode(enc, b"A" * 33, 8)
+    assert e.value.status == orc.E_TOO_LONG
+    orc.naive_encode(enc, b"A" * 32, 8)
+
+
+def test_xor10(orc, kats):  # xor10.rs:17-72 (+ informational encode values)
+    for c in kats["xor10_encode_informational"]["cases"]:
+        nbytes = c["B"] * c["p_bits"] // 8
+        arr = orc.xor10_encode(c["seq"].encode(), nbytes)
+        assert orc.words(arr, c["p_bits"]) == [int(w) for w in c["words"]]
+        # Xor10 == Naive::ACTG as a map (naive.rs:50 vs xor10.rs:21)
+        actg = kats["naive_encodings"]["enc_bytes"]["ACTG"]
+        assert (orc.naive_encode(actg, c["seq"].encode(), nbytes) == arr).all()
+        K = len(c["seq"])
+        assert (orc.xor10_rev_comp(K, arr) == orc.naive_rev_comp(actg, K, arr)).all()
+        assert orc.xor10_decode(arr)[:K] == c["seq"].encode()
+    # the B==1 path of xor10.rs:75-85 is not a reverse complement
+    L = orc.lib()
+    w = orc.words(orc.xor10_encode(b"ACTG", 8), 64)[0]
+    assert L.kmo_xor10_rev_comp_b1_quirk(w, 64) != orc.words(orc.xor10_rev_comp(4, orc.xor10_encode(b"ACTG", 8)), 64)[0]
+
+
+def test_generic_kmer(orc, kats):  # kmer.rs:97-203
+    L = orc.lib()
+    t = kats["generic_kmer"]
+    for p_bytes, K, exp in t["word_for_k"]:
+        assert L.kmo_word_for_k(p_bytes, K) == exp
+    for p_bytes, nb in t["num_bytes_k15"]:
+        assert p_bytes * L.kmo_word_for_k(p_bytes, 15) == nb
+    d = np.array(t["with_data"]["data_u8"], np.uint8)
+    p = d.ctypes.data_as(C.POINTER(C.c_uint8))
+    assert [L.kmo_generic_get(p, 1, i) for i in range(4)] == t["with_data"]["fields"]
+    encs = kats["naive_encodings"]["enc_bytes"]
+    for c in t["naive_encoder"]:
+        arr = orc.naive_encode(encs[c["enc"]], c["seq"].encode(), 1)
+        p = arr.ctypes.data_as(C.POINTER(C.c_uint8))
+        assert [L.kmo_generic_get(p, 1, i) for i in range(4)] == c["fields"]
+    pr = t["prefix"]
+    arr = orc.naive_encode(encs[pr["enc"]], pr["seq"].encode(), 8)
+    out = C.c_uint64()
+    assert L.kmo_generic_get_prefix(arr.ctypes.data_as(C.POINTER(C.c_uint8)), 8, 64, pr["len"], C.byref(out)) == orc.OK
+    assert out.value == pr["value"]
+    buf = np.zeros(pr["len"], np.uint8)
+    L.kmo_bitmer_to_bytes(out.value, pr["len"], buf.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert buf.tobytes() == pr["bitmer_to_bytes"].encode()
+
+
+def test_generic_acgt_equals_naive_impl(orc, kats):  # SURVEY A.8 cross-check
+    enc = kats["naive_encodings"]["enc_bytes"]["ACGT"]
+    rng = random.Random(7)
+    for _ in range(500):
+        k = rng.randint(1, 31)
+        s = "".join(rng.choice("ACGTacgt") for _ in range(k)).encode()
+        assert orc.words(orc.naive_encode(enc, s, 8), 64)[0] == orc.kmer_from_bytes(s).data
+
+
+# ------------------------------------------------------- batch-driver sanity
+
+def _py_windows(read: bytes, k: int):
+    """Independent pure-python model: every length-k window free of non-ACGT bytes."""
+    code = {65: 0, 67: 1, 71: 2, 84: 3, 97: 0, 99: 1, 103: 2, 116: 3}
+    out = []
+    for p in range(len(read) - k + 1):
+        w = read[p:p + k]
+        if all(c in code for c in w):
+            fw = sum(code[c] << (2 * i) for i, c in enumerate(w))
+            rc = sum((3 - code[c]) << (2 * (k - 1 - i)) for i, c in enumerate(w))
+            out.append((p, fw, rc))
+    return out
+
+
+@pytest.mark.parametrize("k", [1, 5, 16, 17, 21, 31])
+def test_batch_drivers_vs_python_model(orc, k):
+    rng = random.Random(100 + k)
+    reads, offsets = [], [0]
+    for _ in range(40):
+        n = rng.choice([0, 1, k - 1, k, k + 1, 40, 150])
+        n = max(n, 0)
+        s = bytes(rng.choice(b"ACGTacgtACGTACGTN") for _ in range(n))
+        reads.append(s)
+        offsets.append(offsets[-1] + n)
+    blob = np.frombuffer(b"".join(reads), np.uint8)
+    fw, rc, canon, flags = orc.canonical_windows(blob, len(reads), 0, k, offsets=offsets)
+    wo = orc.win_offsets_for(len(reads), 0, k, offsets)
+    n_valid = 0
+    total = 0
+    for r, s in enumerate(reads):
+        model = _py_windows(s, k)
+        base = int(wo[r])
+        nwin = int(wo[r + 1]) - base
+        valid_pos = {p for p, _, _ in model}
+        for p in range(nwin):
+            assert (flags[base + p] & 1) == (1 if p in valid_pos else 0)
+        for p, f, c in model:
+            assert int(fw[base + p]) == f and int(rc[base + p]) == c
+            assert int(canon[base + p]) == min(f, c)
+            assert bool(flags[base + p] & 2) == (f < c)
+            total = (total + min(f, c)) & (2**64 - 1)
+        n_valid += len(model)
+    s = orc.canonical_reduce(blob, len(reads), 0, k, hasher_k=k, offsets=offsets)
+    assert s.n_valid == n_valid and s.sum_canon == total
+
+
+def test_reduce2_matches_python_model(orc):
+    rng = random.Random(5)
+    k = 63
+    s = bytes(rng.choice(b"ACGTNacgt" + b"ACGT" * 20) for _ in range(400))
+    blob = np.frombuffer(s, np.uint8)
+    fw, rc, canon, flags = orc.canonical_windows2(blob, 1, len(s), k)
+    model = _py_windows(s, k)
+    assert int(flags.sum() if (flags <= 1).all() else (flags & 1).sum()) == len(model)
+    for p, f, c in model:
+        assert int(fw[p, 0]) | (int(fw[p, 1]) << 64) == f
+        assert int(rc[p, 0]) | (int(rc[p, 1]) << 64) == c
+        assert int(canon[p, 0]) | (int(canon[p, 1]) << 64) == min(f, c)
+    sm = orc.canonical_reduce2(blob, 1, len(s), k, with_hash=True)
+    assert sm.n_valid == len(model)
+    assert sm.sum_lo == sum(min(f, c) & (2**64 - 1) for _, f, c in model) & (2**64 - 1)
+    assert sm.sum_hi == sum(min(f, c) >> 64 for _, f, c in model) & (2**64 - 1)
+
+
+def test_generator_is_uniform_acgt(orc):
+    a = orc.gen_reads(0x6B6D6572735F7631, 0, 1 << 16)
+    assert set(np.unique(a)) == {65, 67, 71, 84}
+    b = orc.gen_reads(0x6B6D6572735F7631, 1000, 5000)
+    assert (a[1000:6000] == b).all()  # position-addressable
+    counts = np.bincount(a, minlength=256)[[65, 67, 71, 84]]
+    assert counts.min() > 0.23 * a.size
