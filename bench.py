@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- canonical k-mers/s at k=31 on 150 bp reads (BASELINE.json metric), MI355X.
+
+One "step" = one pass of the hot path (kmx_canonical_reduce: encode + sliding window + reverse
+complement + canonical min + wrapping-sum reduce) over this rank's shard of synthetic reads,
+already resident in HBM.  N=1 workload = BASELINE configs[1]: 1e8 x 150 bp reads, k=31
+(15.0 GB in, 1.2e10 canonical k-mers per step).  N>1: reads shard embarrassingly, one process
+per GPU, the same 1e8 reads per GPU (weak scaling), no data-path collective; torch.distributed
+(RCCL) is used only for the barrier / max-over-ranks timing and the checksum combine.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured-copy ceiling
+
+
+def cpu_baseline(host_sample, n_reads, L, k, seconds_target=12.0):
+    """Time the CPU oracle (plain-C port of the reference's naive_impl streaming iterator,
+    canonical_kmer_iterator.rs:42-116) on this box's host cores: 1 thread and all threads."""
+    import numpy as np
+    from oracle import oracle
+
+    lib = oracle.lib(native=True)
+    cores = os.cpu_count() or 1
+
+    def run(nthreads, reads_each):
+        outs = [None] * nthreads
+
+        def work(i):
+            lo = (i * reads_each) % max(n_reads - reads_each + 1, 1)
+            outs[i] = oracle.canonical_reduce(host_sample[lo * L:(lo + reads_each) * L], reads_each, L, k, native_lib=lib)
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+        return sum(o.n_valid for o in outs) / dt, dt
+
+    # calibrate on a small slice, then size the sample for ~seconds_target/2 per leg
+    rate1, _ = run(1, min(n_reads, 50_000))
+    reads_1t = int(min(n_reads, max(50_000, rate1 * (seconds_target / 2) / (L - k + 1))))
+    rate1, dt1 = run(1, reads_1t)
+    reads_mt = int(min(n_reads, max(50_000, rate1 * (seconds_target / 2) / (L - k + 1))))
+    rate_mt, dt_mt = run(cores, reads_mt)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": rate_mt, "unit": "canonical k-mers/s", "cores": cores, "kind": "port",
+        "value_1thread": rate1,
+        "sample": f"{cores} threads x {reads_mt} reads x {L} bp (same synthetic stream as the GPU run), k={k}, "
+                  f"{dt_mt:.1f}s; 1 thread x {reads_1t} reads {dt1:.1f}s; oracle = plain-C port of "
+                  f"naive_impl CanonicalKmerIterator, gcc -O3 -march=native",
+        "cpu_model": model,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads-per-gpu", type=int, default=100_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("-k", type=int, default=31)
+    ap.add_argument("--hash", action="store_true", help="also fold the LexHasher(k) word hash (BASELINE configs[3])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the kmx path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from kmers_amd import _lib
+    from kmers_amd.api import SEED_DEFAULT, Context
+
+    ctx = Context(local_rank)
+    L, k, n = args.read_len, args.k, args.reads_per_gpu
+    nbytes = n * L
+    hasher, hk = (_lib.HASH_LEX, k) if args.hash else (_lib.HASH_NONE, 0)
+
+    # synthetic reads generated on the device; rank r owns stream bytes [r*nbytes, (r+1)*nbytes)
+    bases = ctx.gen_reads(nbytes, SEED_DEFAULT, rank * nbytes)
+    out = ctx.empty(4, torch.int64)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.canonical_reduce_async(bases, n, L, k, hasher, hk, 0, out=out)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(ctx.stream)
+        step()
+        b.record(ctx.stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    summ = out.cpu().numpy().view(np.uint64)
+    n_valid, sum_canon = int(summ[0]), int(summ[1])
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    cnt = torch.tensor([n_valid], dtype=torch.int64, device="cuda")
+    chk = torch.tensor([np.int64(np.uint64(sum_canon).view(np.int64))], dtype=torch.int64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)  # wrapping add of per-shard checksums
+    elapsed_max = float(t.item())
+    total_kmers_per_step = int(cnt.item())
+
+    if rank == 0:
+        value = total_kmers_per_step * args.steps / elapsed_max
+        algo_bytes = float(nbytes)  # algorithmic bytes per launch: L bytes read per read, writes negligible
+        achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        # parity spot-check against the CPU oracle on the head of this rank's shard (outside the timed region)
+        from oracle import oracle
+
+        n_chk = min(n, 200_000)
+        host = bases[: n_chk * L].cpu().numpy()
+        o = oracle.canonical_reduce(host, n_chk, L, k, hasher_k=hk)
+        g = ctx.canonical_reduce(bases[: n_chk * L], n_chk, L, k, hasher, hk, 0)
+        parity = (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash if args.hash else 0)
+        parity = parity and n_valid == n * max(L - k + 1, 0)
+        res = {
+            "metric": "canonical k-mers/sec at k=31, 150 bp reads; HBM GB/s vs peak",
+            "value": value,
+            "unit": "canonical k-mers/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"k={k} encode+canonicalize{'+lex-hash' if args.hash else ''} (reduce mode), "
+                            f"{n} x {L} bp synthetic reads per GPU (BASELINE configs[1])",
+                "reads_per_gpu": n, "read_len": L, "k": k, "parallelism": f"shard{world}",
+                "bytes_per_gpu": nbytes,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "kmx::scan_uniform_kernel<10,2,2,%s>" % ("true" if args.hash else "false"),
+                "avg_kernel_ms": avg_kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
+            },
+            "parity_vs_oracle": "ok" if parity else "MISMATCH",
+            "checksum": f"{int(chk.item()) & (2**64 - 1):#018x}",
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n_s = min(n, 4_000_000)
+            res["cpu_baseline"] = cpu_baseline(bases[: n_s * L].cpu().numpy(), n_s, L, k)
+        print(json.dumps(res), flush=True)
+        if not parity:
+            sys.exit(3)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

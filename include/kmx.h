@@ -1,0 +1,197 @@
+/*
+ * kmx.h -- C ABI of libkmx: the MI355X (gfx950) implementation of the streaming
+ * 2-bit k-mer encode / canonicalise / hash hot path of COMBINE-lab/kmers.
+ *
+ * This header is the drop-in boundary.  The reference is a pure-Rust crate with
+ * scalar per-k-mer calls; a GPU is a drop-in only at batch granularity, so every
+ * entry point below is the batch restatement of one reference interface (cited
+ * as file:line under /root/reference) with identical per-element results.
+ * INTEGRATION.md shows the Rust `extern "C"` binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only: pointers + sizes, no C++/torch types.
+ *   - every `d_*` pointer is a DEVICE pointer valid on the ctx's GPU (from
+ *     kmx_malloc, hipMalloc, or a torch CUDA tensor's data_ptr()).
+ *   - all calls are asynchronous on the ctx's HIP stream unless stated; results
+ *     are visible after kmx_ctx_synchronize() (or stream sync by the owner).
+ *   - return value: KMX_OK or a KMX_E_* code; nothing ever unwinds across the ABI.
+ *   - k-mer word layout (reference A.2): base i at bits [2i,2i+1], first base
+ *     lowest; multi-word k-mers are little-endian by u64 word.
+ */
+#ifndef KMX_H
+#define KMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMX_VERSION 1
+
+/* ---- status codes (reference panics become codes; SURVEY 8b "Errors") ---- */
+#define KMX_OK 0
+#define KMX_E_ARG 1          /* null / inconsistent argument */
+#define KMX_E_K_RANGE 2      /* k outside the supported domain of the call */
+#define KMX_E_HIP 3          /* HIP runtime error; see kmx_last_error() */
+#define KMX_E_INVALID_BASE 4 /* naive_impl::encode_binary panic (src/naive_impl/mod.rs:35) */
+#define KMX_E_TOO_LONG 5     /* Kmer::from len>32 panic (src/naive_impl/kmer.rs:211-213,236-238); bit_field OOB in Encoding::encode */
+#define KMX_E_NOMEM 6
+
+/* ---- hashers (src/naive_impl/hash.rs) ---- */
+#define KMX_HASH_NONE 0     /* no hash folded into the summary */
+#define KMX_HASH_LEX 1      /* LexHasher{k}: hash.rs:22-72 */
+#define KMX_HASH_IDENTITY 2 /* impl Hash for Kmer feeds write_u64(data) (hash.rs:4-8) into an identity hasher */
+
+/* ---- MatchType (src/naive_impl/canonical_kmer.rs:7-12) ---- */
+#define KMX_NO_MATCH 0
+#define KMX_IDENTITY_MATCH 1
+#define KMX_TWIN_MATCH 2
+
+/* ---- per-window flags written by kmx_canonical_windows ---- */
+#define KMX_WIN_VALID 1u        /* the iterator yields this position (no non-ACGTacgt byte in the window) */
+#define KMX_WIN_FW_CANONICAL 2u /* CanonicalKmer::is_fw_canonical: fw < rc (canonical_kmer.rs:67-69) */
+
+typedef struct kmx_ctx kmx_ctx;
+
+/* A batch of reads resident in device memory.
+ * offsets == NULL: uniform layout, read r = d_bases[r*read_len .. (r+1)*read_len).
+ * offsets != NULL: ragged layout, read r = d_bases[offsets[r] .. offsets[r+1]) (n_reads+1 device u64). */
+typedef struct {
+    const uint8_t *d_bases;
+    uint64_t n_reads;
+    uint32_t read_len;
+    const uint64_t *d_offsets;
+} kmx_reads;
+
+/* Result of a streaming reduce pass (device-resident, 32 bytes).
+ * == what a consumer loop over CanonicalKmerIterator accumulates
+ * (src/naive_impl/canonical_kmer_iterator.rs:42-116; benches/simple_benchmark.rs:14-22 `.sum()` shape). */
+typedef struct {
+    uint64_t n_valid;   /* windows yielded */
+    uint64_t sum_canon; /* wrapping sum of get_canonical_word() (canonical_kmer.rs:113-119) */
+    uint64_t xor_hash;  /* xor of hash_one(hasher, canonical kmer) (hash.rs:10-20); 0 for KMX_HASH_NONE */
+    uint64_t sum_fw;    /* wrapping sum of get_fw_word() == compute_naive on valid input; 0 unless KMX_REDUCE_SUM_FW */
+} kmx_summary;
+
+/* [u64;2] k-mers (k in 33..64), BUILD-DEFINED extension of the above */
+typedef struct {
+    uint64_t n_valid;
+    uint64_t sum_lo, sum_hi;
+    uint64_t xor_lo, xor_hi;
+} kmx_summary2;
+
+#define KMX_REDUCE_SUM_FW 1u /* also accumulate sum_fw */
+
+/* ------------------------------------------------------------ context ---- */
+int kmx_ctx_create(int device, kmx_ctx **out);                 /* owns a new non-blocking stream */
+int kmx_ctx_create_on_stream(int device, void *hip_stream, kmx_ctx **out); /* borrows the caller's hipStream_t (NULL = default stream) */
+void kmx_ctx_destroy(kmx_ctx *ctx);
+int kmx_ctx_synchronize(kmx_ctx *ctx);
+int kmx_ctx_device(const kmx_ctx *ctx);
+const char *kmx_strerror(int status);
+const char *kmx_last_error(const kmx_ctx *ctx); /* text of the last HIP failure on this ctx */
+int kmx_version(void);
+
+/* device memory helpers so a host language needs no HIP binding of its own */
+int kmx_malloc(kmx_ctx *ctx, size_t nbytes, void **d_out);
+int kmx_free(kmx_ctx *ctx, void *d_ptr);
+int kmx_memcpy_h2d(kmx_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes); /* synchronous */
+int kmx_memcpy_d2h(kmx_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes); /* synchronous */
+int kmx_memset(kmx_ctx *ctx, void *d_dst, int value, size_t nbytes);
+
+/* ------------------------------------------- the streaming hot path ---- */
+
+/* Replaces: CanonicalKmerIterator::{from_u8_slice,find_next,inc,get} over every read
+ * (src/naive_impl/canonical_kmer_iterator.rs:42-116) + CanonicalKmer::append_base /
+ * get_canonical_word (canonical_kmer.rs:90-94,113-119) + Kmer::{append,prepend}_base
+ * (kmer.rs:91-102) + encode_binary_u8 (mod.rs:40-50) + optional hash_one (hash.rs:10-20).
+ * k in [1,31] (the reference's MASK_TABLE[32]==0, kmer.rs:617, breaks its own rolling at k=32).
+ * hasher: KMX_HASH_*; hasher_k: LexHasher's k (usually == k), ignored otherwise.
+ * d_out is OVERWRITTEN with this batch's summary. */
+int kmx_canonical_reduce(kmx_ctx *ctx, const kmx_reads *reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
+                         uint32_t flags, kmx_summary *d_out);
+
+/* Same pass, materialising per-window state: slot(read r, pos p) = win_off(r) + p with
+ * win_off(r) = r*(read_len-k+1) (uniform) or d_win_offsets[r] (ragged; n_reads+1 device u64,
+ * exclusive prefix sum of max(len-k+1,0)).  Any of the four outputs may be NULL.
+ * d_fw/d_rc/d_canon: get_fw_word / get_rc_word / get_canonical_word of the iterator state at
+ * that pos (canonical_kmer.rs:113-139); invalid slots are written as 0 with flags 0. */
+int kmx_canonical_windows(kmx_ctx *ctx, const kmx_reads *reads, const uint64_t *d_win_offsets, uint32_t k,
+                          uint64_t *d_fw, uint64_t *d_rc, uint64_t *d_canon, uint8_t *d_flags);
+
+/* BUILD-DEFINED [u64;2] variants, k in [33,64] (word_for_k::<u64,K>() == 2, src/kmer.rs:67-69):
+ * rolling = kmer.rs:91-102 carried across words, order = 2K-bit little-endian integer,
+ * hash = 2-bit-group reversal of the 2K-bit value.  Outputs are 2 u64 per slot. */
+int kmx_canonical_reduce2(kmx_ctx *ctx, const kmx_reads *reads, uint32_t k, uint32_t with_hash, kmx_summary2 *d_out);
+int kmx_canonical_windows2(kmx_ctx *ctx, const kmx_reads *reads, const uint64_t *d_win_offsets, uint32_t k,
+                           uint64_t *d_fw2, uint64_t *d_rc2, uint64_t *d_canon2, uint8_t *d_flags);
+
+/* Per-bucket occupancy of hash(canonical k-mer): d_counts[bucket] += 1 for every yielded window;
+ * bucket = (hash * 0x9E3779B97F4A7C15) >> (64 - log2_buckets)  (BUILD-DEFINED bucket function).
+ * d_counts (2^log2_buckets device u64) is ACCUMULATED into; the caller zeroes it and, across
+ * GPUs, all-reduces it (RCCL ncclSum/uint64). */
+int kmx_histogram(kmx_ctx *ctx, const kmx_reads *reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
+                  uint32_t log2_buckets, uint64_t *d_counts);
+
+/* Deterministic synthetic reads (BUILD-DEFINED; the reference bench input is unseeded,
+ * benches/simple_benchmark.rs:59-65): byte g of the stream = "ACGT"[(splitmix64(seed + g/32) >> 2*(g%32)) & 3].
+ * Writes nbytes bytes for stream positions [first_byte, first_byte+nbytes). */
+int kmx_gen_reads(kmx_ctx *ctx, uint64_t seed, uint64_t first_byte, uint8_t *d_out, uint64_t nbytes);
+
+/* -------------------------------------- element-wise batch operations ---- */
+
+/* naive_impl::Kmer::from(&[u8]) for n sequences of k bytes each, contiguous (kmer.rs:234-251).
+ * Strict semantics: returns KMX_E_INVALID_BASE if any byte is not ACGTacgt (the reference panics,
+ * mod.rs:35); *h_first_bad (host, may be NULL) receives the lowest offending byte index.
+ * k in [1,32].  SYNCHRONOUS (it has to report the status). */
+int kmx_kmers_from_bytes(kmx_ctx *ctx, const uint8_t *d_seqs, uint64_t n, uint32_t k, uint64_t *d_words,
+                         uint64_t *h_first_bad);
+
+/* Kmer::to_reverse_complement / get_reverse_complement_word (kmer.rs:124-147), k in [1,32] */
+int kmx_revcomp_words(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint32_t k, uint64_t *d_out);
+
+/* Kmer::to_canonical + is_canonical (kmer.rs:55-74): d_canon[i] = min(w, rc(w)); d_is_canonical[i] = (w <= rc(w)).
+ * Either output may be NULL. */
+int kmx_canonical_words(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint32_t k, uint64_t *d_canon,
+                        uint8_t *d_is_canonical);
+
+/* hash_one(&state, Kmer) with state = LexHasherState::new(hasher_k) (hash.rs:10-20,60-71) or identity */
+int kmx_hash_words(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint32_t hasher, uint32_t hasher_k, uint64_t *d_out);
+
+/* CanonicalKmer::get_word_equivalency (canonical_kmer.rs:152-161): out[i] in KMX_{NO,IDENTITY,TWIN}_MATCH */
+int kmx_match_words(kmx_ctx *ctx, const uint64_t *d_fw, const uint64_t *d_rc, const uint64_t *d_other, uint64_t n,
+                    uint8_t *d_out);
+
+/* CanonicalKmer::append_base / prepend_base on n independent (fw, rc) states, in place
+ * (canonical_kmer.rs:90-101; Kmer::append_base/prepend_base kmer.rs:91-102).  d_bases are 2-bit
+ * codes (A0 C1 G2 T3); d_dropped (may be NULL) receives the shifted-off base.  k in [1,31]. */
+int kmx_ck_append_bases(kmx_ctx *ctx, uint64_t *d_fw, uint64_t *d_rc, const uint8_t *d_bases, uint64_t n, uint32_t k,
+                        uint8_t *d_dropped);
+int kmx_ck_prepend_bases(kmx_ctx *ctx, uint64_t *d_fw, uint64_t *d_rc, const uint8_t *d_bases, uint64_t n, uint32_t k,
+                         uint8_t *d_dropped);
+
+/* Encoding::encode for encoding::Naive (src/encoding/naive.rs:116-124) / Xor10 (xor10.rs:52-60):
+ * n sequences of seq_len bytes each (contiguous) -> words_per_kmer u64 each, i.e.
+ * Kmer::<u64,K,B>::new(seq, &enc).  enc_byte is the Naive discriminant (naive.rs:48-74);
+ * Xor10 == 0x1B (Naive::ACTG).  No validity check (naive.rs:14-16 maps every byte).
+ * KMX_E_TOO_LONG if seq_len > 32*words_per_kmer (bit_field would panic). */
+int kmx_encode_kmers(kmx_ctx *ctx, const uint8_t *d_seqs, uint64_t n, uint32_t seq_len, uint8_t enc_byte,
+                     uint32_t words_per_kmer, uint64_t *d_words);
+/* Same for every length-k window of every read: the benches' `b.windows(K).map(Kmer::new)` shape
+ * (benches/simple_benchmark.rs:24-34); slot layout as kmx_canonical_windows (uniform reads only). */
+int kmx_encode_windows(kmx_ctx *ctx, const kmx_reads *reads, uint32_t k, uint8_t enc_byte, uint32_t words_per_kmer,
+                       uint64_t *d_words);
+/* Encoding::rev_comp::<K> (naive.rs:138-154; xor10.rs:86-103 B>1 loop): result base i =
+ * complement(base K-1-i) for i<K, bits >= 2K unchanged.  K in [2, 32*words_per_kmer]. */
+int kmx_encoding_rev_comp(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint32_t K, uint8_t enc_byte,
+                          uint32_t words_per_kmer, uint64_t *d_out);
+/* Encoding::decode (naive.rs:126-136): emits ALL 32*words_per_kmer letters per k-mer */
+int kmx_encoding_decode(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint8_t enc_byte, uint32_t words_per_kmer,
+                        uint8_t *d_seqs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMX_H */

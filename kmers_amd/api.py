@@ -1,0 +1,215 @@
+"""Batch API over the libkmx C ABI with torch tensors as device buffers.
+
+torch is plumbing here (device memory, streams, torch.distributed); every computation is a
+hand-written HIP kernel behind include/kmx.h.  All functions run on `Context.stream` (by
+default torch's current stream of the device) and are asynchronous like any torch CUDA op.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (HASH_IDENTITY, HASH_LEX, HASH_NONE, REDUCE_SUM_FW, KmxError, Reads, Summary, Summary2)
+
+SEED_DEFAULT = 0x6B6D6572735F7631  # "kmers_v1"
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError("kmx expects contiguous CUDA tensors")
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(int(t))
+
+
+def u64_numpy(t: torch.Tensor) -> np.ndarray:
+    """int64 CUDA tensor holding u64 words -> numpy uint64 (host)."""
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+class Context:
+    """One kmx_ctx bound to a device and a HIP stream (borrowed from torch)."""
+
+    def __init__(self, device: int | torch.device | None = None, stream: torch.cuda.Stream | None = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise KmxError(_lib.E_HIP, "no HIP device visible: kmers_amd is GPU-only (no CPU fallback)")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
+        with torch.cuda.device(self.device):
+            self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        st = self.lib.kmx_ctx_create_on_stream(self.device.index, C.c_void_p(self.stream.cuda_stream), C.byref(h))
+        _lib.check(self.lib, None, st)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.kmx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st):
+        _lib.check(self.lib, self._h, st)
+
+    def synchronize(self):
+        self._ck(self.lib.kmx_ctx_synchronize(self._h))
+
+    # ------------------------------------------------------------- helpers
+    def empty(self, n, dtype):
+        return torch.empty(int(n), dtype=dtype, device=self.device)
+
+    def to_device(self, a) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device).contiguous()
+        if isinstance(a, (bytes, bytearray)):
+            a = np.frombuffer(bytes(a), dtype=np.uint8)
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.uint64:
+            a = a.view(np.int64)
+        return torch.from_numpy(a.copy()).to(self.device)
+
+    def _reads(self, bases: torch.Tensor, n_reads: int, read_len: int, offsets: torch.Tensor | None) -> Reads:
+        return Reads(_ptr(bases) if bases is not None and bases.numel() else None, int(n_reads), int(read_len),
+                     _ptr(offsets))
+
+    # ------------------------------------------------------------ hot path
+    def gen_reads(self, nbytes: int, seed: int = SEED_DEFAULT, first_byte: int = 0, out: torch.Tensor | None = None):
+        """Deterministic synthetic ACGT stream (kmx_gen_reads)."""
+        if out is None:
+            out = self.empty(nbytes, torch.uint8)
+        self._ck(self.lib.kmx_gen_reads(self._h, seed & (2**64 - 1), first_byte, _ptr(out), int(nbytes)))
+        return out
+
+    def canonical_reduce_async(self, bases, n_reads, read_len, k, hasher=HASH_NONE, hasher_k=0, flags=0, offsets=None,
+                               out: torch.Tensor | None = None) -> torch.Tensor:
+        """kmx_canonical_reduce; returns the device-resident summary (4 x int64 viewable as u64)."""
+        if out is None:
+            out = self.empty(4, torch.int64)
+        r = self._reads(bases, n_reads, read_len, offsets)
+        self._ck(self.lib.kmx_canonical_reduce(self._h, C.byref(r), k, hasher, hasher_k, flags, _ptr(out)))
+        return out
+
+    def canonical_reduce(self, bases, n_reads, read_len, k, hasher=HASH_NONE, hasher_k=0, flags=0, offsets=None) -> Summary:
+        out = self.canonical_reduce_async(bases, n_reads, read_len, k, hasher, hasher_k, flags, offsets)
+        v = u64_numpy(out)
+        return Summary(int(v[0]), int(v[1]), int(v[2]), int(v[3]))
+
+    def win_offsets(self, n_reads, read_len, k, offsets=None) -> np.ndarray:
+        if offsets is None:
+            w = max(read_len - k + 1, 0)
+            return np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(w)
+        lens = np.diff(np.asarray(offsets).astype(np.int64))
+        return np.concatenate([[0], np.cumsum(np.maximum(lens - k + 1, 0))]).astype(np.uint64)
+
+    def canonical_windows(self, bases, n_reads, read_len, k, offsets=None, host_offsets=None, want=("fw", "rc", "canon", "flags")):
+        """kmx_canonical_windows -> dict of device tensors (u64 words as int64, flags uint8)."""
+        wo_host = self.win_offsets(n_reads, read_len, k, host_offsets)
+        total = int(wo_host[-1])
+        d_wo = self.to_device(wo_host) if offsets is not None else None
+        outs = {n: (self.empty(total, torch.uint8) if n == "flags" else self.empty(total, torch.int64)) for n in want}
+        r = self._reads(bases, n_reads, read_len, offsets)
+        self._ck(self.lib.kmx_canonical_windows(self._h, C.byref(r), _ptr(d_wo), k, _ptr(outs.get("fw")), _ptr(outs.get("rc")),
+                                                _ptr(outs.get("canon")), _ptr(outs.get("flags"))))
+        return outs
+
+    def canonical_reduce2(self, bases, n_reads, read_len, k, with_hash=False, offsets=None) -> Summary2:
+        out = self.empty(5, torch.int64)
+        r = self._reads(bases, n_reads, read_len, offsets)
+        self._ck(self.lib.kmx_canonical_reduce2(self._h, C.byref(r), k, int(with_hash), _ptr(out)))
+        v = u64_numpy(out)
+        return Summary2(*[int(x) for x in v])
+
+    def canonical_windows2(self, bases, n_reads, read_len, k, offsets=None, host_offsets=None):
+        wo_host = self.win_offsets(n_reads, read_len, k, host_offsets)
+        total = int(wo_host[-1])
+        d_wo = self.to_device(wo_host) if offsets is not None else None
+        outs = {n: self.empty(2 * total, torch.int64) for n in ("fw", "rc", "canon")}
+        outs["flags"] = self.empty(total, torch.uint8)
+        r = self._reads(bases, n_reads, read_len, offsets)
+        self._ck(self.lib.kmx_canonical_windows2(self._h, C.byref(r), _ptr(d_wo), k, _ptr(outs["fw"]), _ptr(outs["rc"]),
+                                                 _ptr(outs["canon"]), _ptr(outs["flags"])))
+        return outs
+
+    def histogram(self, bases, n_reads, read_len, k, hasher, hasher_k, log2_buckets, offsets=None,
+                  counts: torch.Tensor | None = None) -> torch.Tensor:
+        if counts is None:
+            counts = torch.zeros(1 << log2_buckets, dtype=torch.int64, device=self.device)
+        r = self._reads(bases, n_reads, read_len, offsets)
+        self._ck(self.lib.kmx_histogram(self._h, C.byref(r), k, hasher, hasher_k, log2_buckets, _ptr(counts)))
+        return counts
+
+    # --------------------------------------------------------- element-wise
+    def kmers_from_bytes(self, seqs: torch.Tensor, n: int, k: int) -> torch.Tensor:
+        out = self.empty(n, torch.int64)
+        bad = C.c_uint64()
+        st = self.lib.kmx_kmers_from_bytes(self._h, _ptr(seqs) if n else None, n, k, _ptr(out) if n else None, C.byref(bad))
+        if st == _lib.E_INVALID_BASE:
+            e = KmxError(st, f"invalid base at byte {bad.value}")
+            e.first_bad = bad.value
+            raise e
+        self._ck(st)
+        return out
+
+    def revcomp_words(self, words: torch.Tensor, k: int) -> torch.Tensor:
+        out = torch.empty_like(words)
+        self._ck(self.lib.kmx_revcomp_words(self._h, _ptr(words), words.numel(), k, _ptr(out)))
+        return out
+
+    def canonical_words(self, words: torch.Tensor, k: int):
+        canon = torch.empty_like(words)
+        isc = self.empty(words.numel(), torch.uint8)
+        self._ck(self.lib.kmx_canonical_words(self._h, _ptr(words), words.numel(), k, _ptr(canon), _ptr(isc)))
+        return canon, isc
+
+    def hash_words(self, words: torch.Tensor, hasher: int, hasher_k: int) -> torch.Tensor:
+        out = torch.empty_like(words)
+        self._ck(self.lib.kmx_hash_words(self._h, _ptr(words), words.numel(), hasher, hasher_k, _ptr(out)))
+        return out
+
+    def match_words(self, fw, rc, other) -> torch.Tensor:
+        out = self.empty(fw.numel(), torch.uint8)
+        self._ck(self.lib.kmx_match_words(self._h, _ptr(fw), _ptr(rc), _ptr(other), fw.numel(), _ptr(out)))
+        return out
+
+    def ck_shift(self, fw, rc, bases, k, append=True) -> torch.Tensor:
+        dropped = self.empty(fw.numel(), torch.uint8)
+        fn = self.lib.kmx_ck_append_bases if append else self.lib.kmx_ck_prepend_bases
+        self._ck(fn(self._h, _ptr(fw), _ptr(rc), _ptr(bases), fw.numel(), k, _ptr(dropped)))
+        return dropped
+
+    def encode_kmers(self, seqs: torch.Tensor, n: int, seq_len: int, enc_byte: int, words_per_kmer: int) -> torch.Tensor:
+        out = self.empty(n * words_per_kmer, torch.int64)
+        self._ck(self.lib.kmx_encode_kmers(self._h, _ptr(seqs) if seqs.numel() else None, n, seq_len, enc_byte,
+                                           words_per_kmer, _ptr(out)))
+        return out
+
+    def encode_windows(self, bases, n_reads, read_len, k, enc_byte, words_per_kmer) -> torch.Tensor:
+        nwin = max(read_len - k + 1, 0)
+        out = self.empty(n_reads * nwin * words_per_kmer, torch.int64)
+        r = self._reads(bases, n_reads, read_len, None)
+        self._ck(self.lib.kmx_encode_windows(self._h, C.byref(r), k, enc_byte, words_per_kmer, _ptr(out)))
+        return out
+
+    def encoding_rev_comp(self, words: torch.Tensor, K: int, enc_byte: int, words_per_kmer: int) -> torch.Tensor:
+        out = torch.empty_like(words)
+        self._ck(self.lib.kmx_encoding_rev_comp(self._h, _ptr(words), words.numel() // words_per_kmer, K, enc_byte,
+                                                words_per_kmer, _ptr(out)))
+        return out
+
+    def encoding_decode(self, words: torch.Tensor, enc_byte: int, words_per_kmer: int) -> torch.Tensor:
+        n = words.numel() // words_per_kmer
+        out = self.empty(n * 32 * words_per_kmer, torch.uint8)
+        self._ck(self.lib.kmx_encoding_decode(self._h, _ptr(words), n, enc_byte, words_per_kmer, _ptr(out)))
+        return out

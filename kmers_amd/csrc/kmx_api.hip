@@ -1,0 +1,443 @@
+// kmx_api.hip -- the extern "C" boundary declared in include/kmx.h: argument checking,
+// kernel selection and HIP error mapping.  No CPU compute path exists here: every entry
+// point launches a gfx950 kernel or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/kmx.h"
+
+namespace kmx {
+typedef uint32_t u32;
+typedef uint64_t u64;
+// kmx_scan.hip
+hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
+                               kmx_summary* out, int n_cu, hipStream_t stream, bool* handled);
+// kmx_generic.hip
+hipError_t launch_reduce_generic(const kmx_reads* r, u32 k, u32 hasher, u32 hk, u32 want_sumfw, kmx_summary* out,
+                                 int n_cu, hipStream_t st);
+hipError_t launch_windows_generic(const kmx_reads* r, const u64* win_off, u32 k, u64* fw, u64* rc, u64* canon,
+                                  uint8_t* flags, int n_cu, hipStream_t st);
+hipError_t launch_histogram_generic(const kmx_reads* r, u32 k, u32 hasher, u32 hk, u32 log2_buckets, u64* counts,
+                                    int n_cu, hipStream_t st);
+hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_summary2* out, int n_cu, hipStream_t st);
+hipError_t launch_windows2_generic(const kmx_reads* r, const u64* win_off, u32 k, u64* fw, u64* rc, u64* canon,
+                                   uint8_t* flags, int n_cu, hipStream_t st);
+// kmx_elem.hip
+hipError_t launch_gen_reads(u64 seed, u64 first_byte, uint8_t* out, u64 nbytes, int n_cu, hipStream_t st);
+hipError_t launch_kmers_from_bytes(const uint8_t* seqs, u64 n, u32 k, u64* words, unsigned long long* first_bad, int n_cu,
+                                   hipStream_t st);
+hipError_t launch_revcomp_words(const u64* in, u64 n, u32 k, u64* out, int n_cu, hipStream_t st);
+hipError_t launch_canonical_words(const u64* in, u64 n, u32 k, u64* canon, uint8_t* is_canon, int n_cu, hipStream_t st);
+hipError_t launch_hash_words(const u64* in, u64 n, u32 hasher, u32 hk, u64* out, int n_cu, hipStream_t st);
+hipError_t launch_match_words(const u64* fw, const u64* rc, const u64* other, u64 n, uint8_t* out, int n_cu, hipStream_t st);
+hipError_t launch_ck_shift(bool append, u64* fw, u64* rc, const uint8_t* bases, u64 n, u32 k, uint8_t* dropped, int n_cu,
+                           hipStream_t st);
+hipError_t launch_encode_kmers(const uint8_t* seqs, u64 n, u32 seq_len, u32 enc, u32 B, u64* words, int n_cu, hipStream_t st);
+hipError_t launch_encode_windows(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 enc, u32 B, u64* words, int n_cu,
+                                 hipStream_t st);
+hipError_t launch_encoding_rev_comp(const u64* in, u64 n, u32 K, u32 comp_lut, u32 B, u64* out, int n_cu, hipStream_t st);
+hipError_t launch_encoding_decode(const u64* in, u64 n, u32 nuc_lut, u32 B, uint8_t* seqs, int n_cu, hipStream_t st);
+}  // namespace kmx
+
+using kmx::u32;
+using kmx::u64;
+
+struct kmx_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+    int n_cu;
+    unsigned long long* d_scratch;  // 8 bytes: first_bad
+    char last_error[256];
+};
+
+namespace {
+
+int fail_hip(kmx_ctx* ctx, hipError_t e, const char* where) {
+    if (ctx) std::snprintf(ctx->last_error, sizeof ctx->last_error, "%s: %s", where, hipGetErrorString(e));
+    return KMX_E_HIP;
+}
+
+#define KMX_HIP(ctx, expr)                                   \
+    do {                                                     \
+        hipError_t e__ = (expr);                             \
+        if (e__ != hipSuccess) return fail_hip(ctx, e__, #expr); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+bool reads_ok(const kmx_reads* r) {
+    if (!r) return false;
+    if (r->n_reads && !r->d_bases && (r->d_offsets || r->read_len)) return false;
+    return true;
+}
+
+// ---- host-side restatement of the per-encoding tables of src/encoding/naive.rs ----
+// rev_encoding (naive.rs:28-39)
+u32 rev_encoding(u32 enc) {
+    u32 rev = 0;
+    rev ^= 0u << (6 - ((enc >> 6) * 2));
+    rev ^= 1u << (6 - (((enc >> 4) & 3) * 2));
+    rev ^= 2u << (6 - (((enc >> 2) & 3) * 2));
+    rev ^= 3u << (6 - ((enc & 3) * 2));
+    return rev & 0xFFu;
+}
+// complement (naive.rs:98-109) for the four codes, packed 2 bits each
+u32 comp_lut_for(u32 enc) {
+    const u32 rev = rev_encoding(enc);
+    u32 lut = 0;
+    for (u32 bits = 0; bits < 4; ++bits) {
+        const u32 internal = (rev >> (6 - bits * 2)) & 3;
+        const u32 comp_internal = (internal ^ 2u) & 3;
+        lut |= ((enc >> (6 - comp_internal * 2)) & 3) << (2 * bits);
+    }
+    return lut;
+}
+// bits2nuc (naive.rs:88-95, INTERNAL2NUC :19) for the four codes, one letter per byte
+u32 nuc_lut_for(u32 enc) {
+    static const unsigned char internal2nuc[4] = {'A', 'C', 'T', 'G'};
+    const u32 rev = rev_encoding(enc);
+    u32 lut = 0;
+    for (u32 bits = 0; bits < 4; ++bits) lut |= (u32)internal2nuc[(rev >> (6 - bits * 2)) & 3] << (8 * bits);
+    return lut;
+}
+// the 24 discriminants of `enum Naive` (naive.rs:48-74) are exactly the bytes whose four 2-bit
+// fields are a permutation of {0,1,2,3}
+bool enc_ok(u32 enc) {
+    if (enc > 0xFFu) return false;
+    u32 seen = 0;
+    for (int i = 0; i < 4; ++i) seen |= 1u << ((enc >> (2 * i)) & 3);
+    return seen == 0xFu;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kmx_version(void) { return KMX_VERSION; }
+
+const char* kmx_strerror(int status) {
+    switch (status) {
+    case KMX_OK: return "ok";
+    case KMX_E_ARG: return "invalid argument";
+    case KMX_E_K_RANGE: return "k outside the supported range for this call";
+    case KMX_E_HIP: return "HIP runtime error (see kmx_last_error)";
+    case KMX_E_INVALID_BASE: return "byte is not one of ACGTacgt (reference: encode_binary panics)";
+    case KMX_E_TOO_LONG: return "sequence longer than the k-mer storage (reference panics)";
+    case KMX_E_NOMEM: return "out of memory";
+    default: return "unknown kmx status";
+    }
+}
+
+static int ctx_create_common(int device, hipStream_t stream, bool owns, kmx_ctx** out) {
+    if (!out) return KMX_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return KMX_E_HIP;  // fail loudly: no GPU, no kmx
+    if (device < 0 || device >= count) return KMX_E_ARG;
+    kmx_ctx* c = new (std::nothrow) kmx_ctx();
+    if (!c) return KMX_E_NOMEM;
+    c->device = device;
+    c->stream = stream;
+    c->owns_stream = owns;
+    c->d_scratch = nullptr;
+    c->last_error[0] = 0;
+    DeviceGuard g(device);
+    hipDeviceProp_t prop;
+    hipError_t e = g.ok ? hipGetDeviceProperties(&prop, device) : hipErrorInvalidDevice;
+    if (e == hipSuccess && owns) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_scratch), 64);
+    if (e != hipSuccess) {
+        delete c;
+        return KMX_E_HIP;
+    }
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = c;
+    return KMX_OK;
+}
+
+int kmx_ctx_create(int device, kmx_ctx** out) { return ctx_create_common(device, nullptr, true, out); }
+
+int kmx_ctx_create_on_stream(int device, void* hip_stream, kmx_ctx** out) {
+    return ctx_create_common(device, static_cast<hipStream_t>(hip_stream), false, out);
+}
+
+void kmx_ctx_destroy(kmx_ctx* ctx) {
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int kmx_ctx_synchronize(kmx_ctx* ctx) {
+    if (!ctx) return KMX_E_ARG;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_ctx_device(const kmx_ctx* ctx) { return ctx ? ctx->device : -1; }
+
+const char* kmx_last_error(const kmx_ctx* ctx) { return ctx ? ctx->last_error : "null ctx"; }
+
+int kmx_malloc(kmx_ctx* ctx, size_t nbytes, void** d_out) {
+    if (!ctx || !d_out) return KMX_E_ARG;
+    DeviceGuard g(ctx->device);
+    *d_out = nullptr;
+    if (nbytes == 0) return KMX_OK;
+    hipError_t e = hipMalloc(d_out, nbytes);
+    if (e == hipErrorOutOfMemory) return KMX_E_NOMEM;
+    KMX_HIP(ctx, e);
+    return KMX_OK;
+}
+
+int kmx_free(kmx_ctx* ctx, void* d_ptr) {
+    if (!ctx) return KMX_E_ARG;
+    if (!d_ptr) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipFree(d_ptr));
+    return KMX_OK;
+}
+
+int kmx_memcpy_h2d(kmx_ctx* ctx, void* d_dst, const void* h_src, size_t nbytes) {
+    if (!ctx || (nbytes && (!d_dst || !h_src))) return KMX_E_ARG;
+    if (!nbytes) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_memcpy_d2h(kmx_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes) {
+    if (!ctx || (nbytes && (!h_dst || !d_src))) return KMX_E_ARG;
+    if (!nbytes) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipMemcpyAsync(h_dst, d_src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_memset(kmx_ctx* ctx, void* d_dst, int value, size_t nbytes) {
+    if (!ctx || (nbytes && !d_dst)) return KMX_E_ARG;
+    if (!nbytes) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipMemsetAsync(d_dst, value, nbytes, ctx->stream));
+    return KMX_OK;
+}
+
+/* ------------------------------------------------------------ hot path ---- */
+
+int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
+                         uint32_t flags, kmx_summary* d_out) {
+    if (!ctx || !reads_ok(reads) || !d_out) return KMX_E_ARG;
+    if (k < 1 || k > 31) return KMX_E_K_RANGE;  // MASK_TABLE[32]==0 (kmer.rs:617) breaks the reference's own rolling at 32
+    if (hasher > KMX_HASH_IDENTITY) return KMX_E_ARG;
+    if (hasher == KMX_HASH_LEX && (hasher_k < 1 || hasher_k > 32)) return KMX_E_K_RANGE;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(kmx_summary), ctx->stream));
+    if (reads->n_reads == 0) return KMX_OK;
+    const bool want_sumfw = (flags & KMX_REDUCE_SUM_FW) != 0;
+    const bool lex_same_k = hasher == KMX_HASH_LEX && hasher_k == k;
+    if (!reads->d_offsets && (hasher == KMX_HASH_NONE || lex_same_k)) {
+        bool handled = false;
+        KMX_HIP(ctx, kmx::launch_scan_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
+                                              d_out, ctx->n_cu, ctx->stream, &handled));
+        if (handled) return KMX_OK;
+    }
+    KMX_HIP(ctx, kmx::launch_reduce_generic(reads, k, hasher, hasher_k, want_sumfw ? 1u : 0u, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* d_win_offsets, uint32_t k,
+                          uint64_t* d_fw, uint64_t* d_rc, uint64_t* d_canon, uint8_t* d_flags) {
+    if (!ctx || !reads_ok(reads)) return KMX_E_ARG;
+    if (k < 1 || k > 31) return KMX_E_K_RANGE;
+    if (reads->d_offsets && !d_win_offsets) return KMX_E_ARG;
+    if (reads->n_reads == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_windows_generic(reads, d_win_offsets, k, d_fw, d_rc, d_canon, d_flags, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t with_hash, kmx_summary2* d_out) {
+    if (!ctx || !reads_ok(reads) || !d_out) return KMX_E_ARG;
+    if (k < 33 || k > 64) return KMX_E_K_RANGE;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(kmx_summary2), ctx->stream));
+    if (reads->n_reads == 0) return KMX_OK;
+    KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_canonical_windows2(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* d_win_offsets, uint32_t k,
+                           uint64_t* d_fw2, uint64_t* d_rc2, uint64_t* d_canon2, uint8_t* d_flags) {
+    if (!ctx || !reads_ok(reads)) return KMX_E_ARG;
+    if (k < 33 || k > 64) return KMX_E_K_RANGE;
+    if (reads->d_offsets && !d_win_offsets) return KMX_E_ARG;
+    if (reads->n_reads == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_windows2_generic(reads, d_win_offsets, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_histogram(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
+                  uint32_t log2_buckets, uint64_t* d_counts) {
+    if (!ctx || !reads_ok(reads) || !d_counts) return KMX_E_ARG;
+    if (k < 1 || k > 31) return KMX_E_K_RANGE;
+    if (hasher > KMX_HASH_IDENTITY || log2_buckets > 30) return KMX_E_ARG;
+    if (hasher == KMX_HASH_LEX && (hasher_k < 1 || hasher_k > 32)) return KMX_E_K_RANGE;
+    if (reads->n_reads == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_histogram_generic(reads, k, hasher, hasher_k, log2_buckets, d_counts, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_gen_reads(kmx_ctx* ctx, uint64_t seed, uint64_t first_byte, uint8_t* d_out, uint64_t nbytes) {
+    if (!ctx || (nbytes && !d_out)) return KMX_E_ARG;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_gen_reads(seed, first_byte, d_out, nbytes, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+/* -------------------------------------------------------- element-wise ---- */
+
+int kmx_kmers_from_bytes(kmx_ctx* ctx, const uint8_t* d_seqs, uint64_t n, uint32_t k, uint64_t* d_words,
+                         uint64_t* h_first_bad) {
+    if (!ctx || (n && (!d_seqs || !d_words))) return KMX_E_ARG;
+    if (k > 32) return KMX_E_TOO_LONG;  // kmer.rs:236-238
+    if (k < 1) return KMX_E_K_RANGE;
+    if (h_first_bad) *h_first_bad = ~0ull;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0xFF, 8, ctx->stream));
+    KMX_HIP(ctx, kmx::launch_kmers_from_bytes(d_seqs, n, k, d_words, ctx->d_scratch, ctx->n_cu, ctx->stream));
+    unsigned long long bad = 0;
+    KMX_HIP(ctx, hipMemcpyAsync(&bad, ctx->d_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad != ~0ull) {
+        if (h_first_bad) *h_first_bad = bad;
+        return KMX_E_INVALID_BASE;
+    }
+    return KMX_OK;
+}
+
+int kmx_revcomp_words(kmx_ctx* ctx, const uint64_t* d_in, uint64_t n, uint32_t k, uint64_t* d_out) {
+    if (!ctx || (n && (!d_in || !d_out))) return KMX_E_ARG;
+    if (k < 1 || k > 32) return KMX_E_K_RANGE;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_revcomp_words(d_in, n, k, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_canonical_words(kmx_ctx* ctx, const uint64_t* d_in, uint64_t n, uint32_t k, uint64_t* d_canon,
+                        uint8_t* d_is_canonical) {
+    if (!ctx || (n && !d_in)) return KMX_E_ARG;
+    if (k < 1 || k > 32) return KMX_E_K_RANGE;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_canonical_words(d_in, n, k, d_canon, d_is_canonical, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_hash_words(kmx_ctx* ctx, const uint64_t* d_in, uint64_t n, uint32_t hasher, uint32_t hasher_k, uint64_t* d_out) {
+    if (!ctx || (n && (!d_in || !d_out))) return KMX_E_ARG;
+    if (hasher != KMX_HASH_LEX && hasher != KMX_HASH_IDENTITY) return KMX_E_ARG;
+    if (hasher == KMX_HASH_LEX && (hasher_k < 1 || hasher_k > 32)) return KMX_E_K_RANGE;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_hash_words(d_in, n, hasher, hasher_k, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_match_words(kmx_ctx* ctx, const uint64_t* d_fw, const uint64_t* d_rc, const uint64_t* d_other, uint64_t n,
+                    uint8_t* d_out) {
+    if (!ctx || (n && (!d_fw || !d_rc || !d_other || !d_out))) return KMX_E_ARG;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_match_words(d_fw, d_rc, d_other, n, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+static int ck_shift(kmx_ctx* ctx, bool append, uint64_t* d_fw, uint64_t* d_rc, const uint8_t* d_bases, uint64_t n,
+                    uint32_t k, uint8_t* d_dropped) {
+    if (!ctx || (n && (!d_fw || !d_rc || !d_bases))) return KMX_E_ARG;
+    if (k < 1 || k > 31) return KMX_E_K_RANGE;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_ck_shift(append, d_fw, d_rc, d_bases, n, k, d_dropped, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_ck_append_bases(kmx_ctx* ctx, uint64_t* d_fw, uint64_t* d_rc, const uint8_t* d_bases, uint64_t n, uint32_t k,
+                        uint8_t* d_dropped) {
+    return ck_shift(ctx, true, d_fw, d_rc, d_bases, n, k, d_dropped);
+}
+
+int kmx_ck_prepend_bases(kmx_ctx* ctx, uint64_t* d_fw, uint64_t* d_rc, const uint8_t* d_bases, uint64_t n, uint32_t k,
+                         uint8_t* d_dropped) {
+    return ck_shift(ctx, false, d_fw, d_rc, d_bases, n, k, d_dropped);
+}
+
+int kmx_encode_kmers(kmx_ctx* ctx, const uint8_t* d_seqs, uint64_t n, uint32_t seq_len, uint8_t enc_byte,
+                     uint32_t words_per_kmer, uint64_t* d_words) {
+    if (!ctx || (n && ((seq_len && !d_seqs) || !d_words))) return KMX_E_ARG;
+    if (!enc_ok(enc_byte) || words_per_kmer < 1 || words_per_kmer > 4) return KMX_E_ARG;
+    if (seq_len > 32u * words_per_kmer) return KMX_E_TOO_LONG;  // bit_field set_bits would panic
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_encode_kmers(d_seqs, n, seq_len, enc_byte, words_per_kmer, d_words, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_encode_windows(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint8_t enc_byte, uint32_t words_per_kmer,
+                       uint64_t* d_words) {
+    if (!ctx || !reads_ok(reads) || reads->d_offsets) return KMX_E_ARG;
+    if (!enc_ok(enc_byte) || words_per_kmer < 1 || words_per_kmer > 4) return KMX_E_ARG;
+    if (k < 1) return KMX_E_K_RANGE;
+    if (k > 32u * words_per_kmer) return KMX_E_TOO_LONG;
+    if (reads->n_reads == 0 || reads->read_len < k) return KMX_OK;
+    if (!d_words) return KMX_E_ARG;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_encode_windows(reads->d_bases, reads->n_reads, reads->read_len, k, enc_byte, words_per_kmer,
+                                            d_words, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_encoding_rev_comp(kmx_ctx* ctx, const uint64_t* d_in, uint64_t n, uint32_t K, uint8_t enc_byte,
+                          uint32_t words_per_kmer, uint64_t* d_out) {
+    if (!ctx || (n && (!d_in || !d_out))) return KMX_E_ARG;
+    if (!enc_ok(enc_byte) || words_per_kmer < 1 || words_per_kmer > 4) return KMX_E_ARG;
+    if (K < 2 || K > 32u * words_per_kmer) return KMX_E_K_RANGE;  // K=1 underflows usize in the reference (naive.rs:140,150)
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_encoding_rev_comp(d_in, n, K, comp_lut_for(enc_byte), words_per_kmer, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_encoding_decode(kmx_ctx* ctx, const uint64_t* d_in, uint64_t n, uint8_t enc_byte, uint32_t words_per_kmer,
+                        uint8_t* d_seqs) {
+    if (!ctx || (n && (!d_in || !d_seqs))) return KMX_E_ARG;
+    if (!enc_ok(enc_byte) || words_per_kmer < 1 || words_per_kmer > 4) return KMX_E_ARG;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_encoding_decode(d_in, n, nuc_lut_for(enc_byte), words_per_kmer, d_seqs, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+}  // extern "C"

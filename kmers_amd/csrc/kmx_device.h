@@ -1,0 +1,146 @@
+// kmx_device.h -- gfx950 device helpers shared by the kmx kernels.
+// Pure integer bit manipulation; wave64; no MFMA (the path is HBM/VALU-bound byte work).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kmx.h"
+
+namespace kmx {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int WAVE = 64;
+
+// ({hi,lo} >> sh[4:0])[31:0]  -> v_alignbit_b32
+__device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+
+// ASCII -> 2-bit.  (c>>1)&3 gives the "internal" code A0 C1 T2 G3 for both cases
+// (reference src/encoding/naive.rs:14-16); naive_impl codes are A0 C1 G2 T3
+// (src/naive_impl/mod.rs:20-24), obtained per 2-bit group as i ^ (i>>1).
+//
+// encode16: 16 ASCII bytes (one dwordx4) -> 16 bases packed in one dword, first base lowest,
+// in naive_impl (ACGT) codes, plus `bad`: OR of (byte ^ expected upper-case letter) over the 16
+// bytes -- the chunk is all-ACGTacgt  <=>  (bad & 0xDFDFDFDF) == 0  (exact, case-insensitive,
+// same accept set as encode_binary_u8, src/naive_impl/mod.rs:40-50).
+__device__ __forceinline__ u32 encode16(uint4 w, u32& bad) {
+    // expected letter by internal code*2 as v_perm selector: 0->'A' 2->'C' 4->'T' 6->'G'
+    constexpr u32 TBL_LO = 0x00430041u;  // bytes 0..3 : 'A', -, 'C', -
+    constexpr u32 TBL_HI = 0x00470054u;  // bytes 4..7 : 'T', -, 'G', -
+    constexpr u32 W4 = 0x40100401u;      // dot4 weights 1,4,16,64
+    const u32 t0 = w.x & 0x06060606u, t1 = w.y & 0x06060606u, t2 = w.z & 0x06060606u, t3 = w.w & 0x06060606u;
+    const u32 x0 = w.x ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t0);
+    const u32 x1 = w.y ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t1);
+    const u32 x2 = w.z ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t2);
+    const u32 x3 = w.w ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t3);
+    bad = bad | x0 | x1;
+    bad = bad | x2 | x3;
+    // v_dot4_u32_u8: sum of (2*code_i) * 4^i  = 2 * (4 bases packed in 8 bits)
+    const u32 d0 = __builtin_amdgcn_udot4(t0, W4, 0u, false);
+    const u32 d1 = __builtin_amdgcn_udot4(t1, W4, 0u, false);
+    const u32 d2 = __builtin_amdgcn_udot4(t2, W4, 0u, false);
+    const u32 d3 = __builtin_amdgcn_udot4(t3, W4, 0u, false);
+    u32 p = ((d0 | (d1 << 8) | (d2 << 16)) >> 1) | (d3 << 23);
+    p ^= (p >> 1) & 0x55555555u;  // internal (ACTG) -> naive_impl (ACGT) codes
+    return p;
+}
+
+__device__ __forceinline__ bool chunk_has_invalid(u32 bad) { return (bad & 0xDFDFDFDFu) != 0u; }
+
+// reverse the 16 2-bit groups of a dword (v_bfrev_b32 + swap the two bits of each pair)
+__device__ __forceinline__ u32 revgroups32(u32 x) {
+    const u32 y = __builtin_bitreverse32(x);
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
+
+// reverse the 32 2-bit groups of a u64
+__device__ __forceinline__ u64 revgroups64(u64 x) {
+    return ((u64)revgroups32((u32)x) << 32) | (u64)revgroups32((u32)(x >> 32));
+}
+
+// Kmer::to_reverse_complement (src/naive_impl/kmer.rs:124-136), k in [1,32]
+__device__ __forceinline__ u64 revcomp_word(u64 w, u32 k) { return revgroups64(~w) >> (2u * (32u - k)); }
+
+// LexHasher::write_u64 (src/naive_impl/hash.rs:60-71), hasher_k in [1,32]
+__device__ __forceinline__ u64 lex_hash(u64 w, u32 hk) { return revgroups64(w) >> (2u * (32u - hk)); }
+
+// MASK_TABLE[k] for k in [0,31] (src/naive_impl/kmer.rs:584-616)
+__device__ __host__ __forceinline__ u64 mask2k(u32 k) { return k >= 32 ? ~0ull : ((1ull << (2u * k)) - 1ull); }
+
+// encode_binary_u8 (src/naive_impl/mod.rs:40-50): code 0..3, or 4 for "invalid" (reference: u64::MAX)
+__device__ __forceinline__ u32 encode_base(u32 c) {
+    const u32 u = c & 0xDFu;
+    const u32 i = (c >> 1) & 3u;          // A0 C1 T2 G3
+    const u32 expect = (0x47544341u >> (8u * i)) & 0xFFu;  // 'A','C','T','G'
+    return (u == expect) ? (i ^ (i >> 1)) : 4u;
+}
+
+__device__ __forceinline__ u64 splitmix64(u64 x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ u64 bucket_of(u64 h, u32 log2_buckets) {
+    return log2_buckets ? (h * 0x9E3779B97F4A7C15ull) >> (64u - log2_buckets) : 0ull;
+}
+
+__device__ __forceinline__ u64 wave_sum(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ u64 wave_xor(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// accumulators of one reduce pass, per lane
+struct Acc {
+    u64 n_valid = 0, sum_canon = 0, xor_hash = 0, sum_fw = 0;
+};
+
+// one set of 64-bit atomics per wave; want_hash / want_sumfw are wave-uniform
+__device__ __forceinline__ void flush_acc(const Acc& a, kmx_summary* out, bool want_hash, bool want_sumfw) {
+    const u64 n = wave_sum(a.n_valid);
+    const u64 s = wave_sum(a.sum_canon);
+    u64 x = 0, f = 0;
+    if (want_hash) x = wave_xor(a.xor_hash);
+    if (want_sumfw) f = wave_sum(a.sum_fw);
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        atomicAdd((unsigned long long*)&out->n_valid, (unsigned long long)n);
+        atomicAdd((unsigned long long*)&out->sum_canon, (unsigned long long)s);
+        if (want_hash) atomicXor((unsigned long long*)&out->xor_hash, (unsigned long long)x);
+        if (want_sumfw) atomicAdd((unsigned long long*)&out->sum_fw, (unsigned long long)f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Reference-shaped per-lane rolling over one read (generic path: ragged reads, reads
+// with invalid bytes, partial tiles, any k in [1,31]).  Direct restatement of
+// CanonicalKmerIterator::find_next (src/naive_impl/canonical_kmer_iterator.rs:42-70) with
+// CanonicalKmer::append_base (canonical_kmer.rs:90-94): one lane walks one read.
+// `emit(pos, fw, rc)` is called for every yielded window, in increasing pos.
+template <typename Emit>
+__device__ __forceinline__ void roll_read(const uint8_t* __restrict__ s, u32 len, u32 k, Emit&& emit) {
+    const u64 mask = mask2k(k);
+    const u32 top = 2u * k - 2u;
+    u64 fw = 0, rc = ~0ull;  // CanonicalKmer::blank_of_size (canonical_kmer.rs:22-29)
+    int last_invalid = -1;
+    for (u32 l = 0; l < len; ++l) {
+        const u32 b = encode_base(s[l]);
+        if (b < 4u) {
+            fw = (fw >> 2) | ((u64)b << top);                  // kmer.rs:98-102
+            rc = mask & ((rc << 2) | (u64)(3u - b));           // kmer.rs:91-95, mod.rs:81-84
+            if ((int)l - last_invalid >= (int)k) emit(l + 1u - k, fw, rc);
+        } else {
+            last_invalid = (int)l;
+        }
+    }
+}
+
+}  // namespace kmx

@@ -1,0 +1,275 @@
+// kmx_elem.hip -- K0 synthetic read generator + K5 element-wise batch operations
+// (one element per lane).  Each kernel cites the reference function it restates.
+#include "kmx_device.h"
+
+namespace kmx {
+
+// ---------------------------------------------------------------- K0 generator
+// byte g of the stream = "ACGT"[(splitmix64(seed + g/32) >> 2*(g%32)) & 3]   (BUILD-DEFINED)
+__device__ __forceinline__ u32 expand4(u32 b) {  // 4 two-bit codes -> 4 ASCII letters
+    const u32 sel = (b & 0x03u) | ((b & 0x0Cu) << 6) | ((b & 0x30u) << 12) | ((b & 0xC0u) << 18);
+    return __builtin_amdgcn_perm(0u, 0x54474341u /* 'A','C','G','T' */, sel);
+}
+
+// fast path: first_byte % 16 == 0 and out 16-byte aligned; one 16-byte chunk per thread
+__global__ void __launch_bounds__(256) gen_reads_vec_kernel(u64 seed, u64 first_byte, uint4* __restrict__ out, u64 n_chunks) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += stride) {
+        const u64 pos = first_byte + 16u * c;
+        const u64 z = splitmix64(seed + (pos >> 5));
+        const u32 h = (u32)(z >> (2u * (u32)(pos & 31u)));
+        uint4 v;
+        v.x = expand4(h & 0xFFu);
+        v.y = expand4((h >> 8) & 0xFFu);
+        v.z = expand4((h >> 16) & 0xFFu);
+        v.w = expand4(h >> 24);
+        out[c] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) gen_reads_byte_kernel(u64 seed, u64 first_byte, uint8_t* __restrict__ out, u64 n) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u64 g = first_byte + i;
+        const u64 z = splitmix64(seed + (g >> 5));
+        out[i] = (uint8_t)((0x54474341u >> (8u * (u32)((z >> (2u * (u32)(g & 31u))) & 3u))) & 0xFFu);
+    }
+}
+
+// ------------------------------------------------------- naive_impl element ops
+
+// Kmer::from(&[u8]) (src/naive_impl/kmer.rs:234-251): bytes reversed, w = (w<<2)|code; strict:
+// a non-ACGTacgt byte is a panic in the reference (mod.rs:35) -> record the lowest offending index
+__global__ void __launch_bounds__(256)
+kmers_from_bytes_kernel(const uint8_t* __restrict__ seqs, u64 n, u32 k, u64* __restrict__ words,
+                        unsigned long long* __restrict__ first_bad) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const uint8_t* s = seqs + e * (u64)k;
+        u64 w = 0;
+        for (int i = (int)k - 1; i >= 0; --i) {
+            const u32 b = encode_base(s[i]);
+            if (b >= 4u) atomicMin(first_bad, (unsigned long long)(e * (u64)k + (u64)i));
+            w = (w << 2) | (u64)(b & 3u);
+        }
+        words[e] = w;
+    }
+}
+
+// Kmer::to_reverse_complement (kmer.rs:124-136)
+__global__ void __launch_bounds__(256) revcomp_words_kernel(const u64* __restrict__ in, u64 n, u32 k, u64* __restrict__ out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) out[e] = revcomp_word(in[e], k);
+}
+
+// Kmer::to_canonical / is_canonical (kmer.rs:55-74): canonical <=> data <= rc.data
+__global__ void __launch_bounds__(256)
+canonical_words_kernel(const u64* __restrict__ in, u64 n, u32 k, u64* __restrict__ canon, uint8_t* __restrict__ is_canon) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const u64 w = in[e], rc = revcomp_word(w, k);
+        const bool c = w <= rc;
+        if (canon) canon[e] = c ? w : rc;
+        if (is_canon) is_canon[e] = c ? 1 : 0;
+    }
+}
+
+// hash_one(&LexHasherState::new(hk), kmer) (hash.rs:10-20,60-71) / identity (hash.rs:4-8)
+__global__ void __launch_bounds__(256)
+hash_words_kernel(const u64* __restrict__ in, u64 n, u32 hasher, u32 hk, u64* __restrict__ out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
+        out[e] = hasher == KMX_HASH_LEX ? lex_hash(in[e], hk) : in[e];
+}
+
+// CanonicalKmer::get_word_equivalency (canonical_kmer.rs:152-161)
+__global__ void __launch_bounds__(256)
+match_words_kernel(const u64* __restrict__ fw, const u64* __restrict__ rc, const u64* __restrict__ other, u64 n,
+                   uint8_t* __restrict__ out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const u64 o = other[e];
+        out[e] = fw[e] == o ? KMX_IDENTITY_MATCH : (rc[e] == o ? KMX_TWIN_MATCH : KMX_NO_MATCH);
+    }
+}
+
+// CanonicalKmer::append_base (canonical_kmer.rs:90-94) / prepend_base (:97-101)
+template <bool APPEND>
+__global__ void __launch_bounds__(256)
+ck_shift_kernel(u64* __restrict__ fw, u64* __restrict__ rc, const uint8_t* __restrict__ bases, u64 n, u32 k,
+                uint8_t* __restrict__ dropped) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 mask = mask2k(k);
+    const u32 top = 2u * k - 2u;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const u64 b = bases[e] & 3u, cb = 3u - b;
+        u64 f = fw[e], r = rc[e];
+        u64 d;
+        if (APPEND) {
+            d = f & 3u;                          // kmer.rs:98-102 on fw
+            f = (f >> 2) | (b << top);
+            r = mask & ((r << 2) | cb);          // kmer.rs:91-95 on rc
+        } else {
+            d = (f >> top) & 3u;                 // kmer.rs:91-95 on fw
+            f = mask & ((f << 2) | b);
+            r = (r >> 2) | (cb << top);          // kmer.rs:98-102 on rc
+        }
+        fw[e] = f;
+        rc[e] = r;
+        if (dropped) dropped[e] = (uint8_t)d;
+    }
+}
+
+// ------------------------------------------------- encoding::{Naive,Xor10} ops
+
+// code of a nucleotide under enc: nuc2bits (src/encoding/naive.rs:78-85, :14-16)
+__device__ __forceinline__ u32 nuc2bits(u32 enc, u32 nuc) { return (enc >> (6u - 2u * ((nuc >> 1) & 3u))) & 3u; }
+
+// Encoding::encode (naive.rs:116-124 / xor10.rs:52-60): base idx -> flat bits 2idx..2idx+1
+__global__ void __launch_bounds__(256)
+encode_kmers_kernel(const uint8_t* __restrict__ seqs, u64 n, u32 seq_len, u32 enc, u32 B, u64* __restrict__ words) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const uint8_t* s = seqs + e * (u64)seq_len;
+        for (u32 wd = 0; wd < B; ++wd) {
+            u64 w = 0;
+            const u32 lo = wd * 32u;
+            const u32 hi = seq_len < lo + 32u ? seq_len : lo + 32u;
+            for (u32 i = lo; i < hi; ++i) w |= (u64)nuc2bits(enc, s[i]) << (2u * (i - lo));
+            words[e * B + wd] = w;
+        }
+    }
+}
+
+// b.windows(K).map(|x| Kmer::new(x,&enc)) (benches/simple_benchmark.rs:24-34), uniform reads
+__global__ void __launch_bounds__(256)
+encode_windows_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, u32 enc, u32 B, u64* __restrict__ words) {
+    const u32 nwin = L - k + 1u;
+    const u64 total = n_reads * (u64)nwin;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const u64 r = e / nwin;
+        const u32 p = (u32)(e - r * nwin);
+        const uint8_t* s = bases + r * (u64)L + p;
+        for (u32 wd = 0; wd < B; ++wd) {
+            u64 w = 0;
+            const u32 lo = wd * 32u;
+            const u32 hi = k < lo + 32u ? k : lo + 32u;
+            for (u32 i = lo; i < hi; ++i) w |= (u64)nuc2bits(enc, s[i]) << (2u * (i - lo));
+            words[e * B + wd] = w;
+        }
+    }
+}
+
+// Encoding::rev_comp::<K> (naive.rs:138-154): out base i = complement(in base K-1-i) for i<K,
+// bits >= 2K untouched.  comp_lut: 4 x 2-bit complement table for this enc (host-computed from
+// naive.rs:98-109), packed in one byte.
+__global__ void __launch_bounds__(256)
+encoding_rev_comp_kernel(const u64* __restrict__ in, u64 n, u32 K, u32 comp_lut, u32 B, u64* __restrict__ out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const u64* a = in + e * B;
+        u64 res[4];
+        for (u32 wd = 0; wd < B; ++wd) res[wd] = a[wd];
+        for (u32 i = 0; i < K; ++i) {
+            const u32 j = K - 1u - i;
+            const u32 c = (u32)(a[j >> 5] >> (2u * (j & 31u))) & 3u;
+            const u64 cc = (comp_lut >> (2u * c)) & 3u;
+            const u32 sh = 2u * (i & 31u);
+            res[i >> 5] = (res[i >> 5] & ~(3ull << sh)) | (cc << sh);
+        }
+        for (u32 wd = 0; wd < B; ++wd) out[e * B + wd] = res[wd];
+    }
+}
+
+// Encoding::decode (naive.rs:126-136): ALL 32*B slots; nuc_lut = 4 letters indexed by code
+__global__ void __launch_bounds__(256)
+encoding_decode_kernel(const u64* __restrict__ in, u64 n, u32 nuc_lut, u32 B, uint8_t* __restrict__ seqs) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        for (u32 wd = 0; wd < B; ++wd) {
+            u64 w = in[e * B + wd];
+            uint8_t* o = seqs + (e * B + wd) * 32u;
+            for (u32 i = 0; i < 32u; ++i) {
+                o[i] = (uint8_t)((nuc_lut >> (8u * (u32)(w & 3u))) & 0xFFu);
+                w >>= 2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+
+static inline unsigned egrid(u64 n, int n_cu) {
+    u64 g = (n + 255u) / 256u;
+    const u64 cap = (u64)n_cu * 16u;
+    if (g > cap) g = cap;
+    return (unsigned)(g ? g : 1);
+}
+
+hipError_t launch_gen_reads(u64 seed, u64 first_byte, uint8_t* out, u64 nbytes, int n_cu, hipStream_t st) {
+    if (nbytes == 0) return hipSuccess;
+    if (((first_byte & 15u) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
+        const u64 n_chunks = nbytes >> 4;
+        if (n_chunks)
+            hipLaunchKernelGGL(gen_reads_vec_kernel, dim3(egrid(n_chunks, n_cu)), dim3(256), 0, st, seed, first_byte,
+                               reinterpret_cast<uint4*>(out), n_chunks);
+        const u64 tail = nbytes & 15u;
+        if (tail)
+            hipLaunchKernelGGL(gen_reads_byte_kernel, dim3(1), dim3(64), 0, st, seed, first_byte + (n_chunks << 4),
+                               out + (n_chunks << 4), tail);
+    } else {
+        hipLaunchKernelGGL(gen_reads_byte_kernel, dim3(egrid(nbytes, n_cu)), dim3(256), 0, st, seed, first_byte, out, nbytes);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_kmers_from_bytes(const uint8_t* seqs, u64 n, u32 k, u64* words, unsigned long long* first_bad, int n_cu,
+                                   hipStream_t st) {
+    hipLaunchKernelGGL(kmers_from_bytes_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, seqs, n, k, words, first_bad);
+    return hipGetLastError();
+}
+hipError_t launch_revcomp_words(const u64* in, u64 n, u32 k, u64* out, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(revcomp_words_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, in, n, k, out);
+    return hipGetLastError();
+}
+hipError_t launch_canonical_words(const u64* in, u64 n, u32 k, u64* canon, uint8_t* is_canon, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(canonical_words_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, in, n, k, canon, is_canon);
+    return hipGetLastError();
+}
+hipError_t launch_hash_words(const u64* in, u64 n, u32 hasher, u32 hk, u64* out, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(hash_words_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, in, n, hasher, hk, out);
+    return hipGetLastError();
+}
+hipError_t launch_match_words(const u64* fw, const u64* rc, const u64* other, u64 n, uint8_t* out, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(match_words_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, fw, rc, other, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_ck_shift(bool append, u64* fw, u64* rc, const uint8_t* bases, u64 n, u32 k, uint8_t* dropped, int n_cu,
+                           hipStream_t st) {
+    if (append)
+        hipLaunchKernelGGL(ck_shift_kernel<true>, dim3(egrid(n, n_cu)), dim3(256), 0, st, fw, rc, bases, n, k, dropped);
+    else
+        hipLaunchKernelGGL(ck_shift_kernel<false>, dim3(egrid(n, n_cu)), dim3(256), 0, st, fw, rc, bases, n, k, dropped);
+    return hipGetLastError();
+}
+hipError_t launch_encode_kmers(const uint8_t* seqs, u64 n, u32 seq_len, u32 enc, u32 B, u64* words, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(encode_kmers_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, seqs, n, seq_len, enc, B, words);
+    return hipGetLastError();
+}
+hipError_t launch_encode_windows(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 enc, u32 B, u64* words, int n_cu,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(encode_windows_kernel, dim3(egrid(n_reads * (u64)(L - k + 1u), n_cu)), dim3(256), 0, st, bases,
+                       n_reads, L, k, enc, B, words);
+    return hipGetLastError();
+}
+hipError_t launch_encoding_rev_comp(const u64* in, u64 n, u32 K, u32 comp_lut, u32 B, u64* out, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(encoding_rev_comp_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, in, n, K, comp_lut, B, out);
+    return hipGetLastError();
+}
+hipError_t launch_encoding_decode(const u64* in, u64 n, u32 nuc_lut, u32 B, uint8_t* seqs, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(encoding_decode_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, in, n, nuc_lut, B, seqs);
+    return hipGetLastError();
+}
+
+}  // namespace kmx

@@ -1,0 +1,420 @@
+"""GPU parity tests: the HIP path (through the libkmx C ABI) against the CPU oracle on the
+same inputs, bit-exact (all arithmetic is unsigned integer).  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M64 = 2**64 - 1
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from kmers_amd.api import Context
+
+    c = Context()
+    yield c
+    c.close()
+
+
+def _dirty(rng, n, p_bad=0.02):
+    alpha = np.frombuffer(b"ACGTacgt", np.uint8)
+    a = alpha[rng.integers(0, 8, n)]
+    bad = rng.random(n) < p_bad
+    a = a.copy()
+    a[bad] = rng.integers(0, 256, int(bad.sum()), dtype=np.uint8)
+    return a
+
+
+def _cmp_summary(g, o, want_hash, want_sumfw):
+    assert g.n_valid == o.n_valid
+    assert g.sum_canon == o.sum_canon
+    assert g.xor_hash == (o.xor_hash if want_hash else 0)
+    assert g.sum_fw == (o.sum_fw if want_sumfw else 0)
+
+
+# ------------------------------------------------------------------ generator
+
+@pytest.mark.parametrize("first,n", [(0, 1 << 16), (16, 4096 + 5), (7, 1000), (150 * 64, 150 * 1000), (31, 1)])
+def test_gen_reads_matches_oracle(ctx, orc, first, n):
+    from kmers_amd.api import SEED_DEFAULT
+
+    g = ctx.gen_reads(n, SEED_DEFAULT, first).cpu().numpy()
+    assert (g == orc.gen_reads(SEED_DEFAULT, first, n)).all()
+
+
+# --------------------------------------------------------- reduce, clean input
+
+@pytest.mark.parametrize("k", [1, 2, 5, 15, 16, 17, 18, 21, 27, 31])
+@pytest.mark.parametrize("L,n_reads", [(150, 10_000), (150, 63), (150, 64), (150, 257)])
+def test_reduce_uniform_clean(ctx, orc, k, L, n_reads):
+    from kmers_amd import _lib
+
+    bases = ctx.gen_reads(n_reads * L, first_byte=L * 12345)
+    host = bases.cpu().numpy()
+    o = orc.canonical_reduce(host, n_reads, L, k, hasher_k=k)
+    g = ctx.canonical_reduce(bases, n_reads, L, k)
+    _cmp_summary(g, o, False, False)
+    g = ctx.canonical_reduce(bases, n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _cmp_summary(g, o, True, True)
+    g = ctx.canonical_reduce(bases, n_reads, L, k, _lib.HASH_LEX, k, 0)
+    _cmp_summary(g, o, True, False)
+    assert o.n_valid == n_reads * (L - k + 1)
+
+
+@pytest.mark.parametrize("L", [31, 32, 33, 47, 48, 100, 101, 112, 149, 151, 159, 160, 161, 176, 250, 255, 256, 257, 300])
+@pytest.mark.parametrize("k", [11, 31])
+def test_reduce_uniform_lengths(ctx, orc, L, k):
+    from kmers_amd import _lib
+
+    n_reads = 64 * 5 + 17
+    bases = ctx.gen_reads(n_reads * L, first_byte=99)
+    host = bases.cpu().numpy()
+    o = orc.canonical_reduce(host, n_reads, L, k, hasher_k=k)
+    g = ctx.canonical_reduce(bases, n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _cmp_summary(g, o, True, True)
+
+
+def test_reduce_config1_shape_matches_compute_naive(ctx, orc):
+    """BASELINE config 1: 10k x 150 bp, k=31; sum_fw == benches' compute_naive per read."""
+    from kmers_amd import _lib
+
+    L, n, k = 150, 10_000, 31
+    bases = ctx.gen_reads(n * L)
+    host = bases.cpu().numpy()
+    g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    tot = 0
+    for r in range(0, n, 997):
+        tot += 1
+        assert orc.compute_naive(host[r * L:(r + 1) * L], k) == orc.canonical_reduce(host[r * L:(r + 1) * L], 1, L, k).sum_fw
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+    _cmp_summary(g, o, True, True)
+    assert g.n_valid == n * 120
+
+
+def test_reduce_hasher_k_differs_and_identity(ctx, orc):
+    from kmers_amd import _lib
+
+    L, n, k = 150, 1000, 21
+    bases = ctx.gen_reads(n * L, first_byte=5)
+    host = bases.cpu().numpy()
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=25)
+    g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, 25, 0)
+    _cmp_summary(g, o, True, False)
+    # identity hasher: xor of the canonical words themselves
+    _, _, canon, flags = orc.canonical_windows(host, n, L, k)
+    g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_IDENTITY, 0, 0)
+    assert g.xor_hash == int(np.bitwise_xor.reduce(canon[flags & 1 == 1]))
+
+
+def test_reduce_misaligned_base_pointer(ctx, orc):
+    L, n, k = 150, 500, 31
+    buf = ctx.gen_reads(n * L + 16)
+    view = buf[3:3 + n * L]  # 3-byte offset: not 16-byte aligned
+    host = view.cpu().numpy()
+    o = orc.canonical_reduce(host, n, L, k)
+    r = ctx._reads(None, 0, 0, None)
+    out = ctx.empty(4, __import__("torch").int64)
+    from kmers_amd import _lib
+
+    rd = _lib.Reads(C.c_void_p(view.data_ptr()), n, L, None)
+    ctx._ck(ctx.lib.kmx_canonical_reduce(ctx._h, C.byref(rd), k, 0, 0, 0, C.c_void_p(out.data_ptr())))
+    v = out.cpu().numpy().view(np.uint64)
+    assert (int(v[0]), int(v[1])) == (o.n_valid, o.sum_canon)
+    del r
+
+
+# --------------------------------------------------------- reduce, dirty input
+
+@pytest.mark.parametrize("k", [1, 7, 16, 17, 21, 31])
+@pytest.mark.parametrize("p_bad", [0.0005, 0.02, 0.5])
+def test_reduce_uniform_dirty(ctx, orc, k, p_bad):
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(1000 + k)
+    L, n = 150, 64 * 40 + 9
+    host = _dirty(rng, n * L, p_bad)
+    bases = ctx.to_device(host)
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+    g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _cmp_summary(g, o, True, True)
+
+
+def test_reduce_every_byte_value_once(ctx, orc):
+    """one bad byte at a time, every one of the 256 byte values, placed inside an otherwise clean tile"""
+    L, n, k = 150, 64, 31
+    clean = orc.gen_reads(1, 0, n * L)
+    for b in range(256):
+        host = clean.copy()
+        host[(b * 37) % (n * L)] = b
+        g = ctx.canonical_reduce(ctx.to_device(host), n, L, k)
+        o = orc.canonical_reduce(host, n, L, k)
+        assert (g.n_valid, g.sum_canon) == (o.n_valid, o.sum_canon), b
+
+
+def test_reduce_edge_shapes(ctx, orc):
+    from kmers_amd import _lib
+
+    k = 31
+    # empty batch
+    g = ctx.canonical_reduce(ctx.empty(0, __import__("torch").uint8), 0, 150, k)
+    assert (g.n_valid, g.sum_canon) == (0, 0)
+    # reads shorter than k: iterator exhausted immediately (canonical_kmer_iterator.rs:50,69)
+    bases = ctx.gen_reads(100 * 20)
+    g = ctx.canonical_reduce(bases, 100, 20, k)
+    assert g.n_valid == 0
+    # L == k
+    bases = ctx.gen_reads(77 * 31)
+    host = bases.cpu().numpy()
+    g = ctx.canonical_reduce(bases, 77, 31, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _cmp_summary(g, orc.canonical_reduce(host, 77, 31, k, hasher_k=k), True, True)
+    # homopolymers / palindromes: fw == rc ties
+    host = np.frombuffer((b"A" * 150 + b"T" * 150 + b"AT" * 75 + b"ACGT" * 37 + b"AC") * 32, np.uint8)
+    n = host.size // 150
+    g = ctx.canonical_reduce(ctx.to_device(host), n, 150, 30)
+    o = orc.canonical_reduce(host, n, 150, 30)
+    assert (g.n_valid, g.sum_canon) == (o.n_valid, o.sum_canon)
+
+
+def test_k_range_errors(ctx):
+    from kmers_amd import _lib
+
+    bases = ctx.gen_reads(150 * 64)
+    for k in (0, 32, 33):
+        with pytest.raises(_lib.KmxError) as e:
+            ctx.canonical_reduce(bases, 64, 150, k)
+        assert e.value.status == _lib.E_K_RANGE
+    with pytest.raises(_lib.KmxError) as e:
+        ctx.canonical_reduce2(bases, 64, 150, 32)
+    assert e.value.status == _lib.E_K_RANGE
+
+
+def test_oracle_shows_the_k32_quirk(orc):
+    """why k=32 is rejected: MASK_TABLE[32]==0 (kmer.rs:617) zeroes rc in the reference's own rolling"""
+    host = orc.gen_reads(3, 0, 64)
+    fw, rc, canon, flags = orc.canonical_windows(host, 1, 64, 32)
+    assert (rc == 0).all() and (canon == 0).all() and flags.all()
+
+
+# --------------------------------------------------------------- ragged reads
+
+def test_reduce_and_windows_ragged(ctx, orc):
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(7)
+    k = 21
+    lens = rng.choice([0, 1, 20, 21, 22, 40, 150, 151, 300], size=500)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]), 0.01)
+    bases = ctx.to_device(host)
+    d_off = ctx.to_device(offsets)
+    o = orc.canonical_reduce(host, len(lens), 0, k, hasher_k=k, offsets=offsets)
+    g = ctx.canonical_reduce(bases, len(lens), 0, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=d_off)
+    _cmp_summary(g, o, True, True)
+    fw, rc, canon, flags = orc.canonical_windows(host, len(lens), 0, k, offsets=offsets)
+    outs = ctx.canonical_windows(bases, len(lens), 0, k, offsets=d_off, host_offsets=offsets)
+    assert (outs["fw"].cpu().numpy().view(np.uint64) == fw).all()
+    assert (outs["rc"].cpu().numpy().view(np.uint64) == rc).all()
+    assert (outs["canon"].cpu().numpy().view(np.uint64) == canon).all()
+    assert (outs["flags"].cpu().numpy() == flags).all()
+
+
+# ---------------------------------------------------------------- materialise
+
+@pytest.mark.parametrize("k", [1, 16, 21, 31])
+@pytest.mark.parametrize("p_bad", [0.0, 0.03])
+def test_windows_uniform(ctx, orc, k, p_bad):
+    rng = np.random.default_rng(k)
+    L, n = 150, 300
+    host = _dirty(rng, n * L, p_bad)
+    bases = ctx.to_device(host)
+    fw, rc, canon, flags = orc.canonical_windows(host, n, L, k)
+    outs = ctx.canonical_windows(bases, n, L, k)
+    assert (outs["flags"].cpu().numpy() == flags).all()
+    assert (outs["fw"].cpu().numpy().view(np.uint64) == fw).all()
+    assert (outs["rc"].cpu().numpy().view(np.uint64) == rc).all()
+    assert (outs["canon"].cpu().numpy().view(np.uint64) == canon).all()
+    only = ctx.canonical_windows(bases, n, L, k, want=("canon",))
+    assert (only["canon"].cpu().numpy().view(np.uint64) == canon).all()
+
+
+def test_reference_iterator_kats_on_gpu(ctx, orc, kats):
+    """canonical_kmer_iterator.rs:123-206 through the HIP path: the iterator state after init/inc/inc_by
+    is the (fw, rc) of the n-th valid slot."""
+    k = kats["iterator"]["k"]
+    for case in kats["iterator"]["cases"]:
+        r = kats["read_R"].encode()
+        if case["insert_N_at"] is not None:
+            i = case["insert_N_at"]
+            r = r[:i] + b"N" + r[i:]
+        outs = ctx.canonical_windows(ctx.to_device(r), 1, len(r), k)
+        flags = outs["flags"].cpu().numpy()
+        valid_pos = np.nonzero(flags & 1)[0]
+        pos = int(valid_pos[case["inc_by"]])
+        assert pos == case["expect_pos"]
+        s = case["expect_window_start"]
+        fk = orc.ck_from_bytes(r[s:s + k])
+        assert int(outs["fw"].cpu().numpy().view(np.uint64)[pos]) == fk.fw.data
+        assert int(outs["rc"].cpu().numpy().view(np.uint64)[pos]) == fk.rc.data
+    d = kats["derived_R_k31"]
+    r = kats["read_R"].encode()
+    g = ctx.canonical_reduce(ctx.to_device(r), 1, len(r), k, 1, k, 1)
+    assert g.n_valid == d["n_windows"] and g.sum_canon == int(d["sum_canon"], 16)
+
+
+# ------------------------------------------------------------ [u64;2] k-mers
+
+@pytest.mark.parametrize("k", [33, 47, 63, 64])
+def test_reduce2_windows2(ctx, orc, k):
+    rng = np.random.default_rng(k)
+    L, n = 150, 200
+    host = _dirty(rng, n * L, 0.004)
+    bases = ctx.to_device(host)
+    o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+    g = ctx.canonical_reduce2(bases, n, L, k, with_hash=True)
+    assert tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
+    fw, rc, canon, flags = orc.canonical_windows2(host, n, L, k)
+    outs = ctx.canonical_windows2(bases, n, L, k)
+    assert (outs["flags"].cpu().numpy() == flags).all()
+    assert (outs["fw"].cpu().numpy().view(np.uint64).reshape(-1, 2) == fw).all()
+    assert (outs["rc"].cpu().numpy().view(np.uint64).reshape(-1, 2) == rc).all()
+    assert (outs["canon"].cpu().numpy().view(np.uint64).reshape(-1, 2) == canon).all()
+
+
+# ------------------------------------------------------------------ histogram
+
+@pytest.mark.parametrize("hasher,hk", [(1, 31), (2, 0), (1, 20)])
+def test_histogram(ctx, orc, hasher, hk):
+    rng = np.random.default_rng(3)
+    L, n, k, b = 150, 700, 31, 12
+    host = _dirty(rng, n * L, 0.002)
+    bases = ctx.to_device(host)
+    o = orc.histogram(host, n, L, k, hk if hasher == 1 else 0, b)
+    g = ctx.histogram(bases, n, L, k, hasher, hk, b).cpu().numpy().view(np.uint64)
+    assert (g == o).all()
+    # accumulates: second call doubles
+    c = ctx.histogram(bases, n, L, k, hasher, hk, b)
+    c = ctx.histogram(bases, n, L, k, hasher, hk, b, counts=c)
+    assert (c.cpu().numpy().view(np.uint64) == 2 * o).all()
+
+
+# ---------------------------------------------------------------- elementwise
+
+def test_kmers_from_bytes_and_word_ops(ctx, orc, kats):
+    from kmers_amd import _lib
+
+    L = orc.lib()
+    rng = random.Random(11)
+    for k in (1, 3, 14, 31, 32):
+        seqs = ["".join(rng.choice("ACGTacgt") for _ in range(k)) for _ in range(300)]
+        blob = "".join(seqs).encode()
+        words = ctx.kmers_from_bytes(ctx.to_device(blob), len(seqs), k)
+        w = words.cpu().numpy().view(np.uint64)
+        exp = np.array([orc.kmer_from_bytes(s.encode()).data for s in seqs], np.uint64)
+        assert (w == exp).all()
+        rc = ctx.revcomp_words(words, k).cpu().numpy().view(np.uint64)
+        assert (rc == np.array([L.kmo_revcomp_word(int(x), k) for x in exp], np.uint64)).all()
+        canon, isc = ctx.canonical_words(words, k)
+        for x, c, i in zip(exp, canon.cpu().numpy().view(np.uint64), isc.cpu().numpy()):
+            km = orc.Kmer(k, int(x))
+            assert int(c) == L.kmo_kmer_to_canonical(km).data
+            assert bool(i) == bool(L.kmo_kmer_is_canonical(km))
+        h = ctx.hash_words(words, _lib.HASH_LEX, k).cpu().numpy().view(np.uint64)
+        assert (h == np.array([L.kmo_lex_hash_u64(int(x), k) for x in exp], np.uint64)).all()
+    # strict semantics: Kmer::from panics on N (mod.rs:35) -> error + first offending index
+    blob = b"ACGTACGTACNTACGT"
+    with pytest.raises(_lib.KmxError) as e:
+        ctx.kmers_from_bytes(ctx.to_device(blob), 4, 4)
+    assert e.value.status == _lib.E_INVALID_BASE and e.value.first_bad == 10
+    with pytest.raises(_lib.KmxError) as e:
+        ctx.kmers_from_bytes(ctx.to_device(b"A" * 66), 2, 33)
+    assert e.value.status == _lib.E_TOO_LONG
+    # reference KATs (kmer.rs:386-424, hash.rs:83-104) through the GPU
+    for s, r in kats["reverse_complement"]["cases"]:
+        w = ctx.kmers_from_bytes(ctx.to_device(s.encode()), 1, len(s))
+        assert int(ctx.revcomp_words(w, len(s)).cpu().numpy().view(np.uint64)[0]) == orc.kmer_from_bytes(r.encode()).data
+    for s, v in kats["lex_hasher"]["cases"]:
+        w = ctx.kmers_from_bytes(ctx.to_device(s.encode()), 1, len(s))
+        assert int(ctx.hash_words(w, _lib.HASH_LEX, kats["lex_hasher"]["k"]).cpu().numpy().view(np.uint64)[0]) == v
+
+
+def test_ck_shift_and_match(ctx, orc):
+    L = orc.lib()
+    rng = random.Random(5)
+    k = 31
+    n = 500
+    words = np.array([rng.getrandbits(62) for _ in range(n)], np.uint64)
+    cks = [L.kmo_ck_from_u64(int(w), k) for w in words]
+    fw = ctx.to_device(np.array([c.fw.data for c in cks], np.uint64))
+    rc = ctx.to_device(np.array([c.rc.data for c in cks], np.uint64))
+    bases = np.array([rng.randrange(4) for _ in range(n)], np.uint8)
+    d_b = ctx.to_device(bases)
+    for append in (True, False):
+        f2, r2 = fw.clone(), rc.clone()
+        dropped = ctx.ck_shift(f2, r2, d_b, k, append=append).cpu().numpy()
+        for i in range(n):
+            c = L.kmo_ck_from_u64(int(words[i]), k)
+            d = (L.kmo_ck_append_base if append else L.kmo_ck_prepend_base)(C.byref(c), int(bases[i]))
+            assert d == dropped[i]
+            assert int(f2[i].item()) & M64 == c.fw.data and int(r2[i].item()) & M64 == c.rc.data
+    other = np.array([cks[i].fw.data if i % 3 == 0 else (cks[i].rc.data if i % 3 == 1 else rng.getrandbits(62)) for i in range(n)], np.uint64)
+    m = ctx.match_words(fw, rc, ctx.to_device(other)).cpu().numpy()
+    for i in range(n):
+        assert m[i] == L.kmo_ck_get_word_equivalency(C.byref(cks[i]), int(other[i]))
+
+
+def test_generic_encodings(ctx, orc, kats):
+    encs = kats["naive_encodings"]["enc_bytes"]
+    rng = random.Random(2)
+    # reference KATs (naive.rs:297-445) for P=u64 through the GPU, then all 24 encodings vs the oracle
+    c = [x for x in kats["naive_encode_kats"]["cases"] if x["name"] == "k45pu64"][0]
+    w = ctx.encode_kmers(ctx.to_device(c["seq"].encode()), 1, c["K"], encs["ACGT"], 2)
+    assert [int(x) for x in w.cpu().numpy().view(np.uint64)] == [int(x) for x in c["words"]]
+    rcw = ctx.encoding_rev_comp(w, c["K"], encs["ACGT"], 2)
+    assert ctx.encoding_decode(rcw, encs["ACGT"], 2).cpu().numpy().tobytes() == c["decode_rev_comp"].encode()
+    assert ctx.encoding_decode(w, encs["ACGT"], 2).cpu().numpy().tobytes() == c["decode"].encode()
+    for name, enc in encs.items():
+        for K, B in ((2, 1), (15, 1), (31, 1), (32, 1), (33, 2), (45, 2), (63, 2), (64, 2), (100, 4)):
+            n = 20
+            seqs = bytes(rng.choice(b"ACGTacgtNnUu") for _ in range(n * K))
+            w = ctx.encode_kmers(ctx.to_device(seqs), n, K, enc, B)
+            wn = w.cpu().numpy().view(np.uint64).reshape(n, B)
+            rcw = ctx.encoding_rev_comp(w, K, enc, B).cpu().numpy().view(np.uint64).reshape(n, B)
+            dec = ctx.encoding_decode(w, enc, B).cpu().numpy().reshape(n, 32 * B)
+            for i in range(n):
+                arr = orc.naive_encode(enc, seqs[i * K:(i + 1) * K], 8 * B)
+                assert orc.words(arr, 64) == [int(x) for x in wn[i]], (name, K)
+                assert orc.words(orc.naive_rev_comp(enc, K, arr), 64) == [int(x) for x in rcw[i]], (name, K)
+                assert orc.naive_decode(enc, arr) == dec[i].tobytes()
+    # Xor10 == Naive::ACTG (xor10.rs:17-22 vs naive.rs:50)
+    seq = b"TAAGGATTCTAATCATAAGGATTCTAATCATAAGGATTCTAATCA"
+    w = ctx.encode_kmers(ctx.to_device(seq), 1, 45, encs["ACTG"], 2)
+    assert [int(x) for x in w.cpu().numpy().view(np.uint64)] == orc.words(orc.xor10_encode(seq, 16), 64)
+    # encode_windows == the benches' b.windows(K).map(Kmer::new) shape
+    L, n, k = 80, 30, 31
+    host = orc.gen_reads(9, 0, L * n)
+    ww = ctx.encode_windows(ctx.to_device(host), n, L, k, encs["ACGT"], 1).cpu().numpy().view(np.uint64)
+    fw, _, _, _ = orc.canonical_windows(host, n, L, k)
+    assert (ww == fw).all()  # Naive::ACGT encode == naive_impl::Kmer::from on valid input
+
+
+def test_encoding_errors(ctx):
+    from kmers_amd import _lib
+
+    seqs = ctx.to_device(b"A" * 200)
+    with pytest.raises(_lib.KmxError) as e:
+        ctx.encode_kmers(seqs, 1, 33, 0x1E, 1)
+    assert e.value.status == _lib.E_TOO_LONG
+    with pytest.raises(_lib.KmxError) as e:
+        ctx.encode_kmers(seqs, 1, 10, 0x00, 1)  # not one of the 24 discriminants
+    assert e.value.status == _lib.E_ARG
+    w = ctx.encode_kmers(seqs, 1, 10, 0x1E, 1)
+    with pytest.raises(_lib.KmxError) as e:
+        ctx.encoding_rev_comp(w, 1, 0x1E, 1)  # K=1 underflows in the reference
+    assert e.value.status == _lib.E_K_RANGE
