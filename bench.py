@@ -25,6 +25,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured-copy ceiling
 
 
+def usable_cores() -> int:
+    """host threads this process may really use: affinity mask capped by the cgroup cpu quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(host_sample, n_reads, L, k, seconds_target=12.0):
     """Time the CPU oracle (plain-C port of the reference's naive_impl streaming iterator,
     canonical_kmer_iterator.rs:42-116) on this box's host cores: 1 thread and all threads."""
@@ -32,7 +45,7 @@ def cpu_baseline(host_sample, n_reads, L, k, seconds_target=12.0):
     from oracle import oracle
 
     lib = oracle.lib(native=True)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
 
     def run(nthreads, reads_each):
         outs = [None] * nthreads
@@ -50,11 +63,13 @@ def cpu_baseline(host_sample, n_reads, L, k, seconds_target=12.0):
         dt = time.perf_counter() - t0
         return sum(o.n_valid for o in outs) / dt, dt
 
-    # calibrate on a small slice, then size the sample for ~seconds_target/2 per leg
-    rate1, _ = run(1, min(n_reads, 50_000))
-    reads_1t = int(min(n_reads, max(50_000, rate1 * (seconds_target / 2) / (L - k + 1))))
+    # calibrate each leg on a small slice, then size its sample for ~seconds_target/2 of wall time
+    per = L - k + 1
+    rate1, _ = run(1, min(n_reads, 20_000))
+    reads_1t = int(min(n_reads, max(20_000, rate1 * (seconds_target / 2) / per)))
     rate1, dt1 = run(1, reads_1t)
-    reads_mt = int(min(n_reads, max(50_000, rate1 * (seconds_target / 2) / (L - k + 1))))
+    rate_mt, _ = run(cores, min(n_reads, 20_000))
+    reads_mt = int(min(n_reads, max(20_000, rate_mt / cores * (seconds_target / 2) / per)))
     rate_mt, dt_mt = run(cores, reads_mt)
     model = "unknown"
     try:

@@ -15,6 +15,9 @@ typedef uint64_t u64;
 // kmx_scan.hip
 hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                kmx_summary* out, int n_cu, hipStream_t stream, bool* handled);
+// kmx_bitslice.hip
+hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
+                                 kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 // kmx_generic.hip
 hipError_t launch_reduce_generic(const kmx_reads* r, u32 k, u32 hasher, u32 hk, u32 want_sumfw, kmx_summary* out,
                                  int n_cu, hipStream_t st);
@@ -255,6 +258,10 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
     const bool lex_same_k = hasher == KMX_HASH_LEX && hasher_k == k;
     if (!reads->d_offsets && (hasher == KMX_HASH_NONE || lex_same_k)) {
         bool handled = false;
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 2, 0, 8, ctx->stream));  // tile queue head
+        KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
+                                                d_out, ctx->d_scratch + 2, ctx->n_cu, ctx->stream, &handled));
+        if (handled) return KMX_OK;
         KMX_HIP(ctx, kmx::launch_scan_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
                                               d_out, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;

@@ -1,0 +1,439 @@
+// kmx_bitslice.hip -- K1b: bit-sliced canonical k-mer scan (the headline kernel for k=31 / k=21).
+//
+// Why: on gfx950 only the simplest VALU ops (v_and/or/xor/not, v_lshrrev, v_add_u32, v_bitop3_b32)
+// issue at 32 lanes/clk; v_alignbit, v_perm, v_cmp*, v_cndmask, carry adds, 64-bit ops and v_bcnt
+// run at half that (measured, tools/ubench2.hip, profiles/r01_valu_rates.txt).  A word-per-k-mer
+// window costs >= 16 full-rate issue slots, which caps the scan near 45 % of the HBM roofline.
+// Bit-slicing ACROSS 32 READS turns the per-window work into ~7 slots per k-mer:
+//
+//   * a register holds ONE bit (base i, bit b) of 32 different reads ("plane");
+//   * fw < rc is a ripple of v_bitop3_b32 over the top ceil(k/2) base pairs only, because rc is the
+//     complemented mirror of fw: fw base k-1-j meets rc base = ~(fw base j)   (kmer.rs:124-136);
+//   * the wrapping sum of canonical words needs no select and no 64-bit add: with m = (fw < rc),
+//       sum(canon) = sum_{t,b} 2^(2t+b) * (C[t][b] + C[k-1-t][b]) - popcount(m)*MASK[k] + sum(all rc)
+//     where C[t][b] += popcount(m & plane(t,b)) (v_and + v_bcnt_u32_b32 with accumulate) and
+//     sum(all rc), sum(all fw) and the LexHasher xor-fold follow from per-plane popcount totals.
+//
+// Data flow per 64-read tile (one wave, no block barrier):
+//   A. coalesced 16 B/lane global loads -> encode16 (v_dot4_u32_u8 pack, v_perm_b32 validate) -> LDS
+//   B. lane r pulls read r's packed words back (ds_read_b32) and realigns them (v_alignbit_b32)
+//   C. 32x32 bit transposes across lanes, 5 x (ds_swizzle xor-d, rotate, bit-select) per 16 bases:
+//      lane p of each half-wave ends with plane p -> LDS plane array of the half's 32 reads
+//   D. the 64 lanes split the 2*(L-k+1) (set, window) items; each item = 2k plane loads
+//      (ds_read_b64), a k-step v_bitop3 ripple and 2k masked popcounts.
+// A tile with any non-ACGTacgt byte, and the final partial tile, take roll_read (exact iterator
+// semantics, canonical_kmer_iterator.rs:42-70) exactly like the word-domain kernel.
+#include "kmx_device.h"
+
+namespace kmx {
+
+// per-plane weights of sum over all windows of fw / rc (closed form; evaluated once per wave)
+__device__ __forceinline__ void plane_weights(u32 i, u32 L, u32 k, u64& wf, u64& wr) {
+    wf = 0;
+    wr = 0;
+    if (i >= L) return;
+    const int o_lo = (int)i - (int)k + 1 > 0 ? (int)i - (int)k + 1 : 0;
+    const int o_hi = (int)i < (int)(L - k) ? (int)i : (int)(L - k);
+    if (o_lo > o_hi) return;
+    // wf = sum_{o} 4^(i-o) ; wr = sum_{o} 4^(k-1-(i-o))
+    const u32 e_lo = i - (u32)o_hi, e_hi = i - (u32)o_lo;  // exponents of 4, e_hi <= k-1
+    wf = ((1ull << (2u * (e_hi + 1u))) - (1ull << (2u * e_lo))) / 3ull;
+    const u32 f_lo = k - 1u - e_hi, f_hi = k - 1u - e_lo;
+    wr = ((1ull << (2u * (f_hi + 1u))) - (1ull << (2u * f_lo))) / 3ull;
+}
+
+// one step of the fw<rc ripple: lt' = (~a & ~q) | ((a ^ q) & lt) as a single v_bitop3_b32
+// (truth table with S0=lt=0xF0, S1=a=0xCC, S2=q=0xAA: 0x11 | (0x66 & 0xF0) = 0x71)
+__device__ __forceinline__ u32 ripple(u32 lt, u32 a, u32 q) { return __builtin_amdgcn_bitop3_b32(lt, a, q, 0x71); }
+
+// d += popcount(x) as ONE v_bcnt_u32_b32 (hipcc otherwise splits it into v_bcnt(x,0) + v_add3_u32)
+__device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x)); }
+
+template <int K, int NW>
+__global__ void __launch_bounds__(256, 3)
+scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
+                      kmx_summary* __restrict__ out, unsigned long long* __restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    // Plane storage of one 32-read set: base beta (2 planes = one u64) lives at u64 index
+    // (beta & 3) * S2 + (beta >> 2).  In phase D lane g reads bases 4g+i: consecutive lanes then touch
+    // consecutive u64s (conflict-free ds_read_b64) instead of a 32-byte stride (4-way bank conflicts,
+    // measured SQ_LDS_BANK_CONFLICT = 65 % of LDS cycles with the linear layout).
+    constexpr int S2 = 4 * NW + 1;       // u64 row pitch (odd, so the 4 rows start on different banks)
+    constexpr int PLANES = 8 * S2;       // dwords per set (>= 32*NW)
+    const u32 lane = threadIdx.x & 63u;
+    const u32 half = lane >> 5, p = lane & 31u;
+    const u32 wib = threadIdx.x >> 6;
+    const u32 chunks = 4u * L;
+    const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;          // packed region (as in kmx_scan.hip)
+    u32* P = lds + wib * (ldsw + 4u * PLANES);
+    u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
+
+    const u64 n_full = n_reads >> 6;
+    const u64 n_waves = (u64)gridDim.x * 4u;
+    const u64 wave_id = (u64)blockIdx.x * 4u + wib;
+
+    const u32 posF = lane * L + 16u;
+    const u32 qF = posF >> 4, aF = 2u * (posF & 15u);
+    const u32 W = L - (u32)K + 1u;      // windows per read
+    const u32 NG = (W + 3u) >> 2;       // groups of 4 windows per read
+    const u32 rounds = (2u * NG + 63u) >> 6;   // (set, group) items per tile, 64 per round
+    constexpr u64 MASKK = (K >= 32) ? ~0ull : ((1ull << (2 * K)) - 1ull);
+
+    // transpose stage constants: rotate amount and keep-mask per butterfly distance
+    u32 tr_sh[5], tr_keep[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const u32 d = 16u >> s;
+        u32 md = 0xFFFFFFFFu / ((1u << d) + 1u);             // bits whose index has bit d clear: 0x0000FFFF,0x00FF00FF,...
+        tr_sh[s] = (p & d) ? d : 32u - d;
+        tr_keep[s] = (p & d) ? ~md : md;
+    }
+
+    // D[2t+b], t <= (K-1)/2: sum of popcount(m & plane(t,b)) + popcount(m & plane(K-1-t,b)) -- the two
+    // always enter the result as a sum (weights are symmetric under t <-> K-1-t), so they share a counter
+    constexpr int NT = (K + 1) / 2;     // distinct t classes (the middle one of odd K pairs with itself)
+    u32 D[2 * NT];
+#pragma unroll
+    for (int q = 0; q < 2 * NT; ++q) D[q] = 0;
+    u32 mcnt = 0;                       // sum popcount(m)
+    // per-plane popcount totals of the planes this lane produces live in LDS (TOT[half][32g+p]); only this
+    // lane ever touches its own slots, so plain read-modify-write is enough
+    u32* TOT = PL + 2u * PLANES;
+#pragma unroll
+    for (int g = 0; g < NW; ++g) TOT[half * PLANES + 32u * g + p] = 0;
+    u32 n_bs_tiles = 0;
+    Acc acc;                            // word-domain accumulators of the fallback path
+
+#ifdef KMX_BS_TIMING
+    const u64 k_c0 = __builtin_readcyclecounter(), k_w0 = wall_clock64();
+    u64 tph[6] = {0, 0, 0, 0, 0, 0};
+#define KMX_T(i) { const u64 t_now = __builtin_readcyclecounter(); tph[i] += t_now - t_last; t_last = t_now; }
+#else
+#define KMX_T(i)
+#endif
+    // software pipeline: the loads of tile t+1 are issued right after tile t has been packed, so they
+    // are in flight during the realign / transpose / item phases of tile t (HBM latency ~4 us under load)
+    uint4 w[NW];
+    auto issue_loads = [&](u64 tile) {
+        const uint4* __restrict__ tb = reinterpret_cast<const uint4*>(bases + tile * 64u * (u64)L);
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            // lanes past the tile end re-read its last chunk: no branch, so all loads of a tile sit in
+            // one basic block and stay in flight together (a guarded load would be fenced by vmcnt(0))
+            u32 c = it * 64u + lane;
+            c = c < chunks ? c : chunks - 1u;
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb + c));  // streamed once
+            w[it] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
+    // Dynamic tile queue: waves pull chunks of CH consecutive tiles from one device-scope counter.  Static
+    // striding ends with a long under-occupied tail because VALU arbitration favours the oldest waves on a
+    // SIMD (measured: the 3 blocks of a CU finished at 3.2 / 3.9 / 4.7 ms with equal work).  The next chunk
+    // is requested one chunk ahead, so the atomic's latency is never exposed.
+    constexpr u64 CH = 8;
+    auto dequeue = [&]() -> u64 {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(queue, (unsigned long long)CH);
+        const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+        return ((u64)hi << 32) | lo;
+    };
+    u64 tile = dequeue();
+    u64 tile_end = tile + CH < n_full ? tile + CH : n_full;
+    u64 next_chunk = dequeue();
+    if (tile < n_full) issue_loads(tile);
+    while (tile < n_full) {
+        // successor tile (for the prefetch) and chunk bookkeeping
+        const bool last_of_chunk = tile + 1 >= tile_end;
+        const u64 succ = last_of_chunk ? next_chunk : tile + 1;
+        auto advance = [&]() {
+            if (last_of_chunk) {
+                tile = next_chunk;
+                tile_end = tile + CH < n_full ? tile + CH : n_full;
+                next_chunk = dequeue();
+            } else {
+                tile += 1;
+            }
+        };
+#ifdef KMX_BS_TIMING
+        u64 t_last = __builtin_readcyclecounter();
+#endif
+        // ---- A. pack + validate the tile loaded during the previous iteration
+        u32 bad = 0;
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            const u32 c = it * 64u + lane;
+            if (c < chunks) P[1u + c] = encode16(w[it], bad);
+        }
+        {   // prefetch (clamped, so unconditional and in this basic block; pinned here by the sched barriers)
+            const u64 nxt = succ < n_full ? succ : tile;
+            __builtin_amdgcn_sched_barrier(0);
+            issue_loads(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        KMX_T(1)
+
+        if (__any(chunk_has_invalid(bad))) {
+            const uint8_t* s = bases + (tile * 64u + lane) * (u64)L;
+            roll_read(s, L, (u32)K, [&](u32, u64 fw, u64 rc) {
+                const u64 canon = fw < rc ? fw : rc;
+                acc.n_valid += 1;
+                acc.sum_canon += canon;
+                acc.xor_hash ^= lex_hash(canon, (u32)K);
+                acc.sum_fw += fw;
+            });
+            advance();
+            continue;
+        }
+
+        // ---- B. this lane's read, realigned: F[g] = bases [16g, 16g+16)
+        u32 F[NW];
+        {
+            u32 R[NW + 1];
+#pragma unroll
+            for (int j = 0; j <= NW; ++j) R[j] = P[qF + j];
+#pragma unroll
+            for (int g = 0; g < NW; ++g) F[g] = alignbit(R[g + 1], R[g], aF);
+        }
+        KMX_T(2)
+        // ---- C. transpose each 32 reads x 32 bits block across the 32 lanes of the half-wave
+#pragma unroll
+        for (int g = 0; g < NW; ++g) {
+            u32 x = F[g];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                u32 y;
+                switch (s) {  // ds_swizzle pattern must be an immediate: xor_mask<<10 | and_mask 0x1f
+                case 0: y = (u32)__builtin_amdgcn_ds_swizzle((int)x, (16 << 10) | 0x1f); break;
+                case 1: y = (u32)__builtin_amdgcn_ds_swizzle((int)x, (8 << 10) | 0x1f); break;
+                case 2: y = (u32)__builtin_amdgcn_ds_swizzle((int)x, (4 << 10) | 0x1f); break;
+                case 3: y = (u32)__builtin_amdgcn_ds_swizzle((int)x, (2 << 10) | 0x1f); break;
+                default: y = (u32)__builtin_amdgcn_ds_swizzle((int)x, (1 << 10) | 0x1f); break;
+                }
+                const u32 rot = alignbit(y, y, tr_sh[s]);
+                x = (x & tr_keep[s]) | (rot & ~tr_keep[s]);
+            }
+            {   // plane index q = 32g+p  <->  base beta = 16g + p/2, bit p&1
+                const u32 beta = 16u * g + (p >> 1);
+                PL[half * PLANES + 2u * ((beta & 3u) * S2 + (beta >> 2)) + (p & 1u)] = x;
+            }
+            TOT[half * PLANES + 32u * g + p] += __builtin_popcount(x);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        KMX_T(3)
+        // ---- D. a lane handles the 4 windows o..o+3 of one set (o = 4*group): they share the planes of
+        //      bases o..o+K+2, streamed twice from LDS as u64 (2 planes per base):
+        //      pass 1 = four interleaved fw<rc ripples, pass 2 = masked popcounts.
+#pragma unroll 1
+        for (u32 r = 0; r < rounds; ++r) {
+            const u32 gidx = r * 64u + lane;
+            const bool active = gidx < 2u * NG;
+            const u32 set = (gidx >= NG && active) ? 1u : 0u;
+            const u32 o = active ? 4u * (gidx - set * NG) : 0u;
+            const u32 nwin = active ? (W - o < 4u ? W - o : 4u) : 0u;   // valid windows in this group
+            // base o+i  ->  u64 index (i & 3) * S2 + (o >> 2) + (i >> 2)   (o is a multiple of 4)
+            const u64* __restrict__ src = reinterpret_cast<const u64*>(PL + set * PLANES) + (o >> 2);
+#define KMX_PLANE(i) src[((i) & 3) * S2 + ((i) >> 2)]
+            u32 lt[4] = {0u, 0u, 0u, 0u};
+            {
+                u64 Pv[K + 3];
+                bool have[K + 3];
+#pragma unroll
+                for (int i = 0; i < K + 3; ++i) have[i] = false;
+                // ripple from the least significant deciding pair (j = ceil(K/2)-1) to the most significant (j = 0);
+                // window w compares fw base K-1-j (plane o+w+K-1-j) with rc base = ~(fw base j) (plane o+w+j)
+#pragma unroll
+                for (int j = (K + 1) / 2 - 1; j >= 0; --j) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int ia = K - 1 - j + w, iq = j + w;
+                        if (!have[ia]) { Pv[ia] = KMX_PLANE(ia); have[ia] = true; }
+                        if (!have[iq]) { Pv[iq] = KMX_PLANE(iq); have[iq] = true; }
+                        const u32 a0 = (u32)Pv[ia], a1 = (u32)(Pv[ia] >> 32);
+                        const u32 q0 = (u32)Pv[iq], q1 = (u32)(Pv[iq] >> 32);
+                        lt[w] = ripple(lt[w], a0, q0);
+                        lt[w] = ripple(lt[w], a1, q1);
+                    }
+                }
+            }
+            u32 m[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                m[w] = ((u32)w < nwin) ? lt[w] : 0u;
+                pc_acc(mcnt, m[w]);
+            }
+            asm volatile("" ::: "memory");   // pass 2 re-reads the planes instead of keeping 2K+6 registers live
+#pragma unroll
+            for (int i = 0; i < K + 3; ++i) {
+                const u64 v = KMX_PLANE(i);
+                const u32 p0 = (u32)v, p1 = (u32)(v >> 32);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int t = i - w;                 // plane i is base t of window w
+                    if (t < 0 || t > K - 1) continue;
+                    const int tc = t < K - 1 - t ? t : K - 1 - t;
+                    pc_acc(D[2 * tc], m[w] & p0);
+                    pc_acc(D[2 * tc + 1], m[w] & p1);
+                }
+            }
+        }
+#undef KMX_PLANE
+        n_bs_tiles += 1;
+        KMX_T(4)
+        advance();
+    }
+#ifdef KMX_BS_TIMING
+    if (lane == 0 && wave_id < 4096) {
+        u64* dbg = reinterpret_cast<u64*>(out) + 8 + wave_id * 8;
+        for (int i = 0; i < 5; ++i) dbg[i] = tph[i];
+        dbg[5] = n_bs_tiles;
+        dbg[6] = __builtin_readcyclecounter() - k_c0;   // shader cycles of this wave's whole run
+        dbg[7] = wall_clock64() - k_w0;                 // same interval in 100 MHz ticks
+        dbg[4] = k_w0;                                  // absolute start (100 MHz ticks)
+    }
+#endif
+
+    // ---- final partial tile: per-lane rolling
+    const u32 rem = (u32)(n_reads & 63u);
+    if (rem != 0u && wave_id == 0 && lane < rem) {
+        const uint8_t* s = bases + (n_full * 64u + lane) * (u64)L;
+        roll_read(s, L, (u32)K, [&](u32, u64 fw, u64 rc) {
+            const u64 canon = fw < rc ? fw : rc;
+            acc.n_valid += 1;
+            acc.sum_canon += canon;
+            acc.xor_hash ^= lex_hash(canon, (u32)K);
+            acc.sum_fw += fw;
+        });
+    }
+
+    // ---- combine the bit-sliced counters into word-domain results (once per wave)
+    // (wave-uniform branch; skipped entirely by waves that only ran the fallback)
+    u64 bs_sum = 0, bs_fw = 0, bs_hash = 0, bs_n = 0;
+    if (n_bs_tiles != 0u) {
+        const u64 nk = (u64)n_bs_tiles * 64u * (u64)W;     // k-mers handled bit-sliced by this wave
+        bs_n = nk;
+        // per-plane totals: lanes p and p+32 hold the same plane index for the two sets
+        u64 fwall = 0, rcsub = 0;
+        u32 tot[NW];
+#pragma unroll
+        for (int g = 0; g < NW; ++g) {
+            const u32 qidx = 32u * g + p;
+            const u32 pcq = TOT[half * PLANES + qidx];
+            u64 wf, wr;
+            plane_weights(qidx >> 1, L, (u32)K, wf, wr);
+            fwall += (u64)pcq * (wf << (qidx & 1u));
+            rcsub += (u64)pcq * (wr << (qidx & 1u));
+            tot[g] = pcq + __shfl_xor(pcq, 32, WAVE);
+        }
+        fwall = wave_sum(fwall);
+        rcsub = wave_sum(rcsub);
+        const u64 mc = wave_sum((u64)mcnt);
+        // D[] -> LDS (wave-reduced), then lane q = 2t+b (t < NT) owns one symmetric counter class
+        u64* CS = reinterpret_cast<u64*>(PL + PLANES);      // set-1 plane area is free now
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 2 * NT; ++q) {
+            const u64 v = wave_sum((u64)D[q]);
+            if (lane == 0) CS[q] = v;
+        }
+#pragma unroll
+        for (int g = 0; g < NW; ++g)
+            if (half == 0) PL[32u * g + p] = tot[g];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        u64 a_lane = 0, h_lane = 0;
+        if (lane < 2u * (u32)NT) {
+            const u32 t = lane >> 1, bb = lane & 1u;
+            const u32 t2 = (u32)K - 1u - t;                 // mirror base; == t for the middle class of odd K
+            const u64 cc = CS[lane];                        // = C[t][b] + C[K-1-t][b]  (middle class: C[t][b] once)
+            if (t2 != t) {
+                a_lane = (cc << (2u * t + bb)) + (cc << (2u * t2 + bb));
+            } else {
+                a_lane = (cc + cc) << (2u * t + bb);        // A counts C[t][b] + C[K-1-t][b] = 2*C[mid][b]
+            }
+            if (want_hash) {
+                // xor-fold of LexHasher(K)(canon): hash bit (K-1-t', b) = parity over all k-mers of canon bit (t', b)
+                //   = parity( C[t'][b] + C[K-1-t'][b] + (nk - mc) - Tq[t'][b] ),  Tq[t'][b] = sum_o popcount(plane(o+K-1-t', b))
+                // evaluated for t' = t and t' = t2 (same counter sum, different Tq)
+                const u64 ccp = (t2 != t) ? cc : (cc + cc);
+                u32 tq1 = 0, tq2 = 0;
+                for (u32 i = (u32)K - 1u - t; i <= L - 1u - t; ++i) tq1 += PL[2u * i + bb];
+                for (u32 i = (u32)K - 1u - t2; i <= L - 1u - t2; ++i) tq2 += PL[2u * i + bb];
+                const u64 par1 = (ccp + (nk - mc) - (u64)tq1) & 1ull;
+                const u64 par2 = (ccp + (nk - mc) - (u64)tq2) & 1ull;
+                h_lane = par1 << (2u * ((u32)K - 1u - t) + bb);
+                if (t2 != t) h_lane |= par2 << (2u * ((u32)K - 1u - t2) + bb);
+            }
+        }
+        const u64 A = wave_sum(a_lane);
+        bs_sum = A + (nk - mc) * MASKK - rcsub;   // sum(canon) = sum m*fw - sum m*rc + sum(all rc)
+        bs_fw = fwall;
+        bs_hash = wave_xor(h_lane);
+    }
+
+    // ---- one set of atomics per wave
+    const u64 n = wave_sum(acc.n_valid) + bs_n;
+    const u64 s = wave_sum(acc.sum_canon) + bs_sum;
+    const u64 x = wave_xor(acc.xor_hash) ^ bs_hash;
+    const u64 f = wave_sum(acc.sum_fw) + bs_fw;
+    if (lane == 0) {
+        atomicAdd((unsigned long long*)&out->n_valid, (unsigned long long)n);
+        atomicAdd((unsigned long long*)&out->sum_canon, (unsigned long long)s);
+        if (want_hash) atomicXor((unsigned long long*)&out->xor_hash, (unsigned long long)x);
+        if (want_sumfw) atomicAdd((unsigned long long*)&out->sum_fw, (unsigned long long)f);
+    }
+}
+
+// ------------------------------------------------------------------ launcher
+
+template <int K, int NW>
+static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, kmx_summary* out,
+                            unsigned long long* queue, int n_cu, hipStream_t stream) {
+    auto kern = scan_bitsliced_kernel<K, NW>;
+    const u32 chunks = 4u * L;
+    const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
+    const size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u)) * 4u * 4u;
+    static int bpc = 0;
+    static size_t bpc_lds = 0;
+    if (bpc == 0 || bpc_lds != lds_bytes) {
+        int b = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, 256, lds_bytes);
+        if (e != hipSuccess) return e;
+        bpc = b > 0 ? b : 1;
+        bpc_lds = lds_bytes;
+    }
+    const u64 n_tiles = (n_reads + 63u) >> 6;
+    u64 grid = (u64)n_cu * (u64)bpc;
+    const u64 need = (n_tiles + 3u) / 4u;
+    if (grid > need) grid = need;
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue);
+    return hipGetLastError();
+}
+
+// handled=false when (L,k) is outside the instantiated bit-sliced kernels
+// `queue`: one zeroed device u64 (tile dequeue counter) owned by the caller for the duration of the launch
+hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
+                                 kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
+    *handled = false;
+    if (L < k || L > 160 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
+    if (n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
+    if (k == 31) {
+        *handled = true;
+        return launch_bs<31, 10>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+    }
+    if (k == 21) {
+        *handled = true;
+        return launch_bs<21, 10>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+    }
+    return hipSuccess;
+}
+
+}  // namespace kmx
