@@ -206,7 +206,8 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                 "kernel": "kmx::scan_uniform_kernel<10,2,2,%s>" % ("true" if args.hash else "false"),
-                "avg_kernel_ms": avg_kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                "avg_kernel_ms": avg_kernel_ms, "min_kernel_ms": min(kernel_ms),
+                "median_kernel_ms": sorted(kernel_ms)[len(kernel_ms) // 2], "algorithmic_bytes_per_launch": algo_bytes,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
             },
             "parity_vs_oracle": "ok" if parity else "MISMATCH",

@@ -53,7 +53,7 @@ struct kmx_ctx {
     hipStream_t stream;
     bool owns_stream;
     int n_cu;
-    unsigned long long* d_scratch;  // 8 bytes: first_bad
+    unsigned long long* d_scratch;  // 8 KiB: [0] first_bad, [16..] tile-queue heads
     char last_error[256];
 };
 
@@ -163,7 +163,7 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, kmx_ctx*
     hipDeviceProp_t prop;
     hipError_t e = g.ok ? hipGetDeviceProperties(&prop, device) : hipErrorInvalidDevice;
     if (e == hipSuccess && owns) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_scratch), 64);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_scratch), 8192);
     if (e != hipSuccess) {
         delete c;
         return KMX_E_HIP;
@@ -258,9 +258,9 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
     const bool lex_same_k = hasher == KMX_HASH_LEX && hasher_k == k;
     if (!reads->d_offsets && (hasher == KMX_HASH_NONE || lex_same_k)) {
         bool handled = false;
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 2, 0, 8, ctx->stream));  // tile queue head
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));  // 32 tile-queue heads, 128 B apart
         KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
-                                                d_out, ctx->d_scratch + 2, ctx->n_cu, ctx->stream, &handled));
+                                                d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
         KMX_HIP(ctx, kmx::launch_scan_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
                                               d_out, ctx->n_cu, ctx->stream, &handled));

@@ -25,6 +25,15 @@
 // semantics, canonical_kmer_iterator.rs:42-70) exactly like the word-domain kernel.
 #include "kmx_device.h"
 
+#include <cstdlib>
+
+#ifndef KMX_BS_SWZ
+#define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
+#endif
+#ifndef KMX_BS_ABLATE
+#define KMX_BS_ABLATE 0   // dev: bitmask of phases to skip (timing experiments only; results become wrong)
+#endif
+
 namespace kmx {
 
 // per-plane weights of sum over all windows of fw / rc (closed form; evaluated once per wave)
@@ -92,6 +101,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // D[2t+b], t <= (K-1)/2: sum of popcount(m & plane(t,b)) + popcount(m & plane(K-1-t,b)) -- the two
     // always enter the result as a sum (weights are symmetric under t <-> K-1-t), so they share a counter
     constexpr int NT = (K + 1) / 2;     // distinct t classes (the middle one of odd K pairs with itself)
+    // v_perm_b32 selectors of the byte-granular stages ({S0=y: bytes 4-7, S1=x: bytes 0-3})
+    const u32 tr_sel16 = (p & 16u) ? 0x03020706u : 0x05040100u;   // keep x.hi, take y.hi>>16  |  keep x.lo, take y.lo<<16
+    const u32 tr_sel8 = (p & 8u) ? 0x03070105u : 0x06020400u;     // odd bytes kept, even from y.odd | even kept, odd from y.even
     u32 D[2 * NT];
 #pragma unroll
     for (int q = 0; q < 2 * NT; ++q) D[q] = 0;
@@ -114,51 +126,63 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // software pipeline: the loads of tile t+1 are issued right after tile t has been packed, so they
     // are in flight during the realign / transpose / item phases of tile t (HBM latency ~4 us under load)
     uint4 w[NW];
+    // address = wave-uniform tile base (SGPR pair) + 32-bit per-lane byte offset: no per-chunk 64-bit
+    // pointers stay live across the loop
+    const u32 lane16 = lane * 16u;
+    const u32 last_off = (chunks - 1u) * 16u;
     auto issue_loads = [&](u64 tile) {
-        const uint4* __restrict__ tb = reinterpret_cast<const uint4*>(bases + tile * 64u * (u64)L);
+        const uint8_t* __restrict__ tb = bases + tile * 64u * (u64)L;
 #pragma unroll
         for (int it = 0; it < NW; ++it) {
             // lanes past the tile end re-read its last chunk: no branch, so all loads of a tile sit in
             // one basic block and stay in flight together (a guarded load would be fenced by vmcnt(0))
-            u32 c = it * 64u + lane;
-            c = c < chunks ? c : chunks - 1u;
+            u32 off = lane16 + (u32)it * 1024u;
+            if (it == NW - 1) off = off < last_off ? off : last_off;
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb + c));  // streamed once
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb + off));  // streamed once
             w[it] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    // Dynamic tile queue: waves pull chunks of CH consecutive tiles from one device-scope counter.  Static
-    // striding ends with a long under-occupied tail because VALU arbitration favours the oldest waves on a
-    // SIMD (measured: the 3 blocks of a CU finished at 3.2 / 3.9 / 4.7 ms with equal work).  The next chunk
-    // is requested one chunk ahead, so the atomic's latency is never exposed.
-    constexpr u64 CH = 8;
+    // Dynamic tile queue.  Static striding ends with a long under-occupied tail because VALU arbitration
+    // favours the oldest waves on a SIMD (measured: the 3 blocks of a CU finished at 3.2 / 3.9 / 4.7 ms with
+    // equal work).  Tiles are handed out ONE at a time so that the tiles in flight across the chip stay
+    // adjacent in memory (handing out runs of 8 tiles cost 30 % of read bandwidth: 5.0 vs 7.1 TB/s in a
+    // compute-free build); to stay far below the ~88 atomics/us a single word sustains, there are NQ queue
+    // heads, each on its own cache line, head q owning the tiles == q (mod NQ).  A head is shared by the
+    // three co-resident blocks of 8 CUs (old and young waves alike), so heads drain at equal rates.
+    // The next ticket is requested one tile ahead, so the atomic's latency is never exposed.
+    constexpr u32 NQ = 32;
+    u32 qid = (blockIdx.x & 255u) >> 3;
+    u32 heads_left = NQ;                                // heads this wave has not yet seen exhausted
     auto dequeue = [&]() -> u64 {
-        unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(queue, (unsigned long long)CH);
-        const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
-        return ((u64)hi << 32) | lo;
+        while (heads_left != 0u) {
+            unsigned long long v = 0;
+            if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);   // heads are 128 bytes apart
+            const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+            const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
+            if (t < n_full) return t;
+            qid = (qid + 1u) & (NQ - 1u);               // this head is drained: help with the next one
+            heads_left -= 1u;
+        }
+        return ~0ull;
     };
     u64 tile = dequeue();
-    u64 tile_end = tile + CH < n_full ? tile + CH : n_full;
-    u64 next_chunk = dequeue();
+    u64 next_tile = dequeue();
     if (tile < n_full) issue_loads(tile);
     while (tile < n_full) {
-        // successor tile (for the prefetch) and chunk bookkeeping
-        const bool last_of_chunk = tile + 1 >= tile_end;
-        const u64 succ = last_of_chunk ? next_chunk : tile + 1;
+        const u64 succ = next_tile;
         auto advance = [&]() {
-            if (last_of_chunk) {
-                tile = next_chunk;
-                tile_end = tile + CH < n_full ? tile + CH : n_full;
-                next_chunk = dequeue();
-            } else {
-                tile += 1;
-            }
+            tile = next_tile;
+            next_tile = dequeue();
         };
 #ifdef KMX_BS_TIMING
         u64 t_last = __builtin_readcyclecounter();
 #endif
         // ---- A. pack + validate the tile loaded during the previous iteration
+#ifdef KMX_BS_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KMX_T(0)
+#endif
         u32 bad = 0;
 #pragma unroll
         for (int it = 0; it < NW; ++it) {
@@ -168,7 +192,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         {   // prefetch (clamped, so unconditional and in this basic block; pinned here by the sched barriers)
             const u64 nxt = succ < n_full ? succ : tile;
             __builtin_amdgcn_sched_barrier(0);
-            issue_loads(nxt);
+            if (!(KMX_BS_ABLATE & 128)) issue_loads(nxt);   // (dev) 128: compute-only, keep re-using the first tile
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -189,6 +213,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             continue;
         }
 
+        if (KMX_BS_ABLATE & 32) { mcnt += bad; n_bs_tiles += 1; advance(); continue; }
         // ---- B. this lane's read, realigned: F[g] = bases [16g, 16g+16)
         u32 F[NW];
         {
@@ -199,28 +224,59 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             for (int g = 0; g < NW; ++g) F[g] = alignbit(R[g + 1], R[g], aF);
         }
         KMX_T(2)
-        // ---- C. transpose each 32 reads x 32 bits block across the 32 lanes of the half-wave
+        // ---- C. transpose each 32 reads x 32 bits block across the 32 lanes of the half-wave, entirely in
+        //      the VALU (no LDS round trips): butterfly stage d exchanges with lane^d and keeps/merges the
+        //      bits whose index has bit d clear/set.
+        //        d=16: v_permlane16_swap_b32 (rows of 16 lanes) + byte merge (v_perm_b32)
+        //        d=8 : two bank-masked DPP row shifts            + byte merge (v_perm_b32)
+        //        d=4 : two bank-masked DPP row shifts            + rotate (v_alignbit) + bit select (v_bitop3)
+        //        d=2,1: DPP quad_perm                             + rotate + bit select
 #pragma unroll
         for (int g = 0; g < NW; ++g) {
             u32 x = F[g];
+            if (!(KMX_BS_ABLATE & 4)) {
+#if KMX_BS_SWZ
 #pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                u32 y;
-                switch (s) {  // ds_swizzle pattern must be an immediate: xor_mask<<10 | and_mask 0x1f
-                case 0: y = (u32)__builtin_amdgcn_ds_swizzle((int)x, (16 << 10) | 0x1f); break;
-                case 1: y = (u32)__builtin_amdgcn_ds_swizzle((int)x, (8 << 10) | 0x1f); break;
-                case 2: y = (u32)__builtin_amdgcn_ds_swizzle((int)x, (4 << 10) | 0x1f); break;
-                case 3: y = (u32)__builtin_amdgcn_ds_swizzle((int)x, (2 << 10) | 0x1f); break;
-                default: y = (u32)__builtin_amdgcn_ds_swizzle((int)x, (1 << 10) | 0x1f); break;
-                }
+            for (int s3 = 0; s3 < 3; ++s3) {   // d = 16, 8, 4 through the LDS crossbar (no VALU for the exchange)
+                const u32 y = s3 == 0 ? (u32)__builtin_amdgcn_ds_swizzle((int)x, (16 << 10) | 0x1f)
+                            : s3 == 1 ? (u32)__builtin_amdgcn_ds_swizzle((int)x, (8 << 10) | 0x1f)
+                                      : (u32)__builtin_amdgcn_ds_swizzle((int)x, (4 << 10) | 0x1f);
+                if (s3 == 0) x = __builtin_amdgcn_perm(y, x, tr_sel16);
+                else if (s3 == 1) x = __builtin_amdgcn_perm(y, x, tr_sel8);
+                else { const u32 rot = alignbit(y, y, tr_sh[2]); x = (x & tr_keep[2]) | (rot & ~tr_keep[2]); }
+            }
+#else
+            {   // d = 16
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                const v2u sw = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+                const u32 y = (p & 16u) ? sw.x : sw.y;          // value held by lane ^ 16
+                x = __builtin_amdgcn_perm(y, x, tr_sel16);      // low half from x / high from y<<16, or mirrored
+            }
+            {   // d = 8
+                u32 y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x108 /* row_shl:8 */, 0xF, 0x3, false);
+                y = (u32)__builtin_amdgcn_update_dpp((int)y, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xC, false);
+                x = __builtin_amdgcn_perm(y, x, tr_sel8);
+            }
+            {   // d = 4
+                u32 y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+                y = (u32)__builtin_amdgcn_update_dpp((int)y, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+                const u32 rot = alignbit(y, y, tr_sh[2]);
+                x = (x & tr_keep[2]) | (rot & ~tr_keep[2]);
+            }
+#endif
+#pragma unroll
+            for (int s = 3; s < 5; ++s) {
+                const u32 y = s == 3 ? (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, false)
+                                     : (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
                 const u32 rot = alignbit(y, y, tr_sh[s]);
                 x = (x & tr_keep[s]) | (rot & ~tr_keep[s]);
+            }
             }
             {   // plane index q = 32g+p  <->  base beta = 16g + p/2, bit p&1
                 const u32 beta = 16u * g + (p >> 1);
                 PL[half * PLANES + 2u * ((beta & 3u) * S2 + (beta >> 2)) + (p & 1u)] = x;
             }
-            TOT[half * PLANES + 32u * g + p] += __builtin_popcount(x);
+            atomicAdd(&TOT[half * PLANES + 32u * g + p], (u32)__builtin_popcount(x));   // ds_add_u32, no return: no LDS round trip
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -231,7 +287,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         //      bases o..o+K+2, streamed twice from LDS as u64 (2 planes per base):
         //      pass 1 = four interleaved fw<rc ripples, pass 2 = masked popcounts.
 #pragma unroll 1
-        for (u32 r = 0; r < rounds; ++r) {
+        for (u32 r = 0; r < ((KMX_BS_ABLATE & 64) ? 0u : rounds); ++r) {
             const u32 gidx = r * 64u + lane;
             const bool active = gidx < 2u * NG;
             const u32 set = (gidx >= NG && active) ? 1u : 0u;
@@ -249,7 +305,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 // ripple from the least significant deciding pair (j = ceil(K/2)-1) to the most significant (j = 0);
                 // window w compares fw base K-1-j (plane o+w+K-1-j) with rc base = ~(fw base j) (plane o+w+j)
 #pragma unroll
-                for (int j = (K + 1) / 2 - 1; j >= 0; --j) {
+                for (int j = (K + 1) / 2 - 1; j >= ((KMX_BS_ABLATE & 2) ? (K + 1) / 2 - 1 : 0); --j) {
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         const int ia = K - 1 - j + w, iq = j + w;
@@ -270,7 +326,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             asm volatile("" ::: "memory");   // pass 2 re-reads the planes instead of keeping 2K+6 registers live
 #pragma unroll
-            for (int i = 0; i < K + 3; ++i) {
+            for (int i = 0; i < ((KMX_BS_ABLATE & 1) ? 1 : K + 3); ++i) {
                 const u64 v = KMX_PLANE(i);
                 const u32 p0 = (u32)v, p1 = (u32)(v >> 32);
 #pragma unroll
@@ -295,7 +351,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         dbg[5] = n_bs_tiles;
         dbg[6] = __builtin_readcyclecounter() - k_c0;   // shader cycles of this wave's whole run
         dbg[7] = wall_clock64() - k_w0;                 // same interval in 100 MHz ticks
-        dbg[4] = k_w0;                                  // absolute start (100 MHz ticks)
+        dbg[6] = (__builtin_readcyclecounter() - k_c0);
+        dbg[5] = ((u64)n_bs_tiles) | (k_w0 << 20);      // tiles in the low 20 bits, absolute start above
     }
 #endif
 
@@ -399,7 +456,8 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     auto kern = scan_bitsliced_kernel<K, NW>;
     const u32 chunks = 4u * L;
     const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
-    const size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u)) * 4u * 4u;
+    size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u)) * 4u * 4u;
+    if (const char* e = getenv("KMX_BS_EXTRA_LDS")) lds_bytes += (size_t)atol(e);   // dev knob: caps blocks per CU
     static int bpc = 0;
     static size_t bpc_lds = 0;
     if (bpc == 0 || bpc_lds != lds_bytes) {

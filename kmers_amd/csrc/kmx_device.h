@@ -25,7 +25,14 @@ __device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh) { return __built
 // in naive_impl (ACGT) codes, plus `bad`: OR of (byte ^ expected upper-case letter) over the 16
 // bytes -- the chunk is all-ACGTacgt  <=>  (bad & 0xDFDFDFDF) == 0  (exact, case-insensitive,
 // same accept set as encode_binary_u8, src/naive_impl/mod.rs:40-50).
+#ifndef KMX_BS_ABLATE
+#define KMX_BS_ABLATE 0
+#endif
 __device__ __forceinline__ u32 encode16(uint4 w, u32& bad) {
+#if (KMX_BS_ABLATE & 16)
+    bad |= 0u;
+    return w.x ^ w.y ^ w.z ^ w.w;   // dev ablation: no packing, no validation
+#endif
     // expected letter by internal code*2 as v_perm selector: 0->'A' 2->'C' 4->'T' 6->'G'
     constexpr u32 TBL_LO = 0x00430041u;  // bytes 0..3 : 'A', -, 'C', -
     constexpr u32 TBL_HI = 0x00470054u;  // bytes 4..7 : 'T', -, 'G', -
@@ -35,8 +42,10 @@ __device__ __forceinline__ u32 encode16(uint4 w, u32& bad) {
     const u32 x1 = w.y ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t1);
     const u32 x2 = w.z ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t2);
     const u32 x3 = w.w ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t3);
-    bad = bad | x0 | x1;
-    bad = bad | x2 | x3;
+#if !(KMX_BS_ABLATE & 8)
+    bad = __builtin_amdgcn_bitop3_b32(bad, x0, x1, 0xFE);   // 3-input OR at full rate (v_or3_b32 is half rate)
+    bad = __builtin_amdgcn_bitop3_b32(bad, x2, x3, 0xFE);
+#endif
     // v_dot4_u32_u8: sum of (2*code_i) * 4^i  = 2 * (4 bases packed in 8 bits)
     const u32 d0 = __builtin_amdgcn_udot4(t0, W4, 0u, false);
     const u32 d1 = __builtin_amdgcn_udot4(t1, W4, 0u, false);

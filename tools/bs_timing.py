@@ -20,14 +20,19 @@ ms = [a.elapsed_time(b) for a, b in ev]
 print("kernel ms per launch (events): min %.3f median %.3f max %.3f -> %.0f GB/s at median" % (min(ms), sorted(ms)[len(ms)//2], max(ms), n * L / sorted(ms)[len(ms)//2] / 1e6))
 v = out.cpu().numpy().view(np.uint64)
 d = v[8:8 + NWV * 8].reshape(NWV, 8).astype(np.float64)
-d = d[d[:, 5] > 0]
-st = (d[:, 4] - d[:, 4].min()) / 1e5
+raw5 = v[8:8 + NWV * 8].reshape(NWV, 8)[:, 5]
+start_abs = (raw5 >> np.uint64(20)).astype(np.float64)
+d[:, 5] = (raw5 & np.uint64((1 << 20) - 1)).astype(np.float64)
+keep = d[:, 5] > 0
+start_abs = start_abs[keep]
+d = d[keep]
+st = (start_abs - start_abs.min()) / 1e5
 en = st + d[:, 7] / 1e5
 print("waves", len(d), "start ms: min %.3f p50 %.3f p90 %.3f max %.3f | end ms: min %.3f p50 %.3f max %.3f" % (st.min(), np.median(st), np.percentile(st, 90), st.max(), en.min(), np.median(en), en.max()))
 print("late starters (>0.1 ms):", int((st > 0.1).sum()))
 print("per-wave lifetime ms (first 64 waves): min %.3f max %.3f" % (d[:,7].min()/1e5, d[:,7].max()/1e5))
 tiles = d[:, 5]
-names = ["A1 wait loads", "A2 encode+lds", "B realign", "C transpose", "D main loop"]
+names = ["A0 wait loads", "A encode+lds", "B realign", "C transpose", "D main loop"]
 print("tiles per wave", tiles.mean())
 tot = 0
 for i, nme in enumerate(names):
@@ -37,16 +42,3 @@ for i, nme in enumerate(names):
 print("total", tot)
 clk = (d[:, 6] / (d[:, 7] / 100e6)).mean() / 1e9
 print(f"effective shader clock during the kernel: {clk:.3f} GHz (cycle counter vs 100 MHz wall clock); wave lifetime {d[:,7].mean()/100e6*1e3:.3f} ms")
-# --- finish time vs placement
-full = v[8:8 + NWV * 8].reshape(NWV, 8).astype(np.float64)
-ok = full[:, 5] > 0
-wid = np.nonzero(ok)[0]
-en_all = (full[ok, 4] - full[ok, 4].min() + full[ok, 7]) / 1e5
-blk = wid // 4
-print("by XCD (block%8): ", " ".join("%.2f" % en_all[blk % 8 == x].mean() for x in range(8)))
-print("by wave-in-block: ", " ".join("%.2f" % en_all[wid % 4 == x].mean() for x in range(4)))
-nb = blk.max() + 1
-print("by block third:   ", " ".join("%.2f" % en_all[(blk >= nb * i // 3) & (blk < nb * (i + 1) // 3)].mean() for i in range(3)))
-print("per-block spread within block (max-min) mean: %.3f" % np.mean([en_all[blk == b].max() - en_all[blk == b].min() for b in range(0, nb, 7)]))
-h, e = np.histogram(en_all, bins=12)
-print("hist", list(h), ["%.2f" % x for x in e])
