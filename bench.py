@@ -100,6 +100,8 @@ def main():
     ap.add_argument("-k", type=int, default=31)
     ap.add_argument("--hash", action="store_true", help="also fold the LexHasher(k) word hash (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--histogram", type=int, default=0, metavar="LOG2_BUCKETS",
+                    help="also time the bucket histogram + RCCL all-reduce (BASELINE configs[4]); reported in 'histogram'")
     args = ap.parse_args()
 
     import numpy as np
@@ -160,15 +162,32 @@ def main():
     summ = out.cpu().numpy().view(np.uint64)
     n_valid, sum_canon = int(summ[0]), int(summ[1])
 
+    from kmers_amd import dist as kd
+
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    cnt = torch.tensor([n_valid], dtype=torch.int64, device="cuda")
-    chk = torch.tensor([np.int64(np.uint64(sum_canon).view(np.int64))], dtype=torch.int64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        dist.all_reduce(chk, op=dist.ReduceOp.SUM)  # wrapping add of per-shard checksums
     elapsed_max = float(t.item())
-    total_kmers_per_step = int(cnt.item())
+    tot = kd.combine_summaries({"n_valid": n_valid, "sum_canon": sum_canon, "xor_hash": int(summ[2]), "sum_fw": 0},
+                               device=ctx.device)   # wrapping add / xor of the per-shard summaries
+    total_kmers_per_step = tot["n_valid"]
+
+    hist_info = None
+    if args.histogram:
+        b = args.histogram
+        counts = torch.zeros(1 << b, dtype=torch.int64, device=ctx.device)
+        ctx.histogram(bases, n, L, k, _lib.HASH_LEX, k, b, counts=counts)   # warm-up
+        counts.zero_()
+        barrier()
+        t0 = time.perf_counter()
+        ctx.histogram(bases, n, L, k, _lib.HASH_LEX, k, b, counts=counts)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        kd.allreduce_histogram(counts)       # the path's only real collective: all-reduce(sum, int64) over RCCL/xGMI
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        hist_info = {"log2_buckets": b, "scan_ms": (t1 - t0) * 1e3, "allreduce_ms": (t2 - t1) * 1e3,
+                     "total_count": int(counts.sum().item()), "expect": total_kmers_per_step}
 
     if rank == 0:
         value = total_kmers_per_step * args.steps / elapsed_max
@@ -205,14 +224,16 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": "kmx::scan_uniform_kernel<10,2,2,%s>" % ("true" if args.hash else "false"),
+                "kernel": "kmx::scan_bitsliced_kernel<%d,10>" % k if k in (21, 31) and L <= 160 else "kmx::scan_uniform_kernel",
                 "avg_kernel_ms": avg_kernel_ms, "min_kernel_ms": min(kernel_ms),
                 "median_kernel_ms": sorted(kernel_ms)[len(kernel_ms) // 2], "algorithmic_bytes_per_launch": algo_bytes,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
             },
             "parity_vs_oracle": "ok" if parity else "MISMATCH",
-            "checksum": f"{int(chk.item()) & (2**64 - 1):#018x}",
+            "checksum": f"{tot['sum_canon']:#018x}",
         }
+        if hist_info is not None:
+            res["histogram"] = hist_info
         if world == 1 and not args.no_cpu_baseline:
             n_s = min(n, 4_000_000)
             res["cpu_baseline"] = cpu_baseline(bases[: n_s * L].cpu().numpy(), n_s, L, k)

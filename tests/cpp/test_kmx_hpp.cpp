@@ -1,0 +1,138 @@
+// C++ host-layer test: reads like the reference's inline test modules (cited per block), every value
+// computed by the libkmx HIP kernels through include/kmx.hpp.  Exit code 0 = all passed.
+#include <cstdio>
+#include <string>
+
+#include "kmx.hpp"
+
+using namespace kmx;
+using namespace kmx::naive_impl;
+
+static int fails = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); ++fails; } } while (0)
+template <typename F> static bool panics(F f) { try { f(); } catch (const Panic&) { return true; } return false; }
+
+int main() {
+    // ---- src/naive_impl/kmer.rs tests
+    {   // test_into_canon / test_is_canon (:292-317)
+        CHECK(Kmer::from("taa").to_canonical() == Kmer::from("taa"));
+        CHECK(Kmer::from("tta").to_canonical() == Kmer::from("taa"));
+        CHECK(Kmer::from("atc").to_canonical() == Kmer::from("atc"));
+        CHECK(Kmer::from("gat").to_canonical() == Kmer::from("atc"));
+        Kmer not_canon = Kmer::from("gatacataggatgg");
+        CHECK(not_canon.to_reverse_complement() == not_canon.to_canonical());
+        CHECK(Kmer::from("agatacataggatgg").is_canonical());
+        CHECK(!Kmer::from("gatacataggatgg").is_canonical());
+    }
+    CHECK(Kmer::from("tcc") < Kmer::from("cct"));  // test_ord (:319-322)
+    {   // test_append / test_prepend (:324-384)
+        Kmer k1 = Kmer::from("att");
+        CHECK(k1.append_base_u8('c') == A && k1 == Kmer::from("ttc"));
+        k1 = Kmer::from("ttcga");
+        CHECK(k1.append_base_u8('g') == T && k1 == Kmer::from("tcgag"));
+        k1 = Kmer::from("att");
+        CHECK(k1.append_base(encode_binary_u8('c')) == A && k1 == Kmer::from("ttc"));
+        k1 = Kmer::from("att");
+        CHECK(k1.prepend_base_u8('c') == T && k1 == Kmer::from("cat"));
+        k1 = Kmer::from("ttcga");
+        CHECK(k1.prepend_base_u8('g') == A && k1 == Kmer::from("gttcg"));
+    }
+    {   // test_rc (:386-424)
+        CHECK((Kmer{1, 0}.to_reverse_complement() == Kmer::from("t")));
+        CHECK(Kmer::from("aaa").to_reverse_complement() == Kmer::from("ttt"));
+        CHECK(Kmer::from("ta").to_reverse_complement() == Kmer::from("ta"));
+        CHECK(Kmer::from("ccg").to_reverse_complement() == Kmer::from("cgg"));
+        CHECK(Kmer::from("aat").to_reverse_complement() == Kmer::from("att"));
+        CHECK(Kmer::from("gatacataggatgg").to_reverse_complement() == Kmer::from("ccatcctatgtatc"));
+    }
+    CHECK(Kmer::from("catagatacat").to_string() == "catagatacat");  // str_repr (:426-431)
+    CHECK(Kmer::from("aac").into_u64() == 0b010000 && Kmer::from("acc").into_u64() == 0b010100 && Kmer::from("ccc").into_u64() == 0b010101);  // bin_repr
+    CHECK(Kmer::from("aaa") == Kmer::from_u64(0, 3));
+    CHECK(Kmer::from("aaa") == Kmer::from("AAA") && Kmer::from("aCa") == Kmer::from("AcA") && Kmer::from("a") != Kmer::from("aa"));  // test_eq
+    CHECK(panics([] { Kmer::from(std::string(33, 'a')); }));  // too_long (:476-480)
+    CHECK(!panics([] { Kmer::from(std::string(32, 'a')); }));
+    CHECK(panics([] { encode_binary('N'); }));                // encode_panics (:499-503)
+    CHECK(encode_binary('A') == A && encode_binary('c') == C && encode_binary('G') == G && encode_binary('t') == T);
+    CHECK(encode_binary_u8('N') == UINT64_MAX);               // mod.rs:48
+    CHECK(complement_base(A) == T && complement_base(C) == G && is_valid_nuc(T) && !is_valid_nuc(5));
+
+    // ---- src/naive_impl/canonical_kmer.rs tests (:243-297)
+    {
+        CanonicalKmer ck = CanonicalKmer::from("acttg");
+        CHECK(ck.fw.to_string() == "acttg" && ck.rc.to_string() == "caagt");
+        Kmer km = Kmer::from("acttg");
+        CanonicalKmer ck2 = CanonicalKmer::from_u64(km.into_u64(), (uint8_t)km.len());
+        CHECK(ck2 == ck);
+        ck.swap();
+        CHECK(ck.rc.to_string() == "acttg" && ck.fw.to_string() == "caagt");
+        ck = CanonicalKmer::from("acttg");
+        ck.append_base_u8('a');
+        CHECK(ck.fw.to_string() == "cttga" && ck.rc.to_string() == "tcaag");
+        ck.prepend_base_u8('c');
+        CHECK(ck.rc.to_string() == "caagg" && ck.fw.to_string() == "ccttg");
+        CanonicalKmer a = CanonicalKmer::from("acttg"), b = CanonicalKmer::from("caagt");
+        CHECK(a.get_kmer_equivalency(b.get_fw_mer()) == MatchType::TwinMatch);
+        b.swap();
+        CHECK(a.get_kmer_equivalency(b.get_fw_mer()) == MatchType::IdentityMatch);
+        b.append_base_u8('c');
+        CHECK(a.get_kmer_equivalency(b.get_fw_mer()) == MatchType::NoMatch);
+    }
+    // ---- src/naive_impl/canonical_kmer_iterator.rs tests (:123-206)
+    {
+        const std::string r = "TTTTGGCCATTTTTCCTGTTCTTCAAGAAAACAGGAGATAACTAGAAGGACTAGAGAATGGGGCTGCCAGAACTAGTGGGAAGCTCCCTAGAAATGGTGACATCGCCCACCAAACAGACC";
+        const uint8_t k = 31;
+        auto it = CanonicalKmerIterator::from_u8_slice(r, k);
+        CHECK(it.get().km == CanonicalKmer::from(r.substr(0, 31)) && it.get().pos == 0);   // test_iter_init
+        it.inc();
+        CHECK(it.get().km == CanonicalKmer::from(r.substr(1, 31)) && it.get().pos == 1);   // test_iter_inc
+        it = CanonicalKmerIterator::from_u8_slice(r, k);
+        it.inc_by(10);
+        CHECK(it.get().km == CanonicalKmer::from(r.substr(10, 31)) && it.get().pos == 10); // test_iter_inc_by
+        std::string rn = r.substr(0, 4) + "N" + r.substr(4);
+        it = CanonicalKmerIterator::from_u8_slice(rn, k);
+        CHECK(it.get().km == CanonicalKmer::from(rn.substr(5, 31)) && it.get().pos == 5);  // test_iter_init_invalid
+        rn = r.substr(0, 35) + "N" + r.substr(35);
+        it = CanonicalKmerIterator::from_u8_slice(rn, k);
+        it.inc_by(5);
+        CHECK(it.get().km == CanonicalKmer::from(rn.substr(36, 31)) && it.get().pos == 36); // test_iter_inc_by_invalid
+        it = CanonicalKmerIterator::from_u8_slice(r, k);                                    // test_exhausted_works
+        it.inc_by(20);
+        CHECK(!it.exhausted());
+        it.inc_by(r.size() - 20);
+        CHECK(it.exhausted());
+        it.inc();
+        CHECK(it.exhausted());
+        // short read: exhausted immediately, pos stays -1 (:50,69)
+        it = CanonicalKmerIterator::from_u8_slice(std::string("ACGT"), k);
+        CHECK(it.exhausted() && it.get().pos == -1);
+    }
+    // ---- src/naive_impl/hash.rs lex_order (:83-104)
+    {
+        hash::LexHasherState seed(3);
+        CHECK(hash::hash_one(seed, Kmer::from("aaa")) == 0);
+        CHECK(hash::hash_one(seed, Kmer::from("aac")) == 0b000001);
+        CHECK(hash::hash_one(seed, Kmer::from("caa")) == 0b010000);
+        CHECK(hash::hash_one(seed, Kmer::from("cac")) == 0b010001);
+    }
+    // ---- src/encoding/naive.rs k45pu64 (:388-416), src/kmer.rs kmer_prefix / kmer_naive_encoder (:173-203)
+    {
+        using encoding::Naive;
+        const std::string s = "TAAGGATTCTAATCATAAGGATTCTAATCATAAGGATTCTAATCA";
+        auto a = encoding::encode<2>(Naive::ACGT, s);
+        CHECK(a[0] == 3585846758293238403ull && a[1] == 7397160ull);
+        CHECK(encoding::decode<2>(Naive::ACGT, a) == s + std::string(19, 'A'));
+        CHECK(encoding::decode<2>(Naive::ACGT, encoding::rev_comp<45, 2>(Naive::ACGT, a)) ==
+              "TGATTAGAATCCTTATGATTAGAATCCTTATGATTAGAATCCTTA" + std::string(19, 'A'));
+        auto x = encoding::encode<2>(encoding::Xor10{}, s);   // xor10.rs commented KAT value (informational)
+        CHECK(x[0] == 2414607732474225602ull && x[1] == 6330940ull);
+        auto km = kmer::Kmer<31>::new_("GTAC", Naive::ACGT);
+        CHECK(km.get_prefix(4) == 0b01001110 && kmer::bitmer_to_bytes(km.get_prefix(4), 4) == "GTAC");
+        auto k4 = kmer::Kmer<4>::new_("ACTG", Naive::TAGC);
+        CHECK(k4.get(0) == 0b01 && k4.get(1) == 0b11 && k4.get(2) == 0b00 && k4.get(3) == 0b10);
+        CHECK((kmer::word_for_k<8, 32>() == 1) && (kmer::word_for_k<8, 64>() == 2) && (kmer::word_for_k<16, 65>() == 2));
+        CHECK(kmer::Kmer<15>().num_bytes() == 8 && kmer::Kmer<15>().k() == 15);
+        CHECK(panics([] { encoding::encode<1>(Naive::ACGT, std::string(33, 'A')); }));
+    }
+    std::printf(fails ? "%d check(s) FAILED\n" : "all C++ host-layer checks passed\n", fails);
+    return fails ? 1 : 0;
+}

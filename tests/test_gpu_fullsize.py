@@ -1,0 +1,91 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle cannot scan
+1.2e10 k-mers in seconds): exact window counts, shard linearity (checksum of checksums), an oracle-checked
+prefix, and exact accounting of injected invalid bytes."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_FULL = int(os.environ.get("KMX_TEST_FULL_READS", 100_000_000))  # BASELINE configs[1]: 1e8 x 150 bp
+L = 150
+M64 = 2**64 - 1
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from kmers_amd.api import Context
+
+    c = Context()
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def big(ctx):
+    return ctx.gen_reads(N_FULL * L)
+
+
+@pytest.mark.parametrize("k", [31, 21])
+def test_full_size_counts_linearity_and_prefix(ctx, orc, big, k):
+    from kmers_amd import _lib
+
+    whole = ctx.canonical_reduce(big, N_FULL, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    assert whole.n_valid == N_FULL * (L - k + 1)          # clean synthetic input: every window is valid
+    # shard linearity: summaries of disjoint read ranges combine (wrapping add / xor) to the whole
+    cuts = [0, N_FULL // 3 + 5, N_FULL // 2 + 64 * 7 + 1, N_FULL]
+    acc = dict(n=0, s=0, x=0, f=0)
+    for a, b in zip(cuts, cuts[1:]):
+        part = ctx.canonical_reduce(big[a * L:b * L], b - a, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        acc["n"] += part.n_valid
+        acc["s"] = (acc["s"] + part.sum_canon) & M64
+        acc["x"] ^= part.xor_hash
+        acc["f"] = (acc["f"] + part.sum_fw) & M64
+    assert (acc["n"], acc["s"], acc["x"], acc["f"]) == (whole.n_valid, whole.sum_canon, whole.xor_hash, whole.sum_fw)
+    # oracle-checked prefix (1e6 reads = 1.2e8 k-mers)
+    n_chk = min(N_FULL, 1_000_000)
+    host = big[: n_chk * L].cpu().numpy()
+    o = orc.canonical_reduce(host, n_chk, L, k, hasher_k=k)
+    g = ctx.canonical_reduce(big[: n_chk * L], n_chk, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
+    # the generic (reference-shaped) kernel and the fast kernel agree on a mid-size slice
+    n_mid = min(N_FULL, 3_000_000)
+    off = ctx.to_device(np.arange(n_mid + 1, dtype=np.uint64) * np.uint64(L))
+    gg = ctx.canonical_reduce(big[: n_mid * L], n_mid, 0, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=off)
+    gf = ctx.canonical_reduce(big[: n_mid * L], n_mid, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    assert (gg.n_valid, gg.sum_canon, gg.xor_hash, gg.sum_fw) == (gf.n_valid, gf.sum_canon, gf.xor_hash, gf.sum_fw)
+
+
+def test_full_size_invalid_byte_accounting(ctx, big):
+    """an 'N' at read offset p kills exactly min(p, L-k) - max(0, p-k+1) + 1 windows of that read"""
+    import torch
+
+    k = 31
+    clean = ctx.canonical_reduce(big, N_FULL, L, k)
+    rng = np.random.default_rng(5)
+    reads = rng.choice(N_FULL, size=1000, replace=False)
+    offs = rng.integers(0, L, size=1000)
+    idx = torch.from_numpy((reads.astype(np.int64) * L + offs)).to(big.device)
+    saved = big[idx].clone()
+    big[idx] = ord("N")
+    try:
+        dirty = ctx.canonical_reduce(big, N_FULL, L, k)
+    finally:
+        big[idx] = saved
+    killed = sum(min(int(p), L - k) - max(0, int(p) - k + 1) + 1 for p in offs)
+    assert dirty.n_valid == clean.n_valid - killed
+    again = ctx.canonical_reduce(big, N_FULL, L, k)
+    assert (again.n_valid, again.sum_canon) == (clean.n_valid, clean.sum_canon)  # restored, idempotent
+
+
+def test_full_size_k63_two_word(ctx, orc, big):
+    """BASELINE configs[2]: k=63 ([u64;2] storage, build-defined order); counts + oracle-checked prefix"""
+    k = 63
+    n = min(N_FULL, 20_000_000)
+    g = ctx.canonical_reduce2(big[: n * L], n, L, k, with_hash=True)
+    assert g.n_valid == n * (L - k + 1)
+    n_chk = min(n, 300_000)
+    o = orc.canonical_reduce2(big[: n_chk * L].cpu().numpy(), n_chk, L, k, with_hash=True)
+    gp = ctx.canonical_reduce2(big[: n_chk * L], n_chk, L, k, with_hash=True)
+    assert tuple(getattr(gp, f) for f, _ in gp._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
