@@ -202,6 +202,14 @@ def main():
         g = ctx.canonical_reduce(bases[: n_chk * L], n_chk, L, k, hasher, hk, 0)
         parity = (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash if args.hash else 0)
         parity = parity and n_valid == n * max(L - k + 1, 0)
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (same kernel, same workload only)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if (k, L, n, args.hash) == (31, 150, 100_000_000, False):
+                traffic = pt["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "canonical k-mers/sec at k=31, 150 bp reads; HBM GB/s vs peak",
             "value": value,
@@ -223,7 +231,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "kernel": "kmx::scan_bitsliced_kernel<%d,10>" % k if k in (21, 31) and L <= 160 else "kmx::scan_uniform_kernel",
                 "avg_kernel_ms": avg_kernel_ms, "min_kernel_ms": min(kernel_ms),
                 "median_kernel_ms": sorted(kernel_ms)[len(kernel_ms) // 2], "algorithmic_bytes_per_launch": algo_bytes,
