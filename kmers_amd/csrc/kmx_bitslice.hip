@@ -27,6 +27,12 @@
 
 #include <cstdlib>
 
+#ifndef KMX_BS_PREFETCH
+#define KMX_BS_PREFETCH 1   // 1: next tile loaded into registers one tile ahead; 0: loads at tile start (fewer VGPRs, more waves)
+#endif
+#ifndef KMX_BS_WAVES
+#define KMX_BS_WAVES 3      // waves per SIMD the register allocation is sized for
+#endif
 #ifndef KMX_BS_SWZ
 #define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
 #endif
@@ -58,8 +64,8 @@ __device__ __forceinline__ u32 ripple(u32 lt, u32 a, u32 q) { return __builtin_a
 // d += popcount(x) as ONE v_bcnt_u32_b32 (hipcc otherwise splits it into v_bcnt(x,0) + v_add3_u32)
 __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x)); }
 
-template <int K, int NW>
-__global__ void __launch_bounds__(256, 3)
+template <int K, int NW, int WPL>
+__global__ void __launch_bounds__(256, KMX_BS_WAVES)
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       kmx_summary* __restrict__ out, unsigned long long* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -67,6 +73,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // (beta & 3) * S2 + (beta >> 2).  In phase D lane g reads bases 4g+i: consecutive lanes then touch
     // consecutive u64s (conflict-free ds_read_b64) instead of a 32-byte stride (4-way bank conflicts,
     // measured SQ_LDS_BANK_CONFLICT = 65 % of LDS cycles with the linear layout).
+    // (For an odd number of windows per lane the lane stride is an odd number of u64s and the plain linear
+    // layout is already conflict-free.)
     constexpr int S2 = 4 * NW + 1;       // u64 row pitch (odd, so the 4 rows start on different banks)
     constexpr int PLANES = 8 * S2;       // dwords per set (>= 32*NW)
     const u32 lane = threadIdx.x & 63u;
@@ -84,7 +92,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 posF = lane * L + 16u;
     const u32 qF = posF >> 4, aF = 2u * (posF & 15u);
     const u32 W = L - (u32)K + 1u;      // windows per read
-    const u32 NG = (W + 3u) >> 2;       // groups of 4 windows per read
+    const u32 NG = (W + WPL - 1u) / WPL; // groups of WPL adjacent windows per read
     const u32 rounds = (2u * NG + 63u) >> 6;   // (set, group) items per tile, 64 per round
     constexpr u64 MASKK = (K >= 32) ? ~0ull : ((1ull << (2 * K)) - 1ull);
 
@@ -168,7 +176,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     u64 tile = dequeue();
     u64 next_tile = dequeue();
-    if (tile < n_full) issue_loads(tile);
+    if (KMX_BS_PREFETCH && tile < n_full) issue_loads(tile);
     while (tile < n_full) {
         const u64 succ = next_tile;
         auto advance = [&]() {
@@ -178,6 +186,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #ifdef KMX_BS_TIMING
         u64 t_last = __builtin_readcyclecounter();
 #endif
+        if (!KMX_BS_PREFETCH) issue_loads(tile);
         // ---- A. pack + validate the tile loaded during the previous iteration
 #ifdef KMX_BS_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -192,7 +201,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         {   // prefetch (clamped, so unconditional and in this basic block; pinned here by the sched barriers)
             const u64 nxt = succ < n_full ? succ : tile;
             __builtin_amdgcn_sched_barrier(0);
-            if (!(KMX_BS_ABLATE & 128)) issue_loads(nxt);   // (dev) 128: compute-only, keep re-using the first tile
+            if (KMX_BS_PREFETCH && !(KMX_BS_ABLATE & 128)) issue_loads(nxt);   // (dev) 128: compute-only, keep re-using the first tile
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -274,7 +283,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             {   // plane index q = 32g+p  <->  base beta = 16g + p/2, bit p&1
                 const u32 beta = 16u * g + (p >> 1);
-                PL[half * PLANES + 2u * ((beta & 3u) * S2 + (beta >> 2)) + (p & 1u)] = x;
+                const u32 slot = (WPL == 4) ? (beta & 3u) * S2 + (beta >> 2) : beta;
+                PL[half * PLANES + 2u * slot + (p & 1u)] = x;
             }
             atomicAdd(&TOT[half * PLANES + 32u * g + p], (u32)__builtin_popcount(x));   // ds_add_u32, no return: no LDS round trip
         }
@@ -283,31 +293,33 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         KMX_T(3)
-        // ---- D. a lane handles the 4 windows o..o+3 of one set (o = 4*group): they share the planes of
-        //      bases o..o+K+2, streamed twice from LDS as u64 (2 planes per base):
+        // ---- D. a lane handles the WPL windows o..o+WPL-1 of one set (o = WPL*group): they share the planes of
+        //      bases o..o+K+WPL-2, streamed twice from LDS as u64 (2 planes per base):
         //      pass 1 = four interleaved fw<rc ripples, pass 2 = masked popcounts.
 #pragma unroll 1
         for (u32 r = 0; r < ((KMX_BS_ABLATE & 64) ? 0u : rounds); ++r) {
             const u32 gidx = r * 64u + lane;
             const bool active = gidx < 2u * NG;
             const u32 set = (gidx >= NG && active) ? 1u : 0u;
-            const u32 o = active ? 4u * (gidx - set * NG) : 0u;
-            const u32 nwin = active ? (W - o < 4u ? W - o : 4u) : 0u;   // valid windows in this group
-            // base o+i  ->  u64 index (i & 3) * S2 + (o >> 2) + (i >> 2)   (o is a multiple of 4)
-            const u64* __restrict__ src = reinterpret_cast<const u64*>(PL + set * PLANES) + (o >> 2);
-#define KMX_PLANE(i) src[((i) & 3) * S2 + ((i) >> 2)]
-            u32 lt[4] = {0u, 0u, 0u, 0u};
-            {
-                u64 Pv[K + 3];
-                bool have[K + 3];
+            const u32 o = active ? (u32)WPL * (gidx - set * NG) : 0u;
+            const u32 nwin = active ? (W - o < (u32)WPL ? W - o : (u32)WPL) : 0u;   // valid windows in this group
+            // base o+i  ->  u64 index (i & 3) * S2 + (o >> 2) + (i >> 2) for WPL == 4 (o is a multiple of 4), else o + i
+            const u64* __restrict__ src = reinterpret_cast<const u64*>(PL + set * PLANES) + (WPL == 4 ? (o >> 2) : o);
+#define KMX_PLANE(i) src[(WPL == 4) ? (((i) & 3) * S2 + ((i) >> 2)) : (i)]
+            u32 lt[WPL];
 #pragma unroll
-                for (int i = 0; i < K + 3; ++i) have[i] = false;
+            for (int w = 0; w < WPL; ++w) lt[w] = 0u;
+            {
+                u64 Pv[K + WPL - 1];
+                bool have[K + WPL - 1];
+#pragma unroll
+                for (int i = 0; i < K + WPL - 1; ++i) have[i] = false;
                 // ripple from the least significant deciding pair (j = ceil(K/2)-1) to the most significant (j = 0);
                 // window w compares fw base K-1-j (plane o+w+K-1-j) with rc base = ~(fw base j) (plane o+w+j)
 #pragma unroll
                 for (int j = (K + 1) / 2 - 1; j >= ((KMX_BS_ABLATE & 2) ? (K + 1) / 2 - 1 : 0); --j) {
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
+                    for (int w = 0; w < WPL; ++w) {
                         const int ia = K - 1 - j + w, iq = j + w;
                         if (!have[ia]) { Pv[ia] = KMX_PLANE(ia); have[ia] = true; }
                         if (!have[iq]) { Pv[iq] = KMX_PLANE(iq); have[iq] = true; }
@@ -318,19 +330,19 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     }
                 }
             }
-            u32 m[4];
+            u32 m[WPL];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < WPL; ++w) {
                 m[w] = ((u32)w < nwin) ? lt[w] : 0u;
                 pc_acc(mcnt, m[w]);
             }
             asm volatile("" ::: "memory");   // pass 2 re-reads the planes instead of keeping 2K+6 registers live
 #pragma unroll
-            for (int i = 0; i < ((KMX_BS_ABLATE & 1) ? 1 : K + 3); ++i) {
+            for (int i = 0; i < ((KMX_BS_ABLATE & 1) ? 1 : K + WPL - 1); ++i) {
                 const u64 v = KMX_PLANE(i);
                 const u32 p0 = (u32)v, p1 = (u32)(v >> 32);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
+                for (int w = 0; w < WPL; ++w) {
                     const int t = i - w;                 // plane i is base t of window w
                     if (t < 0 || t > K - 1) continue;
                     const int tc = t < K - 1 - t ? t : K - 1 - t;
@@ -450,10 +462,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 
 // ------------------------------------------------------------------ launcher
 
-template <int K, int NW>
+template <int K, int NW, int WPL>
 static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, kmx_summary* out,
                             unsigned long long* queue, int n_cu, hipStream_t stream) {
-    auto kern = scan_bitsliced_kernel<K, NW>;
+    auto kern = scan_bitsliced_kernel<K, NW, WPL>;
     const u32 chunks = 4u * L;
     const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
     size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u)) * 4u * 4u;
@@ -483,13 +495,17 @@ hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k
     *handled = false;
     if (L < k || L > 160 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
     if (n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
+    // windows per lane: the 2*ceil(W/WPL) (set, group) items of a tile should fit the 64 lanes in ONE round
+    const u32 W = L - k + 1u;
     if (k == 31) {
         *handled = true;
-        return launch_bs<31, 10>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        if (W <= 128u) return launch_bs<31, 10, 4>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        return launch_bs<31, 10, 5>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
     }
     if (k == 21) {
         *handled = true;
-        return launch_bs<21, 10>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        if (W <= 128u) return launch_bs<21, 10, 4>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        return launch_bs<21, 10, 5>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
     }
     return hipSuccess;
 }
