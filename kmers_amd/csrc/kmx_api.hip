@@ -14,7 +14,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 // kmx_scan.hip
 hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
-                               kmx_summary* out, int n_cu, hipStream_t stream, bool* handled);
+                               kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 // kmx_bitslice.hip
 hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
@@ -263,7 +263,7 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
                                                 d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
         KMX_HIP(ctx, kmx::launch_scan_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
-                                              d_out, ctx->n_cu, ctx->stream, &handled));
+                                              d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
     }
     KMX_HIP(ctx, kmx::launch_reduce_generic(reads, k, hasher, hasher_k, want_sumfw ? 1u : 0u, d_out, ctx->n_cu, ctx->stream));

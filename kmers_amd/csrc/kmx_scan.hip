@@ -72,7 +72,7 @@ __device__ __forceinline__ void window1(u32 f0, u32 f1, u32 g0, u32 g1, u32 sf, 
 template <int NW, int V, int DW, bool FULL>
 __global__ void __launch_bounds__(256)
 scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, u32 want_hash, u32 want_sumfw,
-                    kmx_summary* __restrict__ out) {
+                    kmx_summary* __restrict__ out, unsigned long long* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const u32 lane = threadIdx.x & 63u;
     const u32 wib = threadIdx.x >> 6;
@@ -100,7 +100,26 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
 
     Acc acc;
 
-    for (u64 tile = wave_id; tile < n_full; tile += n_waves) {
+    // dynamic tile queue (see kmx_bitslice.hip): NQ interleaved heads, one tile per ticket, ticket fetched one
+    // tile ahead; removes the under-occupied tail that static striding leaves behind
+    constexpr u32 NQ = 32;
+    u32 qid = (blockIdx.x & 255u) >> 3;
+    u32 heads_left = NQ;
+    auto dequeue = [&]() -> u64 {
+        while (heads_left != 0u) {
+            unsigned long long v = 0;
+            if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);
+            const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+            const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
+            if (t < n_full) return t;
+            qid = (qid + 1u) & (NQ - 1u);
+            heads_left -= 1u;
+        }
+        return ~0ull;
+    };
+    u64 next_tile = dequeue();
+    for (u64 tile = next_tile; tile < n_full; tile = next_tile) {
+        next_tile = dequeue();
         const uint4* __restrict__ tb = reinterpret_cast<const uint4*>(bases + tile * 64u * (u64)L);
         // ---- 1. stream the tile: all loads in flight before the first use
         uint4 w[NW];
@@ -181,7 +200,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
 
     // ---- final partial tile (n_reads % 64 reads): per-lane rolling
     const u32 rem = (u32)(n_reads & 63u);
-    if (rem != 0u && wave_id == (n_full % n_waves) && lane < rem) {
+    if (rem != 0u && wave_id == 0 && lane < rem) {
         const uint8_t* s = bases + (n_full * 64u + lane) * (u64)L;
         roll_read(s, L, k, [&](u32, u64 fw, u64 rc) {
             const u64 canon = fw < rc ? fw : rc;
@@ -206,7 +225,7 @@ struct ScanCfg {
 
 template <int NW, int V, int DW, bool FULL>
 static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 want_hash, u32 want_sumfw,
-                             kmx_summary* out, int n_cu, hipStream_t stream) {
+                             kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream) {
     auto kern = scan_uniform_kernel<NW, V, DW, FULL>;
     const u32 chunks = 4u * L;
     const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
@@ -225,13 +244,13 @@ static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u3
     const u64 need = (n_tiles + 3u) / 4u;
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, want_hash, want_sumfw, out);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue);
     return hipGetLastError();
 }
 
 // Returns hipSuccess and sets *handled=false when (L,k) is outside the fast kernel's domain.
 hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
-                               kmx_summary* out, int n_cu, hipStream_t stream, bool* handled) {
+                               kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
     if (k < 2 || k > 31 || k == 17 || L < k || L > 256 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
     if (n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
@@ -239,8 +258,8 @@ hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
     const bool big = L > 160;
     const bool full = want_hash || want_sumfw;
 #define KMX_GO(NW, V, DW)                                                                              \
-    return full ? launch_one<NW, V, DW, true>(bases, n_reads, L, k, want_hash, want_sumfw, out, n_cu, stream) \
-                : launch_one<NW, V, DW, false>(bases, n_reads, L, k, 0, 0, out, n_cu, stream)
+    return full ? launch_one<NW, V, DW, true>(bases, n_reads, L, k, want_hash, want_sumfw, out, queue, n_cu, stream) \
+                : launch_one<NW, V, DW, false>(bases, n_reads, L, k, 0, 0, out, queue, n_cu, stream)
     if (k <= 16) {
         if (big) { KMX_GO(16, 1, 1); } else { KMX_GO(10, 1, 1); }
     } else {
