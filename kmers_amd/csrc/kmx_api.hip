@@ -15,6 +15,10 @@ typedef uint64_t u64;
 // kmx_scan.hip
 hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 hasher, u32 hk, u32 log2_buckets,
+                               u64* counts, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon,
+                                  uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 // kmx_bitslice.hip
 hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
@@ -277,6 +281,13 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
     if (reads->d_offsets && !d_win_offsets) return KMX_E_ARG;
     if (reads->n_reads == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
+    if (!reads->d_offsets && !d_win_offsets) {   // uniform layout: fast word-domain kernel
+        bool handled = false;
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+        KMX_HIP(ctx, kmx::launch_windows_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, d_fw, d_rc, d_canon,
+                                                 d_flags, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+        if (handled) return KMX_OK;
+    }
     KMX_HIP(ctx, kmx::launch_windows_generic(reads, d_win_offsets, k, d_fw, d_rc, d_canon, d_flags, ctx->n_cu, ctx->stream));
     return KMX_OK;
 }
@@ -310,6 +321,13 @@ int kmx_histogram(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t has
     if (hasher == KMX_HASH_LEX && (hasher_k < 1 || hasher_k > 32)) return KMX_E_K_RANGE;
     if (reads->n_reads == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
+    if (!reads->d_offsets) {
+        bool handled = false;
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+        KMX_HIP(ctx, kmx::launch_hist_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, hasher, hasher_k,
+                                              log2_buckets, d_counts, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+        if (handled) return KMX_OK;
+    }
     KMX_HIP(ctx, kmx::launch_histogram_generic(reads, k, hasher, hasher_k, log2_buckets, d_counts, ctx->n_cu, ctx->stream));
     return KMX_OK;
 }

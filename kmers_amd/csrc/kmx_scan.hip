@@ -1,6 +1,7 @@
-// kmx_scan.hip -- K1: fused encode + sliding window + reverse complement + canonical (+hash)
-// + reduce over uniform-length reads.  The headline kernel (BASELINE.json: canonical
-// k-mers/s at k=31 on 150 bp reads).
+// kmx_scan.hip -- K1/K2/K4 word-domain scan over uniform-length reads: fused encode + sliding window +
+// reverse complement + canonical, feeding a SINK: reduce (summary), bucket histogram, or materialise
+// (per-window fw / rc / canonical / flags).  Serves every (k, L) the bit-sliced kernel (kmx_bitslice.hip)
+// is not instantiated for, and all histogram / materialise calls on uniform reads.
 //
 // Replaces, per read, the reference's streaming loop
 //   CanonicalKmerIterator::find_next      src/naive_impl/canonical_kmer_iterator.rs:42-70
@@ -8,7 +9,7 @@
 //   Kmer::append_base / prepend_base      src/naive_impl/kmer.rs:91-102
 //   CanonicalKmer::get_canonical_word     src/naive_impl/canonical_kmer.rs:113-119
 //   encode_binary_u8                      src/naive_impl/mod.rs:40-50
-//   LexHasher::write_u64 (optional)       src/naive_impl/hash.rs:60-71
+//   LexHasher::write_u64 / Hash for Kmer  src/naive_impl/hash.rs:4-8,60-71
 //
 // gfx950 design (one wave owns a tile of 64 reads, no block-level barrier anywhere):
 //   1. the wave streams its tile (64*L contiguous bytes) from HBM with 16 B/lane
@@ -16,72 +17,180 @@
 //   2. each 16-byte chunk is packed to 16 two-bit bases (one dword) with v_dot4_u32_u8
 //      and checked for non-ACGTacgt bytes with v_perm_b32 (exact); the packed tile
 //      (4x smaller) is staged in the wave's private LDS slice;
-//   3. each lane pulls ITS read's packed words back from LDS (ds_read_b32, stride ~L/16
-//      dwords, conflict-light) and realigns them with v_alignbit_b32 into a forward word
-//      array F and -- via v_bfrev_b32 -- a reverse-complement array G, both in VGPRs;
+//   3. each lane pulls ITS read's packed words back from LDS (ds_read_b32) and realigns them with
+//      v_alignbit_b32 into a forward word array F and -- via v_bfrev_b32 -- a reverse-complement
+//      array G, both in VGPRs;
 //   4. every window is then two funnel shifts per strand with compile-time shift amounts
-//      (v_alignbit_b32), one 64-bit compare, two v_cndmask and a 64-bit add: ~11 VALU
-//      lane-ops per canonical k-mer.  No per-base rolling, no per-window branches.
-//   A tile that contains any invalid byte (or the final partial tile) takes the
-//   reference-shaped per-lane rolling path instead (roll_read) -- rare on real reads,
-//   and bit-exact with the iterator's skip semantics.
-//
-// Roofline: HBM-read bound by construction (L bytes read per read, ~0 written); the VALU
-// budget at 5.6 TB/s is ~17 lane-ops per k-mer, which is what step 4 is sized for.
+//      (v_alignbit_b32), one 64-bit compare and two v_cndmask.  No per-base rolling, no per-window branches.
+//   A tile that contains any invalid byte (or the final partial tile) takes the reference-shaped
+//   per-lane rolling path instead (roll_read) -- bit-exact with the iterator's skip semantics.
+//   Tiles come from the same interleaved dynamic queue as the bit-sliced kernel.
 #include "kmx_device.h"
 
 namespace kmx {
 
-// One window, two-dword k-mer (k in 18..31).  SF/SR: forward / reverse funnel-shift amounts.
-template <bool FULL>
-__device__ __forceinline__ void window2(u32 f0, u32 f1, u32 f2, u32 g0, u32 g1, u32 g2, u32 sf, u32 sr, u32 mhi,
-                                        u64 maskk, Acc& acc) {
-    const u32 fw_lo = alignbit(f1, f0, sf);
-    const u32 fw_hi = alignbit(f2, f1, sf) & mhi;
-    const u32 rc_lo = alignbit(g1, g0, sr);
-    const u32 rc_hi = alignbit(g2, g1, sr) & mhi;
-    const u64 fw = ((u64)fw_hi << 32) | fw_lo;
-    const u64 rc = ((u64)rc_hi << 32) | rc_lo;
-    const u64 canon = fw < rc ? fw : rc;  // canonical_kmer.rs:113-119
-    acc.sum_canon += canon;
-    if (FULL) {
-        // LexHasher(k)(canon) = MASK[k] & ~max(fw,rc): the 2-bit-group reversal of x is the
-        // complement of revcomp(x) inside 2k bits (hash.rs:60-71 vs kmer.rs:124-136).
-        acc.xor_hash ^= maskk ^ fw ^ rc ^ canon;
-        acc.sum_fw += fw;
-    }
-}
+// ------------------------------------------------------------------------------------------ sinks
+// A sink consumes windows.  fast(o, fw, rc): window o of the lane's read on the all-valid fast path;
+// slow(pos, fw, rc): a window yielded by roll_read (invalid ones are skipped); begin/end bracket one read
+// on the slow path; tile_fast_done(nwin) closes a fast tile.
 
-// One window, single-dword k-mer (k in 2..16)
+struct ReduceParams {
+    kmx_summary* out;
+    u32 want_hash, want_sumfw;
+};
 template <bool FULL>
-__device__ __forceinline__ void window1(u32 f0, u32 f1, u32 g0, u32 g1, u32 sf, u32 sr, u32 mlo, Acc& acc) {
-    const u32 fw = alignbit(f1, f0, sf) & mlo;
-    const u32 rc = alignbit(g1, g0, sr) & mlo;
-    const u32 canon = fw < rc ? fw : rc;
-    acc.sum_canon += canon;
-    if (FULL) {
-        acc.xor_hash ^= (u64)(mlo ^ fw ^ rc ^ canon);
-        acc.sum_fw += fw;
+struct SinkReduce {
+    Acc acc;
+    u64 maskk;
+    u32 k;
+    static constexpr u32 kLdsDwordsPerWave = 0;
+    __device__ SinkReduce(const ReduceParams&, u32 k_, u32, u32*, u32) : maskk(mask2k(k_)), k(k_) {}
+    __device__ __forceinline__ void block_done(u64, u32, u32) {}
+    __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) {
+        const u64 canon = fw < rc ? fw : rc;  // canonical_kmer.rs:113-119
+        acc.sum_canon += canon;
+        if (FULL) {
+            // LexHasher(k)(canon) = MASK[k] & ~max(fw,rc): the 2-bit-group reversal of x is the
+            // complement of revcomp(x) inside 2k bits (hash.rs:60-71 vs kmer.rs:124-136).
+            acc.xor_hash ^= maskk ^ fw ^ rc ^ canon;
+            acc.sum_fw += fw;
+        }
     }
-}
+    __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) {
+        const u64 canon = fw < rc ? fw : rc;
+        acc.n_valid += 1;
+        acc.sum_canon += canon;
+        if (FULL) {
+            acc.xor_hash ^= lex_hash(canon, k);
+            acc.sum_fw += fw;
+        }
+    }
+    __device__ __forceinline__ void begin_read(u64) {}
+    __device__ __forceinline__ void end_read() {}
+    __device__ __forceinline__ void tile_fast_done(u32 nwin) { acc.n_valid += nwin; }
+    __device__ __forceinline__ void finish(const ReduceParams& p) { flush_acc(acc, p.out, FULL && p.want_hash, FULL && p.want_sumfw); }
+};
 
+struct HistParams {
+    u64* counts;
+    u32 hasher, hk, log2_buckets;
+};
+// d_counts[bucket(hash(canonical k-mer))] += 1 with device-scope u64 atomics.  Measured ~24 G atomics/s on MI355X
+// independent of the bucket count (2^12..2^26) and of the atomic scope (XCD-private copies updated with
+// workgroup-scope atomics ran at the same rate), i.e. bound by the atomic issue rate, not by contention.
+struct SinkHist {
+    u64* counts;
+    u64 maskk;
+    u32 hasher, hk, k, b;
+    static constexpr u32 kLdsDwordsPerWave = 0;
+    __device__ __forceinline__ void block_done(u64, u32, u32) {}
+    __device__ SinkHist(const HistParams& p, u32 k_, u32, u32*, u32)
+        : counts(p.counts), maskk(mask2k(k_)), hasher(p.hasher), hk(p.hk), k(k_), b(p.log2_buckets) {}
+    __device__ __forceinline__ void emit(u64 fw, u64 rc) {
+        const u64 canon = fw < rc ? fw : rc;
+        u64 h;
+        if (hasher == KMX_HASH_LEX) h = (hk == k) ? (maskk ^ fw ^ rc ^ canon) : lex_hash(canon, hk);
+        else h = canon;  // identity: write_u64(data), hash.rs:4-8
+        atomicAdd((unsigned long long*)&counts[bucket_of(h, b)], 1ull);
+    }
+    __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) { emit(fw, rc); }
+    __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) { emit(fw, rc); }
+    __device__ __forceinline__ void begin_read(u64) {}
+    __device__ __forceinline__ void end_read() {}
+    __device__ __forceinline__ void tile_fast_done(u32) {}
+    __device__ __forceinline__ void finish(const HistParams&) {}
+};
+
+struct WindowsParams {
+    u64 *fw, *rc, *canon;
+    uint8_t* flags;
+};
+// dense per-window outputs, slot(read, pos) = read*W + pos.  Write-bound by construction (8 B per array per k-mer).
+// Fast path: the 16 windows of a block are staged through LDS (lane-major, pitch 17) and written back transposed,
+// so every store instruction covers 128-byte contiguous runs (16 windows of one read) instead of 64 scattered
+// 8-byte words at a stride of W*8 bytes.
+struct SinkWindows {
+    static constexpr u32 PITCH = 17;                        // u64 per lane row (16 + 1 pad: conflict-free both ways)
+    static constexpr u32 kLdsDwordsPerWave = 3u * 64u * PITCH * 2u + 64u * 16u / 4u;   // 3 u64 planes + flag bytes
+    WindowsParams p;
+    u64* T;        // [3][64][PITCH] staging (fw, rc, canon)
+    uint8_t* TF;   // [64][16] flags
+    u64 base;      // slot of window 0 of the current read (slow path)
+    u32 W, next, lane;
+    __device__ SinkWindows(const WindowsParams& p_, u32, u32 W_, u32* lds, u32 lane_)
+        : p(p_), T(reinterpret_cast<u64*>(lds)), TF(reinterpret_cast<uint8_t*>(lds + 3u * 64u * PITCH * 2u)), base(0), W(W_), next(0), lane(lane_) {}
+    __device__ __forceinline__ void store(u64 slot, u64 fw, u64 rc) {
+        const bool lt = fw < rc;
+        if (p.fw) p.fw[slot] = fw;
+        if (p.rc) p.rc[slot] = rc;
+        if (p.canon) p.canon[slot] = lt ? fw : rc;
+        if (p.flags) p.flags[slot] = (uint8_t)(KMX_WIN_VALID | (lt ? KMX_WIN_FW_CANONICAL : 0u));
+    }
+    __device__ __forceinline__ void zero_to(u32 end) {
+        for (; next < end; ++next) {
+            const u64 s = base + next;
+            if (p.fw) p.fw[s] = 0;
+            if (p.rc) p.rc[s] = 0;
+            if (p.canon) p.canon[s] = 0;
+            if (p.flags) p.flags[s] = 0;
+        }
+    }
+    __device__ __forceinline__ void fast(u32 o, u64 fw, u64 rc) {
+        const u32 s = o & 15u, at = lane * PITCH + s;
+        const bool lt = fw < rc;
+        if (p.fw) T[at] = fw;
+        if (p.rc) T[64u * PITCH + at] = rc;
+        if (p.canon) T[2u * 64u * PITCH + at] = lt ? fw : rc;
+        if (p.flags) TF[lane * 16u + s] = (uint8_t)(KMX_WIN_VALID | (lt ? KMX_WIN_FW_CANONICAL : 0u));
+    }
+    // all 64 lanes have staged windows [o0, o0+cnt) of reads [read0, read0+64): write them out coalesced
+    __device__ __forceinline__ void block_done(u64 read0, u32 o0, u32 cnt) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+        for (u32 it = 0; it < 16u; ++it) {
+            const u32 idx = it * 64u + lane, r = idx >> 4, sw = idx & 15u;
+            if (sw < cnt) {
+                const u64 slot = (read0 + r) * W + o0 + sw;
+                const u32 at = r * PITCH + sw;
+                if (p.fw) p.fw[slot] = T[at];
+                if (p.rc) p.rc[slot] = T[64u * PITCH + at];
+                if (p.canon) p.canon[slot] = T[2u * 64u * PITCH + at];
+                if (p.flags) p.flags[slot] = TF[r * 16u + sw];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ void slow(u32 pos, u64 fw, u64 rc) {
+        zero_to(pos);
+        store(base + pos, fw, rc);
+        next = pos + 1u;
+    }
+    __device__ __forceinline__ void begin_read(u64 read) { base = read * W; next = 0; }
+    __device__ __forceinline__ void end_read() { zero_to(W); }
+    __device__ __forceinline__ void tile_fast_done(u32) {}
+    __device__ __forceinline__ void finish(const WindowsParams&) {}
+};
+
+// ----------------------------------------------------------------------------------------- kernel
 // NW  = packed dwords per read = ceil(L/16) rounded up to an instantiated size (L <= 16*NW)
 // V   = 1: k in [2,17]   2: k in [18,32]   (fixes the static register index of the rc window)
 // DW  = dwords per k-mer (1: k<=16, 2: k>=17)
-// FULL= also fold LexHasher(k) xor and the forward-word sum
-template <int NW, int V, int DW, bool FULL>
+template <int NW, int V, int DW, typename Sink, typename Params>
 __global__ void __launch_bounds__(256)
-scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, u32 want_hash, u32 want_sumfw,
-                    kmx_summary* __restrict__ out, unsigned long long* __restrict__ queue) {
+scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, Params params,
+                    unsigned long long* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const u32 lane = threadIdx.x & 63u;
     const u32 wib = threadIdx.x >> 6;
     const u32 chunks = 4u * L;                      // 16-byte chunks per 64-read tile
     const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u; // front pad 1, tail pad >= 6
-    u32* P = lds + wib * ldsw;
+    u32* P = lds + wib * (ldsw + Sink::kLdsDwordsPerWave);
 
     const u64 n_full = n_reads >> 6;
-    const u64 n_waves = (u64)gridDim.x * 4u;
     const u64 wave_id = (u64)blockIdx.x * 4u + wib;
 
     // per-lane alignment of this lane's read inside the packed tile (LDS index 1+c holds bases [16c,16c+16))
@@ -98,7 +207,19 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     const u32 mhi = (u32)(maskk >> 32);
     const u32 nwin = omax + 1u;
 
-    Acc acc;
+    Sink sink(params, k, nwin, P + ldsw, lane);
+
+    auto window = [&](u32 o, u32 f0, u32 f1, u32 f2, u32 g0, u32 g1, u32 g2, u32 sf, u32 sr) {
+        if (DW == 2) {
+            const u32 fw_lo = alignbit(f1, f0, sf);
+            const u32 fw_hi = alignbit(f2, f1, sf) & mhi;
+            const u32 rc_lo = alignbit(g1, g0, sr);
+            const u32 rc_hi = alignbit(g2, g1, sr) & mhi;
+            sink.fast(o, ((u64)fw_hi << 32) | fw_lo, ((u64)rc_hi << 32) | rc_lo);
+        } else {
+            sink.fast(o, (u64)(alignbit(f1, f0, sf) & mlo), (u64)(alignbit(g1, g0, sr) & mlo));
+        }
+    };
 
     // dynamic tile queue (see kmx_bitslice.hip): NQ interleaved heads, one tile per ticket, ticket fetched one
     // tile ahead; removes the under-occupied tail that static striding leaves behind
@@ -139,18 +260,12 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        const u64 read = tile * 64u + lane;
         if (__any(chunk_has_invalid(bad))) {
             // ---- rare: a non-ACGTacgt byte somewhere in this tile -> exact iterator semantics
-            const uint8_t* s = bases + (tile * 64u + lane) * (u64)L;
-            roll_read(s, L, k, [&](u32, u64 fw, u64 rc) {
-                const u64 canon = fw < rc ? fw : rc;
-                acc.n_valid += 1;
-                acc.sum_canon += canon;
-                if (FULL) {
-                    acc.xor_hash ^= lex_hash(canon, k);
-                    acc.sum_fw += fw;
-                }
-            });
+            sink.begin_read(read);
+            roll_read(bases + read * (u64)L, L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
+            sink.end_read();
             continue;
         }
 
@@ -173,63 +288,42 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         }
 
         // ---- 4. windows: o = 16*i + s;  fw from F[i..i+2] >> 2s;  rc from G[M..M+2] >> (30-2s), M = NW-V-i
+        sink.begin_read(read);
 #pragma unroll
         for (int i = 0; i <= NW - V; ++i) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int M = NW - V - i;
             if ((u32)i < imax) {
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    if (DW == 2)
-                        window2<FULL>(F[i], F[i + 1], F[i + 2], G[M], G[M + 1], G[M + 2], 2 * s, 30 - 2 * s, mhi, maskk, acc);
-                    else
-                        window1<FULL>(F[i], F[i + 1], G[M], G[M + 1], 2 * s, 30 - 2 * s, mlo, acc);
-                }
+                for (int s = 0; s < 16; ++s) window(16 * i + s, F[i], F[i + 1], F[i + 2], G[M], G[M + 1], G[M + 2], 2 * s, 30 - 2 * s);
+                sink.block_done(tile * 64u, 16u * i, 16u);
             } else if ((u32)i == imax) {
-                for (u32 s = 0; s <= smax; ++s) {
-                    if (DW == 2)
-                        window2<FULL>(F[i], F[i + 1], F[i + 2], G[M], G[M + 1], G[M + 2], 2u * s, 30u - 2u * s, mhi, maskk, acc);
-                    else
-                        window1<FULL>(F[i], F[i + 1], G[M], G[M + 1], 2u * s, 30u - 2u * s, mlo, acc);
-                }
+                for (u32 s = 0; s <= smax; ++s) window(16u * i + s, F[i], F[i + 1], F[i + 2], G[M], G[M + 1], G[M + 2], 2u * s, 30u - 2u * s);
+                sink.block_done(tile * 64u, 16u * i, smax + 1u);
             }
         }
-        acc.n_valid += nwin;
+        sink.tile_fast_done(nwin);
     }
 
     // ---- final partial tile (n_reads % 64 reads): per-lane rolling
     const u32 rem = (u32)(n_reads & 63u);
     if (rem != 0u && wave_id == 0 && lane < rem) {
-        const uint8_t* s = bases + (n_full * 64u + lane) * (u64)L;
-        roll_read(s, L, k, [&](u32, u64 fw, u64 rc) {
-            const u64 canon = fw < rc ? fw : rc;
-            acc.n_valid += 1;
-            acc.sum_canon += canon;
-            if (FULL) {
-                acc.xor_hash ^= lex_hash(canon, k);
-                acc.sum_fw += fw;
-            }
-        });
+        const u64 read = n_full * 64u + lane;
+        sink.begin_read(read);
+        roll_read(bases + read * (u64)L, L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
+        sink.end_read();
     }
-
-    flush_acc(acc, out, FULL && want_hash, FULL && want_sumfw);
+    sink.finish(params);
 }
 
-// ------------------------------------------------------------------ launcher
+// ------------------------------------------------------------------ launchers
 
-struct ScanCfg {
-    const void* fn;
-    int blocks_per_cu;  // cached occupancy
-};
-
-template <int NW, int V, int DW, bool FULL>
-static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 want_hash, u32 want_sumfw,
-                             kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream) {
-    auto kern = scan_uniform_kernel<NW, V, DW, FULL>;
+template <int NW, int V, int DW, typename Sink, typename Params>
+static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, const Params& params,
+                             unsigned long long* queue, int n_cu, hipStream_t stream) {
+    auto kern = scan_uniform_kernel<NW, V, DW, Sink, Params>;
     const u32 chunks = 4u * L;
     const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
-    const size_t lds_bytes = (size_t)ldsw * 4u * 4u;
+    const size_t lds_bytes = (size_t)(ldsw + Sink::kLdsDwordsPerWave) * 4u * 4u;
     static int bpc = 0;
     static size_t bpc_lds = 0;
     if (bpc == 0 || bpc_lds != lds_bytes) {
@@ -244,28 +338,52 @@ static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u3
     const u64 need = (n_tiles + 3u) / 4u;
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, params, queue);
     return hipGetLastError();
 }
 
-// Returns hipSuccess and sets *handled=false when (L,k) is outside the fast kernel's domain.
+static bool scan_domain(const uint8_t* bases, u64 n_reads, u32 L, u32 k) {
+    if (k < 2 || k > 31 || k == 17 || L < k || L > 256 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return false;
+    return n_reads * (u64)L < (1ull << 62);
+}
+
+template <typename SinkT, typename Params>
+static hipError_t dispatch(const uint8_t* bases, u64 n_reads, u32 L, u32 k, const Params& p, unsigned long long* queue,
+                           int n_cu, hipStream_t stream) {
+    const bool big = L > 160;
+    if (k <= 16) {
+        if (big) return launch_one<16, 1, 1, SinkT, Params>(bases, n_reads, L, k, p, queue, n_cu, stream);
+        return launch_one<10, 1, 1, SinkT, Params>(bases, n_reads, L, k, p, queue, n_cu, stream);
+    }
+    if (big) return launch_one<16, 2, 2, SinkT, Params>(bases, n_reads, L, k, p, queue, n_cu, stream);
+    return launch_one<10, 2, 2, SinkT, Params>(bases, n_reads, L, k, p, queue, n_cu, stream);
+}
+
+// Each returns hipSuccess and sets *handled=false when (L,k) is outside the fast kernel's domain.
+// `queue`: 32 zeroed u64 heads, 128 B apart, owned by the caller for the duration of the launch.
 hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
-    *handled = false;
-    if (k < 2 || k > 31 || k == 17 || L < k || L > 256 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
-    if (n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
-    *handled = true;
-    const bool big = L > 160;
-    const bool full = want_hash || want_sumfw;
-#define KMX_GO(NW, V, DW)                                                                              \
-    return full ? launch_one<NW, V, DW, true>(bases, n_reads, L, k, want_hash, want_sumfw, out, queue, n_cu, stream) \
-                : launch_one<NW, V, DW, false>(bases, n_reads, L, k, 0, 0, out, queue, n_cu, stream)
-    if (k <= 16) {
-        if (big) { KMX_GO(16, 1, 1); } else { KMX_GO(10, 1, 1); }
-    } else {
-        if (big) { KMX_GO(16, 2, 2); } else { KMX_GO(10, 2, 2); }
-    }
-#undef KMX_GO
+    *handled = scan_domain(bases, n_reads, L, k);
+    if (!*handled) return hipSuccess;
+    const ReduceParams p{out, want_hash ? 1u : 0u, want_sumfw ? 1u : 0u};
+    if (want_hash || want_sumfw) return dispatch<SinkReduce<true>>(bases, n_reads, L, k, p, queue, n_cu, stream);
+    return dispatch<SinkReduce<false>>(bases, n_reads, L, k, p, queue, n_cu, stream);
+}
+
+hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 hasher, u32 hk, u32 log2_buckets,
+                               u64* counts, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
+    *handled = scan_domain(bases, n_reads, L, k);
+    if (!*handled) return hipSuccess;
+    const HistParams p{counts, hasher, hk, log2_buckets};
+    return dispatch<SinkHist>(bases, n_reads, L, k, p, queue, n_cu, stream);
+}
+
+hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon,
+                                  uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
+    *handled = scan_domain(bases, n_reads, L, k);
+    if (!*handled) return hipSuccess;
+    const WindowsParams p{fw, rc, canon, flags};
+    return dispatch<SinkWindows>(bases, n_reads, L, k, p, queue, n_cu, stream);
 }
 
 }  // namespace kmx

@@ -304,6 +304,23 @@ def test_histogram(ctx, orc, hasher, hk):
     assert (c.cpu().numpy().view(np.uint64) == 2 * o).all()
 
 
+@pytest.mark.parametrize("b", [6, 12, 20])
+def test_histogram_fast_kernel_many_tiles(ctx, orc, b):
+    """uniform reads take the word-domain scan kernel with the histogram sink; clean and dirty tiles mixed"""
+    rng = np.random.default_rng(b)
+    L, n, k = 150, 64 * 90 + 11, 31
+    host = _dirty(rng, n * L, 0.0005)
+    bases = ctx.to_device(host)
+    o = orc.histogram(host, n, L, k, k, b)
+    g = ctx.histogram(bases, n, L, k, 1, k, b)
+    assert (g.cpu().numpy().view(np.uint64) == o).all()
+    g = ctx.histogram(bases, n, L, k, 1, k, b, counts=g)      # accumulates into the caller's counters
+    assert (g.cpu().numpy().view(np.uint64) == 2 * o).all()
+    o21 = orc.histogram(host, n, L, 21, 0, b)                 # identity hasher, other k
+    g21 = ctx.histogram(bases, n, L, 21, 2, 0, b)
+    assert (g21.cpu().numpy().view(np.uint64) == o21).all()
+
+
 # ---------------------------------------------------------------- elementwise
 
 def test_kmers_from_bytes_and_word_ops(ctx, orc, kats):
