@@ -140,8 +140,8 @@ __device__ __forceinline__ void roll_read(const uint8_t* __restrict__ s, u32 len
     const u32 top = 2u * k - 2u;
     u64 fw = 0, rc = ~0ull;  // CanonicalKmer::blank_of_size (canonical_kmer.rs:22-29)
     int last_invalid = -1;
-    for (u32 l = 0; l < len; ++l) {
-        const u32 b = encode_base(s[l]);
+    auto step = [&](u32 c, u32 l) {
+        const u32 b = encode_base(c);
         if (b < 4u) {
             fw = (fw >> 2) | ((u64)b << top);                  // kmer.rs:98-102
             rc = mask & ((rc << 2) | (u64)(3u - b));           // kmer.rs:91-95, mod.rs:81-84
@@ -149,7 +149,15 @@ __device__ __forceinline__ void roll_read(const uint8_t* __restrict__ s, u32 len
         } else {
             last_invalid = (int)l;
         }
+    };
+    u32 l = 0;
+    for (; l + 8u <= len; l += 8u) {   // 8 bases per (unaligned) global_load_dwordx2
+        u64 v;
+        __builtin_memcpy(&v, s + l, 8);
+#pragma unroll
+        for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
     }
+    for (; l < len; ++l) step(s[l], l);
 }
 
 }  // namespace kmx

@@ -111,8 +111,8 @@ __device__ __forceinline__ void roll_read2(const uint8_t* __restrict__ s, u32 le
     const u32 top = kb - 2u - 64u;  // bit position of the newest base inside .hi (k>=33)
     U128 fw = {0, 0}, rc = {~0ull, ~0ull};
     int last_invalid = -1;
-    for (u32 l = 0; l < len; ++l) {
-        const u32 b = encode_base(s[l]);
+    auto step = [&](u32 c, u32 l) {
+        const u32 b = encode_base(c);
         if (b < 4u) {
             fw.lo = (fw.lo >> 2) | (fw.hi << 62);
             fw.hi = (fw.hi >> 2) | ((u64)b << top);
@@ -122,7 +122,15 @@ __device__ __forceinline__ void roll_read2(const uint8_t* __restrict__ s, u32 le
         } else {
             last_invalid = (int)l;
         }
+    };
+    u32 l = 0;
+    for (; l + 8u <= len; l += 8u) {
+        u64 v;
+        __builtin_memcpy(&v, s + l, 8);
+#pragma unroll
+        for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
     }
+    for (; l < len; ++l) step(s[l], l);
 }
 
 __global__ void __launch_bounds__(256)
