@@ -44,7 +44,11 @@ def combine_summaries(local: dict[str, int], group=None, device=None) -> dict[st
     t_xor = torch.tensor([local.get("xor_hash", 0) & 0x7FFFFFFFFFFFFFFF, (local.get("xor_hash", 0) >> 63) & 1],
                          dtype=torch.int64, device=device)
     dist.all_reduce(t_add, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(t_xor, op=dist.ReduceOp.BXOR, group=group)
+    # RCCL/NCCL has no BXOR reduction: gather the 16 bytes of every rank and fold locally
+    gathered = [torch.empty_like(t_xor) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(gathered, t_xor, group=group)
+    for i, g in enumerate(gathered):
+        t_xor = g.clone() if i == 0 else torch.bitwise_xor(t_xor, g)
     out = {}
     vals = [int(x) for x in t_add.cpu().tolist()]
     for i, k in enumerate(adds):
