@@ -65,7 +65,7 @@ __device__ __forceinline__ u32 ripple(u32 lt, u32 a, u32 q) { return __builtin_a
 __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x)); }
 
 template <int K, int NW, int WPL>
-__global__ void __launch_bounds__(256, KMX_BS_WAVES)
+__global__ void __launch_bounds__(256, (NW > 10 ? 2 : KMX_BS_WAVES))   // 64 prefetch registers at NW=16
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       kmx_summary* __restrict__ out, unsigned long long* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -493,17 +493,30 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
 hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
-    if (L < k || L > 160 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
+    if (L < k || L > 256 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
     if (n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
     // windows per lane: the 2*ceil(W/WPL) (set, group) items of a tile should fit the 64 lanes in ONE round
     const u32 W = L - k + 1u;
+    if (L > 160) {   // 161..256 bp reads: 16 packed words per read, 8 windows per lane (2*ceil(W/8) <= 64 lanes)
+        if (k == 31) {
+            *handled = true;
+            return launch_bs<31, 16, 8>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        }
+        if (k == 21) {
+            *handled = true;
+            return launch_bs<21, 16, 8>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        }
+        return hipSuccess;
+    }
     if (k == 31) {
         *handled = true;
+        if (W <= 96u) return launch_bs<31, 10, 3>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
         if (W <= 128u) return launch_bs<31, 10, 4>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
         return launch_bs<31, 10, 5>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
     }
     if (k == 21) {
         *handled = true;
+        if (W <= 96u) return launch_bs<21, 10, 3>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
         if (W <= 128u) return launch_bs<21, 10, 4>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
         return launch_bs<21, 10, 5>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
     }
