@@ -22,6 +22,8 @@ hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 
 // kmx_bitslice.hip
 hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
+                                  unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 // kmx_generic.hip
 hipError_t launch_reduce_generic(const kmx_reads* r, u32 k, u32 hasher, u32 hk, u32 want_sumfw, kmx_summary* out,
                                  int n_cu, hipStream_t st);
@@ -298,6 +300,13 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
     DeviceGuard g(ctx->device);
     KMX_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(kmx_summary2), ctx->stream));
     if (reads->n_reads == 0) return KMX_OK;
+    if (!reads->d_offsets) {
+        bool handled = false;
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+        KMX_HIP(ctx, kmx::launch_scan_bitsliced2(reads->d_bases, reads->n_reads, reads->read_len, k, with_hash != 0, d_out,
+                                                 ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+        if (handled) return KMX_OK;
+    }
     KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream));
     return KMX_OK;
 }

@@ -65,9 +65,10 @@ __device__ __forceinline__ u32 ripple(u32 lt, u32 a, u32 q) { return __builtin_a
 __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x)); }
 
 template <int K, int NW, int WPL>
-__global__ void __launch_bounds__(256, (NW > 10 ? 2 : KMX_BS_WAVES))   // 64 prefetch registers at NW=16
+__global__ void __launch_bounds__(256, ((NW > 10 || K > 32) ? 2 : KMX_BS_WAVES))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
-                      kmx_summary* __restrict__ out, unsigned long long* __restrict__ queue) {
+                      void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
+                      unsigned long long* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     // Plane storage of one 32-read set: base beta (2 planes = one u64) lives at u64 index
     // (beta & 3) * S2 + (beta >> 2).  In phase D lane g reads bases 4g+i: consecutive lanes then touch
@@ -94,7 +95,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 W = L - (u32)K + 1u;      // windows per read
     const u32 NG = (W + WPL - 1u) / WPL; // groups of WPL adjacent windows per read
     const u32 rounds = (2u * NG + 63u) >> 6;   // (set, group) items per tile, 64 per round
-    constexpr u64 MASKK = (K >= 32) ? ~0ull : ((1ull << (2 * K)) - 1ull);
 
     // transpose stage constants: rotate amount and keep-mask per butterfly distance
     u32 tr_sh[5], tr_keep[5];
@@ -122,7 +122,29 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
     for (int g = 0; g < NW; ++g) TOT[half * PLANES + 32u * g + p] = 0;
     u32 n_bs_tiles = 0;
-    Acc acc;                            // word-domain accumulators of the fallback path
+    // word-domain accumulators of the fallback path (tiles with invalid bytes, the final partial tile)
+    struct { u64 n = 0, s0 = 0, s1 = 0, x0 = 0, x1 = 0, fw = 0; } fb;
+    auto fallback_read = [&](const uint8_t* s) {
+        if constexpr (K <= 32) {
+            roll_read(s, L, (u32)K, [&](u32, u64 fw, u64 rc) {
+                const u64 canon = fw < rc ? fw : rc;
+                fb.n += 1;
+                fb.s0 += canon;
+                fb.x0 ^= lex_hash(canon, (u32)K);
+                fb.fw += fw;
+            });
+        } else {
+            roll_read2(s, L, (u32)K, [&](u32, U128 fw, U128 rc) {
+                const U128 c = lt128(fw, rc) ? fw : rc;
+                const U128 h = lex_hash128(c, (u32)K);
+                fb.n += 1;
+                fb.s0 += c.lo;
+                fb.s1 += c.hi;
+                fb.x0 ^= h.lo;
+                fb.x1 ^= h.hi;
+            });
+        }
+    };
 
 #ifdef KMX_BS_TIMING
     const u64 k_c0 = __builtin_readcyclecounter(), k_w0 = wall_clock64();
@@ -210,14 +232,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         KMX_T(1)
 
         if (__any(chunk_has_invalid(bad))) {
-            const uint8_t* s = bases + (tile * 64u + lane) * (u64)L;
-            roll_read(s, L, (u32)K, [&](u32, u64 fw, u64 rc) {
-                const u64 canon = fw < rc ? fw : rc;
-                acc.n_valid += 1;
-                acc.sum_canon += canon;
-                acc.xor_hash ^= lex_hash(canon, (u32)K);
-                acc.sum_fw += fw;
-            });
+            fallback_read(bases + (tile * 64u + lane) * (u64)L);
             advance();
             continue;
         }
@@ -370,40 +385,34 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 
     // ---- final partial tile: per-lane rolling
     const u32 rem = (u32)(n_reads & 63u);
-    if (rem != 0u && wave_id == 0 && lane < rem) {
-        const uint8_t* s = bases + (n_full * 64u + lane) * (u64)L;
-        roll_read(s, L, (u32)K, [&](u32, u64 fw, u64 rc) {
-            const u64 canon = fw < rc ? fw : rc;
-            acc.n_valid += 1;
-            acc.sum_canon += canon;
-            acc.xor_hash ^= lex_hash(canon, (u32)K);
-            acc.sum_fw += fw;
-        });
-    }
+    if (rem != 0u && wave_id == 0 && lane < rem) fallback_read(bases + (n_full * 64u + lane) * (u64)L);
 
-    // ---- combine the bit-sliced counters into word-domain results (once per wave)
-    // (wave-uniform branch; skipped entirely by waves that only ran the fallback)
-    u64 bs_sum = 0, bs_fw = 0, bs_hash = 0, bs_n = 0;
+    // ---- combine the bit-sliced counters into word-domain results (once per wave; wave-uniform branch)
+    // Number of set bits of canonical bit (t,b) over all k-mers of the wave:
+    //   cnt(t,b) = C[t][b] + C[K-1-t][b] + (nk - sum popcount(m)) - Tq[t][b],  Tq[t][b] = sum_o popcount(plane(o+K-1-t, b))
+    // (canon bit = m ? fw bit (t,b) : rc bit (t,b) = ~fw bit (K-1-t,b)).  Then
+    //   sum of word w of canon = sum_{t in word w, b} 2^(2(t&31)+b) * cnt(t,b)   (wrapping),
+    //   xor-fold of the 2-bit-group-reversed hash: bit 2(K-1-t)+b = parity of cnt(t,b),
+    //   sum of fw words (K<=32) = sum over planes of popcount total * closed-form per-base weight.
+    u64 bs_n = 0, bs_s0 = 0, bs_s1 = 0, bs_x0 = 0, bs_x1 = 0, bs_fw = 0;
     if (n_bs_tiles != 0u) {
         const u64 nk = (u64)n_bs_tiles * 64u * (u64)W;     // k-mers handled bit-sliced by this wave
         bs_n = nk;
-        // per-plane totals: lanes p and p+32 hold the same plane index for the two sets
-        u64 fwall = 0, rcsub = 0;
+        u64 fwall = 0;
         u32 tot[NW];
 #pragma unroll
         for (int g = 0; g < NW; ++g) {
             const u32 qidx = 32u * g + p;
-            const u32 pcq = TOT[half * PLANES + qidx];
-            u64 wf, wr;
-            plane_weights(qidx >> 1, L, (u32)K, wf, wr);
-            fwall += (u64)pcq * (wf << (qidx & 1u));
-            rcsub += (u64)pcq * (wr << (qidx & 1u));
-            tot[g] = pcq + __shfl_xor(pcq, 32, WAVE);
+            const u32 pcq = TOT[half * PLANES + qidx];     // per-plane totals of this half's set
+            if constexpr (K <= 32) {
+                u64 wf, wr;
+                plane_weights(qidx >> 1, L, (u32)K, wf, wr);
+                fwall += (u64)pcq * (wf << (qidx & 1u));
+            }
+            tot[g] = pcq + __shfl_xor(pcq, 32, WAVE);      // lanes p and p+32 hold the same plane of the two sets
         }
-        fwall = wave_sum(fwall);
-        rcsub = wave_sum(rcsub);
+        if constexpr (K <= 32) bs_fw = wave_sum(fwall);
         const u64 mc = wave_sum((u64)mcnt);
-        // D[] -> LDS (wave-reduced), then lane q = 2t+b (t < NT) owns one symmetric counter class
         u64* CS = reinterpret_cast<u64*>(PL + PLANES);      // set-1 plane area is free now
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -413,57 +422,61 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
 #pragma unroll
         for (int g = 0; g < NW; ++g)
-            if (half == 0) PL[32u * g + p] = tot[g];
+            if (half == 0) PL[32u * g + p] = tot[g];        // PL[2*base + bit] = popcount total of that plane
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        u64 a_lane = 0, h_lane = 0;
-        if (lane < 2u * (u32)NT) {
-            const u32 t = lane >> 1, bb = lane & 1u;
-            const u32 t2 = (u32)K - 1u - t;                 // mirror base; == t for the middle class of odd K
-            const u64 cc = CS[lane];                        // = C[t][b] + C[K-1-t][b]  (middle class: C[t][b] once)
-            if (t2 != t) {
-                a_lane = (cc << (2u * t + bb)) + (cc << (2u * t2 + bb));
-            } else {
-                a_lane = (cc + cc) << (2u * t + bb);        // A counts C[t][b] + C[K-1-t][b] = 2*C[mid][b]
-            }
-            if (want_hash) {
-                // xor-fold of LexHasher(K)(canon): hash bit (K-1-t', b) = parity over all k-mers of canon bit (t', b)
-                //   = parity( C[t'][b] + C[K-1-t'][b] + (nk - mc) - Tq[t'][b] ),  Tq[t'][b] = sum_o popcount(plane(o+K-1-t', b))
-                // evaluated for t' = t and t' = t2 (same counter sum, different Tq)
-                const u64 ccp = (t2 != t) ? cc : (cc + cc);
-                u32 tq1 = 0, tq2 = 0;
-                for (u32 i = (u32)K - 1u - t; i <= L - 1u - t; ++i) tq1 += PL[2u * i + bb];
-                for (u32 i = (u32)K - 1u - t2; i <= L - 1u - t2; ++i) tq2 += PL[2u * i + bb];
-                const u64 par1 = (ccp + (nk - mc) - (u64)tq1) & 1ull;
-                const u64 par2 = (ccp + (nk - mc) - (u64)tq2) & 1ull;
-                h_lane = par1 << (2u * ((u32)K - 1u - t) + bb);
-                if (t2 != t) h_lane |= par2 << (2u * ((u32)K - 1u - t2) + bb);
+        u64 s0 = 0, s1 = 0, x0 = 0, x1 = 0;
+        for (u32 pid = lane; pid < 2u * (u32)K; pid += 64u) {
+            const u32 t = pid >> 1, bb = pid & 1u, t2 = (u32)K - 1u - t;
+            const u32 tc = t < t2 ? t : t2;
+            u64 cc = CS[2u * tc + bb];                      // C[t][b] + C[K-1-t][b]; the middle class holds C[mid][b] once
+            if (t == t2) cc += cc;
+            u64 tq = 0;
+            for (u32 i = t2; i <= L - 1u - t; ++i) tq += PL[2u * i + bb];
+            const u64 cnt = cc + (nk - mc) - tq;
+            const u32 sh = 2u * (t & 31u) + bb;
+            if (t < 32u) s0 += cnt << sh; else s1 += cnt << sh;
+            if (want_hash && (cnt & 1ull)) {
+                const u32 hb = 2u * t2 + bb;
+                if (hb < 64u) x0 ^= 1ull << hb; else x1 ^= 1ull << (hb - 64u);
             }
         }
-        const u64 A = wave_sum(a_lane);
-        bs_sum = A + (nk - mc) * MASKK - rcsub;   // sum(canon) = sum m*fw - sum m*rc + sum(all rc)
-        bs_fw = fwall;
-        bs_hash = wave_xor(h_lane);
+        bs_s0 = wave_sum(s0);
+        bs_s1 = wave_sum(s1);
+        bs_x0 = wave_xor(x0);
+        bs_x1 = wave_xor(x1);
     }
 
     // ---- one set of atomics per wave
-    const u64 n = wave_sum(acc.n_valid) + bs_n;
-    const u64 s = wave_sum(acc.sum_canon) + bs_sum;
-    const u64 x = wave_xor(acc.xor_hash) ^ bs_hash;
-    const u64 f = wave_sum(acc.sum_fw) + bs_fw;
+    const u64 n = wave_sum(fb.n) + bs_n;
+    const u64 r0 = wave_sum(fb.s0) + bs_s0, r1 = wave_sum(fb.s1) + bs_s1;
+    const u64 h0 = wave_xor(fb.x0) ^ bs_x0, h1 = wave_xor(fb.x1) ^ bs_x1;
+    const u64 f = wave_sum(fb.fw) + bs_fw;
     if (lane == 0) {
-        atomicAdd((unsigned long long*)&out->n_valid, (unsigned long long)n);
-        atomicAdd((unsigned long long*)&out->sum_canon, (unsigned long long)s);
-        if (want_hash) atomicXor((unsigned long long*)&out->xor_hash, (unsigned long long)x);
-        if (want_sumfw) atomicAdd((unsigned long long*)&out->sum_fw, (unsigned long long)f);
+        if constexpr (K <= 32) {
+            kmx_summary* o = static_cast<kmx_summary*>(out);
+            atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
+            atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)r0);
+            if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)h0);
+            if (want_sumfw) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
+        } else {
+            kmx_summary2* o = static_cast<kmx_summary2*>(out);
+            atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
+            atomicAdd((unsigned long long*)&o->sum_lo, (unsigned long long)r0);
+            atomicAdd((unsigned long long*)&o->sum_hi, (unsigned long long)r1);
+            if (want_hash) {
+                atomicXor((unsigned long long*)&o->xor_lo, (unsigned long long)h0);
+                atomicXor((unsigned long long*)&o->xor_hi, (unsigned long long)h1);
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------ launcher
 
 template <int K, int NW, int WPL>
-static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, kmx_summary* out,
+static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
                             unsigned long long* queue, int n_cu, hipStream_t stream) {
     auto kern = scan_bitsliced_kernel<K, NW, WPL>;
     const u32 chunks = 4u * L;
@@ -521,6 +534,18 @@ hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k
         return launch_bs<21, 10, 5>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
     }
     return hipSuccess;
+}
+
+// [u64;2] k-mers: k = 63 is instantiated (BASELINE configs[2]); other k in 33..64 take the generic kernel
+hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
+                                  unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
+    *handled = false;
+    if (k != 63 || L < k || L > 160 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
+    if (n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
+    const u32 W = L - k + 1u;
+    *handled = true;
+    if (W <= 64u) return launch_bs<63, 10, 2>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
+    return launch_bs<63, 10, 3>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
 }
 
 }  // namespace kmx

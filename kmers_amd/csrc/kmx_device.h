@@ -160,4 +160,50 @@ __device__ __forceinline__ void roll_read(const uint8_t* __restrict__ s, u32 len
     for (; l < len; ++l) step(s[l], l);
 }
 
+// ---------------------------------------------------------------- [u64;2] k-mers (k in 33..64), BUILD-DEFINED
+struct U128 {
+    u64 lo, hi;
+};
+__device__ __forceinline__ bool lt128(U128 a, U128 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+
+// 2-bit-group reversal of the 2k-bit value (the [u64;2] analogue of LexHasher, hash.rs:60-71)
+__device__ __forceinline__ U128 lex_hash128(U128 c, u32 k) {
+    const u32 sh = 2u * (64u - k);  // 0..62
+    const u64 rl = revgroups64(c.hi), rh = revgroups64(c.lo);
+    U128 h;
+    h.lo = sh ? ((rl >> sh) | (rh << (64u - sh))) : rl;
+    h.hi = rh >> sh;
+    return h;
+}
+
+// same control flow as the iterator (canonical_kmer_iterator.rs:42-70), arithmetic of kmer.rs:91-102 on 128 bits
+template <typename Emit>
+__device__ __forceinline__ void roll_read2(const uint8_t* __restrict__ s, u32 len, u32 k, Emit&& emit) {
+    const u32 kb = 2u * k;  // 66..128
+    const U128 mask = {~0ull, kb >= 128u ? ~0ull : ((1ull << (kb - 64u)) - 1ull)};
+    const u32 top = kb - 2u - 64u;  // bit position of the newest base inside .hi (k>=33)
+    U128 fw = {0, 0}, rc = {~0ull, ~0ull};
+    int last_invalid = -1;
+    auto step = [&](u32 c, u32 l) {
+        const u32 b = encode_base(c);
+        if (b < 4u) {
+            fw.lo = (fw.lo >> 2) | (fw.hi << 62);
+            fw.hi = (fw.hi >> 2) | ((u64)b << top);
+            rc.hi = ((rc.hi << 2) | (rc.lo >> 62)) & mask.hi;
+            rc.lo = (rc.lo << 2) | (u64)(3u - b);
+            if ((int)l - last_invalid >= (int)k) emit(l + 1u - k, fw, rc);
+        } else {
+            last_invalid = (int)l;
+        }
+    };
+    u32 l = 0;
+    for (; l + 8u <= len; l += 8u) {
+        u64 v;
+        __builtin_memcpy(&v, s + l, 8);
+#pragma unroll
+        for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
+    }
+    for (; l < len; ++l) step(s[l], l);
+}
+
 }  // namespace kmx
