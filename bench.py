@@ -135,8 +135,18 @@ def main():
     out = ctx.empty(4, torch.int64)
     torch.cuda.synchronize()
 
+    two_word = k > 32   # [u64;2] k-mers (BASELINE configs[2], k=63): kmx_canonical_reduce2, build-defined order/hash
+    if two_word:
+        import ctypes as C
+
+        out = ctx.empty(5, torch.int64)
+        rd = ctx._reads(bases, n, L, None)
+
     def step():
-        ctx.canonical_reduce_async(bases, n, L, k, hasher, hk, 0, out=out)
+        if two_word:
+            ctx._ck(ctx.lib.kmx_canonical_reduce2(ctx._h, C.byref(rd), k, int(args.hash), C.c_void_p(out.data_ptr())))
+        else:
+            ctx.canonical_reduce_async(bases, n, L, k, hasher, hk, 0, out=out)
 
     for _ in range(args.warmup):
         step()
@@ -168,7 +178,7 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
-    tot = kd.combine_summaries({"n_valid": n_valid, "sum_canon": sum_canon, "xor_hash": int(summ[2]), "sum_fw": 0},
+    tot = kd.combine_summaries({"n_valid": n_valid, "sum_canon": sum_canon, "xor_hash": int(summ[2]) if not two_word else 0, "sum_fw": 0},
                                device=ctx.device)   # wrapping add / xor of the per-shard summaries
     total_kmers_per_step = tot["n_valid"]
 
@@ -198,9 +208,14 @@ def main():
 
         n_chk = min(n, 200_000)
         host = bases[: n_chk * L].cpu().numpy()
-        o = oracle.canonical_reduce(host, n_chk, L, k, hasher_k=hk)
-        g = ctx.canonical_reduce(bases[: n_chk * L], n_chk, L, k, hasher, hk, 0)
-        parity = (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash if args.hash else 0)
+        if two_word:
+            o = oracle.canonical_reduce2(host, n_chk, L, k, with_hash=args.hash)
+            g = ctx.canonical_reduce2(bases[: n_chk * L], n_chk, L, k, with_hash=args.hash)
+            parity = tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
+        else:
+            o = oracle.canonical_reduce(host, n_chk, L, k, hasher_k=hk)
+            g = ctx.canonical_reduce(bases[: n_chk * L], n_chk, L, k, hasher, hk, 0)
+            parity = (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash if args.hash else 0)
         parity = parity and n_valid == n * max(L - k + 1, 0)
         traffic = None
         try:   # HBM bytes per launch from the committed PMC passes (same kernel, same workload only)
@@ -232,7 +247,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": "kmx::scan_bitsliced_kernel<%d,10>" % k if k in (21, 31) and L <= 160 else "kmx::scan_uniform_kernel",
+                "kernel": ("kmx::scan_bitsliced_kernel<%d,%d,*>" % (k, 10 if L <= 160 else 16)) if k in (21, 31, 63) and L <= 256 else "kmx::scan_uniform_kernel",
                 "avg_kernel_ms": avg_kernel_ms, "min_kernel_ms": min(kernel_ms),
                 "median_kernel_ms": sorted(kernel_ms)[len(kernel_ms) // 2], "algorithmic_bytes_per_launch": algo_bytes,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
@@ -242,7 +257,7 @@ def main():
         }
         if hist_info is not None:
             res["histogram"] = hist_info
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not two_word:
             n_s = min(n, 4_000_000)
             res["cpu_baseline"] = cpu_baseline(bases[: n_s * L].cpu().numpy(), n_s, L, k)
         print(json.dumps(res), flush=True)
