@@ -38,7 +38,7 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(host_sample, n_reads, L, k, seconds_target=12.0):
+def cpu_baseline(host_sample, n_reads, L, k, seconds_target=20.0):
     """Time the CPU oracle (plain-C port of the reference's naive_impl streaming iterator,
     canonical_kmer_iterator.rs:42-116) on this box's host cores: 1 thread and all threads."""
     import numpy as np
@@ -47,12 +47,13 @@ def cpu_baseline(host_sample, n_reads, L, k, seconds_target=12.0):
     lib = oracle.lib(native=True)
     cores = usable_cores()
 
-    def run(nthreads, reads_each):
-        outs = [None] * nthreads
+    def run(nthreads, reads_each, reps=1):
+        outs = [0] * nthreads
 
         def work(i):
             lo = (i * reads_each) % max(n_reads - reads_each + 1, 1)
-            outs[i] = oracle.canonical_reduce(host_sample[lo * L:(lo + reads_each) * L], reads_each, L, k, native_lib=lib)
+            for _ in range(reps):   # the sample is re-scanned when it is smaller than the time budget
+                outs[i] += oracle.canonical_reduce(host_sample[lo * L:(lo + reads_each) * L], reads_each, L, k, native_lib=lib).n_valid
 
         ts = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
         t0 = time.perf_counter()
@@ -61,16 +62,20 @@ def cpu_baseline(host_sample, n_reads, L, k, seconds_target=12.0):
         for t in ts:
             t.join()
         dt = time.perf_counter() - t0
-        return sum(o.n_valid for o in outs) / dt, dt
+        return sum(outs) / dt, dt
 
     # calibrate each leg on a small slice, then size its sample for ~seconds_target/2 of wall time
     per = L - k + 1
     rate1, _ = run(1, min(n_reads, 20_000))
-    reads_1t = int(min(n_reads, max(20_000, rate1 * (seconds_target / 2) / per)))
-    rate1, dt1 = run(1, reads_1t)
+    want_1t = max(20_000, rate1 * (seconds_target / 2) / per)
+    reads_1t = int(min(n_reads, want_1t))
+    reps_1t = max(1, int(round(want_1t / reads_1t)))
+    rate1, dt1 = run(1, reads_1t, reps_1t)
     rate_mt, _ = run(cores, min(n_reads, 20_000))
-    reads_mt = int(min(n_reads, max(20_000, rate_mt / cores * (seconds_target / 2) / per)))
-    rate_mt, dt_mt = run(cores, reads_mt)
+    want_mt = max(20_000, rate_mt / cores * (seconds_target / 2) / per)
+    reads_mt = int(min(n_reads // cores if n_reads >= cores * 20_000 else n_reads, want_mt))
+    reps_mt = max(1, int(round(want_mt / reads_mt)))
+    rate_mt, dt_mt = run(cores, reads_mt, reps_mt)
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -83,8 +88,8 @@ def cpu_baseline(host_sample, n_reads, L, k, seconds_target=12.0):
     return {
         "value": rate_mt, "unit": "canonical k-mers/s", "cores": cores, "kind": "port",
         "value_1thread": rate1,
-        "sample": f"{cores} threads x {reads_mt} reads x {L} bp (same synthetic stream as the GPU run), k={k}, "
-                  f"{dt_mt:.1f}s; 1 thread x {reads_1t} reads {dt1:.1f}s; oracle = plain-C port of "
+        "sample": f"{cores} threads x {reads_mt} reads x {reps_mt} passes x {L} bp (same synthetic stream as the GPU run), k={k}, "
+                  f"{dt_mt:.1f}s; 1 thread x {reads_1t} reads x {reps_1t} passes {dt1:.1f}s; oracle = plain-C port of "
                   f"naive_impl CanonicalKmerIterator, gcc -O3 -march=native",
         "cpu_model": model,
     }

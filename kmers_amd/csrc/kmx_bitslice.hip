@@ -290,8 +290,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #endif
 #pragma unroll
             for (int s = 3; s < 5; ++s) {
+#if KMX_BS_SWZ == 2
+                const u32 y = s == 3 ? (u32)__builtin_amdgcn_ds_swizzle((int)x, (2 << 10) | 0x1f)
+                                     : (u32)__builtin_amdgcn_ds_swizzle((int)x, (1 << 10) | 0x1f);
+#else
                 const u32 y = s == 3 ? (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, false)
                                      : (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+#endif
                 const u32 rot = alignbit(y, y, tr_sh[s]);
                 x = (x & tr_keep[s]) | (rot & ~tr_keep[s]);
             }

@@ -28,6 +28,9 @@ __device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh) { return __built
 #ifndef KMX_BS_ABLATE
 #define KMX_BS_ABLATE 0
 #endif
+#ifndef KMX_ENC_CHAIN
+#define KMX_ENC_CHAIN 0
+#endif
 __device__ __forceinline__ u32 encode16(uint4 w, u32& bad) {
 #if (KMX_BS_ABLATE & 16)
     bad |= 0u;
@@ -51,7 +54,13 @@ __device__ __forceinline__ u32 encode16(uint4 w, u32& bad) {
     const u32 d1 = __builtin_amdgcn_udot4(t1, W4, 0u, false);
     const u32 d2 = __builtin_amdgcn_udot4(t2, W4, 0u, false);
     const u32 d3 = __builtin_amdgcn_udot4(t3, W4, 0u, false);
+#if KMX_ENC_CHAIN
+    u32 p = (d1 << 8) | d0;          // v_lshl_or_b32 chain: 2 half-rate ops instead of lshl, lshl, or3
+    p = (d2 << 16) | p;
+    p = (d3 << 23) | (p >> 1);
+#else
     u32 p = ((d0 | (d1 << 8) | (d2 << 16)) >> 1) | (d3 << 23);
+#endif
     p ^= (p >> 1) & 0x55555555u;  // internal (ACTG) -> naive_impl (ACGT) codes
     return p;
 }
