@@ -33,6 +33,9 @@
 #ifndef KMX_BS_WAVES
 #define KMX_BS_WAVES 3      // waves per SIMD the register allocation is sized for
 #endif
+#ifndef KMX_BS_PIPE
+#define KMX_BS_PIPE 1      // per-tile phase order, see the main loop
+#endif
 #ifndef KMX_BS_SWZ
 #define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
 #endif
@@ -60,6 +63,10 @@ __device__ __forceinline__ void plane_weights(u32 i, u32 L, u32 k, u64& wf, u64&
 // one step of the fw<rc ripple: lt' = (~a & ~q) | ((a ^ q) & lt) as a single v_bitop3_b32
 // (truth table with S0=lt=0xF0, S1=a=0xCC, S2=q=0xAA: 0x11 | (0x66 & 0xF0) = 0x71)
 __device__ __forceinline__ u32 ripple(u32 lt, u32 a, u32 q) { return __builtin_amdgcn_bitop3_b32(lt, a, q, 0x71); }
+
+// keep ? x : y per bit as ONE full-rate v_bitop3_b32 (hipcc otherwise emits v_and + half-rate v_and_or)
+// (S0=x=0xF0, S1=y=0xCC, S2=keep=0xAA: (0xF0 & 0xAA) | (0xCC & 0x55) = 0xE4)
+__device__ __forceinline__ u32 bitsel(u32 x, u32 y, u32 keep) { return __builtin_amdgcn_bitop3_b32(x, y, keep, 0xE4); }
 
 // d += popcount(x) as ONE v_bcnt_u32_b32 (hipcc otherwise splits it into v_bcnt(x,0) + v_add3_u32)
 __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x)); }
@@ -196,48 +203,29 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
         return ~0ull;
     };
-    u64 tile = dequeue();
-    u64 next_tile = dequeue();
-    if (KMX_BS_PREFETCH && tile < n_full) issue_loads(tile);
-    while (tile < n_full) {
-        const u64 succ = next_tile;
-        auto advance = [&]() {
-            tile = next_tile;
-            next_tile = dequeue();
-        };
-#ifdef KMX_BS_TIMING
-        u64 t_last = __builtin_readcyclecounter();
-#endif
-        if (!KMX_BS_PREFETCH) issue_loads(tile);
-        // ---- A. pack + validate the tile loaded during the previous iteration
-#ifdef KMX_BS_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        KMX_T(0)
-#endif
+    // ---- per-tile phases (bodies shared by both pipeline orders)
+    auto phase_A = [&]() -> bool {   // pack + validate the tile sitting in w[] into the packed LDS buffer
         u32 bad = 0;
+        if (chunks >= 64u * (NW - 1)) {   // wave-uniform: only the last row of chunks is partial (L = 150: 600 = 9*64 + 24)
 #pragma unroll
-        for (int it = 0; it < NW; ++it) {
-            const u32 c = it * 64u + lane;
-            if (c < chunks) P[1u + c] = encode16(w[it], bad);
+            for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode16(w[it], bad);
+            const u32 c = (NW - 1) * 64u + lane;
+            if (c < chunks) P[1u + c] = encode16(w[NW - 1], bad);
+        } else {
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const u32 c = it * 64u + lane;
+                if (c < chunks) P[1u + c] = encode16(w[it], bad);
+            }
         }
-        {   // prefetch (clamped, so unconditional and in this basic block; pinned here by the sched barriers)
-            const u64 nxt = succ < n_full ? succ : tile;
-            __builtin_amdgcn_sched_barrier(0);
-            if (KMX_BS_PREFETCH && !(KMX_BS_ABLATE & 128)) issue_loads(nxt);   // (dev) 128: compute-only, keep re-using the first tile
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        return __any(chunk_has_invalid(bad));
+    };
+    auto lds_fence = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        KMX_T(1)
-
-        if (__any(chunk_has_invalid(bad))) {
-            fallback_read(bases + (tile * 64u + lane) * (u64)L);
-            advance();
-            continue;
-        }
-
-        if (KMX_BS_ABLATE & 32) { mcnt += bad; n_bs_tiles += 1; advance(); continue; }
+    };
+    auto phase_BC = [&]() {
         // ---- B. this lane's read, realigned: F[g] = bases [16g, 16g+16)
         u32 F[NW];
         {
@@ -247,7 +235,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
             for (int g = 0; g < NW; ++g) F[g] = alignbit(R[g + 1], R[g], aF);
         }
-        KMX_T(2)
         // ---- C. transpose each 32 reads x 32 bits block across the 32 lanes of the half-wave, entirely in
         //      the VALU (no LDS round trips): butterfly stage d exchanges with lane^d and keeps/merges the
         //      bits whose index has bit d clear/set.
@@ -267,7 +254,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                                       : (u32)__builtin_amdgcn_ds_swizzle((int)x, (4 << 10) | 0x1f);
                 if (s3 == 0) x = __builtin_amdgcn_perm(y, x, tr_sel16);
                 else if (s3 == 1) x = __builtin_amdgcn_perm(y, x, tr_sel8);
-                else { const u32 rot = alignbit(y, y, tr_sh[2]); x = (x & tr_keep[2]) | (rot & ~tr_keep[2]); }
+                else { const u32 rot = alignbit(y, y, tr_sh[2]); x = bitsel(x, rot, tr_keep[2]); }
             }
 #else
             {   // d = 16
@@ -285,7 +272,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 u32 y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
                 y = (u32)__builtin_amdgcn_update_dpp((int)y, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
                 const u32 rot = alignbit(y, y, tr_sh[2]);
-                x = (x & tr_keep[2]) | (rot & ~tr_keep[2]);
+                x = bitsel(x, rot, tr_keep[2]);
             }
 #endif
 #pragma unroll
@@ -294,11 +281,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 const u32 y = s == 3 ? (u32)__builtin_amdgcn_ds_swizzle((int)x, (2 << 10) | 0x1f)
                                      : (u32)__builtin_amdgcn_ds_swizzle((int)x, (1 << 10) | 0x1f);
 #else
-                const u32 y = s == 3 ? (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, false)
-                                     : (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+                const u32 y = s == 3 ? (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true)
+                                     : (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
 #endif
                 const u32 rot = alignbit(y, y, tr_sh[s]);
-                x = (x & tr_keep[s]) | (rot & ~tr_keep[s]);
+                x = bitsel(x, rot, tr_keep[s]);
             }
             }
             {   // plane index q = 32g+p  <->  base beta = 16g + p/2, bit p&1
@@ -308,11 +295,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             atomicAdd(&TOT[half * PLANES + 32u * g + p], (u32)__builtin_popcount(x));   // ds_add_u32, no return: no LDS round trip
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lds_fence();
 
-        KMX_T(3)
+    };
+    auto phase_D = [&]() {
         // ---- D. a lane handles the WPL windows o..o+WPL-1 of one set (o = WPL*group): they share the planes of
         //      bases o..o+K+WPL-2, streamed twice from LDS as u64 (2 planes per base):
         //      pass 1 = four interleaved fw<rc ripples, pass 2 = masked popcounts.
@@ -373,9 +359,71 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
 #undef KMX_PLANE
         n_bs_tiles += 1;
-        KMX_T(4)
-        advance();
+    };
+    auto prefetch = [&](u64 t, u64 fallback_t) {   // clamped => unconditional, one basic block, pinned by sched barriers
+        const u64 nxt = t < n_full ? t : fallback_t;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(KMX_BS_ABLATE & 128)) issue_loads(nxt);   // (dev) 128: compute-only
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+#if KMX_BS_PIPE == 2
+    // Pipeline order 2: [B,C of tile t] [A of tile t+1] [D of tile t] [issue loads of tile t+2].
+    // The 4*NW landing registers of the prefetch are then dead during phase D, the register-pressure peak.
+    u64 tile = dequeue();
+    u64 tile1 = dequeue();
+    bool cur_bad = false;
+    if (tile < n_full) {
+        issue_loads(tile);
+        cur_bad = phase_A();
+        lds_fence();
     }
+    u64 tile2 = dequeue();
+    if (tile < n_full) prefetch(tile1, tile);
+    while (tile < n_full) {
+        if (!cur_bad) phase_BC();
+        bool next_bad = false;
+        if (tile1 < n_full) {
+            next_bad = phase_A();          // consumes the loads issued one iteration ago
+            lds_fence();
+        }
+        if (cur_bad) fallback_read(bases + (tile * 64u + lane) * (u64)L);
+        else phase_D();
+        prefetch(tile2, tile);
+        tile = tile1;
+        tile1 = tile2;
+        tile2 = dequeue();
+        cur_bad = next_bad;
+    }
+#else
+    // Pipeline order 1: [A of tile t] [issue loads of tile t+1] [B,C,D of tile t]
+    u64 tile = dequeue();
+    u64 next_tile = dequeue();
+    if (tile < n_full) issue_loads(tile);
+    while (tile < n_full) {
+#ifdef KMX_BS_TIMING
+        u64 t_last = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KMX_T(0)
+#endif
+        const bool bad_tile = phase_A();
+        prefetch(next_tile, tile);
+        lds_fence();
+        KMX_T(1)
+        if (bad_tile) {
+            fallback_read(bases + (tile * 64u + lane) * (u64)L);
+        } else if (!(KMX_BS_ABLATE & 32)) {
+            phase_BC();
+            KMX_T(3)
+            phase_D();
+            KMX_T(4)
+        } else {
+            n_bs_tiles += 1;
+        }
+        tile = next_tile;
+        next_tile = dequeue();
+    }
+#endif
 #ifdef KMX_BS_TIMING
     if (lane == 0 && wave_id < 4096) {
         u64* dbg = reinterpret_cast<u64*>(out) + 8 + wave_id * 8;

@@ -29,8 +29,16 @@ __device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh) { return __built
 #define KMX_BS_ABLATE 0
 #endif
 #ifndef KMX_ENC_CHAIN
-#define KMX_ENC_CHAIN 0
+#define KMX_ENC_CHAIN 1
 #endif
+// a 32-bit constant materialised in a VGPR (pure, so it is hoisted out of loops and shared)
+template <u32 C>
+__device__ __forceinline__ u32 vgpr_const() {
+    u32 r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "i"(C));
+    return r;
+}
+
 __device__ __forceinline__ u32 encode16(uint4 w, u32& bad) {
 #if (KMX_BS_ABLATE & 16)
     bad |= 0u;
@@ -61,8 +69,9 @@ __device__ __forceinline__ u32 encode16(uint4 w, u32& bad) {
 #else
     u32 p = ((d0 | (d1 << 8) | (d2 << 16)) >> 1) | (d3 << 23);
 #endif
-    p ^= (p >> 1) & 0x55555555u;  // internal (ACTG) -> naive_impl (ACGT) codes
-    return p;
+    // internal (ACTG) -> naive_impl (ACGT) codes: p ^ ((p >> 1) & 0x55555555) as one v_bitop3_b32 whose
+    // constant sits in a VGPR (an SGPR source would halve the issue rate)
+    return __builtin_amdgcn_bitop3_b32(p >> 1, p, vgpr_const<0x55555555u>(), 0x6c);
 }
 
 __device__ __forceinline__ bool chunk_has_invalid(u32 bad) { return (bad & 0xDFDFDFDFu) != 0u; }
