@@ -36,6 +36,9 @@
 #ifndef KMX_BS_PIPE
 #define KMX_BS_PIPE 1      // per-tile phase order, see the main loop
 #endif
+#ifndef KMX_BS_PRIO
+#define KMX_BS_PRIO 1      // raise the wave priority around runs of half-rate VALU instructions
+#endif
 #ifndef KMX_BS_SWZ
 #define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
 #endif
@@ -343,8 +346,37 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 pc_acc(mcnt, m[w]);
             }
             asm volatile("" ::: "memory");   // pass 2 re-reads the planes instead of keeping 2K+6 registers live
+            constexpr int NPL = (KMX_BS_ABLATE & 1) ? 1 : K + WPL - 1;
+#if KMX_BS_PRIO
+            u64 vcur = KMX_PLANE(0);
+#endif
 #pragma unroll
-            for (int i = 0; i < ((KMX_BS_ABLATE & 1) ? 1 : K + WPL - 1); ++i) {
+            for (int i = 0; i < NPL; ++i) {
+#if KMX_BS_PRIO
+                // Hand-scheduled: [LDS read of the next plane] [full-rate v_and of this plane] [half-rate v_bcnt run at
+                // raised wave priority].  gfx950 co-issues another wave's full-rate instructions next to a half-rate
+                // run only when the wave running it outranks the others (tools/ubench7.hip: 108 -> 65 ns per
+                // 32 and + 32 bcnt), so the runs are kept apart and bracketed by s_setprio.
+                const u64 vnext = KMX_PLANE(i + 1 < NPL ? i + 1 : i);
+                __builtin_amdgcn_sched_barrier(0);
+                const u32 p0 = (u32)vcur, p1 = (u32)(vcur >> 32);
+                u32 x[2 * WPL];
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) { x[2 * w] = m[w] & p0; x[2 * w + 1] = m[w] & p1; }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) {
+                    const int t = i - w;                 // plane i is base t of window w
+                    if (t < 0 || t > K - 1) continue;
+                    const int tc = t < K - 1 - t ? t : K - 1 - t;
+                    pc_acc(D[2 * tc], x[2 * w]);
+                    pc_acc(D[2 * tc + 1], x[2 * w + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(0);
+                vcur = vnext;
+#else
                 const u64 v = KMX_PLANE(i);
                 const u32 p0 = (u32)v, p1 = (u32)(v >> 32);
 #pragma unroll
@@ -355,6 +387,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     pc_acc(D[2 * tc], m[w] & p0);
                     pc_acc(D[2 * tc + 1], m[w] & p1);
                 }
+#endif
             }
         }
 #undef KMX_PLANE
