@@ -37,7 +37,7 @@
 #define KMX_BS_PIPE 1      // per-tile phase order, see the main loop
 #endif
 #ifndef KMX_BS_PRIO
-#define KMX_BS_PRIO 1      // raise the wave priority around runs of half-rate VALU instructions
+#define KMX_BS_PRIO 2      // raise the wave priority around runs of half-rate VALU instructions (1: phases A and D, 2: also B/C stage-major)
 #endif
 #ifndef KMX_BS_SWZ
 #define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
@@ -170,6 +170,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // pointers stay live across the loop
     const u32 lane16 = lane * 16u;
     const u32 last_off = (chunks - 1u) * 16u;
+    const bool short_rows = chunks < 64u * (NW - 1);   // reads so short that whole rows of the NW x 64 chunk grid lie past the tile
     auto issue_loads = [&](u64 tile) {
         const uint8_t* __restrict__ tb = bases + tile * 64u * (u64)L;
 #pragma unroll
@@ -177,7 +178,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             // lanes past the tile end re-read its last chunk: no branch, so all loads of a tile sit in
             // one basic block and stay in flight together (a guarded load would be fenced by vmcnt(0))
             u32 off = lane16 + (u32)it * 1024u;
-            if (it == NW - 1) off = off < last_off ? off : last_off;
+            if (it == NW - 1 || short_rows) off = off < last_off ? off : last_off;
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb + off));  // streamed once
             w[it] = make_uint4(v.x, v.y, v.z, v.w);
@@ -207,9 +208,54 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         return ~0ull;
     };
     // ---- per-tile phases (bodies shared by both pipeline orders)
+    // encode16, hand-scheduled for the VALU co-issue rule of gfx950 (see phase D, pass 2): the half-rate instructions
+    // (v_perm_b32 validation look-ups; v_dot4_u32_u8 packs + v_lshl_or_b32 merges) run as two raised-priority runs
+    // (one asm statement each, so that nothing else is scheduled into them), the full-rate ones (v_and, v_xor,
+    // v_bitop3, v_lshrrev) around them at base priority.
+    const u32 k55 = vgpr_const<0x55555555u>();
+    auto encode_prio = [&](const uint4& wv, u32& bad) -> u32 {
+        constexpr u32 TBL_LO = 0x00430041u, TBL_HI = 0x00470054u, W4 = 0x40100401u;   // as in encode16
+        u32 t0 = wv.x & 0x06060606u, t1 = wv.y & 0x06060606u, t2 = wv.z & 0x06060606u, t3 = wv.w & 0x06060606u;
+        u32 e0, e1, e2, e3;
+        asm volatile("s_setprio 3\n\t"
+                     "v_perm_b32 %0, %8, %9, %4\n\t"
+                     "v_perm_b32 %1, %8, %9, %5\n\t"
+                     "v_perm_b32 %2, %8, %9, %6\n\t"
+                     "v_perm_b32 %3, %8, %9, %7\n\t"
+                     "s_setprio 0"
+                     : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
+                     : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(TBL_HI), "v"(TBL_LO));
+        e0 ^= wv.x;
+        e1 ^= wv.y;
+        e2 ^= wv.z;
+        e3 ^= wv.w;
+        bad = __builtin_amdgcn_bitop3_b32(bad, e0, e1, 0xFE);
+        bad = __builtin_amdgcn_bitop3_b32(bad, e2, e3, 0xFE);
+        // 2 * (4 bases in 8 bits) per dword, merged to 16 bases in 32 bits: ((d0 | d1<<8 | d2<<16) >> 1) | d3<<23
+        asm volatile("s_setprio 3\n\t"
+                     "v_dot4_u32_u8 %0, %0, %4, 0\n\t"
+                     "v_dot4_u32_u8 %1, %1, %4, 0\n\t"
+                     "v_dot4_u32_u8 %2, %2, %4, 0\n\t"
+                     "v_dot4_u32_u8 %3, %3, %4, 0\n\t"
+                     "s_nop 0\n\t"   // gfx940+: a VALU read of a DOT result needs 3 wait states (hipcc does not look inside asm)
+                     "v_lshl_or_b32 %0, %1, 8, %0\n\t"
+                     "v_lshl_or_b32 %0, %2, 16, %0\n\t"
+                     "v_lshrrev_b32 %0, 1, %0\n\t"
+                     "v_lshl_or_b32 %0, %3, 23, %0\n\t"
+                     "s_setprio 0"
+                     : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3)
+                     : "s"(W4));
+        return __builtin_amdgcn_bitop3_b32(t0 >> 1, t0, k55, 0x6c);   // internal (ACTG) -> naive_impl (ACGT) codes
+    };
     auto phase_A = [&]() -> bool {   // pack + validate the tile sitting in w[] into the packed LDS buffer
         u32 bad = 0;
-        if (chunks >= 64u * (NW - 1)) {   // wave-uniform: only the last row of chunks is partial (L = 150: 600 = 9*64 + 24)
+        if (KMX_BS_PRIO && !(KMX_BS_ABLATE & 24) && chunks >= 64u * (NW - 1)) {
+            // wave-uniform: only the last row of chunks is partial (L = 150: 600 = 9*64 + 24)
+#pragma unroll
+            for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
+            const u32 c = (NW - 1) * 64u + lane;
+            if (c < chunks) P[1u + c] = encode_prio(w[NW - 1], bad);
+        } else if (chunks >= 64u * (NW - 1)) {
 #pragma unroll
             for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode16(w[it], bad);
             const u32 c = (NW - 1) * 64u + lane;
@@ -235,8 +281,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             u32 R[NW + 1];
 #pragma unroll
             for (int j = 0; j <= NW; ++j) R[j] = P[qF + j];
+            if (KMX_BS_PRIO >= 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3); }
 #pragma unroll
             for (int g = 0; g < NW; ++g) F[g] = alignbit(R[g + 1], R[g], aF);
+            if (KMX_BS_PRIO >= 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
         }
         // ---- C. transpose each 32 reads x 32 bits block across the 32 lanes of the half-wave, entirely in
         //      the VALU (no LDS round trips): butterfly stage d exchanges with lane^d and keeps/merges the
@@ -245,6 +293,62 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         //        d=8 : two bank-masked DPP row shifts            + byte merge (v_perm_b32)
         //        d=4 : two bank-masked DPP row shifts            + rotate (v_alignbit) + bit select (v_bitop3)
         //        d=2,1: DPP quad_perm                             + rotate + bit select
+#if KMX_BS_PRIO >= 2
+        // Stage-major order: every butterfly stage runs over all NW groups, with its half-rate instructions
+        // (v_perm_b32 / v_alignbit_b32 / DPP moves) as one raised-priority run and its full-rate bit selects after it.
+        {
+            u32 Y[NW];
+#define KMX_HRUN_BEGIN __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3);
+#define KMX_HRUN_END __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (16 << 10) | 0x1f);
+            KMX_HRUN_BEGIN
+#pragma unroll
+            for (int g = 0; g < NW; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], tr_sel16);
+            KMX_HRUN_END
+#pragma unroll
+            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (8 << 10) | 0x1f);
+            KMX_HRUN_BEGIN
+#pragma unroll
+            for (int g = 0; g < NW; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], tr_sel8);
+            KMX_HRUN_END
+#pragma unroll
+            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (4 << 10) | 0x1f);
+            KMX_HRUN_BEGIN
+#pragma unroll
+            for (int g = 0; g < NW; ++g) Y[g] = alignbit(Y[g], Y[g], tr_sh[2]);
+            KMX_HRUN_END
+#pragma unroll
+            for (int g = 0; g < NW; ++g) F[g] = bitsel(F[g], Y[g], tr_keep[2]);
+#pragma unroll
+            for (int st = 3; st < 5; ++st) {
+                KMX_HRUN_BEGIN
+#pragma unroll
+                for (int g = 0; g < NW; ++g)
+                    Y[g] = st == 3 ? (u32)__builtin_amdgcn_update_dpp(0, (int)F[g], 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true)
+                                   : (u32)__builtin_amdgcn_update_dpp(0, (int)F[g], 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+#pragma unroll
+                for (int g = 0; g < NW; ++g) Y[g] = alignbit(Y[g], Y[g], tr_sh[st]);
+                KMX_HRUN_END
+#pragma unroll
+                for (int g = 0; g < NW; ++g) F[g] = bitsel(F[g], Y[g], tr_keep[st]);
+            }
+#pragma unroll
+            for (int g = 0; g < NW; ++g) {
+                const u32 beta = 16u * g + (p >> 1);
+                const u32 slot = (WPL == 4) ? (beta & 3u) * S2 + (beta >> 2) : beta;
+                PL[half * PLANES + 2u * slot + (p & 1u)] = F[g];
+            }
+            KMX_HRUN_BEGIN
+#pragma unroll
+            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_popcount(F[g]);
+            KMX_HRUN_END
+#pragma unroll
+            for (int g = 0; g < NW; ++g) atomicAdd(&TOT[half * PLANES + 32u * g + p], Y[g]);
+#undef KMX_HRUN_BEGIN
+#undef KMX_HRUN_END
+        }
+#else
 #pragma unroll
         for (int g = 0; g < NW; ++g) {
             u32 x = F[g];
@@ -298,6 +402,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             atomicAdd(&TOT[half * PLANES + 32u * g + p], (u32)__builtin_popcount(x));   // ds_add_u32, no return: no LDS round trip
         }
+#endif
         lds_fence();
 
     };
