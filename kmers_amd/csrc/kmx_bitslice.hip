@@ -322,11 +322,19 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             for (int g = 0; g < NW; ++g) F[g] = bitsel(F[g], Y[g], tr_keep[2]);
 #pragma unroll
             for (int st = 3; st < 5; ++st) {
+#if KMX_BS_SWZ == 2
+#pragma unroll
+                for (int g = 0; g < NW; ++g)
+                    Y[g] = st == 3 ? (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (2 << 10) | 0x1f)
+                                   : (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (1 << 10) | 0x1f);
+                KMX_HRUN_BEGIN
+#else
                 KMX_HRUN_BEGIN
 #pragma unroll
                 for (int g = 0; g < NW; ++g)
                     Y[g] = st == 3 ? (u32)__builtin_amdgcn_update_dpp(0, (int)F[g], 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true)
                                    : (u32)__builtin_amdgcn_update_dpp(0, (int)F[g], 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+#endif
 #pragma unroll
                 for (int g = 0; g < NW; ++g) Y[g] = alignbit(Y[g], Y[g], tr_sh[st]);
                 KMX_HRUN_END
