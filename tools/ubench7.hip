@@ -54,7 +54,7 @@ int main() {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     struct { const char* name; void (*fn)(uint32_t*, uint32_t); double scale; } es[] = {
         {"no setprio, runs of 32", k_n32, 1}, {"setprio, runs of 4", k_p4, 1}, {"setprio, runs of 8", k_p8, 1},
-        {"setprio, runs of 16", k_p16, 1}, {"setprio, runs of 32", k_p32, 1}, {"setprio, runs of 256", k_p128, 0.125},
+        {"setprio, runs of 16", k_p16, 1}, {"setprio, runs of 32", k_p32, 1}, {"setprio, runs of 128", k_p128, 0.25},
         {"inverse (hi in and), 32", k_i32, 1}, {"setprio, runs of 2", k_p2, 1}, {"setprio, runs of 1", k_p1, 1},
         {"static prio by block, run 1", k_s1, 1}, {"static prio by block, run 32", k_s32, 1}};
     printf("ns per (32 v_and + 32 v_bcnt) per wave per SIMD; 85 = and at 2 cycles, 112 = everything at 4 cycles\n");
