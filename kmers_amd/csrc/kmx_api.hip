@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -16,7 +17,8 @@ typedef uint64_t u64;
 hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 hasher, u32 hk, u32 log2_buckets,
-                               u64* counts, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+                               u64* counts, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
+                               void* (*get_scratch)(void*, size_t), void* user, size_t scratch_budget);
 hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon,
                                   uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 // kmx_bitslice.hip
@@ -60,6 +62,8 @@ struct kmx_ctx {
     bool owns_stream;
     int n_cu;
     unsigned long long* d_scratch;  // 8 KiB: [0] first_bad, [16..] tile-queue heads
+    void* d_big;                    // grow-only work buffer of the partitioned histogram (bucket-id streams)
+    size_t big_bytes;
     char last_error[256];
 };
 
@@ -75,6 +79,36 @@ int fail_hip(kmx_ctx* ctx, hipError_t e, const char* where) {
         hipError_t e__ = (expr);                             \
         if (e__ != hipSuccess) return fail_hip(ctx, e__, #expr); \
     } while (0)
+
+// work buffer of the partitioned histogram: grown on demand (hipFree/hipMalloc synchronise, so only when it must grow),
+// kept until the context is destroyed; nullptr => the caller falls back to the global-atomic kernel
+void* big_scratch(void* user, size_t bytes) {
+    kmx_ctx* ctx = static_cast<kmx_ctx*>(user);
+    if (bytes <= ctx->big_bytes) return ctx->d_big;
+    if (ctx->d_big) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->d_big);
+        ctx->d_big = nullptr;
+        ctx->big_bytes = 0;
+    }
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    ctx->d_big = q;
+    ctx->big_bytes = bytes;
+    return q;
+}
+
+// at most 8 GiB (KMX_HIST_SCRATCH_MB overrides) and at most half of the free device memory
+size_t hist_scratch_budget() {
+    size_t budget = (size_t)8 << 30;
+    if (const char* e = std::getenv("KMX_HIST_SCRATCH_MB")) budget = (size_t)std::strtoull(e, nullptr, 10) << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && budget > free_b / 2) budget = free_b / 2;
+    return budget;
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -164,6 +198,8 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, kmx_ctx*
     c->stream = stream;
     c->owns_stream = owns;
     c->d_scratch = nullptr;
+    c->d_big = nullptr;
+    c->big_bytes = 0;
     c->last_error[0] = 0;
     DeviceGuard g(device);
     hipDeviceProp_t prop;
@@ -189,6 +225,7 @@ void kmx_ctx_destroy(kmx_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_big) (void)hipFree(ctx->d_big);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -334,7 +371,8 @@ int kmx_histogram(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t has
         bool handled = false;
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
         KMX_HIP(ctx, kmx::launch_hist_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, hasher, hasher_k,
-                                              log2_buckets, d_counts, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+                                              log2_buckets, d_counts, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled,
+                                              &big_scratch, ctx, hist_scratch_budget()));
         if (handled) return KMX_OK;
     }
     KMX_HIP(ctx, kmx::launch_histogram_generic(reads, k, hasher, hasher_k, log2_buckets, d_counts, ctx->n_cu, ctx->stream));

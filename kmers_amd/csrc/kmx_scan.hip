@@ -44,7 +44,8 @@ struct SinkReduce {
     u64 maskk;
     u32 k;
     static constexpr u32 kLdsDwordsPerWave = 0;
-    __device__ SinkReduce(const ReduceParams&, u32 k_, u32, u32*, u32) : maskk(mask2k(k_)), k(k_) {}
+    static u32 block_lds_dwords(const ReduceParams&) { return 0; }
+    __device__ SinkReduce(const ReduceParams&, u32 k_, u32, u32*, u32, u32*, u32) : maskk(mask2k(k_)), k(k_) {}
     __device__ __forceinline__ void block_done(u64, u32, u32) {}
     __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) {
         const u64 canon = fw < rc ? fw : rc;  // canonical_kmer.rs:113-119
@@ -84,7 +85,8 @@ struct SinkHist {
     u32 hasher, hk, k, b;
     static constexpr u32 kLdsDwordsPerWave = 0;
     __device__ __forceinline__ void block_done(u64, u32, u32) {}
-    __device__ SinkHist(const HistParams& p, u32 k_, u32, u32*, u32)
+    static u32 block_lds_dwords(const HistParams&) { return 0; }
+    __device__ SinkHist(const HistParams& p, u32 k_, u32, u32*, u32, u32*, u32)
         : counts(p.counts), maskk(mask2k(k_)), hasher(p.hasher), hk(p.hk), k(k_), b(p.log2_buckets) {}
     __device__ __forceinline__ void emit(u64 fw, u64 rc) {
         const u64 canon = fw < rc ? fw : rc;
@@ -100,6 +102,207 @@ struct SinkHist {
     __device__ __forceinline__ void tile_fast_done(u32) {}
     __device__ __forceinline__ void finish(const HistParams&) {}
 };
+
+// Histogram, 2^b <= 2^14 buckets: block-private u32 table in LDS (ds_add_u32, no return), merged into d_counts
+// with one u64 atomic per non-empty bucket per block when the block retires.  The global-atomic sink above is bound
+// by the atomic rate (24 G/s => 0.5 s per 1e8 reads); LDS atomics are not.
+struct SinkHistLds {
+    u64* counts;
+    u32* tab;
+    u64 maskk;
+    u32 hasher, hk, k, b, tid;
+    static constexpr u32 kLdsDwordsPerWave = 0;
+    static u32 block_lds_dwords(const HistParams& p) { return 1u << p.log2_buckets; }
+    __device__ SinkHistLds(const HistParams& p, u32 k_, u32, u32*, u32, u32* block_lds, u32 tid_)
+        : counts(p.counts), tab(block_lds), maskk(mask2k(k_)), hasher(p.hasher), hk(p.hk), k(k_), b(p.log2_buckets), tid(tid_) {
+        for (u32 j = tid; j < (1u << b); j += 256u) tab[j] = 0;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void block_done(u64, u32, u32) {}
+    __device__ __forceinline__ void emit(u64 fw, u64 rc) {
+        const u64 canon = fw < rc ? fw : rc;
+        u64 h;
+        if (hasher == KMX_HASH_LEX) h = (hk == k) ? (maskk ^ fw ^ rc ^ canon) : lex_hash(canon, hk);
+        else h = canon;
+        atomicAdd(&tab[(u32)bucket_of(h, b)], 1u);
+    }
+    __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) { emit(fw, rc); }
+    __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) { emit(fw, rc); }
+    __device__ __forceinline__ void begin_read(u64) {}
+    __device__ __forceinline__ void end_read() {}
+    __device__ __forceinline__ void tile_fast_done(u32) {}
+    __device__ __forceinline__ void finish(const HistParams&) {
+        __syncthreads();
+        for (u32 j = tid; j < (1u << b); j += 256u) {
+            const u32 c = tab[j];
+            if (c) atomicAdd((unsigned long long*)&counts[j], (unsigned long long)c);
+        }
+    }
+};
+
+// Histogram, 2^15..2^21 buckets, pass 1 of 2: scatter the bucket ids into 64 partitions (the top 6 bits of the bucket).
+// Every wave owns a private segment of every partition's stream, so no global cursor and no global atomic is
+// involved.  The low b-6 bits of an id are staged in a 128-entry ring per partition in the wave's LDS slice: ONE
+// ds_add_rtn_u32 on a packed {entries appended : 16 | entries written out : 16} word returns the slot and tells
+// whether the ring has room, one ds_write_b16 stores the id.  After every block of 16 windows the rings holding
+// >= 64 ids write one 128-byte row each to their segment, four partitions at a time (one per quarter-wave).
+// Pass 2 (hist_part_reduce_kernel) builds each partition's 2^(b-6)-bucket table in LDS.  Ids that find their ring or
+// their segment full (adversarial input: everything in one partition) go straight to the global table, so the result
+// is exact for every input.
+struct HistPartParams {
+    u64* counts;
+    u32 hasher, hk, log2_buckets;
+    uint16_t* stream;   // [n_waves][64][cap]
+    u32* seg_len;       // [n_waves][64]
+    u32 cap;            // entries per (wave, partition) segment, multiple of 64
+};
+struct SinkHistPart {
+    static constexpr u32 NP = 64, ROW = 128;   // partitions; ring entries per partition (u16)
+    static constexpr u32 kLdsDwordsPerWave = NP * ROW / 2u + 2u * NP;
+    static u32 block_lds_dwords(const HistPartParams&) { return 0; }
+    HistPartParams p;
+    uint16_t* ring;    // [NP][ROW]
+    u32* word;         // [NP] appended (mod 2^16) << 16 | written out (mod 2^16)
+    u32* cur;          // [NP] ids already in this wave's segment of the partition
+    uint16_t* seg;     // this wave's [NP][cap] segments
+    u64 maskk;
+    u32 k, lane, lowbits;
+    __device__ SinkHistPart(const HistPartParams& p_, u32 k_, u32, u32* lds, u32 lane_, u32*, u32)
+        : p(p_), ring(reinterpret_cast<uint16_t*>(lds)), word(lds + NP * ROW / 2u), cur(lds + NP * ROW / 2u + NP),
+          maskk(mask2k(k_)), k(k_), lane(lane_), lowbits(p_.log2_buckets - 6u) {
+        const u64 wave = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);
+        seg = p.stream + wave * NP * (u64)p.cap;
+        word[lane] = 0;
+        cur[lane] = 0;
+        wave_sync();
+    }
+    __device__ __forceinline__ void wave_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ void emit(u64 fw, u64 rc) {
+        const u64 canon = fw < rc ? fw : rc;
+        u64 h;
+        if (p.hasher == KMX_HASH_LEX) h = (p.hk == k) ? (maskk ^ fw ^ rc ^ canon) : lex_hash(canon, p.hk);
+        else h = canon;
+        const u32 bucket = (u32)bucket_of(h, p.log2_buckets);
+        const u32 q = bucket >> lowbits;
+        const u32 w = atomicAdd(&word[q], 0x10000u);
+        const u32 slot = w >> 16;
+        if (((slot - w) & 0xFFFFu) < ROW) ring[q * ROW + (slot & (ROW - 1u))] = (uint16_t)(bucket & ((1u << lowbits) - 1u));
+        else {   // ring full: take the slot back (every slot handed out past the ring is, so the count ends exact) and divert
+            atomicSub(&word[q], 0x10000u);
+            atomicAdd((unsigned long long*)&p.counts[bucket], 1ull);
+        }
+    }
+    // ids staged and not yet written out
+    static __device__ __forceinline__ u32 staged(u32 w) { return ((w >> 16) - w) & 0xFFFFu; }
+    // The whole wave: every ring with a full 64-id half row writes it out; quarter-wave j handles one ring per round.
+    __device__ __forceinline__ void flush_rows() {
+        wave_sync();
+        u64 m = __ballot(staged(word[lane]) >= 64u);
+        const u32 quarter = lane >> 4, l16 = lane & 15u;
+        while (m) {
+            u32 q = NP;   // this quarter-wave's ring of the round (NP = none)
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) {
+                if (m) {
+                    const u32 qq = (u32)__builtin_ctzll(m);
+                    m &= m - 1u;
+                    if (quarter == j) q = qq;
+                }
+            }
+            if (q < NP) {
+                const u32 w = word[q];
+                const u32 pos = cur[q];
+                const u32 half = w & 64u;   // written-out count is a multiple of 64: the row starts at ring entry 0 or 64
+                const uint2 v = *reinterpret_cast<const uint2*>(ring + q * ROW + half + 4u * l16);
+                if (pos + 64u <= p.cap) {
+                    *reinterpret_cast<uint2*>(seg + (u64)q * p.cap + pos + 4u * l16) = v;
+                } else {   // segment full: the 64 ids go to the global table
+                    const u32 hi = q << lowbits;
+                    atomicAdd((unsigned long long*)&p.counts[hi | (v.x & 0xFFFFu)], 1ull);
+                    atomicAdd((unsigned long long*)&p.counts[hi | (v.x >> 16)], 1ull);
+                    atomicAdd((unsigned long long*)&p.counts[hi | (v.y & 0xFFFFu)], 1ull);
+                    atomicAdd((unsigned long long*)&p.counts[hi | (v.y >> 16)], 1ull);
+                }
+                if (l16 == 0) {
+                    if (pos + 64u <= p.cap) cur[q] = pos + 64u;
+                    word[q] = (w & 0xFFFF0000u) | ((w + 64u) & 0xFFFFu);
+                }
+            }
+            wave_sync();
+        }
+    }
+    __device__ __forceinline__ void block_done(u64, u32, u32) { flush_rows(); }
+    __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) { emit(fw, rc); }
+    __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) { emit(fw, rc); }
+    __device__ __forceinline__ void begin_read(u64) {}
+    // slow path: up to W ids per lane since the last flush (what does not fit the rings went to the global table).
+    // The final partial tile calls this with some lanes masked off; flush_rows needs the whole wave, so it waits.
+    __device__ __forceinline__ void end_read() {
+        if (__ballot(1) == ~0ull) {
+            flush_rows();
+            flush_rows();   // a ring can hold two full half rows
+        }
+    }
+    __device__ __forceinline__ void tile_fast_done(u32) {}
+    __device__ __forceinline__ void finish(const HistPartParams&) {
+        flush_rows();
+        flush_rows();
+        // the tails (< 64 ids per ring), one ring at a time
+        for (u32 q = 0; q < NP; ++q) {
+            const u32 w = word[q];
+            const u32 n = staged(w), pos = cur[q];
+            if (lane < n) {
+                const uint16_t e = ring[q * ROW + ((w + lane) & (ROW - 1u))];
+                if (pos + n <= p.cap) seg[(u64)q * p.cap + pos + lane] = e;
+                else atomicAdd((unsigned long long*)&p.counts[(q << lowbits) | e], 1ull);
+            }
+            wave_sync();
+            if (lane == 0 && pos + n <= p.cap) cur[q] = pos + n;
+            wave_sync();
+        }
+        const u64 wave = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);
+        p.seg_len[wave * NP + lane] = cur[lane];
+    }
+};
+
+// pass 2: block (partition q, group g) adds the segments of the waves w == g (mod gridDim.y) into an LDS table
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+hist_part_reduce_kernel(const uint16_t* __restrict__ stream, const u32* __restrict__ seg_len, u32 cap, u32 n_waves,
+                        u32 log2_buckets, u64* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) u32 tab[];
+    const u32 lowbits = log2_buckets - 6u, nb = 1u << lowbits;
+    const u32 q = blockIdx.x;
+    for (u32 j = threadIdx.x; j < nb; j += THREADS) tab[j] = 0;
+    __syncthreads();
+    for (u32 w = blockIdx.y; w < n_waves; w += gridDim.y) {
+        const u32 len = seg_len[(u64)w * 64u + q];
+        const uint16_t* __restrict__ sp = stream + ((u64)w * 64u + q) * (u64)cap;   // cap is a multiple of 64: 128-byte aligned
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* __restrict__ sp8 = reinterpret_cast<const u32x4*>(sp);
+        for (u32 i = threadIdx.x; i < len / 8u; i += THREADS) {
+            const u32x4 v = __builtin_nontemporal_load(sp8 + i);
+            atomicAdd(&tab[v.x & 0xFFFFu], 1u);
+            atomicAdd(&tab[v.x >> 16], 1u);
+            atomicAdd(&tab[v.y & 0xFFFFu], 1u);
+            atomicAdd(&tab[v.y >> 16], 1u);
+            atomicAdd(&tab[v.z & 0xFFFFu], 1u);
+            atomicAdd(&tab[v.z >> 16], 1u);
+            atomicAdd(&tab[v.w & 0xFFFFu], 1u);
+            atomicAdd(&tab[v.w >> 16], 1u);
+        }
+        for (u32 i = (len & ~7u) + threadIdx.x; i < len; i += THREADS) atomicAdd(&tab[sp[i]], 1u);
+    }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < nb; j += THREADS) {
+        const u32 c = tab[j];
+        if (c) atomicAdd((unsigned long long*)&counts[((u64)q << lowbits) | j], (unsigned long long)c);
+    }
+}
 
 struct WindowsParams {
     u64 *fw, *rc, *canon;
@@ -117,7 +320,8 @@ struct SinkWindows {
     uint8_t* TF;   // [64][16] flags
     u64 base;      // slot of window 0 of the current read (slow path)
     u32 W, next, lane;
-    __device__ SinkWindows(const WindowsParams& p_, u32, u32 W_, u32* lds, u32 lane_)
+    static u32 block_lds_dwords(const WindowsParams&) { return 0; }
+    __device__ SinkWindows(const WindowsParams& p_, u32, u32 W_, u32* lds, u32 lane_, u32*, u32)
         : p(p_), T(reinterpret_cast<u64*>(lds)), TF(reinterpret_cast<uint8_t*>(lds + 3u * 64u * PITCH * 2u)), base(0), W(W_), next(0), lane(lane_) {}
     __device__ __forceinline__ void store(u64 slot, u64 fw, u64 rc) {
         const bool lt = fw < rc;
@@ -207,7 +411,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     const u32 mhi = (u32)(maskk >> 32);
     const u32 nwin = omax + 1u;
 
-    Sink sink(params, k, nwin, P + ldsw, lane);
+    Sink sink(params, k, nwin, P + ldsw, lane, lds + 4u * (ldsw + Sink::kLdsDwordsPerWave), threadIdx.x);
 
     auto window = [&](u32 o, u32 f0, u32 f1, u32 f2, u32 g0, u32 g1, u32 g2, u32 sf, u32 sr) {
         if (DW == 2) {
@@ -317,16 +521,25 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
 
 // ------------------------------------------------------------------ launchers
 
-template <int NW, int V, int DW, typename Sink, typename Params>
-static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, const Params& params,
-                             unsigned long long* queue, int n_cu, hipStream_t stream) {
+// `pre(grid)` runs once the grid size is known and may finish filling `params` (the partitioned histogram sizes its
+// per-wave segments from it); it returns false to abandon the launch.
+struct NoPre {
+    bool operator()(u64) const { return true; }
+};
+template <int NW, int V, int DW, typename Sink, typename Params, typename Pre = NoPre>
+static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Params& params,
+                             unsigned long long* queue, int n_cu, hipStream_t stream, Pre pre = Pre()) {
     auto kern = scan_uniform_kernel<NW, V, DW, Sink, Params>;
     const u32 chunks = 4u * L;
     const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
-    const size_t lds_bytes = (size_t)(ldsw + Sink::kLdsDwordsPerWave) * 4u * 4u;
+    const size_t lds_bytes = (size_t)(ldsw + Sink::kLdsDwordsPerWave) * 4u * 4u + (size_t)Sink::block_lds_dwords(params) * 4u;
     static int bpc = 0;
     static size_t bpc_lds = 0;
     if (bpc == 0 || bpc_lds != lds_bytes) {
+        if (lds_bytes > 64u * 1024u) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
         int b = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, 256, lds_bytes);
         if (e != hipSuccess) return e;
@@ -338,6 +551,7 @@ static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, co
     const u64 need = (n_tiles + 3u) / 4u;
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
+    if (!pre(grid)) return hipErrorOutOfMemory;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, params, queue);
     return hipGetLastError();
 }
@@ -347,16 +561,28 @@ static bool scan_domain(const uint8_t* bases, u64 n_reads, u32 L, u32 k) {
     return n_reads * (u64)L < (1ull << 62);
 }
 
-template <typename SinkT, typename Params>
-static hipError_t dispatch(const uint8_t* bases, u64 n_reads, u32 L, u32 k, const Params& p, unsigned long long* queue,
-                           int n_cu, hipStream_t stream) {
+template <typename SinkT, typename Params, typename Pre = NoPre>
+static hipError_t dispatch(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Params p, unsigned long long* queue,
+                           int n_cu, hipStream_t stream, Pre pre = Pre()) {
     const bool big = L > 160;
     if (k <= 16) {
-        if (big) return launch_one<16, 1, 1, SinkT, Params>(bases, n_reads, L, k, p, queue, n_cu, stream);
-        return launch_one<10, 1, 1, SinkT, Params>(bases, n_reads, L, k, p, queue, n_cu, stream);
+        if (big) return launch_one<16, 1, 1, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+        return launch_one<10, 1, 1, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
     }
-    if (big) return launch_one<16, 2, 2, SinkT, Params>(bases, n_reads, L, k, p, queue, n_cu, stream);
-    return launch_one<10, 2, 2, SinkT, Params>(bases, n_reads, L, k, p, queue, n_cu, stream);
+    if (big) return launch_one<16, 2, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+    return launch_one<10, 2, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+}
+
+template <typename Pre>
+static hipError_t dispatch_part(const uint8_t* bases, u64 n_reads, u32 L, u32 k, HistPartParams& p, unsigned long long* queue,
+                                int n_cu, hipStream_t stream, Pre pre) {
+    const bool big = L > 160;
+    if (k <= 16) {
+        if (big) return launch_one<16, 1, 1, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+        return launch_one<10, 1, 1, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+    }
+    if (big) return launch_one<16, 2, 2, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+    return launch_one<10, 2, 2, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
 }
 
 // Each returns hipSuccess and sets *handled=false when (L,k) is outside the fast kernel's domain.
@@ -370,11 +596,68 @@ hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
     return dispatch<SinkReduce<false>>(bases, n_reads, L, k, p, queue, n_cu, stream);
 }
 
+// Histogram over uniform reads.  2^b <= 2^14: block-private LDS tables (SinkHistLds).  2^15..2^21: two passes through
+// 64 partitions (SinkHistPart + hist_part_reduce_kernel) in chunks of reads sized to `scratch_budget` bytes of
+// caller-provided scratch (`get_scratch(user, bytes)` returns a device buffer of at least `bytes`, or nullptr).
+// Larger tables, or no scratch: device-scope u64 atomics (SinkHist).
 hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 hasher, u32 hk, u32 log2_buckets,
-                               u64* counts, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
+                               u64* counts, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
+                               void* (*get_scratch)(void*, size_t), void* user, size_t scratch_budget) {
     *handled = scan_domain(bases, n_reads, L, k);
     if (!*handled) return hipSuccess;
     const HistParams p{counts, hasher, hk, log2_buckets};
+    if (log2_buckets <= 14u) return dispatch<SinkHistLds>(bases, n_reads, L, k, p, queue, n_cu, stream);
+    if (log2_buckets <= 21u && get_scratch != nullptr && n_reads >= 4096u) {
+        const u64 W = L - k + 1u;
+        // scratch per read: 1.5x slack on 2 bytes per window, plus the fixed per-segment pad; chunk the reads to fit
+        u64 chunk = scratch_budget / (3u * W);
+        if (chunk > n_reads) chunk = n_reads;
+        chunk &= ~63ull;
+        if (chunk >= 4096u) {
+            for (u64 first = 0; first < n_reads; first += chunk) {
+                const u64 n = n_reads - first < chunk ? n_reads - first : chunk;
+                HistPartParams pp{counts, hasher, hk, log2_buckets, nullptr, nullptr, 0};
+                u32 n_waves = 0;
+                auto pre = [&](u64 grid) -> bool {
+                    n_waves = (u32)(grid * 4u);
+                    const u64 per_seg = (n * W * 3u / 2u) / ((u64)n_waves * 64u) + 256u;
+                    pp.cap = (u32)((per_seg + 63u) & ~63ull);
+                    if (pp.cap > (1u << 24)) return false;   // 64 * cap must stay below 2^31 (SinkHistPart::dest)
+                    const size_t stream_bytes = (size_t)n_waves * 64u * pp.cap * 2u;
+                    const size_t len_bytes = (size_t)n_waves * 64u * 4u;
+                    char* buf = static_cast<char*>(get_scratch(user, stream_bytes + len_bytes));
+                    if (!buf) return false;
+                    pp.stream = reinterpret_cast<uint16_t*>(buf);
+                    pp.seg_len = reinterpret_cast<u32*>(buf + stream_bytes);
+                    return true;
+                };
+                if (first != 0) {
+                    hipError_t e = hipMemsetAsync(queue, 0, 32 * 128, stream);
+                    if (e != hipSuccess) return e;
+                }
+                // the hook fills pp through the reference captured above; dispatch takes its params by value, so hand it
+                // a proxy that copies the finished pp at launch time
+                hipError_t e = dispatch_part(bases + first * (u64)L, n, L, k, pp, queue, n_cu, stream, pre);
+                if (e == hipErrorOutOfMemory) {   // no scratch: the atomic sink handles the rest
+                    (void)hipGetLastError();
+                    return dispatch<SinkHist>(bases + first * (u64)L, n_reads - first, L, k, p, queue, n_cu, stream);
+                }
+                if (e != hipSuccess) return e;
+                const u32 nb_bytes = 4u << (log2_buckets - 6u);
+                auto red = hist_part_reduce_kernel<512>;
+                if (nb_bytes > 64u * 1024u) {
+                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(red), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_bytes);
+                    if (e != hipSuccess) return e;
+                }
+                const u32 groups = n_waves < 16u ? n_waves : 16u;
+                hipLaunchKernelGGL(red, dim3(64, groups), dim3(512), nb_bytes, stream, pp.stream, pp.seg_len, pp.cap, n_waves,
+                                   log2_buckets, counts);
+                e = hipGetLastError();
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        }
+    }
     return dispatch<SinkHist>(bases, n_reads, L, k, p, queue, n_cu, stream);
 }
 

@@ -321,6 +321,46 @@ def test_histogram_fast_kernel_many_tiles(ctx, orc, b):
     assert (g21.cpu().numpy().view(np.uint64) == o21).all()
 
 
+@pytest.mark.parametrize("b", [10, 14, 15, 18, 21, 22])
+def test_histogram_three_regimes(ctx, orc, b, monkeypatch):
+    """2^b <= 2^14: block-private LDS tables; 2^15..2^21: 64-way partition + LDS tables (here in several chunks of reads,
+    forced by a 4 MiB work buffer); above: device atomics.  All three must equal the oracle, dirty tiles included."""
+    monkeypatch.setenv("KMX_HIST_SCRATCH_MB", "4")
+    rng = np.random.default_rng(100 + b)
+    L, n, k = 150, 64 * 400 + 37, 31
+    host = _dirty(rng, n * L, 0.0003)
+    bases = ctx.to_device(host)
+    o = orc.histogram(host, n, L, k, k, b)
+    g = ctx.histogram(bases, n, L, k, 1, k, b)
+    assert (g.cpu().numpy().view(np.uint64) == o).all()
+    g = ctx.histogram(bases, n, L, k, 1, k, b, counts=g)
+    assert (g.cpu().numpy().view(np.uint64) == 2 * o).all()
+
+
+@pytest.mark.parametrize("b", [12, 16, 20])
+@pytest.mark.parametrize("L,k", [(150, 31), (100, 21), (250, 27), (64, 11)])
+def test_histogram_shapes(ctx, orc, b, L, k):
+    rng = np.random.default_rng(b * 1000 + L)
+    n = 64 * 130 + 5
+    host = _dirty(rng, n * L, 0.0002)
+    o = orc.histogram(host, n, L, k, k, b)
+    g = ctx.histogram(ctx.to_device(host), n, L, k, 1, k, b)
+    assert (g.cpu().numpy().view(np.uint64) == o).all()
+
+
+@pytest.mark.parametrize("b", [12, 20])
+def test_histogram_adversarial_single_bucket(ctx, orc, b):
+    """every k-mer identical: one staging row / one partition segment takes everything and must spill to the exact fallback"""
+    L, n, k = 150, 64 * 200, 31
+    host = np.frombuffer(b"A" * (n * L), dtype=np.uint8).copy()
+    host[1234 * L + 7] = ord("N")
+    o = orc.histogram(host, n, L, k, k, b)
+    g = ctx.histogram(ctx.to_device(host), n, L, k, 1, k, b)
+    g = g.cpu().numpy().view(np.uint64)
+    assert int(g.sum()) == int(o.sum())
+    assert (g == o).all()
+
+
 # ---------------------------------------------------------------- elementwise
 
 def test_kmers_from_bytes_and_word_ops(ctx, orc, kats):
