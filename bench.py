@@ -105,6 +105,8 @@ def main():
     ap.add_argument("-k", type=int, default=31)
     ap.add_argument("--hash", action="store_true", help="also fold the LexHasher(k) word hash (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--packed", action="store_true",
+                    help="reads held as a 2-bit SeqVector (kmx_seqvec_canonical_reduce): 0.25 B per base from HBM (SURVEY 8f row f1; not the metric)")
     ap.add_argument("--histogram", type=int, default=0, metavar="LOG2_BUCKETS",
                     help="also time the bucket histogram + RCCL all-reduce (BASELINE configs[4]); reported in 'histogram'")
     args = ap.parse_args()
@@ -147,8 +149,17 @@ def main():
         out = ctx.empty(5, torch.int64)
         rd = ctx._reads(bases, n, L, None)
 
-    def step():
+    words = None
+    if args.packed:
         if two_word:
+            raise SystemExit("--packed: single-word k-mers only")
+        words = ctx.seqvec_from_bytes(bases)
+        torch.cuda.synchronize()
+
+    def step():
+        if words is not None:
+            ctx.seqvec_canonical_reduce(words, n, L, k, hasher, hk, 0, out=out, sync=False)
+        elif two_word:
             ctx._ck(ctx.lib.kmx_canonical_reduce2(ctx._h, C.byref(rd), k, int(args.hash), C.c_void_p(out.data_ptr())))
         else:
             ctx.canonical_reduce_async(bases, n, L, k, hasher, hk, 0, out=out)
@@ -206,7 +217,8 @@ def main():
 
     if rank == 0:
         value = total_kmers_per_step * args.steps / elapsed_max
-        algo_bytes = float(nbytes)  # algorithmic bytes per launch: L bytes read per read, writes negligible
+        # algorithmic bytes per launch: L bytes read per read (L/4 when the reads are 2-bit packed), writes negligible
+        algo_bytes = float(nbytes) / (4.0 if args.packed else 1.0)
         achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
         # parity spot-check against the CPU oracle on the head of this rank's shard (outside the timed region)
         from oracle import oracle
@@ -226,7 +238,7 @@ def main():
         try:   # HBM bytes per launch from the committed PMC passes (same kernel, same workload only)
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 pt = json.load(f)
-            if (k, L, n, args.hash) == (31, 150, 100_000_000, False):
+            if (k, L, n, args.hash, args.packed) == (31, 150, 100_000_000, False, False):
                 traffic = pt["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -244,8 +256,8 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": f"k={k} encode+canonicalize{'+lex-hash' if args.hash else ''} (reduce mode), "
-                            f"{n} x {L} bp synthetic reads per GPU (BASELINE configs[1])",
+                "workload": f"k={k} {'canonicalize from a 2-bit SeqVector' if args.packed else 'encode+canonicalize'}{'+lex-hash' if args.hash else ''} (reduce mode), "
+                            f"{n} x {L} bp synthetic reads per GPU" + ("" if args.packed else " (BASELINE configs[1])"),
                 "reads_per_gpu": n, "read_len": L, "k": k, "parallelism": f"shard{world}",
                 "bytes_per_gpu": nbytes,
             },

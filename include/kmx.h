@@ -191,6 +191,34 @@ int kmx_encoding_rev_comp(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint32
 int kmx_encoding_decode(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint8_t enc_byte, uint32_t words_per_kmer,
                         uint8_t *d_seqs);
 
+/* ----------------------------------------------------------------------------------------------------------------
+ * SeqVector -- the reference's 2-bit packed sequence container (src/naive_impl/seq_vector.rs).
+ * Layout: base i at flat bits [2i, 2i+1] of a little-endian u64 word array, codes A0 C1 G2 T3 (it is built from
+ * Kmer::from of 32-base chunks, seq_vector.rs:346-358); a vector of n bases owns ceil(n/32) words, bits past 2n are 0.
+ * The caller owns `d_words`; reads stored back to back are slices [r*L, (r+1)*L) of one vector (SeqVector::slice).
+ * -------------------------------------------------------------------------------------------------------------- */
+/* SeqVector::push_chars (seq_vector.rs:241-262) / From<&[u8]> (:346-358, n_bases_before = 0): append `n` ASCII bases
+ * to a vector that holds `n_bases_before`.  Strict like Kmer::from (kmer.rs:234-251 panics on a bad base):
+ * KMX_E_INVALID_BASE with *h_first_bad = index into d_bytes of the first offending byte (the words are then
+ * unspecified).  d_words must have room for ceil((n_bases_before + n)/32) words. */
+int kmx_seqvec_push_chars(kmx_ctx *ctx, uint64_t *d_words, uint64_t n_bases_before, const uint8_t *d_bytes, uint64_t n,
+                          uint64_t *h_first_bad);
+/* String::from(&SeqVector) (seq_vector.rs:272-284): n upper-case letters */
+int kmx_seqvec_to_bytes(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_bases, uint8_t *d_bytes);
+/* SeqVector::get_kmer_u64(pos, k) (seq_vector.rs:217-220; get_base = k 1) for n positions; k in [1,32].
+ * A position whose k-mer does not lie inside the vector (the reference asserts pos < len) gives KMX_E_ARG. */
+int kmx_seqvec_get_kmers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_bases, const uint64_t *d_pos, uint64_t n,
+                         uint32_t k, uint64_t *d_out);
+/* SeqVectorSlice::iter_kmers(k) (seq_vector.rs:56-63, 236-243) over the slice [start, end): end-start-k+1 forward
+ * words (not canonicalised), in order. */
+int kmx_seqvec_iter_kmers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_bases, uint64_t start, uint64_t end,
+                          uint32_t k, uint64_t *d_out);
+/* kmx_canonical_reduce over reads held in a SeqVector: read r = slice [r*read_len, (r+1)*read_len).  Every 2-bit code
+ * is a base, so every window counts.  0.25 B per base read from HBM instead of 1.  d_words 16-byte aligned for the
+ * fast kernel (k in {21,31}); any k in [1,31] is served. */
+int kmx_seqvec_canonical_reduce(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_reads, uint32_t read_len, uint32_t k,
+                                uint32_t hasher, uint32_t hasher_k, uint32_t flags, kmx_summary *d_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -316,6 +317,74 @@ inline kmx_summary canonical_reduce(Context& ctx, const kmx_reads& reads, uint32
     ctx.check(kmx_canonical_reduce(ctx.get(), &reads, k, hasher, hasher_k, flags, out.data()), "canonical_reduce");
     return out.download()[0];
 }
+
+// src/naive_impl/seq_vector.rs: the 2-bit packed sequence container, resident on the device.
+class SeqVector {
+  public:
+    explicit SeqVector(size_t capacity_bases = 0, Context& ctx = Context::instance()) : ctx_(&ctx) { reserve(capacity_bases); }   // with_capacity, :231-235
+    explicit SeqVector(const std::string& s, Context& ctx = Context::instance()) : ctx_(&ctx) { push_chars(s); }                 // From<&String>, :323-329
+    size_t len() const { return n_; }              // :208-210
+    bool is_empty() const { return n_ == 0; }      // :212-214
+    void push_chars(const std::string& bytes) {    // :241-262 (panics on a non-ACGTacgt byte like Kmer::from)
+        if (bytes.empty()) return;
+        reserve(n_ + bytes.size());
+        DeviceBuffer<uint8_t> d(*ctx_, reinterpret_cast<const uint8_t*>(bytes.data()), bytes.size());
+        uint64_t bad = 0;
+        int st = kmx_seqvec_push_chars(ctx_->get(), words_->data(), n_, d.data(), bytes.size(), &bad);
+        if (st == KMX_E_INVALID_BASE) throw Panic(st, "SeqVector::push_chars: invalid base at " + std::to_string(bad));
+        ctx_->check(st, "SeqVector::push_chars");
+        n_ += bytes.size();
+    }
+    uint64_t get_kmer_u64(size_t pos, size_t k) const {   // :217-220 (assert!(pos < len))
+        DeviceBuffer<uint64_t> p(*ctx_, 1), o(*ctx_, 1);
+        const uint64_t pp = pos;
+        p.upload(&pp, 1);
+        int st = kmx_seqvec_get_kmers(ctx_->get(), words_->data(), n_, p.data(), 1, static_cast<uint32_t>(k), o.data());
+        if (st == KMX_E_ARG) throw Panic(st, "SeqVector::get_kmer_u64: assertion failed: pos < self.len()");
+        ctx_->check(st, "SeqVector::get_kmer_u64");
+        return o.download()[0];
+    }
+    Kmer get_kmer(size_t pos, size_t k) const { return Kmer::from_u64(get_kmer_u64(pos, k), static_cast<uint8_t>(k)); }   // :212-215
+    uint64_t get_base(size_t pos) const { return get_kmer_u64(pos, 1); }                                                 // :222-224
+    std::vector<uint64_t> iter_kmers(size_t k, size_t start = 0, size_t end = SIZE_MAX) const {   // :236-243 (+ slice, :226-234)
+        if (end == SIZE_MAX) end = n_;
+        const size_t cnt = end - start >= k ? end - start - k + 1 : 0;
+        if (cnt == 0) return {};
+        DeviceBuffer<uint64_t> o(*ctx_, cnt);
+        ctx_->check(kmx_seqvec_iter_kmers(ctx_->get(), words_->data(), n_, start, end, static_cast<uint32_t>(k), o.data()), "SeqVector::iter_kmers");
+        return o.download();
+    }
+    std::string to_string() const {   // String::from(&SeqVector), :272-284
+        if (n_ == 0) return {};
+        DeviceBuffer<uint8_t> o(*ctx_, n_);
+        ctx_->check(kmx_seqvec_to_bytes(ctx_->get(), words_->data(), n_, o.data()), "SeqVector::to_string");
+        auto v = o.download();
+        return std::string(v.begin(), v.end());
+    }
+    // canonical k-mer summary of the reads stored back to back as read_len-base slices (the batch form of the hot path)
+    kmx_summary canonical_reduce(size_t read_len, uint32_t k, uint32_t hasher = KMX_HASH_NONE, uint32_t hasher_k = 0, uint32_t flags = 0) const {
+        DeviceBuffer<kmx_summary> out(*ctx_, 1);
+        ctx_->check(kmx_seqvec_canonical_reduce(ctx_->get(), words_ ? words_->data() : nullptr, read_len ? n_ / read_len : 0,
+                                                static_cast<uint32_t>(read_len), k, hasher, hasher_k, flags, out.data()), "SeqVector::canonical_reduce");
+        return out.download()[0];
+    }
+    const uint64_t* device_words() const { return words_ ? words_->data() : nullptr; }
+
+  private:
+    void reserve(size_t bases) {
+        const size_t need = (bases + 31) / 32;
+        if (words_ && words_->size() >= need) return;
+        const size_t cap = need > 2 * (words_ ? words_->size() : 0) ? need : 2 * words_->size();
+        auto nw = std::make_unique<DeviceBuffer<uint64_t>>(*ctx_, cap ? cap : 1);
+        std::vector<uint64_t> host = words_ ? words_->download() : std::vector<uint64_t>();
+        host.resize(cap ? cap : 1, 0);
+        nw->upload(host.data(), host.size());
+        words_ = std::move(nw);
+    }
+    Context* ctx_;
+    std::unique_ptr<DeviceBuffer<uint64_t>> words_;
+    size_t n_ = 0;
+};
 
 }  // namespace naive_impl
 

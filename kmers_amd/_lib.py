@@ -74,6 +74,11 @@ SIGNATURES = {
     "kmx_encode_windows": (_int, [_vp, _RP, _u32, _u8, _u32, _vp]),
     "kmx_encoding_rev_comp": (_int, [_vp, _vp, _u64, _u32, _u8, _u32, _vp]),
     "kmx_encoding_decode": (_int, [_vp, _vp, _u64, _u8, _u32, _vp]),
+    "kmx_seqvec_push_chars": (_int, [_vp, _vp, _u64, _vp, _u64, C.POINTER(_u64)]),
+    "kmx_seqvec_to_bytes": (_int, [_vp, _vp, _u64, _vp]),
+    "kmx_seqvec_get_kmers": (_int, [_vp, _vp, _u64, _vp, _u64, _u32, _vp]),
+    "kmx_seqvec_iter_kmers": (_int, [_vp, _vp, _u64, _u64, _u64, _u32, _vp]),
+    "kmx_seqvec_canonical_reduce": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp]),
 }
 
 _LIB = None

@@ -208,6 +208,53 @@ class Context:
                                                 words_per_kmer, _ptr(out)))
         return out
 
+    # ---- SeqVector (src/naive_impl/seq_vector.rs): 2-bit packed sequences on the device
+    def seqvec_from_bytes(self, data: torch.Tensor, n: int | None = None) -> torch.Tensor:
+        """SeqVector::from(&[u8]) (seq_vector.rs:346-358): ceil(n/32) u64 words (as int64 tensor), base i at bits [2i,2i+1]"""
+        n = data.numel() if n is None else n
+        words = torch.zeros((n + 31) // 32 + 2, dtype=torch.int64, device=self.device)[: (n + 31) // 32]
+        return self.seqvec_push_chars(words, 0, data, n)
+
+    def seqvec_push_chars(self, words: torch.Tensor, n_before: int, data: torch.Tensor, n: int | None = None) -> torch.Tensor:
+        """SeqVector::push_chars (seq_vector.rs:241-262): append n ASCII bases after the n_before already stored"""
+        n = data.numel() if n is None else n
+        bad = C.c_uint64()
+        st = self.lib.kmx_seqvec_push_chars(self._h, _ptr(words) if words.numel() else None, n_before, _ptr(data) if n else None, n, C.byref(bad))
+        if st == _lib.E_INVALID_BASE:
+            e = KmxError(st, f"invalid base at byte {bad.value}")
+            e.first_bad = bad.value
+            raise e
+        self._ck(st)
+        return words
+
+    def seqvec_to_bytes(self, words: torch.Tensor, n_bases: int) -> torch.Tensor:
+        out = self.empty(n_bases, torch.uint8)
+        self._ck(self.lib.kmx_seqvec_to_bytes(self._h, _ptr(words) if n_bases else None, n_bases, _ptr(out) if n_bases else None))
+        return out
+
+    def seqvec_get_kmers(self, words: torch.Tensor, n_bases: int, pos: torch.Tensor, k: int) -> torch.Tensor:
+        out = self.empty(pos.numel(), torch.int64)
+        n = pos.numel()
+        self._ck(self.lib.kmx_seqvec_get_kmers(self._h, _ptr(words) if n else None, n_bases, _ptr(pos) if n else None, n, k, _ptr(out) if n else None))
+        return out
+
+    def seqvec_iter_kmers(self, words: torch.Tensor, n_bases: int, k: int, start: int = 0, end: int | None = None) -> torch.Tensor:
+        end = n_bases if end is None else end
+        cnt = max(0, end - start - k + 1)
+        out = self.empty(cnt, torch.int64)
+        self._ck(self.lib.kmx_seqvec_iter_kmers(self._h, _ptr(words), n_bases, start, end, k, _ptr(out) if cnt else None))
+        return out
+
+    def seqvec_canonical_reduce(self, words: torch.Tensor, n_reads: int, read_len: int, k: int, hasher: int = 0, hasher_k: int = 0,
+                                flags: int = 0, out: torch.Tensor | None = None, sync: bool = True):
+        """canonical k-mer scan of the reads stored back to back in a SeqVector (read r = slice [r*L, (r+1)*L))"""
+        out = self.empty(4, torch.int64) if out is None else out
+        self._ck(self.lib.kmx_seqvec_canonical_reduce(self._h, _ptr(words) if n_reads else None, n_reads, read_len, k, hasher, hasher_k, flags, _ptr(out)))
+        if not sync:
+            return out
+        v = u64_numpy(out)
+        return Summary(int(v[0]), int(v[1]), int(v[2]), int(v[3]))
+
     def encoding_decode(self, words: torch.Tensor, enc_byte: int, words_per_kmer: int) -> torch.Tensor:
         n = words.numel() // words_per_kmer
         out = self.empty(n * 32 * words_per_kmer, torch.uint8)

@@ -26,6 +26,18 @@ hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
+                                        kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+// kmx_seqvec.hip
+hipError_t launch_seqvec_push(u64* words, u64 first, const uint8_t* bytes, u64 n, unsigned long long* first_bad, int n_cu,
+                              hipStream_t st);
+hipError_t launch_seqvec_to_bytes(const u64* words, u64 n, uint8_t* out, int n_cu, hipStream_t st);
+hipError_t launch_seqvec_get_kmers(const u64* words, u64 n_bases, const u64* pos, u64 n, u32 k, u64* out,
+                                   unsigned long long* first_bad, int n_cu, hipStream_t st);
+hipError_t launch_seqvec_iter_kmers(const u64* words, u64 n_bases, u64 start, u64 count, u32 k, u64* out, int n_cu,
+                                    hipStream_t st);
+hipError_t launch_reduce_packed_generic(const u64* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
+                                        kmx_summary* out, int n_cu, hipStream_t st);
 // kmx_generic.hip
 hipError_t launch_reduce_generic(const kmx_reads* r, u32 k, u32 hasher, u32 hk, u32 want_sumfw, kmx_summary* out,
                                  int n_cu, hipStream_t st);
@@ -509,6 +521,81 @@ int kmx_encoding_decode(kmx_ctx* ctx, const uint64_t* d_in, uint64_t n, uint8_t 
     if (n == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
     KMX_HIP(ctx, kmx::launch_encoding_decode(d_in, n, nuc_lut_for(enc_byte), words_per_kmer, d_seqs, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+/* ------------------------------------------------------------- SeqVector ---- */
+
+int kmx_seqvec_push_chars(kmx_ctx* ctx, uint64_t* d_words, uint64_t n_bases_before, const uint8_t* d_bytes, uint64_t n,
+                          uint64_t* h_first_bad) {
+    if (!ctx || (n && (!d_words || !d_bytes))) return KMX_E_ARG;
+    if (h_first_bad) *h_first_bad = ~0ull;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0xFF, 8, ctx->stream));
+    KMX_HIP(ctx, kmx::launch_seqvec_push(d_words, n_bases_before, d_bytes, n, ctx->d_scratch, ctx->n_cu, ctx->stream));
+    unsigned long long bad = 0;
+    KMX_HIP(ctx, hipMemcpyAsync(&bad, ctx->d_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad != ~0ull) {
+        if (h_first_bad) *h_first_bad = bad;
+        return KMX_E_INVALID_BASE;
+    }
+    return KMX_OK;
+}
+
+int kmx_seqvec_to_bytes(kmx_ctx* ctx, const uint64_t* d_words, uint64_t n_bases, uint8_t* d_bytes) {
+    if (!ctx || (n_bases && (!d_words || !d_bytes))) return KMX_E_ARG;
+    if (n_bases == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_seqvec_to_bytes(d_words, n_bases, d_bytes, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_seqvec_get_kmers(kmx_ctx* ctx, const uint64_t* d_words, uint64_t n_bases, const uint64_t* d_pos, uint64_t n,
+                         uint32_t k, uint64_t* d_out) {
+    if (!ctx || (n && (!d_words || !d_pos || !d_out))) return KMX_E_ARG;
+    if (k < 1 || k > 32) return KMX_E_K_RANGE;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0xFF, 8, ctx->stream));
+    KMX_HIP(ctx, kmx::launch_seqvec_get_kmers(d_words, n_bases, d_pos, n, k, d_out, ctx->d_scratch, ctx->n_cu, ctx->stream));
+    unsigned long long bad = 0;
+    KMX_HIP(ctx, hipMemcpyAsync(&bad, ctx->d_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad != ~0ull) {
+        std::snprintf(ctx->last_error, sizeof ctx->last_error, "kmx_seqvec_get_kmers: element %llu lies outside the vector", bad);
+        return KMX_E_ARG;
+    }
+    return KMX_OK;
+}
+
+int kmx_seqvec_iter_kmers(kmx_ctx* ctx, const uint64_t* d_words, uint64_t n_bases, uint64_t start, uint64_t end, uint32_t k,
+                          uint64_t* d_out) {
+    if (!ctx || start > end || end > n_bases) return KMX_E_ARG;
+    if (k < 1 || k > 32) return KMX_E_K_RANGE;
+    if (end - start < k) return KMX_OK;   // the reference's `len - k + 1` underflows here; an empty iteration is the only sane answer
+    if (!d_words || !d_out) return KMX_E_ARG;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_seqvec_iter_kmers(d_words, n_bases, start, end - start - k + 1u, k, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_seqvec_canonical_reduce(kmx_ctx* ctx, const uint64_t* d_words, uint64_t n_reads, uint32_t read_len, uint32_t k,
+                                uint32_t hasher, uint32_t hasher_k, uint32_t flags, kmx_summary* d_out) {
+    if (!ctx || !d_out || (n_reads && !d_words)) return KMX_E_ARG;
+    if (k < 1 || k > 31) return KMX_E_K_RANGE;   // rolling with MASK_TABLE[32] == 0 is unusable (kmer.rs:617)
+    if (hasher > KMX_HASH_LEX || (hasher == KMX_HASH_LEX && hasher_k != k)) return KMX_E_ARG;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(kmx_summary), ctx->stream));
+    if (n_reads == 0 || read_len < k) return KMX_OK;
+    const bool want_hash = hasher == KMX_HASH_LEX, want_sumfw = (flags & KMX_REDUCE_SUM_FW) != 0;
+    bool handled = false;
+    KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+    KMX_HIP(ctx, kmx::launch_scan_bitsliced_packed(d_words, n_reads, read_len, k, want_hash, want_sumfw, d_out,
+                                                   ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+    if (handled) return KMX_OK;
+    KMX_HIP(ctx, kmx::launch_reduce_packed_generic(d_words, n_reads, read_len, k, want_hash, want_sumfw, d_out, ctx->n_cu, ctx->stream));
     return KMX_OK;
 }
 

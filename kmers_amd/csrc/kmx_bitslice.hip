@@ -74,7 +74,9 @@ __device__ __forceinline__ u32 bitsel(u32 x, u32 y, u32 keep) { return __builtin
 // d += popcount(x) as ONE v_bcnt_u32_b32 (hipcc otherwise splits it into v_bcnt(x,0) + v_add3_u32)
 __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x)); }
 
-template <int K, int NW, int WPL>
+// PACKED: `bases` is a SeqVector (kmx_seqvec.hip), read r = its bases [r*L, (r+1)*L): a tile is 16*L bytes of ready-made
+// 2-bit codes that go from HBM straight into the packed LDS buffer -- no phase A, nothing to validate.
+template <int K, int NW, int WPL, bool PACKED = false>
 __global__ void __launch_bounds__(256, ((NW > 10 || K > 32) ? 2 : KMX_BS_WAVES))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
@@ -92,7 +94,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 half = lane >> 5, p = lane & 31u;
     const u32 wib = threadIdx.x >> 6;
     const u32 chunks = 4u * L;
-    const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;          // packed region (as in kmx_scan.hip)
+    constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
+    const u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
     u32* P = lds + wib * (ldsw + 4u * PLANES);
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
@@ -100,7 +103,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u64 n_waves = (u64)gridDim.x * 4u;
     const u64 wave_id = (u64)blockIdx.x * 4u + wib;
 
-    const u32 posF = lane * L + 16u;
+    const u32 posF = lane * L + 16u * PAD;
     const u32 qF = posF >> 4, aF = 2u * (posF & 15u);
     const u32 W = L - (u32)K + 1u;      // windows per read
     const u32 NG = (W + WPL - 1u) / WPL; // groups of WPL adjacent windows per read
@@ -134,8 +137,18 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u32 n_bs_tiles = 0;
     // word-domain accumulators of the fallback path (tiles with invalid bytes, the final partial tile)
     struct { u64 n = 0, s0 = 0, s1 = 0, x0 = 0, x1 = 0, fw = 0; } fb;
-    auto fallback_read = [&](const uint8_t* s) {
-        if constexpr (K <= 32) {
+    auto fallback_read = [&](u64 read) {
+        const uint8_t* s = bases + read * (u64)L;
+        if constexpr (PACKED) {
+            static_assert(!PACKED || K <= 32, "packed input: single-word k-mers");
+            roll_read_packed(reinterpret_cast<const u64*>(bases), read * (u64)L, L, (u32)K, [&](u32, u64 fw, u64 rc) {
+                const u64 canon = fw < rc ? fw : rc;
+                fb.n += 1;
+                fb.s0 += canon;
+                fb.x0 ^= lex_hash(canon, (u32)K);
+                fb.fw += fw;
+            });
+        } else if constexpr (K <= 32) {
             roll_read(s, L, (u32)K, [&](u32, u64 fw, u64 rc) {
                 const u64 canon = fw < rc ? fw : rc;
                 fb.n += 1;
@@ -165,20 +178,21 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #endif
     // software pipeline: the loads of tile t+1 are issued right after tile t has been packed, so they
     // are in flight during the realign / transpose / item phases of tile t (HBM latency ~4 us under load)
-    uint4 w[NW];
+    constexpr int NLD = PACKED ? (NW + 3) / 4 : NW;   // 16-byte loads per lane and tile (packed: 16*L bytes per tile)
+    uint4 w[NLD];
     // address = wave-uniform tile base (SGPR pair) + 32-bit per-lane byte offset: no per-chunk 64-bit
     // pointers stay live across the loop
     const u32 lane16 = lane * 16u;
-    const u32 last_off = (chunks - 1u) * 16u;
-    const bool short_rows = chunks < 64u * (NW - 1);   // reads so short that whole rows of the NW x 64 chunk grid lie past the tile
+    const u32 last_off = PACKED ? (L - 1u) * 16u : (chunks - 1u) * 16u;
+    const bool short_rows = PACKED || chunks < 64u * (NW - 1);   // whole rows of the load grid may lie past the tile
     auto issue_loads = [&](u64 tile) {
-        const uint8_t* __restrict__ tb = bases + tile * 64u * (u64)L;
+        const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
 #pragma unroll
-        for (int it = 0; it < NW; ++it) {
+        for (int it = 0; it < NLD; ++it) {
             // lanes past the tile end re-read its last chunk: no branch, so all loads of a tile sit in
             // one basic block and stay in flight together (a guarded load would be fenced by vmcnt(0))
             u32 off = lane16 + (u32)it * 1024u;
-            if (it == NW - 1 || short_rows) off = off < last_off ? off : last_off;
+            if (it == NLD - 1 || short_rows) off = off < last_off ? off : last_off;
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb + off));  // streamed once
             w[it] = make_uint4(v.x, v.y, v.z, v.w);
@@ -249,6 +263,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     auto phase_A = [&]() -> bool {   // pack + validate the tile sitting in w[] into the packed LDS buffer
         u32 bad = 0;
+        if constexpr (PACKED) {      // already 2-bit codes: 16 bytes = 4 packed dwords per lane and load
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                const u32 c = it * 64u + lane;
+                if (c < L) *reinterpret_cast<uint4*>(P + PAD + 4u * c) = w[it];
+            }
+            return false;
+        } else {
         if (KMX_BS_PRIO && !(KMX_BS_ABLATE & 24) && chunks >= 64u * (NW - 1)) {
             // wave-uniform: only the last row of chunks is partial (L = 150: 600 = 9*64 + 24)
 #pragma unroll
@@ -268,6 +290,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
         }
         return __any(chunk_has_invalid(bad));
+        }
     };
     auto lds_fence = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -533,7 +556,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             next_bad = phase_A();          // consumes the loads issued one iteration ago
             lds_fence();
         }
-        if (cur_bad) fallback_read(bases + (tile * 64u + lane) * (u64)L);
+        if (cur_bad) fallback_read(tile * 64u + lane);
         else phase_D();
         prefetch(tile2, tile);
         tile = tile1;
@@ -557,7 +580,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         lds_fence();
         KMX_T(1)
         if (bad_tile) {
-            fallback_read(bases + (tile * 64u + lane) * (u64)L);
+            fallback_read(tile * 64u + lane);
         } else if (!(KMX_BS_ABLATE & 32)) {
             phase_BC();
             KMX_T(3)
@@ -584,7 +607,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 
     // ---- final partial tile: per-lane rolling
     const u32 rem = (u32)(n_reads & 63u);
-    if (rem != 0u && wave_id == 0 && lane < rem) fallback_read(bases + (n_full * 64u + lane) * (u64)L);
+    if (rem != 0u && wave_id == 0 && lane < rem) fallback_read(n_full * 64u + lane);
 
     // ---- combine the bit-sliced counters into word-domain results (once per wave; wave-uniform branch)
     // Number of set bits of canonical bit (t,b) over all k-mers of the wave:
@@ -674,12 +697,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 
 // ------------------------------------------------------------------ launcher
 
-template <int K, int NW, int WPL>
+template <int K, int NW, int WPL, bool PACKED = false>
 static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
                             unsigned long long* queue, int n_cu, hipStream_t stream) {
-    auto kern = scan_bitsliced_kernel<K, NW, WPL>;
+    auto kern = scan_bitsliced_kernel<K, NW, WPL, PACKED>;
     const u32 chunks = 4u * L;
-    const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
+    const u32 ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
     size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u)) * 4u * 4u;
     if (const char* e = getenv("KMX_BS_EXTRA_LDS")) lds_bytes += (size_t)atol(e);   // dev knob: caps blocks per CU
     static int bpc = 0;
@@ -736,6 +759,30 @@ hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k
 }
 
 // [u64;2] k-mers: k = 63 is instantiated (BASELINE configs[2]); other k in 33..64 take the generic kernel
+// SeqVector input (kmx_seqvec.hip): read r = bases [r*L, (r+1)*L) of the 2-bit packed vector `words` (16-byte aligned)
+hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
+                                        kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
+    *handled = false;
+    const uint8_t* bases = reinterpret_cast<const uint8_t*>(words);
+    if (L < k || L > 256 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
+    if (n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
+    const u32 W = L - k + 1u;
+    if (k != 31 && k != 21) return hipSuccess;
+    *handled = true;
+    if (L > 160) {
+        if (k == 31) return launch_bs<31, 16, 8, true>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        return launch_bs<21, 16, 8, true>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+    }
+    if (k == 31) {
+        if (W <= 96u) return launch_bs<31, 10, 3, true>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        if (W <= 128u) return launch_bs<31, 10, 4, true>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        return launch_bs<31, 10, 5, true>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+    }
+    if (W <= 96u) return launch_bs<21, 10, 3, true>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+    if (W <= 128u) return launch_bs<21, 10, 4, true>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+    return launch_bs<21, 10, 5, true>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+}
+
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;

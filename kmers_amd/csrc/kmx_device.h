@@ -178,6 +178,29 @@ __device__ __forceinline__ void roll_read(const uint8_t* __restrict__ s, u32 len
     for (; l < len; ++l) step(s[l], l);
 }
 
+// The same walk over a read held in a SeqVector (seq_vector.rs: base i at flat bits [2i,2i+1] of `words`): read =
+// bases [first, first+len).  Every 2-bit code is a valid base, so every window is yielded.
+template <typename Emit>
+__device__ __forceinline__ void roll_read_packed(const u64* __restrict__ words, u64 first, u32 len, u32 k, Emit&& emit) {
+    const u64 mask = mask2k(k);
+    const u32 top = 2u * k - 2u;
+    u64 fw = 0, rc = ~0ull;
+    u64 wi = first >> 5;
+    u32 sh = 2u * (u32)(first & 31u);
+    u64 cur = len ? words[wi] : 0ull;
+    for (u32 l = 0; l < len; ++l) {
+        const u32 b = (u32)(cur >> sh) & 3u;
+        fw = (fw >> 2) | ((u64)b << top);
+        rc = mask & ((rc << 2) | (u64)(3u - b));
+        if (l + 1u >= k) emit(l + 1u - k, fw, rc);
+        sh += 2u;
+        if (sh == 64u && l + 1u < len) {
+            sh = 0;
+            cur = words[++wi];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- [u64;2] k-mers (k in 33..64), BUILD-DEFINED
 struct U128 {
     u64 lo, hi;

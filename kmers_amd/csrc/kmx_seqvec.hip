@@ -1,0 +1,128 @@
+// kmx_seqvec.hip -- SeqVector: the 2-bit packed sequence container of the reference
+// (src/naive_impl/seq_vector.rs) as batch device operations.
+//
+// Layout (seq_vector.rs:346-358 builds it from Kmer::from of 32-base chunks; RawVector is LSB-first): base i occupies
+// flat bits [2i, 2i+1] of a little-endian u64 word array, codes A0 C1 G2 T3; bits past 2*len are zero.
+//   push_chars / From<&[u8]>   seq_vector.rs:241-262, 346-358   -> seqvec_push_kernel (strict: Kmer::from panics on a bad base)
+//   get_kmer_u64 / get_base    seq_vector.rs:217-224            -> seqvec_get_kmers_kernel
+//   iter_kmers                 seq_vector.rs:236-243, 417-428   -> seqvec_iter_kmers_kernel
+//   String::from(&SeqVector)   seq_vector.rs:272-284            -> seqvec_to_bytes_kernel
+// and, for reads stored back to back as L-base slices (SeqVector::slice, :226-234), the canonical k-mer scan of
+// every slice for (k, L) outside the bit-sliced kernel: reduce_packed_generic_kernel (one lane walks one read with
+// CanonicalKmer::append_base, canonical_kmer.rs:90-94).
+#include "kmx_device.h"
+
+namespace kmx {
+
+// the 2k-bit field at base position pos (RawVector::int(pos*2, k*2)), k in [1,32]; words past the end read as 0
+__device__ __forceinline__ u64 seqvec_field(const u64* __restrict__ words, u64 n_words, u64 pos, u32 k) {
+    const u64 wi = pos >> 5;
+    const u32 sh = 2u * (u32)(pos & 31u);
+    const u64 lo = words[wi];
+    const u64 hi = (sh != 0u && wi + 1u < n_words) ? words[wi + 1u] : 0ull;
+    const u64 v = sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
+    return k >= 32u ? v : (v & ((1ull << (2u * k)) - 1ull));
+}
+
+// one thread per output word: bases [first, first+n) arrive as ASCII in bytes[0..n)
+__global__ void __launch_bounds__(256)
+seqvec_push_kernel(u64* __restrict__ words, u64 first, const uint8_t* __restrict__ bytes, u64 n,
+                   unsigned long long* __restrict__ first_bad) {
+    const u64 w0 = first >> 5, w1 = (first + n + 31u) >> 5;   // words [w0, w1) receive bases
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 w = w0 + (u64)blockIdx.x * blockDim.x + threadIdx.x; w < w1; w += stride) {
+        const u64 b_lo = w * 32u > first ? w * 32u : first;
+        const u64 b_hi = (w + 1u) * 32u < first + n ? (w + 1u) * 32u : first + n;
+        u64 v = (b_lo > w * 32u) ? (words[w] & ((1ull << (2u * (u32)(b_lo - w * 32u))) - 1ull)) : 0ull;   // keep what is already there
+        for (u64 b = b_lo; b < b_hi; ++b) {
+            const u32 c = encode_base(bytes[b - first]);
+            if (c >= 4u) atomicMin(first_bad, (unsigned long long)(b - first));
+            v |= (u64)(c & 3u) << (2u * (u32)(b & 31u));
+        }
+        words[w] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+seqvec_to_bytes_kernel(const u64* __restrict__ words, u64 n, uint8_t* __restrict__ out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (uint8_t)("ACGT"[(words[i >> 5] >> (2u * (u32)(i & 31u))) & 3u]);
+}
+
+__global__ void __launch_bounds__(256)
+seqvec_get_kmers_kernel(const u64* __restrict__ words, u64 n_bases, const u64* __restrict__ pos, u64 n, u32 k,
+                        u64* __restrict__ out, unsigned long long* __restrict__ first_bad) {
+    const u64 n_words = (n_bases + 31u) >> 5;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const u64 p = pos[e];
+        if (p >= n_bases || p + k > n_bases) {   // assert!(pos < self.len()), seq_vector.rs:218; the field must lie inside the vector
+            atomicMin(first_bad, (unsigned long long)e);
+            out[e] = 0;
+        } else {
+            out[e] = seqvec_field(words, n_words, p, k);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+seqvec_iter_kmers_kernel(const u64* __restrict__ words, u64 n_bases, u64 start, u64 count, u32 k, u64* __restrict__ out) {
+    const u64 n_words = (n_bases + 31u) >> 5;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride)
+        out[e] = seqvec_field(words, n_words, start + e, k);
+}
+
+// canonical scan of read r = bases [r*L, (r+1)*L) of the vector, one lane per read (any k in [1,31], any L)
+__global__ void __launch_bounds__(256)
+reduce_packed_generic_kernel(const u64* __restrict__ words, u64 n_reads, u32 L, u32 k, u32 want_hash, u32 want_sumfw,
+                             kmx_summary* __restrict__ out) {
+    Acc acc;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += stride) {
+        roll_read_packed(words, r * (u64)L, L, k, [&](u32, u64 fw, u64 rc) {
+            const u64 canon = fw < rc ? fw : rc;
+            acc.n_valid += 1;
+            acc.sum_canon += canon;
+            acc.xor_hash ^= lex_hash(canon, k);
+            acc.sum_fw += fw;
+        });
+    }
+    flush_acc(acc, out, want_hash != 0u, want_sumfw != 0u);
+}
+
+static inline unsigned sgrid(u64 n, int n_cu) {
+    u64 g = (n + 255u) / 256u;
+    const u64 cap = (u64)n_cu * 16u;
+    if (g > cap) g = cap;
+    return (unsigned)(g ? g : 1);
+}
+
+hipError_t launch_seqvec_push(u64* words, u64 first, const uint8_t* bytes, u64 n, unsigned long long* first_bad, int n_cu,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(seqvec_push_kernel, dim3(sgrid((n + 31u) / 32u + 1u, n_cu)), dim3(256), 0, st, words, first, bytes, n, first_bad);
+    return hipGetLastError();
+}
+hipError_t launch_seqvec_to_bytes(const u64* words, u64 n, uint8_t* out, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(seqvec_to_bytes_kernel, dim3(sgrid(n, n_cu)), dim3(256), 0, st, words, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_seqvec_get_kmers(const u64* words, u64 n_bases, const u64* pos, u64 n, u32 k, u64* out,
+                                   unsigned long long* first_bad, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(seqvec_get_kmers_kernel, dim3(sgrid(n, n_cu)), dim3(256), 0, st, words, n_bases, pos, n, k, out, first_bad);
+    return hipGetLastError();
+}
+hipError_t launch_seqvec_iter_kmers(const u64* words, u64 n_bases, u64 start, u64 count, u32 k, u64* out, int n_cu,
+                                    hipStream_t st) {
+    hipLaunchKernelGGL(seqvec_iter_kmers_kernel, dim3(sgrid(count, n_cu)), dim3(256), 0, st, words, n_bases, start, count, k, out);
+    return hipGetLastError();
+}
+hipError_t launch_reduce_packed_generic(const u64* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
+                                        kmx_summary* out, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_packed_generic_kernel, dim3(sgrid(n_reads, n_cu)), dim3(256), 0, st, words, n_reads, L, k,
+                       want_hash ? 1u : 0u, want_sumfw ? 1u : 0u, out);
+    return hipGetLastError();
+}
+
+}  // namespace kmx

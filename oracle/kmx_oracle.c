@@ -629,6 +629,97 @@ static void iter2_inc(iter2 *it) {
     if (!it->invalid) iter2_find_next(it, it->pos, lpos - 1);
 }
 
+/* ------------------------------------------------------------------ SeqVector (seq_vector.rs) ---- */
+
+/* RawVector::push_int(value, width): append `width` bits LSB-first at bit offset `bit_len` */
+static void rawvec_push_int(uint64_t *words, size_t *bit_len, uint64_t value, size_t width) {
+    if (width == 0) return;
+    if (width < 64) value &= ((uint64_t)1 << width) - 1;
+    size_t w = *bit_len >> 6, off = *bit_len & 63;
+    if (off == 0) {
+        words[w] = value;
+    } else {
+        words[w] |= value << off;
+        if (off + width > 64) words[w + 1] = value >> (64 - off);
+    }
+    *bit_len += width;
+}
+
+/* RawVector::int(bit_offset, width), width in [1,64] */
+static uint64_t rawvec_int(const uint64_t *words, size_t n_words, size_t bit_offset, size_t width) {
+    size_t w = bit_offset >> 6, off = bit_offset & 63;
+    uint64_t v = words[w] >> off;
+    if (off != 0 && off + width > 64 && w + 1 < n_words) v |= words[w + 1] << (64 - off);
+    if (width < 64) v &= ((uint64_t)1 << width) - 1;
+    return v;
+}
+
+int kmo_seqvec_push_chars(uint64_t *words, size_t n_before, const uint8_t *bytes, size_t n, size_t *bad_index) {
+    size_t bit_len = 2 * n_before;
+    if ((bit_len & 63) != 0) words[bit_len >> 6] &= (((uint64_t)1 << (bit_len & 63)) - 1);   /* RawVector keeps the tail zero */
+    size_t first_word_len = n % 32;   /* seq_vector.rs:242-243 */
+    size_t done = 0;
+    while (done < n) {
+        size_t chunk = (done == 0 && first_word_len) ? first_word_len : 32;
+        kmo_kmer km;
+        int st = kmo_kmer_from_bytes(bytes + done, chunk, &km);   /* Kmer::from(chunk) */
+        if (st != KMO_OK) {
+            if (bad_index) {
+                for (size_t i = 0; i < chunk; ++i)
+                    if (kmo_encode_binary_u8(bytes[done + i]) > 3) { *bad_index = done + i; break; }
+            }
+            return st;
+        }
+        rawvec_push_int(words, &bit_len, km.data, chunk * 2);
+        done += chunk;
+    }
+    return KMO_OK;
+}
+
+int kmo_seqvec_get_kmer_u64(const uint64_t *words, size_t n_bases, size_t pos, size_t k, uint64_t *out) {
+    if (k < 1 || k > 32 || pos >= n_bases || pos + k > n_bases) return KMO_E_ARG;
+    *out = rawvec_int(words, (n_bases + 31) / 32, pos * 2, k * 2);
+    return KMO_OK;
+}
+
+void kmo_seqvec_to_bytes(const uint64_t *words, size_t n_bases, uint8_t *out) {
+    static const char bases[4] = {'A', 'C', 'G', 'T'};   /* seq_vector.rs:275 */
+    for (size_t i = 0; i < n_bases; ++i) {
+        uint64_t b = 0;
+        kmo_seqvec_get_kmer_u64(words, n_bases, i, 1, &b);
+        out[i] = (uint8_t)bases[b];
+    }
+}
+
+size_t kmo_seqvec_iter_kmers(const uint64_t *words, size_t n_bases, size_t start, size_t end, size_t k, uint64_t *out) {
+    if (end > n_bases || start > end || end - start < k) return 0;
+    size_t len = end - start - k + 1;
+    for (size_t p = 0; p < len; ++p) kmo_seqvec_get_kmer_u64(words, n_bases, start + p, k, &out[p]);
+    return len;
+}
+
+int kmo_seqvec_canonical_reduce(const uint64_t *words, size_t n_reads, size_t read_len, uint8_t k, size_t hasher_k,
+                                kmo_summary *out) {
+    if (k < 1 || k > 32 || hasher_k > 32) return KMO_E_ARG;
+    kmo_summary s = {0, 0, 0, 0};
+    size_t n_bases = n_reads * read_len;
+    for (size_t r = 0; r < n_reads; ++r) {
+        if (read_len < k) break;
+        for (size_t p = 0; p + k <= read_len; ++p) {
+            uint64_t w = 0;
+            kmo_seqvec_get_kmer_u64(words, n_bases, r * read_len + p, k, &w);
+            kmo_kmer canon = kmo_kmer_to_canonical(kmo_kmer_from_u64(w, k));
+            s.n_valid += 1;
+            s.sum_canon += canon.data;
+            s.sum_fw += w;
+            if (hasher_k) s.xor_hash ^= kmo_lex_hash_u64(canon.data, hasher_k);
+        }
+    }
+    *out = s;
+    return KMO_OK;
+}
+
+
 int kmo_canonical_reduce2(const uint8_t *reads, size_t n_reads, size_t read_len, const uint64_t *offsets,
                           uint8_t k, int with_hash, kmo_summary2 *out) {
     if (k < 33 || k > 64) return KMO_E_ARG;

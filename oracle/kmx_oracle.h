@@ -148,6 +148,24 @@ int kmo_compute_naive(const uint8_t *b, size_t len, size_t K, uint64_t *out_sum)
 /* benches/simple_benchmark.rs:36-44 rc_naive shape but keeping the result: sum of min(fw, rc) per window */
 int kmo_compute_naive_canonical(const uint8_t *b, size_t len, size_t K, uint64_t *out_sum);
 
+/* ---- SeqVector (src/naive_impl/seq_vector.rs) ----
+ * `words`: little-endian u64 array, base i at flat bits [2i,2i+1] (RawVector is LSB-first; From<&[u8]> stores
+ * Kmer::from(32-base chunk).into_u64() per word, seq_vector.rs:346-358). */
+/* push_chars (seq_vector.rs:241-262): first len%32 bases, then 32-base chunks, each via Kmer::from + push_int.
+ * n_before = bases already stored; returns KMO_E_INVALID_BASE (with *bad_index) where Kmer::from would panic. */
+int kmo_seqvec_push_chars(uint64_t *words, size_t n_before, const uint8_t *bytes, size_t n, size_t *bad_index);
+/* get_kmer_u64 (seq_vector.rs:217-220): RawVector::int(pos*2, k*2); KMO_E_ARG where the reference asserts (pos >= len)
+ * or where the field would leave the vector */
+int kmo_seqvec_get_kmer_u64(const uint64_t *words, size_t n_bases, size_t pos, size_t k, uint64_t *out);
+/* String::from(&SeqVector) (seq_vector.rs:272-284) */
+void kmo_seqvec_to_bytes(const uint64_t *words, size_t n_bases, uint8_t *out);
+/* iter_kmers over slice [start,end) (seq_vector.rs:56-63,417-428): end-start-k+1 forward words; returns the count */
+size_t kmo_seqvec_iter_kmers(const uint64_t *words, size_t n_bases, size_t start, size_t end, size_t k, uint64_t *out);
+/* canonical scan of reads stored back to back (read r = slice [r*L,(r+1)*L)): every k-mer of every slice via
+ * get_kmer_u64 + Kmer::to_canonical (kmer.rs:68-74); same summary as kmo_canonical_reduce on the decoded letters */
+int kmo_seqvec_canonical_reduce(const uint64_t *words, size_t n_reads, size_t read_len, uint8_t k, size_t hasher_k,
+                                kmo_summary *out);
+
 /* ---- BUILD-DEFINED extensions (no reference counterpart) ---- */
 typedef struct {
     uint64_t n_valid;

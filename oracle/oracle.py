@@ -152,6 +152,11 @@ def _bind(lib):
                                             C.POINTER(Summary2)]),
         "kmo_canonical_windows2": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint8,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "kmo_seqvec_push_chars": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "kmo_seqvec_get_kmer_u64": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, u64p]),
+        "kmo_seqvec_to_bytes": (None, [C.c_void_p, C.c_size_t, C.c_void_p]),
+        "kmo_seqvec_iter_kmers": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+        "kmo_seqvec_canonical_reduce": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint8, C.c_size_t, C.POINTER(Summary)]),
         "kmo_splitmix64": (C.c_uint64, [C.c_uint64]),
         "kmo_gen_reads": (None, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]),
         "kmo_bucket_of": (C.c_uint64, [C.c_uint64, C.c_uint]),
@@ -276,6 +281,57 @@ def canonical_windows2(reads, n_reads, read_len, k, offsets=None):
     if st != OK:
         raise OracleError(st, "canonical_windows2")
     return fw.reshape(-1, 2), rc.reshape(-1, 2), canon.reshape(-1, 2), flags
+
+
+class SeqVector:
+    """host mirror of seq_vector.rs::SeqVector on top of the C restatement (words: np.uint64 array, n: bases)"""
+
+    def __init__(self, data: bytes = b"", capacity: int = 0):
+        self.n = 0
+        self.words = np.zeros(max((max(capacity, len(data)) + 31) // 32, 1) + 1, dtype=np.uint64)
+        if data:
+            self.push_chars(data)
+
+    def push_chars(self, data: bytes) -> None:
+        need = (self.n + len(data) + 31) // 32 + 1
+        if need > self.words.size:
+            self.words = np.concatenate([self.words, np.zeros(need - self.words.size, dtype=np.uint64)])
+        buf = _u8(data)
+        bad = C.c_size_t(0)
+        st = lib().kmo_seqvec_push_chars(_ptr(self.words), self.n, _ptr(buf), buf.size, C.byref(bad))
+        if st != 0:
+            e = OracleError(st, f"invalid base at byte {bad.value}")
+            e.first_bad = bad.value
+            raise e
+        self.n += buf.size
+
+    def __len__(self) -> int:
+        return self.n
+
+    def get_kmer_u64(self, pos: int, k: int) -> int:
+        out = C.c_uint64()
+        st = lib().kmo_seqvec_get_kmer_u64(_ptr(self.words), self.n, pos, k, C.byref(out))
+        if st != 0:
+            raise OracleError(st, "get_kmer_u64 outside the vector")
+        return out.value
+
+    def to_bytes(self) -> bytes:
+        out = np.zeros(self.n, dtype=np.uint8)
+        lib().kmo_seqvec_to_bytes(_ptr(self.words), self.n, _ptr(out))
+        return out.tobytes()
+
+    def iter_kmers(self, k: int, start: int = 0, end: int | None = None) -> np.ndarray:
+        end = self.n if end is None else end
+        out = np.zeros(max(end - start - k + 1, 0), dtype=np.uint64)
+        cnt = lib().kmo_seqvec_iter_kmers(_ptr(self.words), self.n, start, end, k, _ptr(out))
+        return out[:cnt]
+
+    def canonical_reduce(self, n_reads: int, read_len: int, k: int, hasher_k: int = 0) -> "Summary":
+        s = Summary()
+        st = lib().kmo_seqvec_canonical_reduce(_ptr(self.words), n_reads, read_len, k, hasher_k, C.byref(s))
+        if st != 0:
+            raise OracleError(st, "seqvec_canonical_reduce")
+        return s
 
 
 def gen_reads(seed: int, first_byte: int, nbytes: int) -> np.ndarray:

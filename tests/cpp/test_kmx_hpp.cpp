@@ -133,6 +133,39 @@ int main() {
         CHECK(kmer::Kmer<15>().num_bytes() == 8 && kmer::Kmer<15>().k() == 15);
         CHECK(panics([] { encoding::encode<1>(Naive::ACGT, std::string(33, 'A')); }));
     }
+    // ---- src/naive_impl/seq_vector.rs tests (:364-428)
+    {   // push_chars (:386-399)
+        SeqVector sv(64);
+        const std::string a30(30, 'A'), c40(40, 'C');
+        sv.push_chars(a30);
+        CHECK(sv.to_string() == a30 && sv.len() == 30);
+        sv.push_chars(c40);
+        CHECK(sv.len() == 70 && sv.to_string() == a30 + c40);
+    }
+    {   // iter_kmers (:401-416)
+        SeqVector sv(std::string("ACTTGAT"));
+        const char* mers[] = {"act", "ctt", "ttg", "tga", "gat"};
+        auto all = sv.iter_kmers(3);
+        CHECK(all.size() == 5);
+        for (size_t i = 0; i < all.size() && i < 5; ++i) CHECK(Kmer::from_u64(all[i], 3).to_string() == mers[i]);
+        auto mid = sv.iter_kmers(3, 1, sv.len() - 1);   // sv.slice(1, len-1).iter_kmers(3)
+        CHECK(mid.size() == 3);
+        for (size_t i = 0; i < mid.size() && i < 3; ++i) CHECK(Kmer::from_u64(mid[i], 3).to_string() == mers[i + 1]);
+        CHECK(sv.get_kmer(2, 3) == Kmer::from("ttg") && sv.get_base(0) == A && sv.get_base(3) == T);
+        CHECK(panics([&] { sv.get_kmer_u64(7, 1); }));                // assert!(pos < self.len())
+        CHECK(panics([] { SeqVector bad(std::string("ACGNT")); }));   // Kmer::from panics on 'N'
+    }
+    {   // reads stored back to back: the packed scan equals the scan of the letters
+        std::string reads;
+        for (int r = 0; r < 130; ++r)
+            for (int i = 0; i < 150; ++i) reads.push_back("ACGT"[(r * 7 + i * i + (i >> 3)) & 3]);
+        SeqVector sv(reads);
+        DeviceBuffer<uint8_t> d(Context::instance(), reinterpret_cast<const uint8_t*>(reads.data()), reads.size());
+        kmx_reads rd{d.data(), 130, 150, nullptr};
+        kmx_summary a = canonical_reduce(Context::instance(), rd, 31, KMX_HASH_LEX, 31, KMX_REDUCE_SUM_FW);
+        kmx_summary b = sv.canonical_reduce(150, 31, KMX_HASH_LEX, 31, KMX_REDUCE_SUM_FW);
+        CHECK(a.n_valid == b.n_valid && a.sum_canon == b.sum_canon && a.xor_hash == b.xor_hash && a.sum_fw == b.sum_fw && b.n_valid == 130u * 120u);
+    }
     std::printf(fails ? "%d check(s) FAILED\n" : "all C++ host-layer checks passed\n", fails);
     return fails ? 1 : 0;
 }

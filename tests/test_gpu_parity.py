@@ -475,3 +475,99 @@ def test_encoding_errors(ctx):
     with pytest.raises(_lib.KmxError) as e:
         ctx.encoding_rev_comp(w, 1, 0x1E, 1)  # K=1 underflows in the reference
     assert e.value.status == _lib.E_K_RANGE
+
+
+# ---------------------------------------------------------------- SeqVector (packed 2-bit input)
+
+def _acgt(rng, n):
+    return np.frombuffer(b"ACGTacgt", dtype=np.uint8)[rng.integers(0, 8, n)]
+
+
+def test_seqvec_from_bytes_to_bytes_push(ctx, orc):
+    rng = np.random.default_rng(21)
+    for n in (1, 31, 32, 33, 64, 1000, 4097):
+        host = _acgt(rng, n)
+        sv = orc.SeqVector(host.tobytes())
+        words = ctx.seqvec_from_bytes(ctx.to_device(host))
+        assert (words.cpu().numpy().view(np.uint64) == sv.words[: (n + 31) // 32]).all(), n
+        assert ctx.seqvec_to_bytes(words, n).cpu().numpy().tobytes() == host.tobytes().upper()
+    # push_chars in pieces == one from(); seq_vector.rs:241-262
+    import torch
+
+    n = 700
+    host = _acgt(rng, n)
+    words = torch.zeros((n + 31) // 32, dtype=torch.int64, device=ctx.device)
+    cuts = [0, 5, 37, 64, 70, 333, n]
+    for lo, hi in zip(cuts, cuts[1:]):
+        ctx.seqvec_push_chars(words, lo, ctx.to_device(host[lo:hi].copy()))
+    assert (words.cpu().numpy().view(np.uint64) == orc.SeqVector(host.tobytes()).words[: (n + 31) // 32]).all()
+    # strict like Kmer::from: first offending byte reported
+    from kmers_amd import _lib
+    bad = host.copy()
+    bad[123] = ord("N")
+    bad[500] = ord("x")
+    with pytest.raises(Exception) as ei:
+        ctx.seqvec_from_bytes(ctx.to_device(bad))
+    assert ei.value.status == _lib.E_INVALID_BASE and ei.value.first_bad == 123
+
+
+def test_seqvec_kats_on_device(ctx, orc, kats):
+    sv_k = kats["seq_vector"]
+    sw = sv_k["slice_words"]
+    words = ctx.to_device(np.array(sw["words"], dtype=np.uint64))
+    for g in sw["get_kmer_u64"]:
+        got = ctx.seqvec_get_kmers(words, sw["len"], ctx.to_device(np.array([g["pos"]], dtype=np.uint64)), g["k"])
+        assert int(got.cpu().numpy().view(np.uint64)[0]) == g["expect"]
+    for e in sw["slice_equalities"]:
+        a, b = e["slice"]
+        it = ctx.seqvec_iter_kmers(words, sw["len"], e["k"], a, b).cpu().numpy().view(np.uint64)
+        one = ctx.seqvec_get_kmers(words, sw["len"], ctx.to_device(np.array([e["same_as_pos"]], dtype=np.uint64)), e["k"])
+        assert int(it[e["pos"]]) == int(one.cpu().numpy().view(np.uint64)[0])
+    ik = sv_k["iter_kmers"]
+    w = ctx.seqvec_from_bytes(ctx.to_device(ik["seq"].encode()))
+    got = [orc.kmer_to_string(orc.lib().kmo_kmer_from_u64(int(x), ik["k"])) for x in ctx.seqvec_iter_kmers(w, len(ik["seq"]), ik["k"]).cpu().numpy().view(np.uint64)]
+    assert got == ik["expect"]
+    a, b = ik["slice"]
+    got = [orc.kmer_to_string(orc.lib().kmo_kmer_from_u64(int(x), ik["k"])) for x in ctx.seqvec_iter_kmers(w, len(ik["seq"]), ik["k"], a, b).cpu().numpy().view(np.uint64)]
+    assert got == ik["slice_expect"]
+
+
+def test_seqvec_get_and_iter_random(ctx, orc):
+    from kmers_amd import _lib
+    rng = np.random.default_rng(22)
+    n = 5000
+    host = _acgt(rng, n)
+    sv = orc.SeqVector(host.tobytes())
+    words = ctx.seqvec_from_bytes(ctx.to_device(host))
+    for k in (1, 7, 31, 32):
+        pos = rng.integers(0, n - k + 1, 300).astype(np.uint64)
+        pos[:3] = (0, n - k, 31)
+        got = ctx.seqvec_get_kmers(words, n, ctx.to_device(pos), k).cpu().numpy().view(np.uint64)
+        assert [int(x) for x in got] == [sv.get_kmer_u64(int(p), k) for p in pos]
+        assert (ctx.seqvec_iter_kmers(words, n, k).cpu().numpy().view(np.uint64) == sv.iter_kmers(k)).all()
+        assert (ctx.seqvec_iter_kmers(words, n, k, 77, 1234).cpu().numpy().view(np.uint64) == sv.iter_kmers(k, 77, 1234)).all()
+    with pytest.raises(Exception) as ei:   # the reference asserts pos < len
+        ctx.seqvec_get_kmers(words, n, ctx.to_device(np.array([5, n], dtype=np.uint64)), 3)
+    assert ei.value.status == _lib.E_ARG
+    assert ctx.seqvec_iter_kmers(words, n, 31, 10, 20).numel() == 0
+
+
+@pytest.mark.parametrize("k", [31, 21, 27, 11, 1])
+@pytest.mark.parametrize("L,n", [(150, 64 * 50 + 9), (150, 63), (100, 64 * 20), (250, 64 * 11 + 3), (151, 64 * 7), (40, 500)])
+def test_seqvec_canonical_reduce(ctx, orc, L, n, k):
+    """reads stored back to back in a SeqVector: bit-sliced packed kernel (k in {21,31}) and the generic packed kernel
+    against the oracle's get_kmer_u64 + to_canonical walk, and against the ASCII path on the same letters"""
+    from kmers_amd import _lib
+    rng = np.random.default_rng(L * 1000 + n + k)
+    host = _acgt(rng, n * L)
+    words = ctx.seqvec_from_bytes(ctx.to_device(host))
+    if L < k:
+        s = ctx.seqvec_canonical_reduce(words, n, L, k)
+        assert s.n_valid == 0
+        return
+    o = orc.SeqVector(host.tobytes()).canonical_reduce(n, L, k, k)
+    g = ctx.seqvec_canonical_reduce(words, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
+    a = ctx.canonical_reduce(ctx.to_device(host), n, L, k)
+    g0 = ctx.seqvec_canonical_reduce(words, n, L, k)
+    assert (g0.n_valid, g0.sum_canon, g0.xor_hash, g0.sum_fw) == (a.n_valid, a.sum_canon, 0, 0)

@@ -402,3 +402,57 @@ def test_generator_is_uniform_acgt(orc):
     assert (a[1000:6000] == b).all()  # position-addressable
     counts = np.bincount(a, minlength=256)[[65, 67, 71, 84]]
     assert counts.min() > 0.23 * a.size
+
+
+# ---------------------------------------------------------------- SeqVector
+
+def test_seq_vector_kats(orc, kats):  # seq_vector.rs:364-428
+    sv_k = kats["seq_vector"]
+    # seq_slice_test: a vector adopted from raw words [1, 2, 3]
+    sw = sv_k["slice_words"]
+    sv = orc.SeqVector()
+    sv.words = np.array(sw["words"] + [0], dtype=np.uint64)
+    sv.n = sw["len"]
+    for g in sw["get_kmer_u64"]:
+        assert sv.get_kmer_u64(g["pos"], g["k"]) == g["expect"]
+    for e in sw["slice_equalities"]:   # slice(a,b).get_kmer_u64(p,k) == sv.get_kmer_u64(a+p,k)
+        a, b = e["slice"]
+        assert sv.iter_kmers(e["k"], a, b)[e["pos"]] == sv.get_kmer_u64(e["same_as_pos"], e["k"])
+    # push_chars
+    sv = orc.SeqVector(capacity=64)
+    sv.push_chars(b"A" * 30)
+    assert len(sv) == sv_k["push_chars"]["len_after_first"] and sv.to_bytes() == b"A" * 30
+    sv.push_chars(b"C" * 40)
+    assert len(sv) == sv_k["push_chars"]["len_after_second"] and sv.to_bytes() == b"A" * 30 + b"C" * 40
+    # iter_kmers
+    ik = sv_k["iter_kmers"]
+    sv = orc.SeqVector(ik["seq"].encode())
+    got = [orc.kmer_to_string(orc.lib().kmo_kmer_from_u64(int(w), ik["k"])) for w in sv.iter_kmers(ik["k"])]
+    assert got == ik["expect"]
+    a, b = ik["slice"]
+    got = [orc.kmer_to_string(orc.lib().kmo_kmer_from_u64(int(w), ik["k"])) for w in sv.iter_kmers(ik["k"], a, b)]
+    assert got == ik["slice_expect"]
+
+
+def test_seq_vector_layout_and_scan_match_ascii_path(orc):
+    """SeqVector::from(&[u8]) word j == Kmer::from(32-base chunk j) (seq_vector.rs:346-358); scanning the packed reads
+    gives the same summary as the iterator over the letters; push_chars in pieces == one push"""
+    rng = np.random.default_rng(5)
+    L, n, k = 150, 37, 31
+    host = np.frombuffer(b"ACGTacgt", dtype=np.uint8)[rng.integers(0, 8, n * L)]
+    sv = orc.SeqVector(host.tobytes())
+    for j in range(0, n * L, 32):
+        chunk = host[j:j + 32].tobytes()
+        assert int(sv.words[j // 32]) == orc.kmer_from_bytes(chunk).data
+    assert sv.to_bytes() == host.tobytes().upper()
+    a = sv.canonical_reduce(n, L, k, k)
+    b = orc.canonical_reduce(host, n, L, k, k)
+    assert (a.n_valid, a.sum_canon, a.xor_hash, a.sum_fw) == (b.n_valid, b.sum_canon, b.xor_hash, b.sum_fw)
+    sv2 = orc.SeqVector(capacity=n * L)
+    cuts = [0, 5, 37, 64, 70, 1000, n * L]
+    for lo, hi in zip(cuts, cuts[1:]):
+        sv2.push_chars(host[lo:hi].tobytes())
+    assert len(sv2) == n * L and (sv2.words[: (n * L + 31) // 32] == sv.words[: (n * L + 31) // 32]).all()
+    with pytest.raises(orc.OracleError) as ei:
+        orc.SeqVector(b"ACGTNACGT")
+    assert ei.value.first_bad == 4
