@@ -219,6 +219,19 @@ int kmx_seqvec_iter_kmers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_base
 int kmx_seqvec_canonical_reduce(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_reads, uint32_t read_len, uint32_t k,
                                 uint32_t hasher, uint32_t hasher_k, uint32_t flags, kmx_summary *d_out);
 
+/* ---------------------------------------------------------------- minimizers ----
+ * hasher: KMX_HASH_LEX with hasher_k (LexHasherState::new(hasher_k): the k of the hasher is independent of the l-mer
+ * length, minimizers.rs:240 uses 6 for 3-mers) or KMX_HASH_IDENTITY.  std's RandomState has no pinned outputs. */
+/* Kmer::minimizer_word(word, k, width, state) (kmer.rs:170-192) for n k-mer words: the leftmost minimum-hash
+ * sub-word of `width` bases and its offset.  1 <= width <= k <= 32. */
+int kmx_minimizer_words(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n, uint32_t k, uint32_t width, uint32_t hasher,
+                        uint32_t hasher_k, uint64_t *d_mmer, uint32_t *d_offset);
+/* SeqVectorSlice::iter_minimizers(k, w, hasher) (seq_vector.rs:65-72; SeqVecMinimizerIter, minimizers.rs:39-141) for
+ * every read slice [r*read_len, (r+1)*read_len) of a SeqVector: MappedMinimizer{word, pos} per k-mer, slot
+ * r*(read_len-k+1) + i, pos relative to the slice.  read_len >= k (the iterator asserts it), 1 <= w <= k, w <= 32. */
+int kmx_seqvec_minimizers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_reads, uint32_t read_len, uint32_t k,
+                          uint32_t w, uint32_t hasher, uint32_t hasher_k, uint64_t *d_word, uint32_t *d_pos);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@
 #include <stdexcept>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "kmx.h"
@@ -164,6 +165,23 @@ struct Kmer {  // src/naive_impl/kmer.rs:6-10
         uint64_t w = data;
         for (unsigned i = 0; i < k; ++i, w >>= 2) s[i] = base_table[w & 3];
         return s;
+    }
+    // kmer.rs:151-162: panics (assert) unless pos < k and pos + width <= k
+    static uint64_t sub_kmer_word(uint64_t word, size_t k, size_t pos, size_t width) {
+        if (!(pos < k) || !(pos + width <= k)) throw Panic(KMX_E_ARG, "sub_kmer_word: assertion failed");
+        word >>= 2 * pos;
+        return width >= 32 ? word : (word & ((uint64_t{1} << (2 * width)) - 1));
+    }
+    Kmer sub_kmer(size_t pos, size_t width) const { return from_u64(sub_kmer_word(data, k, pos, width), static_cast<uint8_t>(width)); }
+    // kmer.rs:164-192 with the in-crate deterministic hasher: (minimizer, offset), leftmost of equal hashes
+    std::pair<Kmer, size_t> minimizer(size_t width, size_t lex_hasher_k, Context& ctx = Context::instance()) const {
+        DeviceBuffer<uint64_t> in(ctx, &data, 1), mm(ctx, 1);
+        DeviceBuffer<uint32_t> off(ctx, 1);
+        int st = kmx_minimizer_words(ctx.get(), in.data(), 1, k, static_cast<uint32_t>(width), KMX_HASH_LEX,
+                                     static_cast<uint32_t>(lex_hasher_k), mm.data(), off.data());
+        if (st == KMX_E_K_RANGE) throw Panic(st, "Kmer::minimizer: assertion failed: pos + width <= k");
+        ctx.check(st, "Kmer::minimizer");
+        return {from_u64(mm.download()[0], static_cast<uint8_t>(width)), off.download()[0]};
     }
 
   private:
@@ -367,6 +385,27 @@ class SeqVector {
         ctx_->check(kmx_seqvec_canonical_reduce(ctx_->get(), words_ ? words_->data() : nullptr, read_len ? n_ / read_len : 0,
                                                 static_cast<uint32_t>(read_len), k, hasher, hasher_k, flags, out.data()), "SeqVector::canonical_reduce");
         return out.download()[0];
+    }
+    struct MappedMinimizer {   // seq_vector/minimizers.rs:21-37
+        uint64_t word;
+        size_t pos;
+        uint64_t as_u64() const { return word; }
+        bool operator==(const MappedMinimizer& o) const { return word == o.word && pos == o.pos; }
+    };
+    // iter_minimizers(k, w, LexHasherState::new(lex_hasher_k)) collected (seq_vector.rs:245-252; minimizers.rs:39-141)
+    std::vector<MappedMinimizer> iter_minimizers(size_t k, size_t w, size_t lex_hasher_k) const {
+        if (n_ < k) throw Panic(KMX_E_ARG, "SeqVecMinimizerIter::new: assertion failed: sv.len() >= k");
+        const size_t cnt = n_ - k + 1;
+        DeviceBuffer<uint64_t> mw(*ctx_, cnt);
+        DeviceBuffer<uint32_t> mp(*ctx_, cnt);
+        ctx_->check(kmx_seqvec_minimizers(ctx_->get(), words_->data(), 1, static_cast<uint32_t>(n_), static_cast<uint32_t>(k),
+                                          static_cast<uint32_t>(w), KMX_HASH_LEX, static_cast<uint32_t>(lex_hasher_k), mw.data(), mp.data()),
+                    "SeqVector::iter_minimizers");
+        auto a = mw.download();
+        auto b = mp.download();
+        std::vector<MappedMinimizer> out(cnt);
+        for (size_t i = 0; i < cnt; ++i) out[i] = MappedMinimizer{a[i], b[i]};
+        return out;
     }
     const uint64_t* device_words() const { return words_ ? words_->data() : nullptr; }
 

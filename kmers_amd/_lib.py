@@ -79,6 +79,8 @@ SIGNATURES = {
     "kmx_seqvec_get_kmers": (_int, [_vp, _vp, _u64, _vp, _u64, _u32, _vp]),
     "kmx_seqvec_iter_kmers": (_int, [_vp, _vp, _u64, _u64, _u64, _u32, _vp]),
     "kmx_seqvec_canonical_reduce": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp]),
+    "kmx_minimizer_words": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "kmx_seqvec_minimizers": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
 }
 
 _LIB = None

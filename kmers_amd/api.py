@@ -255,6 +255,23 @@ class Context:
         v = u64_numpy(out)
         return Summary(int(v[0]), int(v[1]), int(v[2]), int(v[3]))
 
+    # ---- minimizers
+    def minimizer_words(self, words: torch.Tensor, k: int, width: int, hasher: int, hasher_k: int = 0):
+        """Kmer::minimizer_word (kmer.rs:170-192) per k-mer word -> (mmer words int64, offsets int32)"""
+        n = words.numel()
+        mm, off = self.empty(n, torch.int64), self.empty(n, torch.int32)
+        self._ck(self.lib.kmx_minimizer_words(self._h, _ptr(words) if n else None, n, k, width, hasher, hasher_k,
+                                              _ptr(mm) if n else None, _ptr(off) if n else None))
+        return mm, off
+
+    def seqvec_minimizers(self, words: torch.Tensor, n_reads: int, read_len: int, k: int, w: int, hasher: int, hasher_k: int = 0):
+        """SeqVecMinimizerIter over every read slice -> (word int64, pos int32), slot r*(L-k+1)+i"""
+        tot = n_reads * max(read_len - k + 1, 0)
+        mw, mp = self.empty(tot, torch.int64), self.empty(tot, torch.int32)
+        self._ck(self.lib.kmx_seqvec_minimizers(self._h, _ptr(words) if n_reads else None, n_reads, read_len, k, w, hasher, hasher_k,
+                                                _ptr(mw) if tot else None, _ptr(mp) if tot else None))
+        return mw, mp
+
     def encoding_decode(self, words: torch.Tensor, enc_byte: int, words_per_kmer: int) -> torch.Tensor:
         n = words.numel() // words_per_kmer
         out = self.empty(n * 32 * words_per_kmer, torch.uint8)

@@ -36,6 +36,10 @@ hipError_t launch_seqvec_get_kmers(const u64* words, u64 n_bases, const u64* pos
                                    unsigned long long* first_bad, int n_cu, hipStream_t st);
 hipError_t launch_seqvec_iter_kmers(const u64* words, u64 n_bases, u64 start, u64 count, u32 k, u64* out, int n_cu,
                                     hipStream_t st);
+hipError_t launch_minimizer_words(const u64* in, u64 n, u32 k, u32 w, u32 hasher, u32 hk, u64* out_mm, u32* out_off, int n_cu,
+                                  hipStream_t st);
+hipError_t launch_seqvec_minimizers(const u64* words, u64 n_reads, u32 L, u32 k, u32 w, u32 hasher, u32 hk, u64* out_word,
+                                    u32* out_pos, int n_cu, hipStream_t st);
 hipError_t launch_reduce_packed_generic(const u64* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                         kmx_summary* out, int n_cu, hipStream_t st);
 // kmx_generic.hip
@@ -596,6 +600,37 @@ int kmx_seqvec_canonical_reduce(kmx_ctx* ctx, const uint64_t* d_words, uint64_t 
                                                    ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
     if (handled) return KMX_OK;
     KMX_HIP(ctx, kmx::launch_reduce_packed_generic(d_words, n_reads, read_len, k, want_hash, want_sumfw, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+/* ------------------------------------------------------------- minimizers ---- */
+
+static int mm_hasher_ok(uint32_t hasher, uint32_t hasher_k) {
+    if (hasher == KMX_HASH_IDENTITY) return KMX_OK;
+    if (hasher != KMX_HASH_LEX) return KMX_E_ARG;
+    return (hasher_k >= 1 && hasher_k <= 32) ? KMX_OK : KMX_E_K_RANGE;
+}
+
+int kmx_minimizer_words(kmx_ctx* ctx, const uint64_t* d_words, uint64_t n, uint32_t k, uint32_t width, uint32_t hasher,
+                        uint32_t hasher_k, uint64_t* d_mmer, uint32_t* d_offset) {
+    if (!ctx || (n && (!d_words || !d_mmer || !d_offset))) return KMX_E_ARG;
+    if (k < 1 || k > 32 || width < 1 || width > k) return KMX_E_K_RANGE;   // sub_kmer_word asserts pos + width <= k
+    if (int st = mm_hasher_ok(hasher, hasher_k)) return st;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_minimizer_words(d_words, n, k, width, hasher, hasher_k, d_mmer, d_offset, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_seqvec_minimizers(kmx_ctx* ctx, const uint64_t* d_words, uint64_t n_reads, uint32_t read_len, uint32_t k, uint32_t w,
+                          uint32_t hasher, uint32_t hasher_k, uint64_t* d_word, uint32_t* d_pos) {
+    if (!ctx || (n_reads && (!d_words || !d_word || !d_pos))) return KMX_E_ARG;
+    if (k < 1 || w < 1 || w > k || w > 32) return KMX_E_K_RANGE;
+    if (read_len < k) return KMX_E_ARG;   // SeqVecMinimizerIter::new: assert!(sv.len() >= k)
+    if (int st = mm_hasher_ok(hasher, hasher_k)) return st;
+    if (n_reads == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_seqvec_minimizers(d_words, n_reads, read_len, k, w, hasher, hasher_k, d_word, d_pos, ctx->n_cu, ctx->stream));
     return KMX_OK;
 }
 

@@ -7,6 +7,8 @@
 //   get_kmer_u64 / get_base    seq_vector.rs:217-224            -> seqvec_get_kmers_kernel
 //   iter_kmers                 seq_vector.rs:236-243, 417-428   -> seqvec_iter_kmers_kernel
 //   String::from(&SeqVector)   seq_vector.rs:272-284            -> seqvec_to_bytes_kernel
+//   Kmer::minimizer_word       kmer.rs:170-192                  -> minimizer_words_kernel
+//   SeqVecMinimizerIter        seq_vector/minimizers.rs:39-141  -> seqvec_minimizers_kernel
 // and, for reads stored back to back as L-base slices (SeqVector::slice, :226-234), the canonical k-mer scan of
 // every slice for (k, L) outside the bit-sliced kernel: reduce_packed_generic_kernel (one lane walks one read with
 // CanonicalKmer::append_base, canonical_kmer.rs:90-94).
@@ -92,6 +94,63 @@ reduce_packed_generic_kernel(const u64* __restrict__ words, u64 n_reads, u32 L, 
     flush_acc(acc, out, want_hash != 0u, want_sumfw != 0u);
 }
 
+// ---------------------------------------------------------------- minimizers
+// hash_one(state, lmer) for the hashers with pinned outputs: LexHasher(hk) (hash.rs:60-71) or identity (write_u64(data))
+__device__ __forceinline__ u64 mm_hash(u64 lmer, u32 hasher, u32 hk) { return hasher == KMX_HASH_LEX ? lex_hash(lmer, hk) : lmer; }
+
+// Kmer::minimizer_word (kmer.rs:170-192): leftmost minimum (strict `<` starting from u64::MAX) over the k-w+1 sub-words
+__global__ void __launch_bounds__(256)
+minimizer_words_kernel(const u64* __restrict__ in, u64 n, u32 k, u32 w, u32 hasher, u32 hk, u64* __restrict__ out_mm,
+                       u32* __restrict__ out_off) {
+    const u64 mask = mask2k(w);
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const u64 word = in[e];
+        u64 best = word & mask, best_h = ~0ull;
+        u32 off = 0;
+        for (u32 pos = 0; pos + w <= k; ++pos) {
+            const u64 mm = (word >> (2u * pos)) & mask;   // sub_kmer_word, kmer.rs:156-162
+            const u64 h = mm_hash(mm, hasher, hk);
+            if (h < best_h) {
+                best = mm;
+                best_h = h;
+                off = pos;
+            }
+        }
+        out_mm[e] = best;
+        out_off[e] = off;
+    }
+}
+
+// SeqVecMinimizerIter (seq_vector/minimizers.rs:39-141) for every read slice [r*L, (r+1)*L): the monotone deque yields,
+// for k-mer i, the leftmost minimum-hash l-mer among positions i..i+k-w (`backmer.hash <= dqmer.hash` keeps the
+// earlier of equals); one thread per k-mer evaluates that window directly.
+__global__ void __launch_bounds__(256)
+seqvec_minimizers_kernel(const u64* __restrict__ words, u64 n_reads, u32 L, u32 k, u32 w, u32 hasher, u32 hk,
+                         u64* __restrict__ out_word, u32* __restrict__ out_pos) {
+    const u64 W = L - k + 1u, total = n_reads * W;
+    const u64 n_words = (n_reads * (u64)L + 31u) >> 5;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const u64 r = e / W;
+        const u32 i = (u32)(e - r * W);
+        const u64 base = r * (u64)L;
+        u64 best = 0, best_h = 0;
+        u32 best_pos = i;
+        for (u32 pos = i; pos <= i + k - w; ++pos) {
+            const u64 mm = seqvec_field(words, n_words, base + pos, w);
+            const u64 h = mm_hash(mm, hasher, hk);
+            if (pos == i || h < best_h) {
+                best = mm;
+                best_h = h;
+                best_pos = pos;
+            }
+        }
+        out_word[e] = best;
+        out_pos[e] = best_pos;
+    }
+}
+
 static inline unsigned sgrid(u64 n, int n_cu) {
     u64 g = (n + 255u) / 256u;
     const u64 cap = (u64)n_cu * 16u;
@@ -122,6 +181,18 @@ hipError_t launch_reduce_packed_generic(const u64* words, u64 n_reads, u32 L, u3
                                         kmx_summary* out, int n_cu, hipStream_t st) {
     hipLaunchKernelGGL(reduce_packed_generic_kernel, dim3(sgrid(n_reads, n_cu)), dim3(256), 0, st, words, n_reads, L, k,
                        want_hash ? 1u : 0u, want_sumfw ? 1u : 0u, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_minimizer_words(const u64* in, u64 n, u32 k, u32 w, u32 hasher, u32 hk, u64* out_mm, u32* out_off, int n_cu,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL(minimizer_words_kernel, dim3(sgrid(n, n_cu)), dim3(256), 0, st, in, n, k, w, hasher, hk, out_mm, out_off);
+    return hipGetLastError();
+}
+hipError_t launch_seqvec_minimizers(const u64* words, u64 n_reads, u32 L, u32 k, u32 w, u32 hasher, u32 hk, u64* out_word,
+                                    u32* out_pos, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(seqvec_minimizers_kernel, dim3(sgrid(n_reads * (u64)(L - k + 1u), n_cu)), dim3(256), 0, st, words, n_reads,
+                       L, k, w, hasher, hk, out_word, out_pos);
     return hipGetLastError();
 }
 

@@ -720,6 +720,98 @@ int kmo_seqvec_canonical_reduce(const uint64_t *words, size_t n_reads, size_t re
 }
 
 
+/* ------------------------------------------------------------------ minimizers ---- */
+
+uint64_t kmo_mm_hash(uint64_t lmer, size_t hasher_k) { return hasher_k ? kmo_lex_hash_u64(lmer, hasher_k) : lmer; }
+
+int kmo_minimizer_word(uint64_t word, size_t k, size_t width, size_t hasher_k, uint64_t *out_mmer, size_t *out_offset) {
+    if (k < 1 || k > 32 || width < 1 || width > k) return KMO_E_ARG;   /* sub_kmer_word asserts pos + width <= k */
+    uint64_t min_mmer = 0, min_hash = UINT64_MAX;
+    size_t offset = 0;
+    kmo_sub_kmer_word(word, k, 0, width, &min_mmer);
+    for (size_t pos = 0; pos < k - width + 1; ++pos) {
+        uint64_t mmer = 0;
+        kmo_sub_kmer_word(word, k, pos, width, &mmer);
+        uint64_t h = kmo_mm_hash(mmer, hasher_k);
+        if (h < min_hash) {
+            min_mmer = mmer;
+            min_hash = h;
+            offset = pos;
+        }
+    }
+    *out_mmer = min_mmer;
+    *out_offset = offset;
+    return KMO_OK;
+}
+
+void kmo_mmiter_enqueue(kmo_mmiter *it, kmo_dqmer m) {
+    if (it->len && it->dq[it->head].pos < it->curr_km_i) {   /* at most one falls out of the window */
+        it->head = (it->head + 1) % KMO_DQ_CAP;
+        it->len -= 1;
+    }
+    while (it->len) {
+        const kmo_dqmer *back = &it->dq[(it->head + it->len - 1) % KMO_DQ_CAP];
+        if (back->hash <= m.hash) break;
+        it->len -= 1;
+    }
+    it->dq[(it->head + it->len) % KMO_DQ_CAP] = m;
+    it->len += 1;
+}
+
+static kmo_dqmer mm_dqmer_at(const kmo_mmiter *it, size_t pos) {
+    kmo_dqmer m;
+    m.pos = pos;
+    m.lmer = 0;
+    kmo_seqvec_get_kmer_u64(it->words, it->n_bases, it->start + pos, it->w, &m.lmer);
+    m.hash = kmo_mm_hash(m.lmer, it->hasher_k);
+    return m;
+}
+
+int kmo_mmiter_new(kmo_mmiter *it, const uint64_t *words, size_t n_bases, size_t start, size_t end,
+                   size_t k, size_t w, size_t hasher_k) {
+    if (end > n_bases || start > end || end - start < k || w < 1 || w > k || w > 32 || k - w + 2 > KMO_DQ_CAP) return KMO_E_ARG;
+    it->head = it->len = 0;
+    it->k = k;
+    it->w = w;
+    it->curr_km_i = 0;
+    it->words = words;
+    it->n_bases = n_bases;
+    it->start = start;
+    it->slice_len = end - start;
+    it->hasher_k = hasher_k;
+    for (size_t i = 0; i < k - w; ++i) kmo_mmiter_enqueue(it, mm_dqmer_at(it, i));
+    return KMO_OK;
+}
+
+int kmo_mmiter_next(kmo_mmiter *it, uint64_t *out_word, size_t *out_pos) {
+    if (it->curr_km_i >= it->slice_len - it->k + 1) return 0;
+    kmo_mmiter_enqueue(it, mm_dqmer_at(it, it->curr_km_i + it->k - it->w));
+    *out_word = it->dq[it->head].lmer;
+    *out_pos = it->dq[it->head].pos;
+    it->curr_km_i += 1;
+    return 1;
+}
+
+int kmo_seqvec_minimizers(const uint64_t *words, size_t n_reads, size_t read_len, size_t k, size_t w, size_t hasher_k,
+                          uint64_t *out_word, uint32_t *out_pos) {
+    if (read_len < k) return KMO_OK;
+    const size_t W = read_len - k + 1;
+    for (size_t r = 0; r < n_reads; ++r) {
+        kmo_mmiter it;
+        int st = kmo_mmiter_new(&it, words, n_reads * read_len, r * read_len, (r + 1) * read_len, k, w, hasher_k);
+        if (st != KMO_OK) return st;
+        uint64_t word;
+        size_t pos, i = 0;
+        while (kmo_mmiter_next(&it, &word, &pos)) {
+            out_word[r * W + i] = word;
+            out_pos[r * W + i] = (uint32_t)pos;
+            ++i;
+        }
+    }
+    return KMO_OK;
+}
+
+
 int kmo_canonical_reduce2(const uint8_t *reads, size_t n_reads, size_t read_len, const uint64_t *offsets,
                           uint8_t k, int with_hash, kmo_summary2 *out) {
     if (k < 33 || k > 64) return KMO_E_ARG;

@@ -166,6 +166,35 @@ size_t kmo_seqvec_iter_kmers(const uint64_t *words, size_t n_bases, size_t start
 int kmo_seqvec_canonical_reduce(const uint64_t *words, size_t n_reads, size_t read_len, uint8_t k, size_t hasher_k,
                                 kmo_summary *out);
 
+/* ---- minimizers ----
+ * hasher: 0 = identity (hash == l-mer word: write_u64(data), hash.rs:4-8), else LexHasher(hasher_k) (hash.rs:60-71);
+ * the std RandomState/SipHash hashers the reference also accepts have no pinned outputs. */
+uint64_t kmo_mm_hash(uint64_t lmer, size_t hasher_k);
+/* Kmer::minimizer_word (kmer.rs:170-192): leftmost minimum over the k-w+1 sub-words (strict `<` against u64::MAX) */
+int kmo_minimizer_word(uint64_t word, size_t k, size_t width, size_t hasher_k, uint64_t *out_mmer, size_t *out_offset);
+/* SeqVecMinimizerIter (seq_vector/minimizers.rs:39-141) with its monotone deque, over slice [start, end) */
+#define KMO_DQ_CAP 96
+typedef struct {
+    uint64_t lmer;
+    size_t pos;
+    uint64_t hash;
+} kmo_dqmer;                        /* minimizers.rs:8-13 */
+typedef struct {
+    kmo_dqmer dq[KMO_DQ_CAP];       /* VecDeque: [head, head+len) */
+    size_t head, len;
+    size_t k, w, curr_km_i;
+    const uint64_t *words;
+    size_t n_bases, start, slice_len;
+    size_t hasher_k;
+} kmo_mmiter;
+void kmo_mmiter_enqueue(kmo_mmiter *it, kmo_dqmer m);                                   /* enqueue_dqmer, :60-80 */
+int kmo_mmiter_new(kmo_mmiter *it, const uint64_t *words, size_t n_bases, size_t start, size_t end,
+                   size_t k, size_t w, size_t hasher_k);                               /* new, :97-122 (assert len >= k) */
+int kmo_mmiter_next(kmo_mmiter *it, uint64_t *out_word, size_t *out_pos);              /* next, :127-141; 0 = exhausted */
+/* batch: every read (slice [r*L,(r+1)*L)) -> (word, pos) per k-mer, slot r*(L-k+1)+i */
+int kmo_seqvec_minimizers(const uint64_t *words, size_t n_reads, size_t read_len, size_t k, size_t w, size_t hasher_k,
+                          uint64_t *out_word, uint32_t *out_pos);
+
 /* ---- BUILD-DEFINED extensions (no reference counterpart) ---- */
 typedef struct {
     uint64_t n_valid;

@@ -51,6 +51,19 @@ class Iter(C.Structure):
     ]
 
 
+class DQMer(C.Structure):   # seq_vector/minimizers.rs:8-13
+    _fields_ = [("lmer", C.c_uint64), ("pos", C.c_size_t), ("hash", C.c_uint64)]
+
+
+class MMIter(C.Structure):  # SeqVecMinimizerIter, seq_vector/minimizers.rs:39-46
+    _fields_ = [("dq", DQMer * 96), ("head", C.c_size_t), ("len", C.c_size_t), ("k", C.c_size_t), ("w", C.c_size_t),
+                ("curr_km_i", C.c_size_t), ("words", C.c_void_p), ("n_bases", C.c_size_t), ("start", C.c_size_t),
+                ("slice_len", C.c_size_t), ("hasher_k", C.c_size_t)]
+
+    def dq_hashes(self):
+        return [self.dq[(self.head + i) % 96].hash for i in range(self.len)]
+
+
 class Summary(C.Structure):
     _fields_ = [("n_valid", C.c_uint64), ("sum_canon", C.c_uint64), ("xor_hash", C.c_uint64), ("sum_fw", C.c_uint64)]
 
@@ -157,6 +170,12 @@ def _bind(lib):
         "kmo_seqvec_to_bytes": (None, [C.c_void_p, C.c_size_t, C.c_void_p]),
         "kmo_seqvec_iter_kmers": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
         "kmo_seqvec_canonical_reduce": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint8, C.c_size_t, C.POINTER(Summary)]),
+        "kmo_mm_hash": (C.c_uint64, [C.c_uint64, C.c_size_t]),
+        "kmo_minimizer_word": (C.c_int, [C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, u64p, C.POINTER(C.c_size_t)]),
+        "kmo_mmiter_enqueue": (None, [C.POINTER(MMIter), DQMer]),
+        "kmo_mmiter_new": (C.c_int, [C.POINTER(MMIter), C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
+        "kmo_mmiter_next": (C.c_int, [C.POINTER(MMIter), u64p, C.POINTER(C.c_size_t)]),
+        "kmo_seqvec_minimizers": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
         "kmo_splitmix64": (C.c_uint64, [C.c_uint64]),
         "kmo_gen_reads": (None, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]),
         "kmo_bucket_of": (C.c_uint64, [C.c_uint64, C.c_uint]),
@@ -332,6 +351,38 @@ class SeqVector:
         if st != 0:
             raise OracleError(st, "seqvec_canonical_reduce")
         return s
+
+
+def minimizer_word(word: int, k: int, width: int, hasher_k: int = 0) -> tuple[int, int]:
+    """Kmer::minimizer_word (kmer.rs:170-192); hasher_k == 0: identity hasher, else LexHasher(hasher_k)"""
+    mm, off = C.c_uint64(), C.c_size_t()
+    st = lib().kmo_minimizer_word(word, k, width, hasher_k, C.byref(mm), C.byref(off))
+    if st != 0:
+        raise OracleError(st, "minimizer_word")
+    return mm.value, off.value
+
+
+def seqvec_iter_minimizers(sv: "SeqVector", k: int, w: int, hasher_k: int = 0, start: int = 0, end: int | None = None):
+    """SeqVecMinimizerIter over sv.slice(start, end): list of (word, pos)"""
+    end = sv.n if end is None else end
+    it = MMIter()
+    st = lib().kmo_mmiter_new(C.byref(it), _ptr(sv.words), sv.n, start, end, k, w, hasher_k)
+    if st != 0:
+        raise OracleError(st, "SeqVecMinimizerIter::new")
+    out, word, pos = [], C.c_uint64(), C.c_size_t()
+    while lib().kmo_mmiter_next(C.byref(it), C.byref(word), C.byref(pos)):
+        out.append((word.value, pos.value))
+    return out
+
+
+def seqvec_minimizers(sv: "SeqVector", n_reads: int, read_len: int, k: int, w: int, hasher_k: int = 0):
+    W = max(read_len - k + 1, 0)
+    words = np.zeros(n_reads * W, dtype=np.uint64)
+    pos = np.zeros(n_reads * W, dtype=np.uint32)
+    st = lib().kmo_seqvec_minimizers(_ptr(sv.words), n_reads, read_len, k, w, hasher_k, _ptr(words), _ptr(pos))
+    if st != 0:
+        raise OracleError(st, "seqvec_minimizers")
+    return words, pos
 
 
 def gen_reads(seed: int, first_byte: int, nbytes: int) -> np.ndarray:

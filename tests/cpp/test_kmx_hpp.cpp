@@ -166,6 +166,25 @@ int main() {
         kmx_summary b = sv.canonical_reduce(150, 31, KMX_HASH_LEX, 31, KMX_REDUCE_SUM_FW);
         CHECK(a.n_valid == b.n_valid && a.sum_canon == b.sum_canon && a.xor_hash == b.xor_hash && a.sum_fw == b.sum_fw && b.n_valid == 130u * 120u);
     }
+    // ---- src/naive_impl/seq_vector/minimizers.rs tests (:237-290) and kmer.rs test_minimizer (:560-580)
+    {
+        using MM = SeqVector::MappedMinimizer;
+        const uint64_t aac = 0b010000, acc = 0b010100, aaa = 0, aca = 0b000100;
+        CHECK((SeqVector(std::string("AAACAAA")).iter_minimizers(6, 3, 6) == std::vector<MM>{{0, 0}, {0, 4}}));                      // mmers0
+        CHECK((SeqVector(std::string("AACCAAA")).iter_minimizers(5, 3, 5) == std::vector<MM>{{aac, 0}, {acc, 1}, {aaa, 4}}));          // mmers1
+        CHECK((SeqVector(std::string("CACACACCAC")).iter_minimizers(7, 3, 3) == std::vector<MM>{{aca, 1}, {aca, 1}, {aca, 3}, {aca, 3}}));  // mmers2
+        CHECK((SeqVector(std::string("AAAAAAA")).iter_minimizers(5, 3, 3) == std::vector<MM>{{0, 0}, {0, 1}, {0, 2}}));               // leftmost_mmer
+        const std::string s = "ACTTGAT";
+        Kmer km = Kmer::from(s);
+        for (size_t w = 1; w < s.size(); ++w) {
+            auto [mm, o] = km.minimizer(w, 7);
+            CHECK(mm == Kmer::from(s.substr(o, w)));
+            for (size_t i = 0; i + w <= s.size(); ++i)
+                CHECK(hash::hash_one(hash::LexHasherState(7), mm) <= hash::hash_one(hash::LexHasherState(7), km.sub_kmer(i, w)));
+        }
+        CHECK(Kmer::sub_kmer_word(Kmer::from("acttgat").data, 7, 2, 3) == Kmer::from("ttg").data);
+        CHECK(panics([&] { km.sub_kmer(5, 3); }));
+    }
     std::printf(fails ? "%d check(s) FAILED\n" : "all C++ host-layer checks passed\n", fails);
     return fails ? 1 : 0;
 }

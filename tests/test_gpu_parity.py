@@ -571,3 +571,46 @@ def test_seqvec_canonical_reduce(ctx, orc, L, n, k):
     a = ctx.canonical_reduce(ctx.to_device(host), n, L, k)
     g0 = ctx.seqvec_canonical_reduce(words, n, L, k)
     assert (g0.n_valid, g0.sum_canon, g0.xor_hash, g0.sum_fw) == (a.n_valid, a.sum_canon, 0, 0)
+
+
+# ---------------------------------------------------------------- minimizers
+
+def test_minimizer_kats_on_device(ctx, orc, kats):
+    from kmers_amd import _lib
+    for t in kats["minimizers"]["iter"]:
+        s = t["seq"].encode()
+        words = ctx.seqvec_from_bytes(ctx.to_device(s))
+        hasher = _lib.HASH_LEX if t["hasher_k"] else _lib.HASH_IDENTITY
+        mw, mp = ctx.seqvec_minimizers(words, 1, len(s), t["k"], t["w"], hasher, t["hasher_k"])
+        got = [[int(a), int(b)] for a, b in zip(mw.cpu().numpy().view(np.uint64), mp.cpu().numpy())]
+        assert got == t["expect"], t["name"]
+
+
+@pytest.mark.parametrize("k,w,hk", [(31, 15, 15), (21, 11, 0), (9, 3, 32), (5, 5, 5), (32, 1, 1), (40, 7, 7)])
+def test_seqvec_minimizers_vs_oracle(ctx, orc, k, w, hk):
+    from kmers_amd import _lib
+    rng = np.random.default_rng(k * 100 + w)
+    L, n = 150, 257
+    host = _acgt(rng, n * L)
+    sv = orc.SeqVector(host.tobytes())
+    words = ctx.seqvec_from_bytes(ctx.to_device(host))
+    hasher = _lib.HASH_LEX if hk else _lib.HASH_IDENTITY
+    mw, mp = ctx.seqvec_minimizers(words, n, L, k, w, hasher, hk)
+    ow, op = orc.seqvec_minimizers(sv, n, L, k, w, hk)
+    assert (mw.cpu().numpy().view(np.uint64) == ow).all()
+    assert (mp.cpu().numpy().view(np.uint32) == op).all()
+
+
+def test_minimizer_words_vs_oracle(ctx, orc):
+    from kmers_amd import _lib
+    rng = np.random.default_rng(77)
+    for k, w, hk in ((31, 15, 15), (7, 1, 0), (7, 7, 7), (32, 9, 20), (12, 5, 0)):
+        vals = rng.integers(0, 1 << 62, 500, dtype=np.uint64) & np.uint64((1 << (2 * k)) - 1 if k < 32 else (1 << 64) - 1)
+        hasher = _lib.HASH_LEX if hk else _lib.HASH_IDENTITY
+        mm, off = ctx.minimizer_words(ctx.to_device(vals), k, w, hasher, hk)
+        exp = [orc.minimizer_word(int(v), k, w, hk) for v in vals]
+        assert [int(x) for x in mm.cpu().numpy().view(np.uint64)] == [e[0] for e in exp]
+        assert [int(x) for x in off.cpu().numpy()] == [e[1] for e in exp]
+    with pytest.raises(Exception) as ei:
+        ctx.minimizer_words(ctx.to_device(np.zeros(1, np.uint64)), 5, 6, _lib.HASH_IDENTITY, 0)
+    assert ei.value.status == _lib.E_K_RANGE

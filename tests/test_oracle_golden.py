@@ -456,3 +456,53 @@ def test_seq_vector_layout_and_scan_match_ascii_path(orc):
     with pytest.raises(orc.OracleError) as ei:
         orc.SeqVector(b"ACGTNACGT")
     assert ei.value.first_bad == 4
+
+
+# ---------------------------------------------------------------- minimizers
+
+def test_minimizer_kats(orc, kats):  # seq_vector/minimizers.rs:152-290, kmer.rs:560-580
+    import ctypes as C
+
+    mk = kats["minimizers"]
+    # enqueue_dqmer: the deque after each push, with curr_km_i advanced as the reference test does
+    e = mk["enqueue_dqmer"]
+    it = orc.MMIter()
+    it.k, it.w = e["k"], e["w"]
+    for st in e["steps"]:
+        i = st["enqueue"]
+        orc.lib().kmo_mmiter_enqueue(C.byref(it), orc.DQMer(0, i, e["hashes"][i]))
+        assert it.dq_hashes() == st["dq"], st
+        if st["then_curr_km_i"] is not None:
+            it.curr_km_i = st["then_curr_km_i"]
+    for t in mk["iter"]:
+        sv = orc.SeqVector(t["seq"].encode())
+        got = orc.seqvec_iter_minimizers(sv, t["k"], t["w"], t["hasher_k"])
+        assert [list(x) for x in got] == t["expect"], t["name"]
+    # test_minimizer: property over every width, identity and Lex hashers
+    p = mk["test_minimizer_property"]
+    s = p["seq"]
+    km = orc.kmer_from_bytes(s.encode())
+    for hk in (0, 7, 3):
+        for w in p["widths"]:
+            mm, o = orc.minimizer_word(km.data, len(s), w, hk)
+            hmin = orc.lib().kmo_mm_hash(mm, hk)
+            for i in range(len(s) - w + 1):
+                sub = orc.kmer_from_bytes(s[i:i + w].encode()).data
+                assert hmin <= orc.lib().kmo_mm_hash(sub, hk)
+            assert mm == orc.kmer_from_bytes(s[o:o + w].encode()).data
+
+
+def test_minimizer_iterator_equals_windowed_leftmost_min(orc):
+    """the monotone deque == brute-force leftmost minimum over l-mer positions i..i+k-w, and == minimizer_word of the k-mer"""
+    rng = np.random.default_rng(9)
+    host = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 400)]
+    sv = orc.SeqVector(host.tobytes())
+    for k, w, hk in ((31, 15, 15), (21, 11, 0), (9, 3, 32), (5, 5, 5), (32, 1, 1)):
+        got = orc.seqvec_iter_minimizers(sv, k, w, hk, 17, 333)
+        assert len(got) == 333 - 17 - k + 1
+        for i, (word, pos) in enumerate(got):
+            cands = [(orc.lib().kmo_mm_hash(sv.get_kmer_u64(17 + p, w), hk), p) for p in range(i, i + k - w + 1)]
+            hmin, pmin = min(cands)
+            assert (pos, word) == (pmin, sv.get_kmer_u64(17 + pmin, w))
+            mm, off = orc.minimizer_word(sv.get_kmer_u64(17 + i, k), k, w, hk)
+            assert (mm, i + off) == (word, pos)
