@@ -57,7 +57,9 @@ typedef struct kmx_ctx kmx_ctx;
 
 /* A batch of reads resident in device memory.
  * offsets == NULL: uniform layout, read r = d_bases[r*read_len .. (r+1)*read_len).
- * offsets != NULL: ragged layout, read r = d_bases[offsets[r] .. offsets[r+1]) (n_reads+1 device u64). */
+ * offsets != NULL: ragged layout, read r = d_bases[offsets[r] .. offsets[r+1]) (n_reads+1 device u64); read_len may
+ *   then carry an upper bound of the read lengths (0 = unknown): a bound <= 160 selects the smaller, faster frame of the
+ *   tiled kernels.  It is only a hint -- tiles with a longer read take the exact per-read path. */
 typedef struct {
     const uint8_t *d_bases;
     uint64_t n_reads;

@@ -15,10 +15,11 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 // kmx_scan.hip
 hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
-                               kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+                               kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
+                               const u64* offsets);
 hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 hasher, u32 hk, u32 log2_buckets,
                                u64* counts, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
-                               void* (*get_scratch)(void*, size_t), void* user, size_t scratch_budget);
+                               void* (*get_scratch)(void*, size_t), void* user, size_t scratch_budget, const u64* offsets);
 hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon,
                                   uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 // kmx_bitslice.hip
@@ -315,14 +316,17 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
     if (reads->n_reads == 0) return KMX_OK;
     const bool want_sumfw = (flags & KMX_REDUCE_SUM_FW) != 0;
     const bool lex_same_k = hasher == KMX_HASH_LEX && hasher_k == k;
-    if (!reads->d_offsets && (hasher == KMX_HASH_NONE || lex_same_k)) {
+    if (hasher == KMX_HASH_NONE || lex_same_k) {
         bool handled = false;
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));  // 32 tile-queue heads, 128 B apart
-        KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
-                                                d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
-        if (handled) return KMX_OK;
+        if (!reads->d_offsets) {
+            KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
+                                                    d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+            if (handled) return KMX_OK;
+        }
+        // word-domain kernel: uniform reads of any (k, L) in its domain, and ragged reads (read_len = optional length bound)
         KMX_HIP(ctx, kmx::launch_scan_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
-                                              d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+                                              d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled, reads->d_offsets));
         if (handled) return KMX_OK;
     }
     KMX_HIP(ctx, kmx::launch_reduce_generic(reads, k, hasher, hasher_k, want_sumfw ? 1u : 0u, d_out, ctx->n_cu, ctx->stream));
@@ -383,12 +387,12 @@ int kmx_histogram(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t has
     if (hasher == KMX_HASH_LEX && (hasher_k < 1 || hasher_k > 32)) return KMX_E_K_RANGE;
     if (reads->n_reads == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
-    if (!reads->d_offsets) {
+    {
         bool handled = false;
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
         KMX_HIP(ctx, kmx::launch_hist_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, hasher, hasher_k,
                                               log2_buckets, d_counts, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled,
-                                              &big_scratch, ctx, hist_scratch_budget()));
+                                              &big_scratch, ctx, hist_scratch_budget(), reads->d_offsets));
         if (handled) return KMX_OK;
     }
     KMX_HIP(ctx, kmx::launch_histogram_generic(reads, k, hasher, hasher_k, log2_buckets, d_counts, ctx->n_cu, ctx->stream));

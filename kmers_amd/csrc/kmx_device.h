@@ -115,6 +115,18 @@ __device__ __forceinline__ u64 bucket_of(u64 h, u32 log2_buckets) {
     return log2_buckets ? (h * 0x9E3779B97F4A7C15ull) >> (64u - log2_buckets) : 0ull;
 }
 
+// max over the 64 lanes, returned wave-uniform: DPP inside the 16-lane rows (no LDS round trips), then 4 v_readlane
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+    auto mx = [](u32 a, u32 b) { return a > b ? a : b; };
+    v = mx(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true));
+    v = mx(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true));
+    v = mx(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x124 /* row_ror:4 */, 0xF, 0xF, true));
+    v = mx(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x128 /* row_ror:8 */, 0xF, 0xF, true));
+    const u32 a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const u32 c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return mx(mx(a, b), mx(c, d));
+}
+
 __device__ __forceinline__ u64 wave_sum(u64 v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);

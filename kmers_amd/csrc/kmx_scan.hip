@@ -44,6 +44,7 @@ struct SinkReduce {
     u64 maskk;
     u32 k;
     static constexpr u32 kLdsDwordsPerWave = 0;
+    static constexpr bool kRagged = true;
     static u32 block_lds_dwords(const ReduceParams&) { return 0; }
     __device__ SinkReduce(const ReduceParams&, u32 k_, u32, u32*, u32, u32*, u32) : maskk(mask2k(k_)), k(k_) {}
     __device__ __forceinline__ void block_done(u64, u32, u32) {}
@@ -56,6 +57,10 @@ struct SinkReduce {
             acc.xor_hash ^= maskk ^ fw ^ rc ^ canon;
             acc.sum_fw += fw;
         }
+        // Pin the accumulation order: left alone, LLVM reassociates the ~140 adds of a tile into a balanced tree and
+        // keeps every window's canonical word live for it (228-256 VGPRs, 1-2 waves/SIMD instead of 4).
+        asm volatile("" : "+v"(acc.sum_canon));
+        if (FULL) asm volatile("" : "+v"(acc.xor_hash), "+v"(acc.sum_fw));
     }
     __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) {
         const u64 canon = fw < rc ? fw : rc;
@@ -85,6 +90,7 @@ struct SinkHist {
     u32 hasher, hk, k, b;
     static constexpr u32 kLdsDwordsPerWave = 0;
     __device__ __forceinline__ void block_done(u64, u32, u32) {}
+    static constexpr bool kRagged = true;
     static u32 block_lds_dwords(const HistParams&) { return 0; }
     __device__ SinkHist(const HistParams& p, u32 k_, u32, u32*, u32, u32*, u32)
         : counts(p.counts), maskk(mask2k(k_)), hasher(p.hasher), hk(p.hk), k(k_), b(p.log2_buckets) {}
@@ -112,6 +118,7 @@ struct SinkHistLds {
     u64 maskk;
     u32 hasher, hk, k, b, tid;
     static constexpr u32 kLdsDwordsPerWave = 0;
+    static constexpr bool kRagged = true;
     static u32 block_lds_dwords(const HistParams& p) { return 1u << p.log2_buckets; }
     __device__ SinkHistLds(const HistParams& p, u32 k_, u32, u32*, u32, u32* block_lds, u32 tid_)
         : counts(p.counts), tab(block_lds), maskk(mask2k(k_)), hasher(p.hasher), hk(p.hk), k(k_), b(p.log2_buckets), tid(tid_) {
@@ -159,6 +166,7 @@ struct HistPartParams {
 struct SinkHistPart {
     static constexpr u32 NP = 64, ROW = 128;   // partitions; ring entries per partition (u16)
     static constexpr u32 kLdsDwordsPerWave = NP * ROW / 2u + 2u * NP;
+    static constexpr bool kRagged = false;
     static u32 block_lds_dwords(const HistPartParams&) { return 0; }
     HistPartParams p;
     uint16_t* ring;    // [NP][ROW]
@@ -320,6 +328,7 @@ struct SinkWindows {
     uint8_t* TF;   // [64][16] flags
     u64 base;      // slot of window 0 of the current read (slow path)
     u32 W, next, lane;
+    static constexpr bool kRagged = false;   // the transposed write-back assumes one window count per read
     static u32 block_lds_dwords(const WindowsParams&) { return 0; }
     __device__ SinkWindows(const WindowsParams& p_, u32, u32 W_, u32* lds, u32 lane_, u32*, u32)
         : p(p_), T(reinterpret_cast<u64*>(lds)), TF(reinterpret_cast<uint8_t*>(lds + 3u * 64u * PITCH * 2u)), base(0), W(W_), next(0), lane(lane_) {}
@@ -383,37 +392,54 @@ struct SinkWindows {
 // NW  = packed dwords per read = ceil(L/16) rounded up to an instantiated size (L <= 16*NW)
 // V   = 1: k in [2,17]   2: k in [18,32]   (fixes the static register index of the rc window)
 // DW  = dwords per k-mer (1: k<=16, 2: k>=17)
-template <int NW, int V, int DW, typename Sink, typename Params>
-__global__ void __launch_bounds__(256)
+// RAGGED: reads of different lengths, read r = bases[offsets[r], offsets[r+1]).  A tile is still 64 consecutive reads =
+// one contiguous byte span, streamed from its 16-byte-aligned start; lanes carry their own start and window count,
+// windows past a lane's read are masked.  A tile whose span or longest read does not fit the NW-word frame, or that
+// would load past the end of the buffer, takes the per-lane rolling path.
+#ifndef KMX_SCAN_RAGGED_2COPY
+#define KMX_SCAN_RAGGED_2COPY 0
+#endif
+#ifndef KMX_SCAN_DEV_NOGUARD
+#define KMX_SCAN_DEV_NOGUARD 0   // dev: drop the per-window length mask of the ragged kernel (wrong for unequal lengths; timing only)
+#endif
+#ifndef KMX_SCAN_WAVES
+#define KMX_SCAN_WAVES 1   // waves per SIMD the register allocation is sized for (hipcc otherwise spends up to 256 VGPRs on hoisting)
+#endif
+template <int NW, int V, int DW, typename Sink, typename Params, bool RAGGED = false>
+__global__ void __launch_bounds__(256, KMX_SCAN_WAVES)
 scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, Params params,
-                    unsigned long long* __restrict__ queue) {
+                    unsigned long long* __restrict__ queue, const u64* __restrict__ offsets) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const u32 lane = threadIdx.x & 63u;
     const u32 wib = threadIdx.x >> 6;
-    const u32 chunks = 4u * L;                      // 16-byte chunks per 64-read tile
-    const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u; // front pad 1, tail pad >= 6
+    const u32 chunks_u = RAGGED ? 64u * NW : 4u * L;  // 16-byte chunks per 64-read tile (ragged: the most a tile may span)
+    const u32 ldsw = (chunks_u + 1u + 6u + 3u) & ~3u; // front pad 1, tail pad >= 6
     u32* P = lds + wib * (ldsw + Sink::kLdsDwordsPerWave);
 
     const u64 n_full = n_reads >> 6;
     const u64 wave_id = (u64)blockIdx.x * 4u + wib;
+    const u64 total_bytes = RAGGED ? offsets[n_reads] : 0;
 
     // per-lane alignment of this lane's read inside the packed tile (LDS index 1+c holds bases [16c,16c+16))
-    const u32 posF = lane * L + 16u;
-    const u32 qF = posF >> 4, aF = 2u * (posF & 15u);
+    u32 posF = lane * L + 16u;
+    u32 qF = posF >> 4, aF = 2u * (posF & 15u);
     const u32 delta = (1u - k) & 15u;  // rc stream pre-offset so that rc sub-shift == 30-2s
-    const u32 posR = posF - delta;
-    const u32 qR = posR >> 4, aR = 2u * (posR & 15u);
+    u32 posR = posF - delta;
+    u32 qR = posR >> 4, aR = 2u * (posR & 15u);
 
-    const u32 omax = L - k;  // last window start
-    const u32 imax = omax >> 4, smax = omax & 15u;
+    u32 omax = L - k;  // last window start (uniform: of every read; ragged: the longest read of the tile)
+    u32 imax = omax >> 4, smax = omax & 15u;
     const u64 maskk = mask2k(k);
     const u32 mlo = (u32)maskk;
     const u32 mhi = (u32)(maskk >> 32);
-    const u32 nwin = omax + 1u;
+    u32 nwin = omax + 1u;       // windows of this lane's read
+    u32 chunks = chunks_u;
 
     Sink sink(params, k, nwin, P + ldsw, lane, lds + 4u * (ldsw + Sink::kLdsDwordsPerWave), threadIdx.x);
 
-    auto window = [&](u32 o, u32 f0, u32 f1, u32 f2, u32 g0, u32 g1, u32 g2, u32 sf, u32 sr) {
+    u32 nwin_min = nwin;        // ragged: the shortest read of the tile (blocks of windows below it need no per-lane mask)
+    auto window = [&](u32 o, u32 f0, u32 f1, u32 f2, u32 g0, u32 g1, u32 g2, u32 sf, u32 sr, bool guard = RAGGED) {
+        if (guard && o >= nwin) return;   // past the end of this lane's (shorter) read
         if (DW == 2) {
             const u32 fw_lo = alignbit(f1, f0, sf);
             const u32 fw_hi = alignbit(f2, f1, sf) & mhi;
@@ -443,32 +469,77 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         return ~0ull;
     };
     u64 next_tile = dequeue();
+    // ragged: this lane's [start, end) of the NEXT tile, fetched one tile ahead so that the tile's byte loads never wait
+    // behind a dependent offsets load
+    u64 nx_off = 0, nx_end = 0;
+    if (RAGGED && next_tile < n_full) {
+        nx_off = offsets[next_tile * 64u + lane];
+        nx_end = offsets[next_tile * 64u + lane + 1u];
+    }
     for (u64 tile = next_tile; tile < n_full; tile = next_tile) {
         next_tile = dequeue();
+        const u64 read = tile * 64u + lane;
         const uint4* __restrict__ tb = reinterpret_cast<const uint4*>(bases + tile * 64u * (u64)L);
+        u64 my_off = 0;
+        u32 my_len = 0;
+        bool tile_fits = true;
+        if constexpr (RAGGED) {
+            my_off = nx_off;
+            my_len = (u32)(nx_end - nx_off);
+            const u64 t0 = ((u64)__builtin_amdgcn_readfirstlane((u32)(nx_off >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)nx_off);
+            const u64 t1 = ((u64)__builtin_amdgcn_readlane((u32)(nx_end >> 32), 63) << 32) | __builtin_amdgcn_readlane((u32)nx_end, 63);
+            if (next_tile < n_full) {
+                nx_off = offsets[next_tile * 64u + lane];
+                nx_end = offsets[next_tile * 64u + lane + 1u];
+            }
+            const u64 base_al = t0 & ~15ull;
+            const u64 n_ch = (t1 - base_al + 15u) >> 4;
+            const u32 max_len = (u32)wave_max_u32(my_len);
+            tile_fits = n_ch <= 64u * NW && max_len <= 16u * NW && base_al + 16u * n_ch <= total_bytes;
+            chunks = (u32)n_ch;
+            tb = reinterpret_cast<const uint4*>(bases + base_al);
+            posF = (u32)(my_off - base_al) + 16u;
+            qF = posF >> 4;
+            aF = 2u * (posF & 15u);
+            posR = posF - delta;
+            qR = posR >> 4;
+            aR = 2u * (posR & 15u);
+            nwin = my_len >= k ? my_len - k + 1u : 0u;
+            nwin_min = ~wave_max_u32(~nwin);
+            omax = max_len >= k ? max_len - k : 0u;
+            imax = omax >> 4;
+            smax = omax & 15u;
+            if (max_len < k) {   // nothing to emit in this tile
+                sink.tile_fast_done(0);
+                continue;
+            }
+        }
         // ---- 1. stream the tile: all loads in flight before the first use
         uint4 w[NW];
+        if (tile_fits) {
 #pragma unroll
-        for (int it = 0; it < NW; ++it) {
-            const u32 c = it * 64u + lane;
-            if (c < chunks) w[it] = tb[c];
+            for (int it = 0; it < NW; ++it) {
+                const u32 c = it * 64u + lane;
+                if (c < chunks) w[it] = tb[c];
+            }
         }
         // ---- 2. pack + validate, stage packed words in LDS
         u32 bad = 0;
+        if (tile_fits) {
 #pragma unroll
-        for (int it = 0; it < NW; ++it) {
-            const u32 c = it * 64u + lane;
-            if (c < chunks) P[1u + c] = encode16(w[it], bad);
+            for (int it = 0; it < NW; ++it) {
+                const u32 c = it * 64u + lane;
+                if (c < chunks) P[1u + c] = encode16(w[it], bad);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        const u64 read = tile * 64u + lane;
-        if (__any(chunk_has_invalid(bad))) {
-            // ---- rare: a non-ACGTacgt byte somewhere in this tile -> exact iterator semantics
+        if (!tile_fits || __any(chunk_has_invalid(bad))) {
+            // ---- rare: a non-ACGTacgt byte somewhere in this tile (or a ragged tile outside the frame) -> exact iterator semantics
             sink.begin_read(read);
-            roll_read(bases + read * (u64)L, L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
+            roll_read(RAGGED ? bases + my_off : bases + read * (u64)L, RAGGED ? my_len : L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
             sink.end_read();
             continue;
         }
@@ -497,8 +568,25 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         for (int i = 0; i <= NW - V; ++i) {
             const int M = NW - V - i;
             if ((u32)i < imax) {
+                // Opaque copies of the six source words, made INSIDE the block: LLVM's speculative execution otherwise
+                // hoists the (cheap, side-effect-free) funnel shifts of every block above the chain of uniform branches
+                // and keeps them all live -- 228-256 VGPRs, 1-2 waves per SIMD instead of 4.
+                u32 f0 = F[i], f1 = F[i + 1], f2 = F[i + 2], g0 = G[M], g1 = G[M + 1], g2 = G[M + 2];
+                asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(g0), "+v"(g1), "+v"(g2));
+#if KMX_SCAN_RAGGED_2COPY
+                if (!RAGGED || 16u * i + 16u <= nwin_min) {   // every lane owns all 16 windows: straight-line code
 #pragma unroll
-                for (int s = 0; s < 16; ++s) window(16 * i + s, F[i], F[i + 1], F[i + 2], G[M], G[M + 1], G[M + 2], 2 * s, 30 - 2 * s);
+                    for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, false);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, true);
+                }
+#else
+                // (a second, unmasked copy of the block for tiles of equal-length reads doubles the code past the
+                //  instruction cache and costs more than the per-window mask it saves)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, RAGGED && !KMX_SCAN_DEV_NOGUARD);
+#endif
                 sink.block_done(tile * 64u, 16u * i, 16u);
             } else if ((u32)i == imax) {
                 for (u32 s = 0; s <= smax; ++s) window(16u * i + s, F[i], F[i + 1], F[i + 2], G[M], G[M + 1], G[M + 2], 2u * s, 30u - 2u * s);
@@ -513,7 +601,12 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     if (rem != 0u && wave_id == 0 && lane < rem) {
         const u64 read = n_full * 64u + lane;
         sink.begin_read(read);
-        roll_read(bases + read * (u64)L, L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
+        if constexpr (RAGGED) {
+            const u64 o0 = offsets[read];
+            roll_read(bases + o0, (u32)(offsets[read + 1u] - o0), k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
+        } else {
+            roll_read(bases + read * (u64)L, L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
+        }
         sink.end_read();
     }
     sink.finish(params);
@@ -526,11 +619,11 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
 struct NoPre {
     bool operator()(u64) const { return true; }
 };
-template <int NW, int V, int DW, typename Sink, typename Params, typename Pre = NoPre>
+template <int NW, int V, int DW, typename Sink, typename Params, typename Pre = NoPre, bool RAGGED = false>
 static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Params& params,
-                             unsigned long long* queue, int n_cu, hipStream_t stream, Pre pre = Pre()) {
-    auto kern = scan_uniform_kernel<NW, V, DW, Sink, Params>;
-    const u32 chunks = 4u * L;
+                             unsigned long long* queue, int n_cu, hipStream_t stream, Pre pre = Pre(), const u64* offsets = nullptr) {
+    auto kern = scan_uniform_kernel<NW, V, DW, Sink, Params, RAGGED>;
+    const u32 chunks = RAGGED ? 64u * NW : 4u * L;
     const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
     const size_t lds_bytes = (size_t)(ldsw + Sink::kLdsDwordsPerWave) * 4u * 4u + (size_t)Sink::block_lds_dwords(params) * 4u;
     static int bpc = 0;
@@ -552,7 +645,7 @@ static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Pa
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
     if (!pre(grid)) return hipErrorOutOfMemory;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, params, queue);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, params, queue, offsets);
     return hipGetLastError();
 }
 
@@ -560,11 +653,26 @@ static bool scan_domain(const uint8_t* bases, u64 n_reads, u32 L, u32 k) {
     if (k < 2 || k > 31 || k == 17 || L < k || L > 256 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return false;
     return n_reads * (u64)L < (1ull << 62);
 }
+// ragged reads: L is an optional upper bound of the lengths (0 = unknown); reads longer than the frame fall back per tile
+static bool scan_domain_ragged(const uint8_t* bases, u32 L, u32 k) {
+    return !(k < 2 || k > 31 || k == 17 || L > 256 || (reinterpret_cast<uintptr_t>(bases) & 15u));
+}
 
+// offsets != nullptr: ragged reads; L is then only an upper bound of the read lengths (0 = unknown) that selects the frame
 template <typename SinkT, typename Params, typename Pre = NoPre>
 static hipError_t dispatch(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Params p, unsigned long long* queue,
-                           int n_cu, hipStream_t stream, Pre pre = Pre()) {
-    const bool big = L > 160;
+                           int n_cu, hipStream_t stream, Pre pre = Pre(), const u64* offsets = nullptr) {
+    const bool big = L > 160 || (offsets && L == 0);
+    if constexpr (!SinkT::kRagged) {
+        if (offsets) return hipErrorInvalidValue;
+    } else if (offsets) {
+        if (k <= 16) {
+            if (big) return launch_one<16, 1, 1, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+            return launch_one<10, 1, 1, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+        }
+        if (big) return launch_one<16, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+        return launch_one<10, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+    }
     if (k <= 16) {
         if (big) return launch_one<16, 1, 1, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
         return launch_one<10, 1, 1, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
@@ -588,12 +696,13 @@ static hipError_t dispatch_part(const uint8_t* bases, u64 n_reads, u32 L, u32 k,
 // Each returns hipSuccess and sets *handled=false when (L,k) is outside the fast kernel's domain.
 // `queue`: 32 zeroed u64 heads, 128 B apart, owned by the caller for the duration of the launch.
 hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
-                               kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
-    *handled = scan_domain(bases, n_reads, L, k);
+                               kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
+                               const u64* offsets) {
+    *handled = offsets ? scan_domain_ragged(bases, L, k) : scan_domain(bases, n_reads, L, k);
     if (!*handled) return hipSuccess;
     const ReduceParams p{out, want_hash ? 1u : 0u, want_sumfw ? 1u : 0u};
-    if (want_hash || want_sumfw) return dispatch<SinkReduce<true>>(bases, n_reads, L, k, p, queue, n_cu, stream);
-    return dispatch<SinkReduce<false>>(bases, n_reads, L, k, p, queue, n_cu, stream);
+    if (want_hash || want_sumfw) return dispatch<SinkReduce<true>>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
+    return dispatch<SinkReduce<false>>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
 }
 
 // Histogram over uniform reads.  2^b <= 2^14: block-private LDS tables (SinkHistLds).  2^15..2^21: two passes through
@@ -602,10 +711,14 @@ hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
 // Larger tables, or no scratch: device-scope u64 atomics (SinkHist).
 hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 hasher, u32 hk, u32 log2_buckets,
                                u64* counts, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
-                               void* (*get_scratch)(void*, size_t), void* user, size_t scratch_budget) {
-    *handled = scan_domain(bases, n_reads, L, k);
+                               void* (*get_scratch)(void*, size_t), void* user, size_t scratch_budget, const u64* offsets) {
+    *handled = offsets ? scan_domain_ragged(bases, L, k) : scan_domain(bases, n_reads, L, k);
     if (!*handled) return hipSuccess;
     const HistParams p{counts, hasher, hk, log2_buckets};
+    if (offsets) {   // ragged reads: LDS tables up to 2^14 buckets, device atomics above (the partitioned path sizes its segments from a uniform L)
+        if (log2_buckets <= 14u) return dispatch<SinkHistLds>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
+        return dispatch<SinkHist>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
+    }
     if (log2_buckets <= 14u) return dispatch<SinkHistLds>(bases, n_reads, L, k, p, queue, n_cu, stream);
     if (log2_buckets <= 21u && get_scratch != nullptr && n_reads >= 4096u) {
         const u64 W = L - k + 1u;

@@ -225,6 +225,49 @@ def test_reduce_and_windows_ragged(ctx, orc):
     assert (outs["flags"].cpu().numpy() == flags).all()
 
 
+@pytest.mark.parametrize("k", [31, 21, 11, 5])
+@pytest.mark.parametrize("hint", [0, 160, 256])
+def test_reduce_ragged_tiled_kernel(ctx, orc, k, hint):
+    """ragged reads on the tiled word-domain kernel: mostly 100..160 bp (fits both frames), some empty / shorter than k /
+    longer than the frame (those tiles take the exact path), N bytes, a partial last tile, the last tile's tail chunk"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(1000 + k + hint)
+    lens = rng.integers(100, 161, size=64 * 40 + 21)
+    lens[rng.integers(0, lens.size, 30)] = rng.choice([0, 1, k - 1, k, k + 1, 255, 256, 257, 400], size=30)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]), 0.0005)
+    bases, d_off = ctx.to_device(host), ctx.to_device(offsets)
+    o = orc.canonical_reduce(host, len(lens), 0, k, hasher_k=k, offsets=offsets)
+    g = ctx.canonical_reduce(bases, len(lens), hint, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=d_off)
+    _cmp_summary(g, o, True, True)
+    g0 = ctx.canonical_reduce(bases, len(lens), hint, k, offsets=d_off)
+    assert (g0.n_valid, g0.sum_canon) == (o.n_valid, o.sum_canon)
+
+
+def test_reduce_ragged_equals_uniform_when_lengths_are_equal(ctx, orc):
+    rng = np.random.default_rng(31)
+    L, n, k = 150, 64 * 30 + 5, 31
+    host = _dirty(rng, n * L, 0.0002)
+    offsets = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    a = ctx.canonical_reduce(ctx.to_device(host), n, L, k)
+    b = ctx.canonical_reduce(ctx.to_device(host), n, 160, k, offsets=ctx.to_device(offsets))
+    assert (a.n_valid, a.sum_canon) == (b.n_valid, b.sum_canon)
+
+
+@pytest.mark.parametrize("b", [12, 20])
+def test_histogram_ragged(ctx, orc, b):
+    rng = np.random.default_rng(b + 5)
+    k = 31
+    lens = rng.integers(90, 161, size=64 * 25 + 9)
+    lens[::97] = 300
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]), 0.0005)
+    o = orc.histogram(host, len(lens), 0, k, k, b, offsets=offsets)
+    g = ctx.histogram(ctx.to_device(host), len(lens), 0, k, 1, k, b, offsets=ctx.to_device(offsets))
+    assert (g.cpu().numpy().view(np.uint64) == o).all()
+
+
 # ---------------------------------------------------------------- materialise
 
 @pytest.mark.parametrize("k", [1, 16, 21, 31])

@@ -1,0 +1,27 @@
+"""dev tool: kmx_canonical_reduce on ragged reads (offsets array): tiled word-domain kernel vs what the lengths allow"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from kmers_amd.api import Context
+
+ctx = Context(0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+k = 31
+rng = np.random.default_rng(1)
+for name, lens, hint in (("all 150 (hint 160)", np.full(n, 150), 160), ("all 150 (no hint)", np.full(n, 150), 0),
+                         ("uniform 100..160 (hint 160)", rng.integers(100, 161, n), 160),
+                         ("150 with 2% trimmed to 36..149 (hint 160)", np.where(rng.random(n) < 0.02, rng.integers(36, 150, n), 150), 160)):
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total = int(offsets[-1])
+    bases = ctx.gen_reads(total)
+    d_off = ctx.to_device(offsets)
+    out = ctx.canonical_reduce(bases, n, hint, k, offsets=d_off)
+    exp = int(np.maximum(lens - k + 1, 0).sum())
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); ctx.canonical_reduce_async(bases, n, hint, k, 0, 0, 0, d_off); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = sorted(ts)[2]
+    print(f"{name:46s} {ms:8.3f} ms  {total/ms/1e6:7.0f} GB/s  {exp/ms/1e6:8.1f} G k-mers/s  n_valid {'ok' if out.n_valid == exp else 'WRONG'}")
+    del bases, d_off
