@@ -1,0 +1,757 @@
+// kmx_bitslice_kernel.h -- K1b: bit-sliced canonical k-mer scan (the headline kernel for k=31 / k=21).
+//
+// Why: on gfx950 only the simplest VALU ops (v_and/or/xor/not, v_lshrrev, v_add_u32, v_bitop3_b32)
+// issue at 32 lanes/clk; v_alignbit, v_perm, v_cmp*, v_cndmask, carry adds, 64-bit ops and v_bcnt
+// run at half that (measured, tools/ubench2.hip, profiles/r01_valu_rates.txt).  A word-per-k-mer
+// window costs >= 16 full-rate issue slots, which caps the scan near 45 % of the HBM roofline.
+// Bit-slicing ACROSS 32 READS turns the per-window work into ~7 slots per k-mer:
+//
+//   * a register holds ONE bit (base i, bit b) of 32 different reads ("plane");
+//   * fw < rc is a ripple of v_bitop3_b32 over the top ceil(k/2) base pairs only, because rc is the
+//     complemented mirror of fw: fw base k-1-j meets rc base = ~(fw base j)   (kmer.rs:124-136);
+//   * the wrapping sum of canonical words needs no select and no 64-bit add: with m = (fw < rc),
+//       sum(canon) = sum_{t,b} 2^(2t+b) * (C[t][b] + C[k-1-t][b]) - popcount(m)*MASK[k] + sum(all rc)
+//     where C[t][b] += popcount(m & plane(t,b)) (v_and + v_bcnt_u32_b32 with accumulate) and
+//     sum(all rc), sum(all fw) and the LexHasher xor-fold follow from per-plane popcount totals.
+//
+// Data flow per 64-read tile (one wave, no block barrier):
+//   A. coalesced 16 B/lane global loads -> encode16 (v_dot4_u32_u8 pack, v_perm_b32 validate) -> LDS
+//   B. lane r pulls read r's packed words back (ds_read_b32) and realigns them (v_alignbit_b32)
+//   C. 32x32 bit transposes across lanes, 5 x (ds_swizzle xor-d, rotate, bit-select) per 16 bases:
+//      lane p of each half-wave ends with plane p -> LDS plane array of the half's 32 reads
+//   D. the 64 lanes split the 2*(L-k+1) (set, window) items; each item = 2k plane loads
+//      (ds_read_b64), a k-step v_bitop3 ripple and 2k masked popcounts.
+// A tile with any non-ACGTacgt byte, and the final partial tile, take roll_read (exact iterator
+// semantics, canonical_kmer_iterator.rs:42-70) exactly like the word-domain kernel.
+#pragma once
+#include "kmx_device.h"
+
+#include <cstdlib>
+
+#ifndef KMX_BS_PREFETCH
+#define KMX_BS_PREFETCH 1   // 1: next tile loaded into registers one tile ahead; 0: loads at tile start (fewer VGPRs, more waves)
+#endif
+#ifndef KMX_BS_WAVES
+#define KMX_BS_WAVES 3      // waves per SIMD the register allocation is sized for
+#endif
+#ifndef KMX_BS_PIPE
+#define KMX_BS_PIPE 1      // per-tile phase order, see the main loop
+#endif
+#ifndef KMX_BS_PRIO
+#define KMX_BS_PRIO 2      // raise the wave priority around runs of half-rate VALU instructions (1: phases A and D, 2: also B/C stage-major)
+#endif
+#ifndef KMX_BS_SWZ
+#define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
+#endif
+#ifndef KMX_BS_ABLATE
+#define KMX_BS_ABLATE 0   // dev: bitmask of phases to skip (timing experiments only; results become wrong)
+#endif
+
+namespace kmx {
+
+// per-plane weights of sum over all windows of fw / rc (closed form; evaluated once per wave)
+__device__ __forceinline__ void plane_weights(u32 i, u32 L, u32 k, u64& wf, u64& wr) {
+    wf = 0;
+    wr = 0;
+    if (i >= L) return;
+    const int o_lo = (int)i - (int)k + 1 > 0 ? (int)i - (int)k + 1 : 0;
+    const int o_hi = (int)i < (int)(L - k) ? (int)i : (int)(L - k);
+    if (o_lo > o_hi) return;
+    // wf = sum_{o} 4^(i-o) ; wr = sum_{o} 4^(k-1-(i-o))
+    const u32 e_lo = i - (u32)o_hi, e_hi = i - (u32)o_lo;  // exponents of 4, e_hi <= k-1
+    wf = ((1ull << (2u * (e_hi + 1u))) - (1ull << (2u * e_lo))) / 3ull;
+    const u32 f_lo = k - 1u - e_hi, f_hi = k - 1u - e_lo;
+    wr = ((1ull << (2u * (f_hi + 1u))) - (1ull << (2u * f_lo))) / 3ull;
+}
+
+// one step of the fw<rc ripple: lt' = (~a & ~q) | ((a ^ q) & lt) as a single v_bitop3_b32
+// (truth table with S0=lt=0xF0, S1=a=0xCC, S2=q=0xAA: 0x11 | (0x66 & 0xF0) = 0x71)
+__device__ __forceinline__ u32 ripple(u32 lt, u32 a, u32 q) { return __builtin_amdgcn_bitop3_b32(lt, a, q, 0x71); }
+
+// keep ? x : y per bit as ONE full-rate v_bitop3_b32 (hipcc otherwise emits v_and + half-rate v_and_or)
+// (S0=x=0xF0, S1=y=0xCC, S2=keep=0xAA: (0xF0 & 0xAA) | (0xCC & 0x55) = 0xE4)
+__device__ __forceinline__ u32 bitsel(u32 x, u32 y, u32 keep) { return __builtin_amdgcn_bitop3_b32(x, y, keep, 0xE4); }
+
+// d += popcount(x) as ONE v_bcnt_u32_b32 (hipcc otherwise splits it into v_bcnt(x,0) + v_add3_u32)
+__device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x)); }
+
+// PACKED: `bases` is a SeqVector (kmx_seqvec.hip), read r = its bases [r*L, (r+1)*L): a tile is 16*L bytes of ready-made
+// 2-bit codes that go from HBM straight into the packed LDS buffer -- no phase A, nothing to validate.
+template <int K, int NW, int WPL, bool PACKED = false>
+__global__ void __launch_bounds__(256, ((NW > 10 || K > 32) ? 2 : KMX_BS_WAVES))   // 64 prefetch registers at NW=16; 2x counters at K>32
+scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
+                      void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
+                      unsigned long long* __restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    // Plane storage of one 32-read set: base beta (2 planes = one u64) lives at u64 index
+    // (beta & 3) * S2 + (beta >> 2).  In phase D lane g reads bases 4g+i: consecutive lanes then touch
+    // consecutive u64s (conflict-free ds_read_b64) instead of a 32-byte stride (4-way bank conflicts,
+    // measured SQ_LDS_BANK_CONFLICT = 65 % of LDS cycles with the linear layout).
+    // (For an odd number of windows per lane the lane stride is an odd number of u64s and the plain linear
+    // layout is already conflict-free.)
+    constexpr int S2 = 4 * NW + 1;       // u64 row pitch (odd, so the 4 rows start on different banks)
+    constexpr int PLANES = 8 * S2;       // dwords per set (>= 32*NW)
+    const u32 lane = threadIdx.x & 63u;
+    const u32 half = lane >> 5, p = lane & 31u;
+    const u32 wib = threadIdx.x >> 6;
+    const u32 chunks = 4u * L;
+    constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
+    const u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
+    u32* P = lds + wib * (ldsw + 4u * PLANES);
+    u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
+
+    const u64 n_full = n_reads >> 6;
+    const u64 n_waves = (u64)gridDim.x * 4u;
+    const u64 wave_id = (u64)blockIdx.x * 4u + wib;
+
+    const u32 posF = lane * L + 16u * PAD;
+    const u32 qF = posF >> 4, aF = 2u * (posF & 15u);
+    const u32 W = L - (u32)K + 1u;      // windows per read
+    const u32 NG = (W + WPL - 1u) / WPL; // groups of WPL adjacent windows per read
+    const u32 rounds = (2u * NG + 63u) >> 6;   // (set, group) items per tile, 64 per round
+
+    // transpose stage constants: rotate amount and keep-mask per butterfly distance
+    u32 tr_sh[5], tr_keep[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const u32 d = 16u >> s;
+        u32 md = 0xFFFFFFFFu / ((1u << d) + 1u);             // bits whose index has bit d clear: 0x0000FFFF,0x00FF00FF,...
+        tr_sh[s] = (p & d) ? d : 32u - d;
+        tr_keep[s] = (p & d) ? ~md : md;
+    }
+
+    // D[2t+b], t <= (K-1)/2: sum of popcount(m & plane(t,b)) + popcount(m & plane(K-1-t,b)) -- the two
+    // always enter the result as a sum (weights are symmetric under t <-> K-1-t), so they share a counter
+    constexpr int NT = (K + 1) / 2;     // distinct t classes (the middle one of odd K pairs with itself)
+    // v_perm_b32 selectors of the byte-granular stages ({S0=y: bytes 4-7, S1=x: bytes 0-3})
+    const u32 tr_sel16 = (p & 16u) ? 0x03020706u : 0x05040100u;   // keep x.hi, take y.hi>>16  |  keep x.lo, take y.lo<<16
+    const u32 tr_sel8 = (p & 8u) ? 0x03070105u : 0x06020400u;     // odd bytes kept, even from y.odd | even kept, odd from y.even
+    u32 D[2 * NT];
+#pragma unroll
+    for (int q = 0; q < 2 * NT; ++q) D[q] = 0;
+    u32 mcnt = 0;                       // sum popcount(m)
+    // per-plane popcount totals of the planes this lane produces live in LDS (TOT[half][32g+p]); only this
+    // lane ever touches its own slots, so plain read-modify-write is enough
+    u32* TOT = PL + 2u * PLANES;
+#pragma unroll
+    for (int g = 0; g < NW; ++g) TOT[half * PLANES + 32u * g + p] = 0;
+    u32 n_bs_tiles = 0;
+    // word-domain accumulators of the fallback path (tiles with invalid bytes, the final partial tile)
+    struct { u64 n = 0, s0 = 0, s1 = 0, x0 = 0, x1 = 0, fw = 0; } fb;
+    auto fallback_read = [&](u64 read) {
+        const uint8_t* s = bases + read * (u64)L;
+        if constexpr (PACKED) {
+            static_assert(!PACKED || K <= 32, "packed input: single-word k-mers");
+            roll_read_packed(reinterpret_cast<const u64*>(bases), read * (u64)L, L, (u32)K, [&](u32, u64 fw, u64 rc) {
+                const u64 canon = fw < rc ? fw : rc;
+                fb.n += 1;
+                fb.s0 += canon;
+                fb.x0 ^= lex_hash(canon, (u32)K);
+                fb.fw += fw;
+            });
+        } else if constexpr (K <= 32) {
+            roll_read(s, L, (u32)K, [&](u32, u64 fw, u64 rc) {
+                const u64 canon = fw < rc ? fw : rc;
+                fb.n += 1;
+                fb.s0 += canon;
+                fb.x0 ^= lex_hash(canon, (u32)K);
+                fb.fw += fw;
+            });
+        } else {
+            roll_read2(s, L, (u32)K, [&](u32, U128 fw, U128 rc) {
+                const U128 c = lt128(fw, rc) ? fw : rc;
+                const U128 h = lex_hash128(c, (u32)K);
+                fb.n += 1;
+                fb.s0 += c.lo;
+                fb.s1 += c.hi;
+                fb.x0 ^= h.lo;
+                fb.x1 ^= h.hi;
+            });
+        }
+    };
+
+#ifdef KMX_BS_TIMING
+    const u64 k_c0 = __builtin_readcyclecounter(), k_w0 = wall_clock64();
+    u64 tph[6] = {0, 0, 0, 0, 0, 0};
+#define KMX_T(i) { const u64 t_now = __builtin_readcyclecounter(); tph[i] += t_now - t_last; t_last = t_now; }
+#else
+#define KMX_T(i)
+#endif
+    // software pipeline: the loads of tile t+1 are issued right after tile t has been packed, so they
+    // are in flight during the realign / transpose / item phases of tile t (HBM latency ~4 us under load)
+    constexpr int NLD = PACKED ? (NW + 3) / 4 : NW;   // 16-byte loads per lane and tile (packed: 16*L bytes per tile)
+    uint4 w[NLD];
+    // address = wave-uniform tile base (SGPR pair) + 32-bit per-lane byte offset: no per-chunk 64-bit
+    // pointers stay live across the loop
+    const u32 lane16 = lane * 16u;
+    const u32 last_off = PACKED ? (L - 1u) * 16u : (chunks - 1u) * 16u;
+    const bool short_rows = PACKED || chunks < 64u * (NW - 1);   // whole rows of the load grid may lie past the tile
+    auto issue_loads = [&](u64 tile) {
+        const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            // lanes past the tile end re-read its last chunk: no branch, so all loads of a tile sit in
+            // one basic block and stay in flight together (a guarded load would be fenced by vmcnt(0))
+            u32 off = lane16 + (u32)it * 1024u;
+            if (it == NLD - 1 || short_rows) off = off < last_off ? off : last_off;
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb + off));  // streamed once
+            w[it] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
+    // Dynamic tile queue.  Static striding ends with a long under-occupied tail because VALU arbitration
+    // favours the oldest waves on a SIMD (measured: the 3 blocks of a CU finished at 3.2 / 3.9 / 4.7 ms with
+    // equal work).  Tiles are handed out ONE at a time so that the tiles in flight across the chip stay
+    // adjacent in memory (handing out runs of 8 tiles cost 30 % of read bandwidth: 5.0 vs 7.1 TB/s in a
+    // compute-free build); to stay far below the ~88 atomics/us a single word sustains, there are NQ queue
+    // heads, each on its own cache line, head q owning the tiles == q (mod NQ).  A head is shared by the
+    // three co-resident blocks of 8 CUs (old and young waves alike), so heads drain at equal rates.
+    // The next ticket is requested one tile ahead, so the atomic's latency is never exposed.
+    constexpr u32 NQ = 32;
+    u32 qid = (blockIdx.x & 255u) >> 3;
+    u32 heads_left = NQ;                                // heads this wave has not yet seen exhausted
+    auto dequeue = [&]() -> u64 {
+        while (heads_left != 0u) {
+            unsigned long long v = 0;
+            if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);   // heads are 128 bytes apart
+            const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+            const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
+            if (t < n_full) return t;
+            qid = (qid + 1u) & (NQ - 1u);               // this head is drained: help with the next one
+            heads_left -= 1u;
+        }
+        return ~0ull;
+    };
+    // ---- per-tile phases (bodies shared by both pipeline orders)
+    // encode16, hand-scheduled for the VALU co-issue rule of gfx950 (see phase D, pass 2): the half-rate instructions
+    // (v_perm_b32 validation look-ups; v_dot4_u32_u8 packs + v_lshl_or_b32 merges) run as two raised-priority runs
+    // (one asm statement each, so that nothing else is scheduled into them), the full-rate ones (v_and, v_xor,
+    // v_bitop3, v_lshrrev) around them at base priority.
+    const u32 k55 = vgpr_const<0x55555555u>();
+    auto encode_prio = [&](const uint4& wv, u32& bad) -> u32 {
+        constexpr u32 TBL_LO = 0x00430041u, TBL_HI = 0x00470054u, W4 = 0x40100401u;   // as in encode16
+        u32 t0 = wv.x & 0x06060606u, t1 = wv.y & 0x06060606u, t2 = wv.z & 0x06060606u, t3 = wv.w & 0x06060606u;
+        u32 e0, e1, e2, e3;
+        asm volatile("s_setprio 3\n\t"
+                     "v_perm_b32 %0, %8, %9, %4\n\t"
+                     "v_perm_b32 %1, %8, %9, %5\n\t"
+                     "v_perm_b32 %2, %8, %9, %6\n\t"
+                     "v_perm_b32 %3, %8, %9, %7\n\t"
+                     "s_setprio 0"
+                     : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
+                     : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(TBL_HI), "v"(TBL_LO));
+        e0 ^= wv.x;
+        e1 ^= wv.y;
+        e2 ^= wv.z;
+        e3 ^= wv.w;
+        bad = __builtin_amdgcn_bitop3_b32(bad, e0, e1, 0xFE);
+        bad = __builtin_amdgcn_bitop3_b32(bad, e2, e3, 0xFE);
+        // 2 * (4 bases in 8 bits) per dword, merged to 16 bases in 32 bits: ((d0 | d1<<8 | d2<<16) >> 1) | d3<<23
+        asm volatile("s_setprio 3\n\t"
+                     "v_dot4_u32_u8 %0, %0, %4, 0\n\t"
+                     "v_dot4_u32_u8 %1, %1, %4, 0\n\t"
+                     "v_dot4_u32_u8 %2, %2, %4, 0\n\t"
+                     "v_dot4_u32_u8 %3, %3, %4, 0\n\t"
+                     "s_nop 0\n\t"   // gfx940+: a VALU read of a DOT result needs 3 wait states (hipcc does not look inside asm)
+                     "v_lshl_or_b32 %0, %1, 8, %0\n\t"
+                     "v_lshl_or_b32 %0, %2, 16, %0\n\t"
+                     "v_lshrrev_b32 %0, 1, %0\n\t"
+                     "v_lshl_or_b32 %0, %3, 23, %0\n\t"
+                     "s_setprio 0"
+                     : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3)
+                     : "s"(W4));
+        return __builtin_amdgcn_bitop3_b32(t0 >> 1, t0, k55, 0x6c);   // internal (ACTG) -> naive_impl (ACGT) codes
+    };
+    auto phase_A = [&]() -> bool {   // pack + validate the tile sitting in w[] into the packed LDS buffer
+        u32 bad = 0;
+        if constexpr (PACKED) {      // already 2-bit codes: 16 bytes = 4 packed dwords per lane and load
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                const u32 c = it * 64u + lane;
+                if (c < L) *reinterpret_cast<uint4*>(P + PAD + 4u * c) = w[it];
+            }
+            return false;
+        } else {
+        if (KMX_BS_PRIO && !(KMX_BS_ABLATE & 24) && chunks >= 64u * (NW - 1)) {
+            // wave-uniform: only the last row of chunks is partial (L = 150: 600 = 9*64 + 24)
+#pragma unroll
+            for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
+            const u32 c = (NW - 1) * 64u + lane;
+            if (c < chunks) P[1u + c] = encode_prio(w[NW - 1], bad);
+        } else if (chunks >= 64u * (NW - 1)) {
+#pragma unroll
+            for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode16(w[it], bad);
+            const u32 c = (NW - 1) * 64u + lane;
+            if (c < chunks) P[1u + c] = encode16(w[NW - 1], bad);
+        } else {
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const u32 c = it * 64u + lane;
+                if (c < chunks) P[1u + c] = encode16(w[it], bad);
+            }
+        }
+        return __any(chunk_has_invalid(bad));
+        }
+    };
+    auto lds_fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto phase_BC = [&]() {
+        // ---- B. this lane's read, realigned: F[g] = bases [16g, 16g+16)
+        u32 F[NW];
+        {
+            u32 R[NW + 1];
+#pragma unroll
+            for (int j = 0; j <= NW; ++j) R[j] = P[qF + j];
+            if (KMX_BS_PRIO >= 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3); }
+#pragma unroll
+            for (int g = 0; g < NW; ++g) F[g] = alignbit(R[g + 1], R[g], aF);
+            if (KMX_BS_PRIO >= 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
+        }
+        // ---- C. transpose each 32 reads x 32 bits block across the 32 lanes of the half-wave, entirely in
+        //      the VALU (no LDS round trips): butterfly stage d exchanges with lane^d and keeps/merges the
+        //      bits whose index has bit d clear/set.
+        //        d=16: v_permlane16_swap_b32 (rows of 16 lanes) + byte merge (v_perm_b32)
+        //        d=8 : two bank-masked DPP row shifts            + byte merge (v_perm_b32)
+        //        d=4 : two bank-masked DPP row shifts            + rotate (v_alignbit) + bit select (v_bitop3)
+        //        d=2,1: DPP quad_perm                             + rotate + bit select
+#if KMX_BS_PRIO >= 2
+        // Stage-major order: every butterfly stage runs over all NW groups, with its half-rate instructions
+        // (v_perm_b32 / v_alignbit_b32 / DPP moves) as one raised-priority run and its full-rate bit selects after it.
+        {
+            u32 Y[NW];
+#define KMX_HRUN_BEGIN __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3);
+#define KMX_HRUN_END __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (16 << 10) | 0x1f);
+            KMX_HRUN_BEGIN
+#pragma unroll
+            for (int g = 0; g < NW; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], tr_sel16);
+            KMX_HRUN_END
+#pragma unroll
+            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (8 << 10) | 0x1f);
+            KMX_HRUN_BEGIN
+#pragma unroll
+            for (int g = 0; g < NW; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], tr_sel8);
+            KMX_HRUN_END
+#pragma unroll
+            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (4 << 10) | 0x1f);
+            KMX_HRUN_BEGIN
+#pragma unroll
+            for (int g = 0; g < NW; ++g) Y[g] = alignbit(Y[g], Y[g], tr_sh[2]);
+            KMX_HRUN_END
+#pragma unroll
+            for (int g = 0; g < NW; ++g) F[g] = bitsel(F[g], Y[g], tr_keep[2]);
+#pragma unroll
+            for (int st = 3; st < 5; ++st) {
+#if KMX_BS_SWZ == 2
+#pragma unroll
+                for (int g = 0; g < NW; ++g)
+                    Y[g] = st == 3 ? (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (2 << 10) | 0x1f)
+                                   : (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (1 << 10) | 0x1f);
+                KMX_HRUN_BEGIN
+#else
+                KMX_HRUN_BEGIN
+#pragma unroll
+                for (int g = 0; g < NW; ++g)
+                    Y[g] = st == 3 ? (u32)__builtin_amdgcn_update_dpp(0, (int)F[g], 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true)
+                                   : (u32)__builtin_amdgcn_update_dpp(0, (int)F[g], 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+#endif
+#pragma unroll
+                for (int g = 0; g < NW; ++g) Y[g] = alignbit(Y[g], Y[g], tr_sh[st]);
+                KMX_HRUN_END
+#pragma unroll
+                for (int g = 0; g < NW; ++g) F[g] = bitsel(F[g], Y[g], tr_keep[st]);
+            }
+#pragma unroll
+            for (int g = 0; g < NW; ++g) {
+                const u32 beta = 16u * g + (p >> 1);
+                const u32 slot = (WPL == 4) ? (beta & 3u) * S2 + (beta >> 2) : beta;
+                PL[half * PLANES + 2u * slot + (p & 1u)] = F[g];
+            }
+            KMX_HRUN_BEGIN
+#pragma unroll
+            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_popcount(F[g]);
+            KMX_HRUN_END
+#pragma unroll
+            for (int g = 0; g < NW; ++g) atomicAdd(&TOT[half * PLANES + 32u * g + p], Y[g]);
+#undef KMX_HRUN_BEGIN
+#undef KMX_HRUN_END
+        }
+#else
+#pragma unroll
+        for (int g = 0; g < NW; ++g) {
+            u32 x = F[g];
+            if (!(KMX_BS_ABLATE & 4)) {
+#if KMX_BS_SWZ
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {   // d = 16, 8, 4 through the LDS crossbar (no VALU for the exchange)
+                const u32 y = s3 == 0 ? (u32)__builtin_amdgcn_ds_swizzle((int)x, (16 << 10) | 0x1f)
+                            : s3 == 1 ? (u32)__builtin_amdgcn_ds_swizzle((int)x, (8 << 10) | 0x1f)
+                                      : (u32)__builtin_amdgcn_ds_swizzle((int)x, (4 << 10) | 0x1f);
+                if (s3 == 0) x = __builtin_amdgcn_perm(y, x, tr_sel16);
+                else if (s3 == 1) x = __builtin_amdgcn_perm(y, x, tr_sel8);
+                else { const u32 rot = alignbit(y, y, tr_sh[2]); x = bitsel(x, rot, tr_keep[2]); }
+            }
+#else
+            {   // d = 16
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                const v2u sw = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+                const u32 y = (p & 16u) ? sw.x : sw.y;          // value held by lane ^ 16
+                x = __builtin_amdgcn_perm(y, x, tr_sel16);      // low half from x / high from y<<16, or mirrored
+            }
+            {   // d = 8
+                u32 y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x108 /* row_shl:8 */, 0xF, 0x3, false);
+                y = (u32)__builtin_amdgcn_update_dpp((int)y, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xC, false);
+                x = __builtin_amdgcn_perm(y, x, tr_sel8);
+            }
+            {   // d = 4
+                u32 y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+                y = (u32)__builtin_amdgcn_update_dpp((int)y, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+                const u32 rot = alignbit(y, y, tr_sh[2]);
+                x = bitsel(x, rot, tr_keep[2]);
+            }
+#endif
+#pragma unroll
+            for (int s = 3; s < 5; ++s) {
+#if KMX_BS_SWZ == 2
+                const u32 y = s == 3 ? (u32)__builtin_amdgcn_ds_swizzle((int)x, (2 << 10) | 0x1f)
+                                     : (u32)__builtin_amdgcn_ds_swizzle((int)x, (1 << 10) | 0x1f);
+#else
+                const u32 y = s == 3 ? (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true)
+                                     : (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+#endif
+                const u32 rot = alignbit(y, y, tr_sh[s]);
+                x = bitsel(x, rot, tr_keep[s]);
+            }
+            }
+            {   // plane index q = 32g+p  <->  base beta = 16g + p/2, bit p&1
+                const u32 beta = 16u * g + (p >> 1);
+                const u32 slot = (WPL == 4) ? (beta & 3u) * S2 + (beta >> 2) : beta;
+                PL[half * PLANES + 2u * slot + (p & 1u)] = x;
+            }
+            atomicAdd(&TOT[half * PLANES + 32u * g + p], (u32)__builtin_popcount(x));   // ds_add_u32, no return: no LDS round trip
+        }
+#endif
+        lds_fence();
+
+    };
+    auto phase_D = [&]() {
+        // ---- D. a lane handles the WPL windows o..o+WPL-1 of one set (o = WPL*group): they share the planes of
+        //      bases o..o+K+WPL-2, streamed twice from LDS as u64 (2 planes per base):
+        //      pass 1 = four interleaved fw<rc ripples, pass 2 = masked popcounts.
+#pragma unroll 1
+        for (u32 r = 0; r < ((KMX_BS_ABLATE & 64) ? 0u : rounds); ++r) {
+            const u32 gidx = r * 64u + lane;
+            const bool active = gidx < 2u * NG;
+            const u32 set = (gidx >= NG && active) ? 1u : 0u;
+            const u32 o = active ? (u32)WPL * (gidx - set * NG) : 0u;
+            const u32 nwin = active ? (W - o < (u32)WPL ? W - o : (u32)WPL) : 0u;   // valid windows in this group
+            // base o+i  ->  u64 index (i & 3) * S2 + (o >> 2) + (i >> 2) for WPL == 4 (o is a multiple of 4), else o + i
+            const u64* __restrict__ src = reinterpret_cast<const u64*>(PL + set * PLANES) + (WPL == 4 ? (o >> 2) : o);
+#define KMX_PLANE(i) src[(WPL == 4) ? (((i) & 3) * S2 + ((i) >> 2)) : (i)]
+            u32 lt[WPL];
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) lt[w] = 0u;
+            {
+                u64 Pv[K + WPL - 1];
+                bool have[K + WPL - 1];
+#pragma unroll
+                for (int i = 0; i < K + WPL - 1; ++i) have[i] = false;
+                // ripple from the least significant deciding pair (j = ceil(K/2)-1) to the most significant (j = 0);
+                // window w compares fw base K-1-j (plane o+w+K-1-j) with rc base = ~(fw base j) (plane o+w+j)
+#pragma unroll
+                for (int j = (K + 1) / 2 - 1; j >= ((KMX_BS_ABLATE & 2) ? (K + 1) / 2 - 1 : 0); --j) {
+#pragma unroll
+                    for (int w = 0; w < WPL; ++w) {
+                        const int ia = K - 1 - j + w, iq = j + w;
+                        if (!have[ia]) { Pv[ia] = KMX_PLANE(ia); have[ia] = true; }
+                        if (!have[iq]) { Pv[iq] = KMX_PLANE(iq); have[iq] = true; }
+                        const u32 a0 = (u32)Pv[ia], a1 = (u32)(Pv[ia] >> 32);
+                        const u32 q0 = (u32)Pv[iq], q1 = (u32)(Pv[iq] >> 32);
+                        lt[w] = ripple(lt[w], a0, q0);
+                        lt[w] = ripple(lt[w], a1, q1);
+                    }
+                }
+            }
+            u32 m[WPL];
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) {
+                m[w] = ((u32)w < nwin) ? lt[w] : 0u;
+                pc_acc(mcnt, m[w]);
+            }
+            asm volatile("" ::: "memory");   // pass 2 re-reads the planes instead of keeping 2K+6 registers live
+            constexpr int NPL = (KMX_BS_ABLATE & 1) ? 1 : K + WPL - 1;
+#if KMX_BS_PRIO
+            u64 vcur = KMX_PLANE(0);
+#endif
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+#if KMX_BS_PRIO
+                // Hand-scheduled: [LDS read of the next plane] [full-rate v_and of this plane] [half-rate v_bcnt run at
+                // raised wave priority].  gfx950 co-issues another wave's full-rate instructions next to a half-rate
+                // run only when the wave running it outranks the others (tools/ubench7.hip: 108 -> 65 ns per
+                // 32 and + 32 bcnt), so the runs are kept apart and bracketed by s_setprio.
+                const u64 vnext = KMX_PLANE(i + 1 < NPL ? i + 1 : i);
+                __builtin_amdgcn_sched_barrier(0);
+                const u32 p0 = (u32)vcur, p1 = (u32)(vcur >> 32);
+                u32 x[2 * WPL];
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) { x[2 * w] = m[w] & p0; x[2 * w + 1] = m[w] & p1; }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) {
+                    const int t = i - w;                 // plane i is base t of window w
+                    if (t < 0 || t > K - 1) continue;
+                    const int tc = t < K - 1 - t ? t : K - 1 - t;
+                    pc_acc(D[2 * tc], x[2 * w]);
+                    pc_acc(D[2 * tc + 1], x[2 * w + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(0);
+                vcur = vnext;
+#else
+                const u64 v = KMX_PLANE(i);
+                const u32 p0 = (u32)v, p1 = (u32)(v >> 32);
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) {
+                    const int t = i - w;                 // plane i is base t of window w
+                    if (t < 0 || t > K - 1) continue;
+                    const int tc = t < K - 1 - t ? t : K - 1 - t;
+                    pc_acc(D[2 * tc], m[w] & p0);
+                    pc_acc(D[2 * tc + 1], m[w] & p1);
+                }
+#endif
+            }
+        }
+#undef KMX_PLANE
+        n_bs_tiles += 1;
+    };
+    auto prefetch = [&](u64 t, u64 fallback_t) {   // clamped => unconditional, one basic block, pinned by sched barriers
+        const u64 nxt = t < n_full ? t : fallback_t;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(KMX_BS_ABLATE & 128)) issue_loads(nxt);   // (dev) 128: compute-only
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+#if KMX_BS_PIPE == 2
+    // Pipeline order 2: [B,C of tile t] [A of tile t+1] [D of tile t] [issue loads of tile t+2].
+    // The 4*NW landing registers of the prefetch are then dead during phase D, the register-pressure peak.
+    u64 tile = dequeue();
+    u64 tile1 = dequeue();
+    bool cur_bad = false;
+    if (tile < n_full) {
+        issue_loads(tile);
+        cur_bad = phase_A();
+        lds_fence();
+    }
+    u64 tile2 = dequeue();
+    if (tile < n_full) prefetch(tile1, tile);
+    while (tile < n_full) {
+        if (!cur_bad) phase_BC();
+        bool next_bad = false;
+        if (tile1 < n_full) {
+            next_bad = phase_A();          // consumes the loads issued one iteration ago
+            lds_fence();
+        }
+        if (cur_bad) fallback_read(tile * 64u + lane);
+        else phase_D();
+        prefetch(tile2, tile);
+        tile = tile1;
+        tile1 = tile2;
+        tile2 = dequeue();
+        cur_bad = next_bad;
+    }
+#else
+    // Pipeline order 1: [A of tile t] [issue loads of tile t+1] [B,C,D of tile t]
+    u64 tile = dequeue();
+    u64 next_tile = dequeue();
+    if (tile < n_full) issue_loads(tile);
+    while (tile < n_full) {
+#ifdef KMX_BS_TIMING
+        u64 t_last = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KMX_T(0)
+#endif
+        const bool bad_tile = phase_A();
+        prefetch(next_tile, tile);
+        lds_fence();
+        KMX_T(1)
+        if (bad_tile) {
+            fallback_read(tile * 64u + lane);
+        } else if (!(KMX_BS_ABLATE & 32)) {
+            phase_BC();
+            KMX_T(3)
+            phase_D();
+            KMX_T(4)
+        } else {
+            n_bs_tiles += 1;
+        }
+        tile = next_tile;
+        next_tile = dequeue();
+    }
+#endif
+#ifdef KMX_BS_TIMING
+    if (lane == 0 && wave_id < 4096) {
+        u64* dbg = reinterpret_cast<u64*>(out) + 8 + wave_id * 8;
+        for (int i = 0; i < 5; ++i) dbg[i] = tph[i];
+        dbg[5] = n_bs_tiles;
+        dbg[6] = __builtin_readcyclecounter() - k_c0;   // shader cycles of this wave's whole run
+        dbg[7] = wall_clock64() - k_w0;                 // same interval in 100 MHz ticks
+        dbg[6] = (__builtin_readcyclecounter() - k_c0);
+        dbg[5] = ((u64)n_bs_tiles) | (k_w0 << 20);      // tiles in the low 20 bits, absolute start above
+    }
+#endif
+
+    // ---- final partial tile: per-lane rolling
+    const u32 rem = (u32)(n_reads & 63u);
+    if (rem != 0u && wave_id == 0 && lane < rem) fallback_read(n_full * 64u + lane);
+
+    // ---- combine the bit-sliced counters into word-domain results (once per wave; wave-uniform branch)
+    // Number of set bits of canonical bit (t,b) over all k-mers of the wave:
+    //   cnt(t,b) = C[t][b] + C[K-1-t][b] + (nk - sum popcount(m)) - Tq[t][b],  Tq[t][b] = sum_o popcount(plane(o+K-1-t, b))
+    // (canon bit = m ? fw bit (t,b) : rc bit (t,b) = ~fw bit (K-1-t,b)).  Then
+    //   sum of word w of canon = sum_{t in word w, b} 2^(2(t&31)+b) * cnt(t,b)   (wrapping),
+    //   xor-fold of the 2-bit-group-reversed hash: bit 2(K-1-t)+b = parity of cnt(t,b),
+    //   sum of fw words (K<=32) = sum over planes of popcount total * closed-form per-base weight.
+    u64 bs_n = 0, bs_s0 = 0, bs_s1 = 0, bs_x0 = 0, bs_x1 = 0, bs_fw = 0;
+    if (n_bs_tiles != 0u) {
+        const u64 nk = (u64)n_bs_tiles * 64u * (u64)W;     // k-mers handled bit-sliced by this wave
+        bs_n = nk;
+        u64 fwall = 0;
+        u32 tot[NW];
+#pragma unroll
+        for (int g = 0; g < NW; ++g) {
+            const u32 qidx = 32u * g + p;
+            const u32 pcq = TOT[half * PLANES + qidx];     // per-plane totals of this half's set
+            if constexpr (K <= 32) {
+                u64 wf, wr;
+                plane_weights(qidx >> 1, L, (u32)K, wf, wr);
+                fwall += (u64)pcq * (wf << (qidx & 1u));
+            }
+            tot[g] = pcq + __shfl_xor(pcq, 32, WAVE);      // lanes p and p+32 hold the same plane of the two sets
+        }
+        if constexpr (K <= 32) bs_fw = wave_sum(fwall);
+        const u64 mc = wave_sum((u64)mcnt);
+        u64* CS = reinterpret_cast<u64*>(PL + PLANES);      // set-1 plane area is free now
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 2 * NT; ++q) {
+            const u64 v = wave_sum((u64)D[q]);
+            if (lane == 0) CS[q] = v;
+        }
+#pragma unroll
+        for (int g = 0; g < NW; ++g)
+            if (half == 0) PL[32u * g + p] = tot[g];        // PL[2*base + bit] = popcount total of that plane
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        u64 s0 = 0, s1 = 0, x0 = 0, x1 = 0;
+        for (u32 pid = lane; pid < 2u * (u32)K; pid += 64u) {
+            const u32 t = pid >> 1, bb = pid & 1u, t2 = (u32)K - 1u - t;
+            const u32 tc = t < t2 ? t : t2;
+            u64 cc = CS[2u * tc + bb];                      // C[t][b] + C[K-1-t][b]; the middle class holds C[mid][b] once
+            if (t == t2) cc += cc;
+            u64 tq = 0;
+            for (u32 i = t2; i <= L - 1u - t; ++i) tq += PL[2u * i + bb];
+            const u64 cnt = cc + (nk - mc) - tq;
+            const u32 sh = 2u * (t & 31u) + bb;
+            if (t < 32u) s0 += cnt << sh; else s1 += cnt << sh;
+            if (want_hash && (cnt & 1ull)) {
+                const u32 hb = 2u * t2 + bb;
+                if (hb < 64u) x0 ^= 1ull << hb; else x1 ^= 1ull << (hb - 64u);
+            }
+        }
+        bs_s0 = wave_sum(s0);
+        bs_s1 = wave_sum(s1);
+        bs_x0 = wave_xor(x0);
+        bs_x1 = wave_xor(x1);
+    }
+
+    // ---- one set of atomics per wave
+    const u64 n = wave_sum(fb.n) + bs_n;
+    const u64 r0 = wave_sum(fb.s0) + bs_s0, r1 = wave_sum(fb.s1) + bs_s1;
+    const u64 h0 = wave_xor(fb.x0) ^ bs_x0, h1 = wave_xor(fb.x1) ^ bs_x1;
+    const u64 f = wave_sum(fb.fw) + bs_fw;
+    if (lane == 0) {
+        if constexpr (K <= 32) {
+            kmx_summary* o = static_cast<kmx_summary*>(out);
+            atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
+            atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)r0);
+            if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)h0);
+            if (want_sumfw) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
+        } else {
+            kmx_summary2* o = static_cast<kmx_summary2*>(out);
+            atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
+            atomicAdd((unsigned long long*)&o->sum_lo, (unsigned long long)r0);
+            atomicAdd((unsigned long long*)&o->sum_hi, (unsigned long long)r1);
+            if (want_hash) {
+                atomicXor((unsigned long long*)&o->xor_lo, (unsigned long long)h0);
+                atomicXor((unsigned long long*)&o->xor_hi, (unsigned long long)h1);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ launcher
+
+template <int K, int NW, int WPL, bool PACKED = false>
+static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
+                            unsigned long long* queue, int n_cu, hipStream_t stream) {
+    auto kern = scan_bitsliced_kernel<K, NW, WPL, PACKED>;
+    const u32 chunks = 4u * L;
+    const u32 ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
+    size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u)) * 4u * 4u;
+    if (const char* e = getenv("KMX_BS_EXTRA_LDS")) lds_bytes += (size_t)atol(e);   // dev knob: caps blocks per CU
+    static int bpc = 0;
+    static size_t bpc_lds = 0;
+    if (bpc == 0 || bpc_lds != lds_bytes) {
+        int b = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, 256, lds_bytes);
+        if (e != hipSuccess) return e;
+        bpc = b > 0 ? b : 1;
+        bpc_lds = lds_bytes;
+    }
+    const u64 n_tiles = (n_reads + 63u) >> 6;
+    u64 grid = (u64)n_cu * (u64)bpc;
+    const u64 need = (n_tiles + 3u) / 4u;
+    if (grid > need) grid = need;
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue);
+    return hipGetLastError();
+}
+
+// One entry point per k (the instantiations are spread over several translation units so that they compile in
+// parallel): picks the frame (NW) and the windows per lane (WPL) so that the 2*ceil(W/WPL) (set, group) items of a
+// tile fit the 64 lanes in ONE round.
+template <int K, bool PACKED>
+static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
+                                unsigned long long* queue, int n_cu, hipStream_t stream) {
+    const u32 W = L - (u32)K + 1u;
+    if (L > 160) return launch_bs<K, 16, 8, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);   // 161..256 bp
+    if (W <= 96u) return launch_bs<K, 10, 3, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+    if (W <= 128u) return launch_bs<K, 10, 4, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+    return launch_bs<K, 10, 5, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+}
+
+#define KMX_BS_DECLARE_K(K) \
+    hipError_t launch_bs_k##K(const uint8_t* bases, u64 n_reads, u32 L, bool packed, u32 want_hash, u32 want_sumfw, void* out, \
+                              unsigned long long* queue, int n_cu, hipStream_t stream);
+#define KMX_BS_DEFINE_K(K, WITH_PACKED)                                                                                       \
+    hipError_t launch_bs_k##K(const uint8_t* bases, u64 n_reads, u32 L, bool packed, u32 want_hash, u32 want_sumfw, void* out, \
+                              unsigned long long* queue, int n_cu, hipStream_t stream) {                                      \
+        if constexpr (WITH_PACKED) {                                                                                          \
+            if (packed) return launch_bs_any<K, true>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);    \
+        } else if (packed) {                                                                                                  \
+            return hipErrorInvalidValue;                                                                                      \
+        }                                                                                                                     \
+        return launch_bs_any<K, false>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);                   \
+    }
+// k with an ASCII bit-sliced kernel (u64 k-mers); packed (SeqVector) input: 31 and 21
+#define KMX_BS_FOR_EACH_K(X) X(15) X(17) X(19) X(21) X(23) X(25) X(27) X(29) X(31)
+KMX_BS_FOR_EACH_K(KMX_BS_DECLARE_K)
+
+}  // namespace kmx
