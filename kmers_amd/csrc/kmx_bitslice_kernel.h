@@ -37,6 +37,9 @@
 #ifndef KMX_BS_PIPE
 #define KMX_BS_PIPE 1      // per-tile phase order, see the main loop
 #endif
+#ifndef KMX_BS_QMAP
+#define KMX_BS_QMAP 0      // tile order of the dynamic queue: 0 = heads interleaved tile by tile (in-flight tiles adjacent in memory)
+#endif
 #ifndef KMX_BS_PRIO
 #define KMX_BS_PRIO 2      // raise the wave priority around runs of half-rate VALU instructions (1: phases A and D, 2: also B/C stage-major)
 #endif
@@ -215,7 +218,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             unsigned long long v = 0;
             if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);   // heads are 128 bytes apart
             const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+#if KMX_BS_QMAP == 1
+            // (dev) head q owns the contiguous region [q*R, (q+1)*R): 32 sliding windows spread over the buffer
+            const u64 R = (n_full + NQ - 1u) / NQ, tk = ((u64)hi << 32) | lo;
+            const u64 t = tk < R ? qid * R + tk : ~0ull;
+#else
             const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
+#endif
             if (t < n_full) return t;
             qid = (qid + 1u) & (NQ - 1u);               // this head is drained: help with the next one
             heads_left -= 1u;
