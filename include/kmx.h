@@ -133,7 +133,9 @@ int kmx_canonical_windows2(kmx_ctx *ctx, const kmx_reads *reads, const uint64_t 
 /* Per-bucket occupancy of hash(canonical k-mer): d_counts[bucket] += 1 for every yielded window;
  * bucket = (hash * 0x9E3779B97F4A7C15) >> (64 - log2_buckets)  (BUILD-DEFINED bucket function).
  * d_counts (2^log2_buckets device u64) is ACCUMULATED into; the caller zeroes it and, across
- * GPUs, all-reduces it (RCCL ncclSum/uint64). */
+ * GPUs, all-reduces it (RCCL ncclSum/uint64).
+ * Uniform reads with 2^15..2^21 buckets go through a grow-only work buffer owned by the context (at most 8 GiB or
+ * half of the free device memory; KMX_HIST_SCRATCH_MB overrides): growing it synchronises the stream once. */
 int kmx_histogram(kmx_ctx *ctx, const kmx_reads *reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
                   uint32_t log2_buckets, uint64_t *d_counts);
 

@@ -1,0 +1,22 @@
+"""dev tool: time kmx_seqvec_minimizers / kmx_minimizer_words on synthetic reads"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from kmers_amd.api import Context
+from kmers_amd import _lib
+
+ctx = Context(0)
+L = 150
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+bases = ctx.gen_reads(n * L)
+words = ctx.seqvec_from_bytes(bases)
+for k, w in ((31, 15), (21, 11), (31, 21)):
+    tot = n * (L - k + 1)
+    ctx.seqvec_minimizers(words, n, L, k, w, _lib.HASH_LEX, w)
+    ts = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); ctx.seqvec_minimizers(words, n, L, k, w, _lib.HASH_LEX, w); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = sorted(ts)[1]
+    print(f"seqvec_minimizers k={k} w={w}: {ms:8.3f} ms  {tot/ms/1e6:7.1f} G k-mers/s  ({12*tot/ms/1e6:6.0f} GB/s written)")
