@@ -37,6 +37,12 @@
 #ifndef KMX_BS_PIPE
 #define KMX_BS_PIPE 1      // per-tile phase order, see the main loop
 #endif
+#ifndef KMX_BS_P1D
+#define KMX_BS_P1D 2      // pass 1: ripple steps between the LDS request of a plane and its use
+#endif
+#ifndef KMX_BS_PF2
+#define KMX_BS_PF2 0
+#endif
 #ifndef KMX_BS_RUN2
 #define KMX_BS_RUN2 1      // pass 2: two planes per (v_and run, v_bcnt run) pair when WPL <= 4
 #endif
@@ -468,12 +474,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
             for (int w = 0; w < WPL; ++w) lt[w] = 0u;
             {
+#if KMX_BS_P1D == 0
+                // (dev) plane loads left to the compiler
                 u64 Pv[K + WPL - 1];
                 bool have[K + WPL - 1];
 #pragma unroll
                 for (int i = 0; i < K + WPL - 1; ++i) have[i] = false;
-                // ripple from the least significant deciding pair (j = ceil(K/2)-1) to the most significant (j = 0);
-                // window w compares fw base K-1-j (plane o+w+K-1-j) with rc base = ~(fw base j) (plane o+w+j)
 #pragma unroll
                 for (int j = (K + 1) / 2 - 1; j >= ((KMX_BS_ABLATE & 2) ? (K + 1) / 2 - 1 : 0); --j) {
 #pragma unroll
@@ -488,6 +494,49 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     }
                 }
             }
+#else
+                u64 Pv[K + WPL - 1];
+                // ripple from the least significant deciding pair (j = ceil(K/2)-1) to the most significant (j = 0);
+                // window w compares fw base K-1-j (plane o+w+K-1-j) with rc base = ~(fw base j) (plane o+w+j).
+                // Step J0 needs the planes J0 .. K-1-J0+WPL-1, every later step one more on either side (j and
+                // K-1-j+WPL-1).  They are requested KMX_BS_P1D steps ahead (one step = 2*WPL bit ops, far less than an LDS
+                // round trip): left to hipcc, every second step ended in `ds_read ... s_waitcnt lgkmcnt(0)`.
+                constexpr int J0 = (K + 1) / 2 - 1, JEND = (KMX_BS_ABLATE & 2) ? J0 : 0;
+#pragma unroll
+                for (int i = J0; i <= K - 1 - J0 + WPL - 1; ++i) Pv[i] = KMX_PLANE(i);
+#pragma unroll
+                for (int d = 1; d < KMX_BS_P1D; ++d) {
+                    if (J0 - d >= JEND) {
+                        Pv[J0 - d] = KMX_PLANE(J0 - d);
+                        Pv[K - 1 - (J0 - d) + WPL - 1] = KMX_PLANE(K - 1 - (J0 - d) + WPL - 1);
+                    }
+                }
+#define KMX_PLANE_AT(p, i) (p)[(WPL == 4) ? (((i) & 3) * S2 + ((i) >> 2)) : (i)]
+                auto fetch = [&](int j) {
+                    // an (empty) asm ties the address to the ripple state of the previous step, so the two requests are
+                    // issued here and not hoisted to the top of the unrolled loop (34 planes live = spills)
+                    // (an index, not the pointer: an opaque pointer would lose its LDS address space and turn the reads into flat loads)
+                    u32 z = 0;
+                    asm volatile("" : "+v"(z) : "v"(lt[0]));
+                    const u64* sj = src + z;
+                    Pv[j] = KMX_PLANE_AT(sj, j);
+                    Pv[K - 1 - j + WPL - 1] = KMX_PLANE_AT(sj, K - 1 - j + WPL - 1);
+                };
+#pragma unroll
+                for (int j = J0; j >= JEND; --j) {
+                    if (j - KMX_BS_P1D >= JEND) fetch(j - KMX_BS_P1D);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int w = 0; w < WPL; ++w) {
+                        const int ia = K - 1 - j + w, iq = j + w;
+                        const u32 a0 = (u32)Pv[ia], a1 = (u32)(Pv[ia] >> 32);
+                        const u32 q0 = (u32)Pv[iq], q1 = (u32)(Pv[iq] >> 32);
+                        lt[w] = ripple(lt[w], a0, q0);
+                        lt[w] = ripple(lt[w], a1, q1);
+                    }
+                }
+            }
+#endif
             u32 m[WPL];
 #pragma unroll
             for (int w = 0; w < WPL; ++w) {
@@ -500,9 +549,18 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             if constexpr (KMX_BS_RUN2 && WPL <= 4) {
             // two planes per run (4*WPL v_and, then 4*WPL v_bcnt at raised priority): 0.8 % over one plane per run
             u64 vcur = KMX_PLANE(0), vcur2 = KMX_PLANE(NPL > 1 ? 1 : 0);
+#if KMX_BS_PF2
+            u64 vq = KMX_PLANE(NPL > 2 ? 2 : 0), vq2 = KMX_PLANE(NPL > 3 ? 3 : 0);   // LDS reads run two plane pairs ahead
+#endif
 #pragma unroll
             for (int i = 0; i < NPL; i += 2) {
+#if KMX_BS_PF2
+                const u64 vnext = vq, vnext2 = vq2;
+                vq = KMX_PLANE(i + 4 < NPL ? i + 4 : i);
+                vq2 = KMX_PLANE(i + 5 < NPL ? i + 5 : i);
+#else
                 const u64 vnext = KMX_PLANE(i + 2 < NPL ? i + 2 : i), vnext2 = KMX_PLANE(i + 3 < NPL ? i + 3 : i);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 u32 x[4 * WPL];
 #pragma unroll
@@ -579,6 +637,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
         }
 #undef KMX_PLANE
+#undef KMX_PLANE_AT
         n_bs_tiles += 1;
     };
     auto prefetch = [&](u64 t, u64 fallback_t) {   // clamped => unconditional, one basic block, pinned by sched barriers
