@@ -34,9 +34,6 @@
 #ifndef KMX_BS_WAVES
 #define KMX_BS_WAVES 3      // waves per SIMD the register allocation is sized for
 #endif
-#ifndef KMX_BS_PIPE
-#define KMX_BS_PIPE 1      // per-tile phase order, see the main loop
-#endif
 #ifndef KMX_BS_P1D
 #define KMX_BS_P1D 2      // pass 1: ripple steps between the LDS request of a plane and its use
 #endif
@@ -45,9 +42,6 @@
 #endif
 #ifndef KMX_BS_RUN2
 #define KMX_BS_RUN2 1      // pass 2: two planes per (v_and run, v_bcnt run) pair when WPL <= 4
-#endif
-#ifndef KMX_BS_QMAP
-#define KMX_BS_QMAP 0      // tile order of the dynamic queue: 0 = heads interleaved tile by tile (in-flight tiles adjacent in memory)
 #endif
 #ifndef KMX_BS_PRIO
 #define KMX_BS_PRIO 2      // raise the wave priority around runs of half-rate VALU instructions (1: phases A and D, 2: also B/C stage-major)
@@ -218,7 +212,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // compute-free build); to stay far below the ~88 atomics/us a single word sustains, there are NQ queue
     // heads, each on its own cache line, head q owning the tiles == q (mod NQ).  A head is shared by the
     // three co-resident blocks of 8 CUs (old and young waves alike), so heads drain at equal rates.
-    // The next ticket is requested one tile ahead, so the atomic's latency is never exposed.
+    // (Handing each head a contiguous region instead changed nothing: 2.50 vs 2.55 ms compute-free, equal in the full kernel.)
     constexpr u32 NQ = 32;
     u32 qid = (blockIdx.x & 255u) >> 3;
     u32 heads_left = NQ;                                // heads this wave has not yet seen exhausted
@@ -227,20 +221,31 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             unsigned long long v = 0;
             if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);   // heads are 128 bytes apart
             const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
-#if KMX_BS_QMAP == 1
-            // (dev) head q owns the contiguous region [q*R, (q+1)*R): 32 sliding windows spread over the buffer
-            const u64 R = (n_full + NQ - 1u) / NQ, tk = ((u64)hi << 32) | lo;
-            const u64 t = tk < R ? qid * R + tk : ~0ull;
-#else
             const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
-#endif
             if (t < n_full) return t;
             qid = (qid + 1u) & (NQ - 1u);               // this head is drained: help with the next one
             heads_left -= 1u;
         }
         return ~0ull;
     };
-    // ---- per-tile phases (bodies shared by both pipeline orders)
+    // The ticket for tile t+2 is requested at the end of iteration t and only looked at an iteration later: reading the
+    // atomic's return value right away (as dequeue() does) stalled every wave for a device-atomic round trip per tile.
+    unsigned long long pend = 0;
+    u32 pend_qid = 0;
+    auto ticket_issue = [&]() {
+        pend_qid = qid;
+        if (heads_left != 0u && lane == 0) pend = atomicAdd(queue + qid * 16u, 1ull);
+    };
+    auto ticket_take = [&]() -> u64 {
+        if (heads_left == 0u) return ~0ull;
+        const u32 lo = __builtin_amdgcn_readfirstlane((u32)pend), hi = __builtin_amdgcn_readfirstlane((u32)(pend >> 32));
+        const u64 t = (((u64)hi << 32) | lo) * NQ + pend_qid;
+        if (t < n_full) return t;
+        qid = (pend_qid + 1u) & (NQ - 1u);   // that head is drained: move on, synchronously (rare)
+        heads_left -= 1u;
+        return dequeue();
+    };
+    // ---- per-tile phases
     // encode16, hand-scheduled for the VALU co-issue rule of gfx950 (see phase D, pass 2): the half-rate instructions
     // (v_perm_b32 validation look-ups; v_dot4_u32_u8 packs + v_lshl_or_b32 merges) run as two raised-priority runs
     // (one asm statement each, so that nothing else is scheduled into them), the full-rate ones (v_and, v_xor,
@@ -647,38 +652,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         __builtin_amdgcn_sched_barrier(0);
     };
 
-#if KMX_BS_PIPE == 2
-    // Pipeline order 2: [B,C of tile t] [A of tile t+1] [D of tile t] [issue loads of tile t+2].
-    // The 4*NW landing registers of the prefetch are then dead during phase D, the register-pressure peak.
-    u64 tile = dequeue();
-    u64 tile1 = dequeue();
-    bool cur_bad = false;
-    if (tile < n_full) {
-        issue_loads(tile);
-        cur_bad = phase_A();
-        lds_fence();
-    }
-    u64 tile2 = dequeue();
-    if (tile < n_full) prefetch(tile1, tile);
-    while (tile < n_full) {
-        if (!cur_bad) phase_BC();
-        bool next_bad = false;
-        if (tile1 < n_full) {
-            next_bad = phase_A();          // consumes the loads issued one iteration ago
-            lds_fence();
-        }
-        if (cur_bad) fallback_read(tile * 64u + lane);
-        else phase_D();
-        prefetch(tile2, tile);
-        tile = tile1;
-        tile1 = tile2;
-        tile2 = dequeue();
-        cur_bad = next_bad;
-    }
-#else
     // Pipeline order 1: [A of tile t] [issue loads of tile t+1] [B,C,D of tile t]
     u64 tile = dequeue();
     u64 next_tile = dequeue();
+    ticket_issue();
     if (tile < n_full) issue_loads(tile);
     while (tile < n_full) {
 #ifdef KMX_BS_TIMING
@@ -701,9 +678,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             n_bs_tiles += 1;
         }
         tile = next_tile;
-        next_tile = dequeue();
+        next_tile = ticket_take();     // requested one whole iteration ago
+        ticket_issue();
     }
-#endif
 #ifdef KMX_BS_TIMING
     if (lane == 0 && wave_id < 4096) {
         u64* dbg = reinterpret_cast<u64*>(out) + 8 + wave_id * 8;
