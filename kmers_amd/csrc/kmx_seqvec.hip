@@ -151,6 +151,43 @@ seqvec_minimizers_kernel(const u64* __restrict__ words, u64 n_reads, u32 L, u32 
     }
 }
 
+// The same function with the l-mer hashes shared through LDS: a block hashes every l-mer of its RB reads once
+// (thread per l-mer), then a thread per k-mer scans the k-w+1 staged hashes of its window (leftmost minimum) and
+// re-extracts the winning l-mer.  ~4x fewer instructions than hashing each window's l-mers again.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+seqvec_minimizers_lds_kernel(const u64* __restrict__ words, u64 n_reads, u32 L, u32 k, u32 w, u32 hasher, u32 hk, u32 rb,
+                             u64* __restrict__ out_word, u32* __restrict__ out_pos) {
+    extern __shared__ __attribute__((aligned(16))) u64 hs[];   // [rb][L-w+1]
+    const u32 NL = L - w + 1u, W = L - k + 1u, span = k - w + 1u;
+    const u64 n_words = (n_reads * (u64)L + 31u) >> 5;
+    for (u64 r0 = (u64)blockIdx.x * rb; r0 < n_reads; r0 += (u64)gridDim.x * rb) {
+        const u32 nr = (u32)(n_reads - r0 < rb ? n_reads - r0 : rb);
+        for (u32 e = threadIdx.x; e < nr * NL; e += THREADS) {
+            const u32 r = e / NL, p = e - r * NL;
+            hs[e] = mm_hash(seqvec_field(words, n_words, (r0 + r) * (u64)L + p, w), hasher, hk);
+        }
+        __syncthreads();
+        for (u32 e = threadIdx.x; e < nr * W; e += THREADS) {
+            const u32 r = e / W, i = e - r * W;
+            const u64* __restrict__ h = hs + r * NL + i;
+            u64 best_h = h[0];
+            u32 best = 0;
+            for (u32 j = 1; j < span; ++j) {
+                const u64 v = h[j];
+                if (v < best_h) {   // strict: the earlier of equal hashes stays (minimizers.rs:71 keeps `backmer.hash <= dqmer.hash`)
+                    best_h = v;
+                    best = j;
+                }
+            }
+            const u64 slot = (r0 + r) * (u64)W + i;
+            out_word[slot] = seqvec_field(words, n_words, (r0 + r) * (u64)L + i + best, w);
+            out_pos[slot] = i + best;
+        }
+        __syncthreads();
+    }
+}
+
 static inline unsigned sgrid(u64 n, int n_cu) {
     u64 g = (n + 255u) / 256u;
     const u64 cap = (u64)n_cu * 16u;
@@ -191,6 +228,17 @@ hipError_t launch_minimizer_words(const u64* in, u64 n, u32 k, u32 w, u32 hasher
 }
 hipError_t launch_seqvec_minimizers(const u64* words, u64 n_reads, u32 L, u32 k, u32 w, u32 hasher, u32 hk, u64* out_word,
                                     u32* out_pos, int n_cu, hipStream_t st) {
+    const u32 NL = L - w + 1u;
+    if ((size_t)NL * 8u <= 48u * 1024u) {   // the staged hashes of at least one read fit: LDS-shared kernel
+        u32 rb = (48u * 1024u) / (NL * 8u);
+        if (rb > 16u) rb = 16u;
+        u64 grid = (n_reads + rb - 1u) / rb;
+        const u64 cap = (u64)n_cu * 8u;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL(seqvec_minimizers_lds_kernel<256>, dim3((unsigned)(grid ? grid : 1)), dim3(256), (size_t)rb * NL * 8u, st, words,
+                           n_reads, L, k, w, hasher, hk, rb, out_word, out_pos);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(seqvec_minimizers_kernel, dim3(sgrid(n_reads * (u64)(L - k + 1u), n_cu)), dim3(256), 0, st, words, n_reads,
                        L, k, w, hasher, hk, out_word, out_pos);
     return hipGetLastError();

@@ -657,3 +657,16 @@ def test_minimizer_words_vs_oracle(ctx, orc):
     with pytest.raises(Exception) as ei:
         ctx.minimizer_words(ctx.to_device(np.zeros(1, np.uint64)), 5, 6, _lib.HASH_IDENTITY, 0)
     assert ei.value.status == _lib.E_K_RANGE
+
+
+def test_seqvec_minimizers_long_and_short_reads(ctx, orc):
+    """reads too long for the LDS-staged kernel take the direct one; reads exactly k long yield one minimizer"""
+    from kmers_amd import _lib
+    rng = np.random.default_rng(404)
+    for L, n, k, w in ((7000, 3, 31, 15), (31, 200, 31, 15), (33, 130, 31, 31)):
+        host = _acgt(rng, n * L)
+        sv = orc.SeqVector(host.tobytes())
+        words = ctx.seqvec_from_bytes(ctx.to_device(host))
+        mw, mp = ctx.seqvec_minimizers(words, n, L, k, w, _lib.HASH_LEX, w)
+        ow, op = orc.seqvec_minimizers(sv, n, L, k, w, w)
+        assert (mw.cpu().numpy().view(np.uint64) == ow).all() and (mp.cpu().numpy().view(np.uint32) == op).all()
