@@ -37,9 +37,6 @@
 #ifndef KMX_BS_P1D
 #define KMX_BS_P1D 2      // pass 1: ripple steps between the LDS request of a plane and its use
 #endif
-#ifndef KMX_BS_PF2
-#define KMX_BS_PF2 0
-#endif
 #ifndef KMX_BS_RUN2
 #define KMX_BS_RUN2 1      // pass 2: two planes per (v_and run, v_bcnt run) pair when WPL <= 4
 #endif
@@ -554,18 +551,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             if constexpr (KMX_BS_RUN2 && WPL <= 4) {
             // two planes per run (4*WPL v_and, then 4*WPL v_bcnt at raised priority): 0.8 % over one plane per run
             u64 vcur = KMX_PLANE(0), vcur2 = KMX_PLANE(NPL > 1 ? 1 : 0);
-#if KMX_BS_PF2
-            u64 vq = KMX_PLANE(NPL > 2 ? 2 : 0), vq2 = KMX_PLANE(NPL > 3 ? 3 : 0);   // LDS reads run two plane pairs ahead
-#endif
 #pragma unroll
             for (int i = 0; i < NPL; i += 2) {
-#if KMX_BS_PF2
-                const u64 vnext = vq, vnext2 = vq2;
-                vq = KMX_PLANE(i + 4 < NPL ? i + 4 : i);
-                vq2 = KMX_PLANE(i + 5 < NPL ? i + 5 : i);
-#else
+                // (requesting the planes two pairs ahead instead of one changed nothing: pass 2 does not wait on LDS)
                 const u64 vnext = KMX_PLANE(i + 2 < NPL ? i + 2 : i), vnext2 = KMX_PLANE(i + 3 < NPL ? i + 3 : i);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 u32 x[4 * WPL];
 #pragma unroll
