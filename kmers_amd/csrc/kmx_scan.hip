@@ -149,10 +149,10 @@ struct SinkHistLds {
 
 // Histogram, 2^15..2^21 buckets, pass 1 of 2: scatter the bucket ids into 64 partitions (the top 6 bits of the bucket).
 // Every wave owns a private segment of every partition's stream, so no global cursor and no global atomic is
-// involved.  The low b-6 bits of an id are staged in a 128-entry ring per partition in the wave's LDS slice: ONE
+// involved.  The low b-6 bits of an id are staged in a ROW-entry ring per partition in the wave's LDS slice: ONE
 // ds_add_rtn_u32 on a packed {entries appended : 16 | entries written out : 16} word returns the slot and tells
 // whether the ring has room, one ds_write_b16 stores the id.  After every block of 16 windows the rings holding
-// >= 64 ids write one 128-byte row each to their segment, four partitions at a time (one per quarter-wave).
+// >= ROW/2 ids write one half row each to their segment, four partitions at a time (one per quarter-wave).
 // Pass 2 (hist_part_reduce_kernel) builds each partition's 2^(b-6)-bucket table in LDS.  Ids that find their ring or
 // their segment full (adversarial input: everything in one partition) go straight to the global table, so the result
 // is exact for every input.
@@ -164,7 +164,11 @@ struct HistPartParams {
     u32 cap;            // entries per (wave, partition) segment, multiple of 64
 };
 struct SinkHistPart {
-    static constexpr u32 NP = 64, ROW = 128;   // partitions; ring entries per partition (u16)
+#ifndef KMX_HIST_ROW
+#define KMX_HIST_ROW 64
+#endif
+    static constexpr u32 NP = 64, ROW = KMX_HIST_ROW;   // partitions; ring entries per partition (u16); rows of ROW/2 ids leave together
+    static constexpr u32 HALF = ROW / 2u, PER_LANE = HALF / 16u;   // ids per lane of the quarter-wave that writes a row (2 or 4)
     static constexpr u32 kLdsDwordsPerWave = NP * ROW / 2u + 2u * NP;
     static constexpr bool kRagged = false;
     static u32 block_lds_dwords(const HistPartParams&) { return 0; }
@@ -206,10 +210,10 @@ struct SinkHistPart {
     }
     // ids staged and not yet written out
     static __device__ __forceinline__ u32 staged(u32 w) { return ((w >> 16) - w) & 0xFFFFu; }
-    // The whole wave: every ring with a full 64-id half row writes it out; quarter-wave j handles one ring per round.
+    // The whole wave: every ring with a full half row (HALF ids) writes it out; quarter-wave j handles one ring per round.
     __device__ __forceinline__ void flush_rows() {
         wave_sync();
-        u64 m = __ballot(staged(word[lane]) >= 64u);
+        u64 m = __ballot(staged(word[lane]) >= HALF);
         const u32 quarter = lane >> 4, l16 = lane & 15u;
         while (m) {
             u32 q = NP;   // this quarter-wave's ring of the round (NP = none)
@@ -224,20 +228,24 @@ struct SinkHistPart {
             if (q < NP) {
                 const u32 w = word[q];
                 const u32 pos = cur[q];
-                const u32 half = w & 64u;   // written-out count is a multiple of 64: the row starts at ring entry 0 or 64
-                const uint2 v = *reinterpret_cast<const uint2*>(ring + q * ROW + half + 4u * l16);
-                if (pos + 64u <= p.cap) {
-                    *reinterpret_cast<uint2*>(seg + (u64)q * p.cap + pos + 4u * l16) = v;
-                } else {   // segment full: the 64 ids go to the global table
+                const u32 half = w & HALF;   // written-out count is a multiple of HALF: the row starts at ring entry 0 or HALF
+                u32 v[PER_LANE / 2u];
+#pragma unroll
+                for (u32 i = 0; i < PER_LANE / 2u; ++i) v[i] = reinterpret_cast<const u32*>(ring + q * ROW + half + PER_LANE * l16)[i];
+                if (pos + HALF <= p.cap) {
+#pragma unroll
+                    for (u32 i = 0; i < PER_LANE / 2u; ++i) reinterpret_cast<u32*>(seg + (u64)q * p.cap + pos + PER_LANE * l16)[i] = v[i];
+                } else {   // segment full: the ids go to the global table
                     const u32 hi = q << lowbits;
-                    atomicAdd((unsigned long long*)&p.counts[hi | (v.x & 0xFFFFu)], 1ull);
-                    atomicAdd((unsigned long long*)&p.counts[hi | (v.x >> 16)], 1ull);
-                    atomicAdd((unsigned long long*)&p.counts[hi | (v.y & 0xFFFFu)], 1ull);
-                    atomicAdd((unsigned long long*)&p.counts[hi | (v.y >> 16)], 1ull);
+#pragma unroll
+                    for (u32 i = 0; i < PER_LANE / 2u; ++i) {
+                        atomicAdd((unsigned long long*)&p.counts[hi | (v[i] & 0xFFFFu)], 1ull);
+                        atomicAdd((unsigned long long*)&p.counts[hi | (v[i] >> 16)], 1ull);
+                    }
                 }
                 if (l16 == 0) {
-                    if (pos + 64u <= p.cap) cur[q] = pos + 64u;
-                    word[q] = (w & 0xFFFF0000u) | ((w + 64u) & 0xFFFFu);
+                    if (pos + HALF <= p.cap) cur[q] = pos + HALF;
+                    word[q] = (w & 0xFFFF0000u) | ((w + HALF) & 0xFFFFu);
                 }
             }
             wave_sync();
@@ -259,7 +267,7 @@ struct SinkHistPart {
     __device__ __forceinline__ void finish(const HistPartParams&) {
         flush_rows();
         flush_rows();
-        // the tails (< 64 ids per ring), one ring at a time
+        // the tails (< HALF ids per ring), one ring at a time
         for (u32 q = 0; q < NP; ++q) {
             const u32 w = word[q];
             const u32 n = staged(w), pos = cur[q];
