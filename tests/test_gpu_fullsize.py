@@ -89,3 +89,36 @@ def test_full_size_k63_two_word(ctx, orc, big):
     o = orc.canonical_reduce2(big[: n_chk * L].cpu().numpy(), n_chk, L, k, with_hash=True)
     gp = ctx.canonical_reduce2(big[: n_chk * L], n_chk, L, k, with_hash=True)
     assert tuple(getattr(gp, f) for f, _ in gp._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
+
+
+@pytest.mark.parametrize("k", [31, 27, 17])
+def test_full_size_three_paths_agree(ctx, big, k):
+    """ASCII bit-sliced kernel, ragged word-domain kernel (same reads through an offsets array) and the 2-bit packed
+    bit-sliced kernel (k = 31; lane-per-read kernel otherwise) produce the same summary on the first 2e7 reads"""
+    from kmers_amd import _lib
+
+    n = min(N_FULL, 20_000_000)
+    view = big[: n * L]
+    a = ctx.canonical_reduce(view, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    off = ctx.to_device(np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    r = ctx.canonical_reduce(view, n, 160, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=off)
+    assert (r.n_valid, r.sum_canon, r.xor_hash, r.sum_fw) == (a.n_valid, a.sum_canon, a.xor_hash, a.sum_fw)
+    words = ctx.seqvec_from_bytes(view)
+    p = ctx.seqvec_canonical_reduce(words, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    assert (p.n_valid, p.sum_canon, p.xor_hash, p.sum_fw) == (a.n_valid, a.sum_canon, a.xor_hash, a.sum_fw)
+    assert ctx.seqvec_to_bytes(words, 4096).cpu().numpy().tobytes() == view[:4096].cpu().numpy().tobytes()
+
+
+@pytest.mark.parametrize("b", [12, 20])
+def test_full_size_histogram_totals_and_linearity(ctx, big, b):
+    """the LDS-table and the partitioned histogram count every k-mer exactly once: totals, and two halves add up to the whole"""
+    import torch
+    from kmers_amd import _lib
+
+    n, k = min(N_FULL, 30_000_000), 31
+    whole = ctx.histogram(big[: n * L], n, L, k, _lib.HASH_LEX, k, b)
+    assert int(whole.sum().item()) == n * (L - k + 1)
+    h = n // 2 + 33
+    parts = ctx.histogram(big[: h * L], h, L, k, _lib.HASH_LEX, k, b)
+    parts = ctx.histogram(big[h * L: n * L], n - h, L, k, _lib.HASH_LEX, k, b, counts=parts)
+    assert torch.equal(parts, whole)
