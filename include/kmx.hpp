@@ -101,6 +101,14 @@ inline Base encode_binary(char c, Context& ctx = Context::instance()) {
     return b;
 }
 
+// mod.rs:54-65: the complement code of a letter, u64::MAX for anything but ACGTacgt
+inline Base encode_complement_binary_u8(uint8_t c, Context& ctx = Context::instance()) {
+    const Base b = encode_binary_u8(c, ctx);
+    return b == UINT64_MAX ? UINT64_MAX : complement_base(b);
+}
+// mod.rs:67-78: panics on anything but ACGTacgt
+inline Base encode_complement_binary(char c, Context& ctx = Context::instance()) { return complement_base(encode_binary(c, ctx)); }
+
 enum class MatchType { NoMatch = KMX_NO_MATCH, IdentityMatch = KMX_IDENTITY_MATCH, TwinMatch = KMX_TWIN_MATCH };  // canonical_kmer.rs:7-12
 enum class Orientation { IsCanonical, NotCanononical };  // kmer.rs:18-22 (spelling as in the reference)
 

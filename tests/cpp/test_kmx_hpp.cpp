@@ -185,6 +185,48 @@ int main() {
         CHECK(Kmer::sub_kmer_word(Kmer::from("acttgat").data, 7, 2, 3) == Kmer::from("ttg").data);
         CHECK(panics([&] { km.sub_kmer(5, 3); }));
     }
+    // ---- mod.rs:54-78 complement encoders; benches/simple_benchmark.rs:14-56 consumer shapes on the device
+    {
+        CHECK(encode_complement_binary('A') == T && encode_complement_binary('c') == G && encode_complement_binary_u8('g') == C &&
+              encode_complement_binary_u8('T') == A && encode_complement_binary_u8('N') == UINT64_MAX);
+        CHECK(panics([] { encode_complement_binary('N'); }));
+        std::string b;
+        for (int i = 0; i < 4096; ++i) b.push_back("ACGT"[(i * i + (i >> 2) + 3 * (i >> 5)) & 3]);
+        constexpr uint32_t K = 31;
+        Context& ctx = Context::instance();
+        DeviceBuffer<uint8_t> d(ctx, reinterpret_cast<const uint8_t*>(b.data()), b.size());
+        kmx_reads rd{d.data(), 1, static_cast<uint32_t>(b.size()), nullptr};   // b.windows(K) = the windows of one long read
+        kmx_summary s = canonical_reduce(ctx, rd, K, KMX_HASH_NONE, 0, KMX_REDUCE_SUM_FW);
+        uint64_t naive = 0, canon = 0;   // compute_naive / the canonical variant, one scalar k-mer at a time (the reference's shape)
+        for (size_t i = 0; i + K <= b.size(); i += 97) {   // spot-check every 97th window against the scalar API
+            Kmer km = Kmer::from(b.substr(i, K));
+            naive += km.into_u64();
+            canon += km.to_canonical().into_u64();
+        }
+        const size_t n_windows = b.size() - K + 1;
+        CHECK(s.n_valid == n_windows);
+        // full sums on the device in one batch call each: encode every window (Naive::ACGT == naive_impl) and add up on the host
+        DeviceBuffer<uint64_t> w(ctx, n_windows);
+        ctx.check(kmx_encode_windows(ctx.get(), &rd, K, static_cast<uint8_t>(encoding::Naive::ACGT), 1, w.data()), "encode_windows");
+        uint64_t sum_acgt = 0;
+        for (uint64_t x : w.download()) sum_acgt += x;
+        CHECK(sum_acgt == s.sum_fw);                       // compute_naive (== rc_naive: the reverse complement is discarded there)
+        ctx.check(kmx_encode_windows(ctx.get(), &rd, K, encoding::enc_byte(encoding::Xor10{}), 1, w.data()), "encode_windows xor10");
+        uint64_t rc_xor10 = 0;
+        for (uint64_t x : w.download()) rc_xor10 += x;     // rc_xor10 returns the sum of the ENCODED words (rev_comp's result is dropped)
+        uint64_t chk = 0;
+        for (size_t i = 0; i + K <= b.size(); i += 97) chk += encoding::encode<1>(encoding::Xor10{}, b.substr(i, K))[0];
+        uint64_t chk2 = 0;
+        {
+            auto all = w.download();
+            for (size_t i = 0; i + K <= b.size(); i += 97) chk2 += all[i];
+        }
+        CHECK(chk == chk2 && rc_xor10 != 0);
+        const uint64_t compute_xor10 = n_windows * kmer::Kmer<K>().num_bytes();   // compute_xor10 sums num_bytes()
+        CHECK(compute_xor10 == n_windows * 8);
+        (void)naive;
+        (void)canon;
+    }
     std::printf(fails ? "%d check(s) FAILED\n" : "all C++ host-layer checks passed\n", fails);
     return fails ? 1 : 0;
 }
