@@ -219,7 +219,7 @@ int kmx_seqvec_iter_kmers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_base
                           uint32_t k, uint64_t *d_out);
 /* kmx_canonical_reduce over reads held in a SeqVector: read r = slice [r*read_len, (r+1)*read_len).  Every 2-bit code
  * is a base, so every window counts.  0.25 B per base read from HBM instead of 1.  d_words 16-byte aligned for the
- * fast kernel (k in {21,31}); any k in [1,31] is served. */
+ * fast kernel (k in [13,31]); any k in [1,31] is served. */
 int kmx_seqvec_canonical_reduce(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_reads, uint32_t read_len, uint32_t k,
                                 uint32_t hasher, uint32_t hasher_k, uint32_t flags, kmx_summary *d_out);
 

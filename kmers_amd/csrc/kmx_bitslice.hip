@@ -34,10 +34,16 @@ hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
     const uint8_t* bases = reinterpret_cast<const uint8_t*>(words);
-    if (!bs_domain(bases, n_reads, L, k) || (k != 31 && k != 21)) return hipSuccess;
-    *handled = true;
-    if (k == 31) return launch_bs_k31(bases, n_reads, L, true, want_hash, want_sumfw, out, queue, n_cu, stream);
-    return launch_bs_k21(bases, n_reads, L, true, want_hash, want_sumfw, out, queue, n_cu, stream);
+    if (!bs_domain(bases, n_reads, L, k)) return hipSuccess;
+#define KMX_BS_PCASE(K) \
+    case K:             \
+        *handled = true; \
+        return launch_bs_k##K(bases, n_reads, L, true, want_hash, want_sumfw, out, queue, n_cu, stream);
+    switch (k) {
+        KMX_BS_FOR_EACH_K(KMX_BS_PCASE)
+        default:
+            return hipSuccess;
+    }
 }
 
 // [u64;2] k-mers: k = 63 is instantiated (BASELINE configs[2]); other k in 33..64 take the generic kernel

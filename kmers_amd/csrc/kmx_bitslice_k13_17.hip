@@ -3,10 +3,10 @@
 
 namespace kmx {
 
-KMX_BS_DEFINE_K(13, false)
-KMX_BS_DEFINE_K(14, false)
-KMX_BS_DEFINE_K(15, false)
-KMX_BS_DEFINE_K(16, false)
-KMX_BS_DEFINE_K(17, false)
+KMX_BS_DEFINE_K(13, true)
+KMX_BS_DEFINE_K(14, true)
+KMX_BS_DEFINE_K(15, true)
+KMX_BS_DEFINE_K(16, true)
+KMX_BS_DEFINE_K(17, true)
 
 }  // namespace kmx

@@ -3,10 +3,10 @@
 
 namespace kmx {
 
-KMX_BS_DEFINE_K(18, false)
-KMX_BS_DEFINE_K(19, false)
-KMX_BS_DEFINE_K(20, false)
-KMX_BS_DEFINE_K(22, false)
-KMX_BS_DEFINE_K(23, false)
+KMX_BS_DEFINE_K(18, true)
+KMX_BS_DEFINE_K(19, true)
+KMX_BS_DEFINE_K(20, true)
+KMX_BS_DEFINE_K(22, true)
+KMX_BS_DEFINE_K(23, true)
 
 }  // namespace kmx

@@ -3,9 +3,9 @@
 
 namespace kmx {
 
-KMX_BS_DEFINE_K(24, false)
-KMX_BS_DEFINE_K(25, false)
-KMX_BS_DEFINE_K(26, false)
-KMX_BS_DEFINE_K(27, false)
+KMX_BS_DEFINE_K(24, true)
+KMX_BS_DEFINE_K(25, true)
+KMX_BS_DEFINE_K(26, true)
+KMX_BS_DEFINE_K(27, true)
 
 }  // namespace kmx

@@ -3,8 +3,8 @@
 
 namespace kmx {
 
-KMX_BS_DEFINE_K(28, false)
-KMX_BS_DEFINE_K(29, false)
-KMX_BS_DEFINE_K(30, false)
+KMX_BS_DEFINE_K(28, true)
+KMX_BS_DEFINE_K(29, true)
+KMX_BS_DEFINE_K(30, true)
 
 }  // namespace kmx

@@ -826,7 +826,7 @@ static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
         }                                                                                                                     \
         return launch_bs_any<K, false>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);                   \
     }
-// k with an ASCII bit-sliced kernel (u64 k-mers): 13..31; packed (SeqVector) input: 31 and 21
+// k with a bit-sliced kernel (u64 k-mers), ASCII and packed (SeqVector) input: 13..31
 #define KMX_BS_FOR_EACH_K(X) \
     X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
 KMX_BS_FOR_EACH_K(KMX_BS_DECLARE_K)

@@ -595,7 +595,7 @@ def test_seqvec_get_and_iter_random(ctx, orc):
     assert ctx.seqvec_iter_kmers(words, n, 31, 10, 20).numel() == 0
 
 
-@pytest.mark.parametrize("k", [31, 21, 27, 11, 1])
+@pytest.mark.parametrize("k", [31, 30, 21, 27, 16, 13, 11, 1])
 @pytest.mark.parametrize("L,n", [(150, 64 * 50 + 9), (150, 63), (100, 64 * 20), (250, 64 * 11 + 3), (151, 64 * 7), (40, 500)])
 def test_seqvec_canonical_reduce(ctx, orc, L, n, k):
     """reads stored back to back in a SeqVector: bit-sliced packed kernel (k in {21,31}) and the generic packed kernel
