@@ -264,7 +264,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": ("kmx::scan_bitsliced_kernel<%d,%d,*>" % (k, 10 if L <= 160 else 16)) if (13 <= k <= 31 or k == 63) and L <= 256 else "kmx::scan_uniform_kernel",
+                "kernel": ("kmx::scan_bitsliced_kernel<%d,%d,*>" % (k, 10 if L <= 160 else 16)) if (13 <= k <= 31 or (33 <= k <= 63 and k % 2 == 1 and L <= 160)) and L <= 256 else ("kmx::scan_uniform_kernel" if k <= 31 else "kmx::reduce2_generic_kernel"),
                 "avg_kernel_ms": avg_kernel_ms, "min_kernel_ms": min(kernel_ms),
                 "median_kernel_ms": sorted(kernel_ms)[len(kernel_ms) // 2], "algorithmic_bytes_per_launch": algo_bytes,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,

@@ -46,16 +46,23 @@ hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 
     }
 }
 
-// [u64;2] k-mers: k = 63 is instantiated (BASELINE configs[2]); other k in 33..64 take the generic kernel
+KMX_BS2_DEFINE_K(63)
+
+// [u64;2] k-mers: every odd k from 33 to 63 is instantiated (k = 63 is BASELINE configs[2]); even k take the generic kernel
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
-    if (k != 63 || L < k || L > 160 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
+    if (L < k || L > 160 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
     if (n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
-    const u32 W = L - k + 1u;
-    *handled = true;
-    if (W <= 64u) return launch_bs<63, 10, 2>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
-    return launch_bs<63, 10, 3>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
+#define KMX_BS2_CASE(K) \
+    case K:             \
+        *handled = true; \
+        return launch_bs2_k##K(bases, n_reads, L, want_hash, out, queue, n_cu, stream);
+    switch (k) {
+        KMX_BS2_FOR_EACH_K(KMX_BS2_CASE)
+        default:
+            return hipSuccess;
+    }
 }
 
 }  // namespace kmx

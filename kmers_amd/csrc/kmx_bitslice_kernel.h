@@ -813,6 +813,26 @@ static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
     return launch_bs<K, 10, 5, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
 }
 
+// [u64;2] k-mers (k in 33..64, L <= 160): WPL so that 2*ceil(W/WPL) <= 64
+template <int K>
+static hipError_t launch_bs2_any(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, void* out, unsigned long long* queue,
+                                 int n_cu, hipStream_t stream) {
+    const u32 W = L - (u32)K + 1u;
+    if (W <= 64u) return launch_bs<K, 10, 2>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
+    if (W <= 96u) return launch_bs<K, 10, 3>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
+    return launch_bs<K, 10, 4>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
+}
+#define KMX_BS2_DECLARE_K(K) \
+    hipError_t launch_bs2_k##K(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, void* out, unsigned long long* queue, \
+                               int n_cu, hipStream_t stream);
+#define KMX_BS2_DEFINE_K(K)                                                                                                 \
+    hipError_t launch_bs2_k##K(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, void* out, unsigned long long* queue, \
+                               int n_cu, hipStream_t stream) {                                                               \
+        return launch_bs2_any<K>(bases, n_reads, L, want_hash, out, queue, n_cu, stream);                                    \
+    }
+// two-word k with a bit-sliced kernel: every odd k from 33 to 63
+#define KMX_BS2_FOR_EACH_K(X) X(33) X(35) X(37) X(39) X(41) X(43) X(45) X(47) X(49) X(51) X(53) X(55) X(57) X(59) X(61) X(63)
+
 #define KMX_BS_DECLARE_K(K) \
     hipError_t launch_bs_k##K(const uint8_t* bases, u64 n_reads, u32 L, bool packed, u32 want_hash, u32 want_sumfw, void* out, \
                               unsigned long long* queue, int n_cu, hipStream_t stream);
@@ -830,5 +850,6 @@ static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
 #define KMX_BS_FOR_EACH_K(X) \
     X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
 KMX_BS_FOR_EACH_K(KMX_BS_DECLARE_K)
+KMX_BS2_FOR_EACH_K(KMX_BS2_DECLARE_K)
 
 }  // namespace kmx

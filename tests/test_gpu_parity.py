@@ -330,6 +330,20 @@ def test_reduce2_windows2(ctx, orc, k):
     assert (outs["canon"].cpu().numpy().view(np.uint64).reshape(-1, 2) == canon).all()
 
 
+@pytest.mark.parametrize("k", list(range(33, 64, 2)) + [34, 64])
+@pytest.mark.parametrize("L,n,p_bad", [(150, 64 * 30 + 7, 0.0), (150, 64 * 30 + 7, 0.0005), (100, 64 * 12, 0.0), (160, 64 * 9 + 1, 0.0)])
+def test_reduce2_bitsliced_every_odd_k(ctx, orc, k, L, n, p_bad):
+    """[u64;2] k-mers: odd k from 33 to 63 on the bit-sliced kernel (clean tiles; dirty tiles and the partial tile roll per
+    lane), even k on the lane-per-read kernel -- all against the oracle's 128-bit rolling"""
+    if L < k:
+        pytest.skip("read shorter than k")
+    rng = np.random.default_rng(k * 7 + L)
+    host = _dirty(rng, n * L, p_bad)
+    o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+    g = ctx.canonical_reduce2(ctx.to_device(host), n, L, k, with_hash=True)
+    assert tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
+
+
 # ------------------------------------------------------------------ histogram
 
 @pytest.mark.parametrize("hasher,hk", [(1, 31), (2, 0), (1, 20)])
