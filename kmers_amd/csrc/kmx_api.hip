@@ -27,6 +27,8 @@ hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 L_hint, u32 k, bool want_hash,
+                                        kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 // kmx_seqvec.hip
@@ -322,6 +324,11 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
         if (!reads->d_offsets) {
             KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
                                                     d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+            if (handled) return KMX_OK;
+        }
+        if (reads->d_offsets && !want_sumfw) {   // ragged reads on the bit-sliced kernel (k in {21, 31}; read_len = optional length bound)
+            KMX_HIP(ctx, kmx::launch_scan_bitsliced_ragged(reads->d_bases, reads->d_offsets, reads->n_reads, reads->read_len, k,
+                                                           lex_same_k, d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
             if (handled) return KMX_OK;
         }
         // word-domain kernel: uniform reads of any (k, L) in its domain, and ragged reads (read_len = optional length bound)

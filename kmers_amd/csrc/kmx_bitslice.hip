@@ -48,6 +48,29 @@ hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 
 
 KMX_BS2_DEFINE_K(63)
 
+// Ragged reads (offsets array): `L_hint` = upper bound of the read lengths if the caller knows one (0 = unknown -> the
+// 160-base frame; tiles holding a longer read roll per lane).  No sum_fw in this mode (its closed form needs one length).
+hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 L_hint, u32 k, bool want_hash,
+                                        kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
+    *handled = false;
+    if (!offsets || (reinterpret_cast<uintptr_t>(bases) & 15u) || L_hint > 256) return hipSuccess;
+    if (const char* e = getenv("KMX_BS_RAGGED")) {   // dev knob: 0 = leave ragged reads to the word-domain kernel
+        if (e[0] == '0') return hipSuccess;
+    }
+    u32 Lf = L_hint ? L_hint : 160u;
+    if (Lf < k + 15u) Lf = k + 15u;       // keep at least 16 windows in the frame
+    if (Lf > 256u) return hipSuccess;
+#define KMX_BSR_CASE(K) \
+    case K:             \
+        *handled = true; \
+        return launch_bs_ragged_k##K(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream);
+    switch (k) {
+        KMX_BSR_FOR_EACH_K(KMX_BSR_CASE)
+        default:
+            return hipSuccess;
+    }
+}
+
 // [u64;2] k-mers: every odd k from 33 to 63 is instantiated (k = 63 is BASELINE configs[2]); even k take the generic kernel
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {

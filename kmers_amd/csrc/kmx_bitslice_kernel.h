@@ -27,9 +27,13 @@
 #include "kmx_device.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef KMX_BS_PREFETCH
 #define KMX_BS_PREFETCH 1   // 1: next tile loaded into registers one tile ahead; 0: loads at tile start (fewer VGPRs, more waves)
+#endif
+#ifndef KMX_BSR_WAVES
+#define KMX_BSR_WAVES 2   // waves per SIMD of the ragged variant
 #endif
 #ifndef KMX_BS_WAVES
 #define KMX_BS_WAVES 3      // waves per SIMD the register allocation is sized for
@@ -80,11 +84,25 @@ __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, 
 
 // PACKED: `bases` is a SeqVector (kmx_seqvec.hip), read r = its bases [r*L, (r+1)*L): a tile is 16*L bytes of ready-made
 // 2-bit codes that go from HBM straight into the packed LDS buffer -- no phase A, nothing to validate.
-template <int K, int NW, int WPL, bool PACKED = false>
-__global__ void __launch_bounds__(256, ((NW > 10 || K > 32) ? 2 : KMX_BS_WAVES))   // 64 prefetch registers at NW=16; 2x counters at K>32
+// RAGGED: reads of different lengths, read r = bases[offsets[r], offsets[r+1]); L is then the frame: the longest read a
+// tile may hold (<= 16*NW).  A tile is still 64 consecutive reads = one contiguous byte span, streamed from its
+// 16-byte-aligned start.  Lane r realigns its own read from its own offset and zeroes the bases past its end; two
+// kinds of extra 32x32 transposes ride along with the NW data groups in phase C:
+//   * NV validity words per read (bit o = "window o lies inside this read") -> plane V_o = the reads that own window
+//     o, ANDed into the fw<rc mask of phase D (so a window past a read's end counts for nothing);
+//   * the last K-1 bases of every read (NE dwords): the rc-side sum of the epilogue runs over all planes >= K-1-t of
+//     a read instead of stopping t bases before ITS end, and these per-base totals take the excess back out.
+// A tile whose span or longest read leaves the frame, or that would load past the end of the buffer, and tiles with
+// an invalid byte, take the per-lane rolling path as before.
+template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
+__global__ void __launch_bounds__(256, ((NW > 10 || K > 32) ? 2 : RAGGED ? KMX_BSR_WAVES : KMX_BS_WAVES))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
-                      unsigned long long* __restrict__ queue) {
+                      unsigned long long* __restrict__ queue, const u64* __restrict__ offsets) {
+    static_assert(!RAGGED || (!PACKED && K <= 32 && KMX_BS_PRIO >= 2), "ragged input: ASCII, single-word k-mers");
+    constexpr int NE = RAGGED ? (K - 1 + 15) / 16 : 0;            // dwords holding the last K-1 bases of a read
+    constexpr int NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;  // validity words per read (one bit per window of the frame)
+    constexpr int NXT = NW + NE + NV;                            // 32x32 transposes per half-wave and tile
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     // Plane storage of one 32-read set: base beta (2 planes = one u64) lives at u64 index
     // (beta & 3) * S2 + (beta >> 2).  In phase D lane g reads bases 4g+i: consecutive lanes then touch
@@ -97,18 +115,17 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 lane = threadIdx.x & 63u;
     const u32 half = lane >> 5, p = lane & 31u;
     const u32 wib = threadIdx.x >> 6;
-    const u32 chunks = 4u * L;
+    const u32 chunks = 4u * L + (RAGGED ? 1u : 0u);          // 16-byte chunks a tile may span (ragged: +1 for its unaligned start)
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
     const u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
-    u32* P = lds + wib * (ldsw + 4u * PLANES);
+    u32* P = lds + wib * (ldsw + 4u * PLANES + 64u * NV);
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
     const u64 n_full = n_reads >> 6;
-    const u64 n_waves = (u64)gridDim.x * 4u;
     const u64 wave_id = (u64)blockIdx.x * 4u + wib;
 
-    const u32 posF = lane * L + 16u * PAD;
-    const u32 qF = posF >> 4, aF = 2u * (posF & 15u);
+    u32 posF = lane * L + 16u * PAD;    // (ragged: set per tile from the lane's own offset)
+    u32 qF = posF >> 4, aF = 2u * (posF & 15u);
     const u32 W = L - (u32)K + 1u;      // windows per read
     const u32 NG = (W + WPL - 1u) / WPL; // groups of WPL adjacent windows per read
     const u32 rounds = (2u * NG + 63u) >> 6;   // (set, group) items per tile, 64 per round
@@ -138,12 +155,50 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u32* TOT = PL + 2u * PLANES;
 #pragma unroll
     for (int g = 0; g < NW; ++g) TOT[half * PLANES + 32u * g + p] = 0;
+    u32* VAL = TOT + 2u * PLANES;       // ragged: [2][32*NV] validity planes of the current tile
+    u32 qt[NE > 0 ? NE : 1];            // ragged: running popcount of this lane's plane of the read-end words
+#pragma unroll
+    for (int e = 0; e < (NE > 0 ? NE : 1); ++e) qt[e] = 0;
+    u64 nvr = 0;                        // ragged: windows of this lane's reads in bit-sliced tiles
+    const u64 total_bytes = RAGGED ? offsets[n_reads] : 0;
+    // ragged: per-tile geometry of the current and of the next tile (rel/len per lane, the rest wave-uniform)
+    struct TileMeta { u32 rel = 0, len = 0, n_ch = 0; u64 base = 0; bool fits = true; };
+    TileMeta cur_m, nx_m;
+    // the two offsets of a lane are requested one iteration before anything looks at them (meta_issue / meta_finish)
+    u64 raw_o0 = 0, raw_o1 = 0;
+    auto meta_issue = [&](u64 t) {
+        raw_o0 = offsets[t * 64u + lane];
+        raw_o1 = offsets[t * 64u + lane + 1u];
+    };
+    auto meta_finish = [&](TileMeta& m) {
+        const u64 o0 = raw_o0, o1 = raw_o1;
+        // (the builtins return int: through u32 first, or offsets >= 2^31 get sign-extended into the high word)
+        const u32 t0l = __builtin_amdgcn_readfirstlane((u32)o0), t0h = __builtin_amdgcn_readfirstlane((u32)(o0 >> 32));
+        const u32 t1l = __builtin_amdgcn_readlane((u32)o1, 63), t1h = __builtin_amdgcn_readlane((u32)(o1 >> 32), 63);
+        const u64 t0 = ((u64)t0h << 32) | t0l, t1 = ((u64)t1h << 32) | t1l;
+        m.base = t0 & ~15ull;
+        const u64 nch = (t1 - m.base + 15u) >> 4;
+        const u64 len64 = o1 - o0;
+        m.len = len64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)len64;
+        m.rel = (u32)(o0 - m.base);
+        m.n_ch = (u32)(nch > 0xFFFFFFFFull ? 0xFFFFFFFFull : nch);
+        m.fits = nch <= (u64)chunks && nch <= 64u * NW && wave_max_u32(m.len) <= L && m.base + 16u * nch <= total_bytes;
+    };
     u32 n_bs_tiles = 0;
     // word-domain accumulators of the fallback path (tiles with invalid bytes, the final partial tile)
     struct { u64 n = 0, s0 = 0, s1 = 0, x0 = 0, x1 = 0, fw = 0; } fb;
     auto fallback_read = [&](u64 read) {
         const uint8_t* s = bases + read * (u64)L;
-        if constexpr (PACKED) {
+        if constexpr (RAGGED) {
+            const u64 o0 = offsets[read];
+            roll_read(bases + o0, (u32)(offsets[read + 1u] - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
+                const u64 canon = fw < rc ? fw : rc;
+                fb.n += 1;
+                fb.s0 += canon;
+                fb.x0 ^= lex_hash(canon, (u32)K);
+                fb.fw += fw;
+            });
+        } else if constexpr (PACKED) {
             static_assert(!PACKED || K <= 32, "packed input: single-word k-mers");
             roll_read_packed(reinterpret_cast<const u64*>(bases), read * (u64)L, L, (u32)K, [&](u32, u64 fw, u64 rc) {
                 const u64 canon = fw < rc ? fw : rc;
@@ -189,6 +244,18 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 lane16 = lane * 16u;
     const u32 last_off = PACKED ? (L - 1u) * 16u : (chunks - 1u) * 16u;
     const bool short_rows = PACKED || chunks < 64u * (NW - 1);   // whole rows of the load grid may lie past the tile
+    auto issue_loads_ragged = [&](const TileMeta& m) {
+        const uint8_t* __restrict__ tb = bases + m.base;
+        const u32 lo = (m.n_ch - 1u) * 16u;
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            u32 off = lane16 + (u32)it * 1024u;
+            off = off < lo ? off : lo;
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb + off));
+            w[it] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
     auto issue_loads = [&](u64 tile) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
 #pragma unroll
@@ -284,7 +351,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     auto phase_A = [&]() -> bool {   // pack + validate the tile sitting in w[] into the packed LDS buffer
         u32 bad = 0;
-        if constexpr (PACKED) {      // already 2-bit codes: 16 bytes = 4 packed dwords per lane and load
+        if constexpr (RAGGED) {      // the tile spans cur_m.n_ch chunks from its aligned start (neighbouring tiles' bytes at both ends)
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const u32 c = it * 64u + lane;
+                if (c < cur_m.n_ch) P[1u + c] = encode_prio(w[it], bad);
+            }
+            return __any(chunk_has_invalid(bad));
+        } else if constexpr (PACKED) {      // already 2-bit codes: 16 bytes = 4 packed dwords per lane and load
 #pragma unroll
             for (int it = 0; it < NLD; ++it) {
                 const u32 c = it * 64u + lane;
@@ -320,7 +394,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     auto phase_BC = [&]() {
         // ---- B. this lane's read, realigned: F[g] = bases [16g, 16g+16)
-        u32 F[NW];
+        u32 F[NXT];
+        if constexpr (RAGGED) {
+            posF = cur_m.rel + 16u * PAD;
+            qF = posF >> 4;
+            aF = 2u * (posF & 15u);
+        }
         {
             u32 R[NW + 1];
 #pragma unroll
@@ -329,6 +408,31 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
             for (int g = 0; g < NW; ++g) F[g] = alignbit(R[g + 1], R[g], aF);
             if (KMX_BS_PRIO >= 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
+        }
+        if constexpr (RAGGED) {
+            const u32 len = cur_m.len >= (u32)K ? cur_m.len : 0u;   // a read shorter than k owns no window: it is blanked out entirely
+            // bases past the end of the read belong to the next read: zero them
+#pragma unroll
+            for (int g = 0; g < NW; ++g) {
+                const u32 keep = len > 16u * g ? (len - 16u * g < 16u ? len - 16u * g : 16u) : 0u;
+                F[g] = keep >= 16u ? F[g] : (F[g] & ((1u << (2u * keep)) - 1u));
+            }
+            // the last K-1 bases of the read, base len-K+1+i at position i of the NE dwords
+            const u32 posE = len ? posF + len - (u32)(K - 1) : posF;
+            const u32 qE = posE >> 4, aE = 2u * (posE & 15u);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                u32 v = alignbit(P[qE + e + 1], P[qE + e], aE);
+                constexpr int tail = (K - 1) - 16 * (NE - 1);          // bases in the last dword (1..16)
+                if (e == NE - 1 && tail < 16) v &= (1u << (2 * tail)) - 1u;
+                F[NW + e] = len ? v : 0u;
+            }
+            // validity: bit o of word o/32 = window o lies inside the read
+            const u32 wr = len ? len - (u32)K + 1u : 0u;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                F[NW + NE + j] = wr >= 32u * (j + 1) ? ~0u : (wr > 32u * j ? (1u << (wr - 32u * j)) - 1u : 0u);
+            nvr += wr;
         }
         // ---- C. transpose each 32 reads x 32 bits block across the 32 lanes of the half-wave, entirely in
         //      the VALU (no LDS round trips): butterfly stage d exchanges with lane^d and keeps/merges the
@@ -341,49 +445,49 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         // Stage-major order: every butterfly stage runs over all NW groups, with its half-rate instructions
         // (v_perm_b32 / v_alignbit_b32 / DPP moves) as one raised-priority run and its full-rate bit selects after it.
         {
-            u32 Y[NW];
+            u32 Y[NXT];
 #define KMX_HRUN_BEGIN __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3);
 #define KMX_HRUN_END __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (16 << 10) | 0x1f);
+            for (int g = 0; g < NXT; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (16 << 10) | 0x1f);
             KMX_HRUN_BEGIN
 #pragma unroll
-            for (int g = 0; g < NW; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], tr_sel16);
+            for (int g = 0; g < NXT; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], tr_sel16);
             KMX_HRUN_END
 #pragma unroll
-            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (8 << 10) | 0x1f);
+            for (int g = 0; g < NXT; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (8 << 10) | 0x1f);
             KMX_HRUN_BEGIN
 #pragma unroll
-            for (int g = 0; g < NW; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], tr_sel8);
+            for (int g = 0; g < NXT; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], tr_sel8);
             KMX_HRUN_END
 #pragma unroll
-            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (4 << 10) | 0x1f);
+            for (int g = 0; g < NXT; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (4 << 10) | 0x1f);
             KMX_HRUN_BEGIN
 #pragma unroll
-            for (int g = 0; g < NW; ++g) Y[g] = alignbit(Y[g], Y[g], tr_sh[2]);
+            for (int g = 0; g < NXT; ++g) Y[g] = alignbit(Y[g], Y[g], tr_sh[2]);
             KMX_HRUN_END
 #pragma unroll
-            for (int g = 0; g < NW; ++g) F[g] = bitsel(F[g], Y[g], tr_keep[2]);
+            for (int g = 0; g < NXT; ++g) F[g] = bitsel(F[g], Y[g], tr_keep[2]);
 #pragma unroll
             for (int st = 3; st < 5; ++st) {
 #if KMX_BS_SWZ == 2
 #pragma unroll
-                for (int g = 0; g < NW; ++g)
+                for (int g = 0; g < NXT; ++g)
                     Y[g] = st == 3 ? (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (2 << 10) | 0x1f)
                                    : (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (1 << 10) | 0x1f);
                 KMX_HRUN_BEGIN
 #else
                 KMX_HRUN_BEGIN
 #pragma unroll
-                for (int g = 0; g < NW; ++g)
+                for (int g = 0; g < NXT; ++g)
                     Y[g] = st == 3 ? (u32)__builtin_amdgcn_update_dpp(0, (int)F[g], 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true)
                                    : (u32)__builtin_amdgcn_update_dpp(0, (int)F[g], 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
 #endif
 #pragma unroll
-                for (int g = 0; g < NW; ++g) Y[g] = alignbit(Y[g], Y[g], tr_sh[st]);
+                for (int g = 0; g < NXT; ++g) Y[g] = alignbit(Y[g], Y[g], tr_sh[st]);
                 KMX_HRUN_END
 #pragma unroll
-                for (int g = 0; g < NW; ++g) F[g] = bitsel(F[g], Y[g], tr_keep[st]);
+                for (int g = 0; g < NXT; ++g) F[g] = bitsel(F[g], Y[g], tr_keep[st]);
             }
 #pragma unroll
             for (int g = 0; g < NW; ++g) {
@@ -391,12 +495,16 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 const u32 slot = (WPL == 4) ? (beta & 3u) * S2 + (beta >> 2) : beta;
                 PL[half * PLANES + 2u * slot + (p & 1u)] = F[g];
             }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) VAL[half * 32u * NV + 32u * j + p] = F[NW + NE + j];   // ragged: plane V_(32j+p) of this set
             KMX_HRUN_BEGIN
 #pragma unroll
-            for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_popcount(F[g]);
+            for (int g = 0; g < NW + NE; ++g) Y[g] = (u32)__builtin_popcount(F[g]);
             KMX_HRUN_END
 #pragma unroll
             for (int g = 0; g < NW; ++g) atomicAdd(&TOT[half * PLANES + 32u * g + p], Y[g]);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) qt[e] += Y[NW + e];                                     // ragged: read-end planes, totals only
 #undef KMX_HRUN_BEGIN
 #undef KMX_HRUN_END
         }
@@ -542,7 +650,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             u32 m[WPL];
 #pragma unroll
             for (int w = 0; w < WPL; ++w) {
-                m[w] = ((u32)w < nwin) ? lt[w] : 0u;
+                if constexpr (RAGGED) {   // only the reads that own window o+w (none of them past the frame)
+                    const u32 ow = o + (u32)w;
+                    m[w] = (active && ow < 32u * NV) ? (lt[w] & VAL[set * 32u * NV + ow]) : 0u;
+                } else {
+                    m[w] = ((u32)w < nwin) ? lt[w] : 0u;
+                }
                 pc_acc(mcnt, m[w]);
             }
             asm volatile("" ::: "memory");   // pass 2 re-reads the planes instead of keeping 2K+6 registers live
@@ -645,18 +758,41 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u64 tile = dequeue();
     u64 next_tile = dequeue();
     ticket_issue();
-    if (tile < n_full) issue_loads(tile);
+    if constexpr (RAGGED) {
+        if (tile < n_full) {
+            meta_issue(tile);
+            meta_finish(cur_m);
+            if (cur_m.fits) issue_loads_ragged(cur_m);
+        }
+        if (next_tile < n_full) meta_issue(next_tile);
+    } else {
+        if (tile < n_full) issue_loads(tile);
+    }
     while (tile < n_full) {
 #ifdef KMX_BS_TIMING
         u64 t_last = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         KMX_T(0)
 #endif
-        const bool bad_tile = phase_A();
-        prefetch(next_tile, tile);
+        bool bad_tile;
+        if constexpr (RAGGED) {
+            bad_tile = !cur_m.fits || phase_A();
+            __builtin_amdgcn_sched_barrier(0);
+            if (next_tile < n_full) {
+                meta_finish(nx_m);            // offsets requested a whole iteration ago
+                if (nx_m.fits) issue_loads_ragged(nx_m);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            bad_tile = phase_A();
+            prefetch(next_tile, tile);
+        }
         lds_fence();
         KMX_T(1)
         if (bad_tile) {
+#ifdef KMX_DBG_FB
+            if constexpr (RAGGED) { if (lane == 0) fb.n += cur_m.fits ? (1ull << 40) : (1ull << 52); }
+#endif
             fallback_read(tile * 64u + lane);
         } else if (!(KMX_BS_ABLATE & 32)) {
             phase_BC();
@@ -669,6 +805,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         tile = next_tile;
         next_tile = ticket_take();     // requested one whole iteration ago
         ticket_issue();
+        if constexpr (RAGGED) {
+            cur_m = nx_m;
+            if (next_tile < n_full) meta_issue(next_tile);
+        }
     }
 #ifdef KMX_BS_TIMING
     if (lane == 0 && wave_id < 4096) {
@@ -695,7 +835,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     //   sum of fw words (K<=32) = sum over planes of popcount total * closed-form per-base weight.
     u64 bs_n = 0, bs_s0 = 0, bs_s1 = 0, bs_x0 = 0, bs_x1 = 0, bs_fw = 0;
     if (n_bs_tiles != 0u) {
-        const u64 nk = (u64)n_bs_tiles * 64u * (u64)W;     // k-mers handled bit-sliced by this wave
+        // k-mers handled bit-sliced by this wave
+        const u64 nk = RAGGED ? wave_sum(nvr) : (u64)n_bs_tiles * 64u * (u64)W;
         bs_n = nk;
         u64 fwall = 0;
         u32 tot[NW];
@@ -703,7 +844,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         for (int g = 0; g < NW; ++g) {
             const u32 qidx = 32u * g + p;
             const u32 pcq = TOT[half * PLANES + qidx];     // per-plane totals of this half's set
-            if constexpr (K <= 32) {
+            if constexpr (K <= 32 && !RAGGED) {
                 u64 wf, wr;
                 plane_weights(qidx >> 1, L, (u32)K, wf, wr);
                 fwall += (u64)pcq * (wf << (qidx & 1u));
@@ -722,6 +863,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
         for (int g = 0; g < NW; ++g)
             if (half == 0) PL[32u * g + p] = tot[g];        // PL[2*base + bit] = popcount total of that plane
+        // ragged: QE[2*i + bit] = how many reads have that bit set in base i of their last K-1 bases (base len-K+1+i)
+        u32* QE = VAL;   // (the validity planes are dead by now; the plane area right after the totals holds the counter sums)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const u32 both = qt[e] + __shfl_xor(qt[e], 32, WAVE);
+            if (half == 0) QE[32u * e + p] = both;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -732,7 +880,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             u64 cc = CS[2u * tc + bb];                      // C[t][b] + C[K-1-t][b]; the middle class holds C[mid][b] once
             if (t == t2) cc += cc;
             u64 tq = 0;
-            for (u32 i = t2; i <= L - 1u - t; ++i) tq += PL[2u * i + bb];
+            if constexpr (RAGGED) {
+                // every plane from t2 up (bases past a read's end are zero) minus the last t bases of every read
+                for (u32 i = t2; i <= L - 1u; ++i) tq += PL[2u * i + bb];
+                for (u32 i = (u32)K - 1u - t; i + 2u <= (u32)K; ++i) tq -= QE[2u * i + bb];
+            } else {
+                for (u32 i = t2; i <= L - 1u - t; ++i) tq += PL[2u * i + bb];
+            }
             const u64 cnt = cc + (nk - mc) - tq;
             const u32 sh = 2u * (t & 31u) + bb;
             if (t < 32u) s0 += cnt << sh; else s1 += cnt << sh;
@@ -774,13 +928,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 
 // ------------------------------------------------------------------ launcher
 
-template <int K, int NW, int WPL, bool PACKED = false>
+template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
 static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
-                            unsigned long long* queue, int n_cu, hipStream_t stream) {
-    auto kern = scan_bitsliced_kernel<K, NW, WPL, PACKED>;
-    const u32 chunks = 4u * L;
+                            unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets = nullptr) {
+    auto kern = scan_bitsliced_kernel<K, NW, WPL, PACKED, RAGGED>;
+    const u32 chunks = 4u * L + (RAGGED ? 1u : 0u);
     const u32 ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
-    size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u)) * 4u * 4u;
+    constexpr u32 NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;
+    size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u) + 64u * NV) * 4u * 4u;
     if (const char* e = getenv("KMX_BS_EXTRA_LDS")) lds_bytes += (size_t)atol(e);   // dev knob: caps blocks per CU
     static int bpc = 0;
     static size_t bpc_lds = 0;
@@ -796,7 +951,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     const u64 need = (n_tiles + 3u) / 4u;
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets);
     return hipGetLastError();
 }
 
@@ -833,6 +988,27 @@ static hipError_t launch_bs2_any(const uint8_t* bases, u64 n_reads, u32 L, u32 w
 // two-word k with a bit-sliced kernel: every odd k from 33 to 63
 #define KMX_BS2_FOR_EACH_K(X) X(33) X(35) X(37) X(39) X(41) X(43) X(45) X(47) X(49) X(51) X(53) X(55) X(57) X(59) X(61) X(63)
 
+// ragged reads: Lf = the frame (longest read a tile may hold; a tile with a longer read rolls per lane)
+template <int K>
+static hipError_t launch_bs_ragged_any(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out,
+                                       unsigned long long* queue, int n_cu, hipStream_t stream) {
+    const u32 W = Lf - (u32)K + 1u;
+    if (Lf > 160) return launch_bs<K, 16, 8, false, true>(bases, n_reads, Lf, want_hash, 0, out, queue, n_cu, stream, offsets);
+    if (W <= 96u) return launch_bs<K, 10, 3, false, true>(bases, n_reads, Lf, want_hash, 0, out, queue, n_cu, stream, offsets);
+    if (W <= 128u) return launch_bs<K, 10, 4, false, true>(bases, n_reads, Lf, want_hash, 0, out, queue, n_cu, stream, offsets);
+    return launch_bs<K, 10, 5, false, true>(bases, n_reads, Lf, want_hash, 0, out, queue, n_cu, stream, offsets);
+}
+#define KMX_BSR_DECLARE_K(K) \
+    hipError_t launch_bs_ragged_k##K(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out, \
+                                     unsigned long long* queue, int n_cu, hipStream_t stream);
+#define KMX_BSR_DEFINE_K(K)                                                                                                  \
+    hipError_t launch_bs_ragged_k##K(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out, \
+                                     unsigned long long* queue, int n_cu, hipStream_t stream) {                               \
+        return launch_bs_ragged_any<K>(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream);                     \
+    }
+// k with a bit-sliced kernel for ragged reads
+#define KMX_BSR_FOR_EACH_K(X) X(21) X(31)
+
 #define KMX_BS_DECLARE_K(K) \
     hipError_t launch_bs_k##K(const uint8_t* bases, u64 n_reads, u32 L, bool packed, u32 want_hash, u32 want_sumfw, void* out, \
                               unsigned long long* queue, int n_cu, hipStream_t stream);
@@ -851,5 +1027,6 @@ static hipError_t launch_bs2_any(const uint8_t* bases, u64 n_reads, u32 L, u32 w
     X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
 KMX_BS_FOR_EACH_K(KMX_BS_DECLARE_K)
 KMX_BS2_FOR_EACH_K(KMX_BS2_DECLARE_K)
+KMX_BSR_FOR_EACH_K(KMX_BSR_DECLARE_K)
 
 }  // namespace kmx

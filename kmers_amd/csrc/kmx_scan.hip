@@ -494,8 +494,10 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         if constexpr (RAGGED) {
             my_off = nx_off;
             my_len = (u32)(nx_end - nx_off);
-            const u64 t0 = ((u64)__builtin_amdgcn_readfirstlane((u32)(nx_off >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)nx_off);
-            const u64 t1 = ((u64)__builtin_amdgcn_readlane((u32)(nx_end >> 32), 63) << 32) | __builtin_amdgcn_readlane((u32)nx_end, 63);
+            // (the builtins return int: through u32 first, or offsets >= 2^31 get sign-extended into the high word)
+            const u32 t0l = __builtin_amdgcn_readfirstlane((u32)nx_off), t0h = __builtin_amdgcn_readfirstlane((u32)(nx_off >> 32));
+            const u32 t1l = __builtin_amdgcn_readlane((u32)nx_end, 63), t1h = __builtin_amdgcn_readlane((u32)(nx_end >> 32), 63);
+            const u64 t0 = ((u64)t0h << 32) | t0l, t1 = ((u64)t1h << 32) | t1l;
             if (next_tile < n_full) {
                 nx_off = offsets[next_tile * 64u + lane];
                 nx_end = offsets[next_tile * 64u + lane + 1u];

@@ -241,8 +241,10 @@ def test_reduce_ragged_tiled_kernel(ctx, orc, k, hint):
     o = orc.canonical_reduce(host, len(lens), 0, k, hasher_k=k, offsets=offsets)
     g = ctx.canonical_reduce(bases, len(lens), hint, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=d_off)
     _cmp_summary(g, o, True, True)
-    g0 = ctx.canonical_reduce(bases, len(lens), hint, k, offsets=d_off)
+    g0 = ctx.canonical_reduce(bases, len(lens), hint, k, offsets=d_off)          # k in {21, 31}: ragged bit-sliced kernel
     assert (g0.n_valid, g0.sum_canon) == (o.n_valid, o.sum_canon)
+    g1 = ctx.canonical_reduce(bases, len(lens), hint, k, _lib.HASH_LEX, k, 0, offsets=d_off)
+    assert (g1.n_valid, g1.sum_canon, g1.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
 
 
 def test_reduce_ragged_equals_uniform_when_lengths_are_equal(ctx, orc):

@@ -10,10 +10,15 @@ bases = ctx.gen_reads(n * L)
 NWV = 4096
 out = torch.zeros(8 + NWV * 8, dtype=torch.int64, device="cuda")
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"   # the same reads behind an offsets array (frame 160)
+d_off = ctx.to_device((np.arange(n + 1, dtype=np.uint64) * np.uint64(L))) if ragged else None
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
 for a, b in ev:
     a.record()
-    ctx.canonical_reduce_async(bases, n, L, k, out=out)
+    if ragged:
+        ctx.canonical_reduce_async(bases, n, 160, k, 0, 0, 0, d_off, out=out)
+    else:
+        ctx.canonical_reduce_async(bases, n, L, k, out=out)
     b.record()
 torch.cuda.synchronize()
 ms = [a.elapsed_time(b) for a, b in ev]
