@@ -236,6 +236,25 @@ int kmx_minimizer_words(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n, uint3
 int kmx_seqvec_minimizers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_reads, uint32_t read_len, uint32_t k,
                           uint32_t w, uint32_t hasher, uint32_t hasher_k, uint64_t *d_word, uint32_t *d_pos);
 
+/* ---------------------------------------------------------------- FASTA / FASTQ ingestion ----
+ * BUILD-DEFINED: the reference has no parser (its iterators take `&[u8]` reads, canonical_kmer_iterator.rs:72-83);
+ * this call produces, from a file image in device memory, the ragged-reads input of the calls above:
+ * d_bases = the reads back to back, d_offsets[r] = first base of read r, d_offsets[n_reads] = n_bases.
+ *   KMX_FASTX_FASTQ: strict 4-line records, line i is a read iff i % 4 == 1.
+ *   KMX_FASTX_FASTA: a line starting with '>' opens a record; every other line up to the next '>' line is its sequence.
+ *   KMX_FASTX_AUTO:  by the first byte ('@' / '>').
+ * Lines end at '\n'; every '\r' on a sequence line is dropped; the last line may lack its '\n'.  Bases are copied as
+ * they are (lower case, N, ...: the k-mer calls treat them as the reference's iterator does).  A text that does not
+ * start with '@' / '>' gives KMX_E_ARG.
+ * d_text 16-byte aligned.  d_bases: room for n_bases bytes (n_bytes always suffices); d_offsets: max_reads+1 words.
+ * With d_bases == d_offsets == NULL only the counts are computed; if n_reads > max_reads nothing is written, the counts
+ * are returned and the status is KMX_E_NOMEM.  Synchronises the context's stream (the counts come back to the host). */
+#define KMX_FASTX_AUTO 0
+#define KMX_FASTX_FASTQ 1
+#define KMX_FASTX_FASTA 2
+int kmx_fastx_parse(kmx_ctx *ctx, const uint8_t *d_text, uint64_t n_bytes, uint32_t format, uint8_t *d_bases,
+                    uint64_t *d_offsets, uint64_t max_reads, uint64_t *h_n_reads, uint64_t *h_n_bases);
+
 #ifdef __cplusplus
 }
 #endif

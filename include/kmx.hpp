@@ -344,6 +344,46 @@ inline kmx_summary canonical_reduce(Context& ctx, const kmx_reads& reads, uint32
     return out.download()[0];
 }
 
+// FASTA / FASTQ ingestion (build-defined, the reference has no parser): a file image -> the reads
+// back to back on the device + their offsets, i.e. the ragged `kmx_reads` the calls above take.
+class FastxReads {
+  public:
+    FastxReads(const std::string& text, Context& ctx = Context::instance(), uint32_t format = KMX_FASTX_AUTO) : ctx_(&ctx) {
+        DeviceBuffer<uint8_t> d(ctx, text.size() ? text.size() : 1);
+        if (!text.empty()) d.upload(reinterpret_cast<const uint8_t*>(text.data()), text.size());
+        uint64_t nr = 0, nb = 0;
+        ctx.check(kmx_fastx_parse(ctx.get(), d.data(), text.size(), format, nullptr, nullptr, 0, &nr, &nb), "fastx_parse (count)");
+        bases_.reset(new DeviceBuffer<uint8_t>(ctx, nb ? nb : 1));
+        offsets_.reset(new DeviceBuffer<uint64_t>(ctx, nr + 1));
+        ctx.check(kmx_fastx_parse(ctx.get(), d.data(), text.size(), format, bases_->data(), offsets_->data(), nr, &nr, &nb), "fastx_parse");
+        n_reads_ = nr;
+        n_bases_ = nb;
+    }
+    size_t len() const { return n_reads_; }
+    size_t n_bases() const { return n_bases_; }
+    // read_len_bound: 0 = unknown; an upper bound of the read lengths lets the bit-sliced kernel size its frame
+    kmx_reads reads(uint32_t read_len_bound = 0) const {
+        kmx_reads r{};
+        r.d_bases = bases_->data();
+        r.n_reads = n_reads_;
+        r.read_len = read_len_bound;
+        r.d_offsets = offsets_->data();
+        return r;
+    }
+    std::vector<uint64_t> offsets() const { return offsets_->download(); }
+    std::string read(size_t i) const {
+        auto off = offsets();
+        auto all = bases_->download();
+        return std::string(all.begin() + off.at(i), all.begin() + off.at(i + 1));
+    }
+
+  private:
+    Context* ctx_;
+    std::unique_ptr<DeviceBuffer<uint8_t>> bases_;
+    std::unique_ptr<DeviceBuffer<uint64_t>> offsets_;
+    size_t n_reads_ = 0, n_bases_ = 0;
+};
+
 // src/naive_impl/seq_vector.rs: the 2-bit packed sequence container, resident on the device.
 class SeqVector {
   public:

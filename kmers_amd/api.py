@@ -272,6 +272,18 @@ class Context:
                                                 _ptr(mw) if tot else None, _ptr(mp) if tot else None))
         return mw, mp
 
+    def fastx_parse(self, text: torch.Tensor, fmt: int = 0):
+        """kmx_fastx_parse: FASTA/FASTQ file image (uint8, on the device) -> (bases uint8[n_bases], offsets int64[n_reads+1]).
+        Two calls: the counts, then the emit into exactly sized buffers."""
+        n = int(text.numel())
+        nr, nb = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.lib.kmx_fastx_parse(self._h, _ptr(text) if n else None, n, fmt, None, None, 0, C.byref(nr), C.byref(nb)))
+        bases = self.empty(max(nb.value, 1), torch.uint8)
+        offsets = self.empty(nr.value + 1, torch.int64)
+        self._ck(self.lib.kmx_fastx_parse(self._h, _ptr(text) if n else None, n, fmt, _ptr(bases), _ptr(offsets), nr.value,
+                                          C.byref(nr), C.byref(nb)))
+        return bases[:nb.value], offsets
+
     def encoding_decode(self, words: torch.Tensor, enc_byte: int, words_per_kmer: int) -> torch.Tensor:
         n = words.numel() // words_per_kmer
         out = self.empty(n * 32 * words_per_kmer, torch.uint8)

@@ -31,6 +31,11 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+// kmx_fastx.hip
+size_t fastx_scratch_bytes(u64 n_bytes);
+hipError_t launch_fastx_count(const uint8_t* text, u64 n, bool fasta, void* scratch, unsigned long long* totals, hipStream_t st);
+hipError_t launch_fastx_emit(const uint8_t* text, u64 n, bool fasta, const void* scratch, const unsigned long long* totals,
+                             uint8_t* bases, u64* offsets, hipStream_t st);
 // kmx_seqvec.hip
 hipError_t launch_seqvec_push(u64* words, u64 first, const uint8_t* bytes, u64 n, unsigned long long* first_bad, int n_cu,
                               hipStream_t st);
@@ -642,6 +647,49 @@ int kmx_seqvec_minimizers(kmx_ctx* ctx, const uint64_t* d_words, uint64_t n_read
     if (n_reads == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
     KMX_HIP(ctx, kmx::launch_seqvec_minimizers(d_words, n_reads, read_len, k, w, hasher, hasher_k, d_word, d_pos, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_fastx_parse(kmx_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, uint32_t format, uint8_t* d_bases,
+                    uint64_t* d_offsets, uint64_t max_reads, uint64_t* h_n_reads, uint64_t* h_n_bases) {
+    if (!ctx || format > KMX_FASTX_FASTA || (n_bytes && !d_text) || (!d_bases != !d_offsets)) return KMX_E_ARG;
+    if (reinterpret_cast<uintptr_t>(d_text) & 15u) return KMX_E_ARG;
+    if (h_n_reads) *h_n_reads = 0;
+    if (h_n_bases) *h_n_bases = 0;
+    DeviceGuard g(ctx->device);
+    if (n_bytes == 0) {
+        if (d_offsets) {
+            KMX_HIP(ctx, hipMemsetAsync(d_offsets, 0, 8, ctx->stream));
+            KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return KMX_OK;
+    }
+    uint8_t first = 0;
+    KMX_HIP(ctx, hipMemcpyAsync(&first, d_text, 1, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (format == KMX_FASTX_AUTO) format = first == '@' ? KMX_FASTX_FASTQ : first == '>' ? KMX_FASTX_FASTA : 3u;
+    if (format == 3u || first != (format == KMX_FASTX_FASTQ ? '@' : '>')) {
+        std::snprintf(ctx->last_error, sizeof ctx->last_error, "kmx_fastx_parse: the text starts with byte 0x%02x, not with '@' (FASTQ) or '>' (FASTA)", first);
+        return KMX_E_ARG;
+    }
+    const bool fasta = format == KMX_FASTX_FASTA;
+    void* scratch = big_scratch(ctx, kmx::fastx_scratch_bytes(n_bytes));
+    if (!scratch) return KMX_E_NOMEM;
+    unsigned long long* d_totals = ctx->d_scratch + 2;
+    KMX_HIP(ctx, kmx::launch_fastx_count(d_text, n_bytes, fasta, scratch, d_totals, ctx->stream));
+    unsigned long long totals[2] = {0, 0};
+    KMX_HIP(ctx, hipMemcpyAsync(totals, d_totals, 16, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_n_reads) *h_n_reads = totals[0];
+    if (h_n_bases) *h_n_bases = totals[1];
+    if (!d_bases) return KMX_OK;
+    if (totals[0] > max_reads) {
+        std::snprintf(ctx->last_error, sizeof ctx->last_error, "kmx_fastx_parse: %llu reads, room for %llu", totals[0],
+                      (unsigned long long)max_reads);
+        return KMX_E_NOMEM;
+    }
+    KMX_HIP(ctx, kmx::launch_fastx_emit(d_text, n_bytes, fasta, scratch, d_totals, d_bases, d_offsets, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KMX_OK;
 }
 

@@ -911,3 +911,45 @@ int kmo_histogram(const uint8_t *reads, size_t n_reads, size_t read_len, const u
     }
     return KMO_OK;
 }
+
+/* BUILD-DEFINED (no reference counterpart): see kmx_oracle.h */
+int kmo_fastx_parse(const uint8_t *text, size_t n, unsigned format, uint8_t *bases, uint64_t *offsets,
+                    size_t *n_reads, size_t *n_bases) {
+    size_t nr = 0, nb = 0;
+    if (format > 2) return KMO_E_ARG;
+    if (n == 0) {
+        if (offsets) offsets[0] = 0;
+        *n_reads = 0;
+        *n_bases = 0;
+        return KMO_OK;
+    }
+    if (format == 0) format = text[0] == '@' ? 1 : text[0] == '>' ? 2 : 3;
+    if (format == 3 || (format == 1 && text[0] != '@') || (format == 2 && text[0] != '>')) return KMO_E_ARG;
+    size_t line = 0;       /* index of the current line */
+    int at_start = 1;      /* the next byte is the first of its line */
+    int seq_line = 0;      /* the current line is a sequence line */
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t b = text[i];
+        if (at_start) {    /* a line exists as soon as it has a byte (or is terminated: an empty line still has its \n) */
+            at_start = 0;
+            if (format == 1) {
+                seq_line = (line & 3) == 1;
+                if (seq_line) { if (offsets) offsets[nr] = nb; nr += 1; }
+            } else {
+                seq_line = b != '>';
+                if (!seq_line) { if (offsets) offsets[nr] = nb; nr += 1; }
+            }
+        }
+        if (b == '\n') {
+            line += 1;
+            at_start = 1;
+        } else if (seq_line && b != '\r') {
+            if (bases) bases[nb] = b;
+            nb += 1;
+        }
+    }
+    if (offsets) offsets[nr] = nb;
+    *n_reads = nr;
+    *n_bases = nb;
+    return KMO_OK;
+}

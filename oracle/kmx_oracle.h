@@ -207,6 +207,15 @@ int kmo_canonical_reduce2(const uint8_t *reads, size_t n_reads, size_t read_len,
 int kmo_canonical_windows2(const uint8_t *reads, size_t n_reads, size_t read_len, const uint64_t *offsets,
                            const uint64_t *win_offsets, uint8_t k,
                            uint64_t *out_fw2, uint64_t *out_rc2, uint64_t *out_canon2, uint8_t *out_flags);
+/* FASTA/FASTQ record splitting -- BUILD-DEFINED: the reference has no parser, so nothing pins
+ * this; the Python restatement (oracle.fastx_parse, written from the prose spec in DESIGN.md with bytes.split) and
+ * this byte-at-a-time state machine are checked against each other.
+ * format: 1 = FASTQ (strict 4-line records: line i is a read iff i % 4 == 1), 2 = FASTA ('>' lines start a record,
+ * all other lines up to the next '>' line are its sequence), 0 = by the first byte ('@' / '>').  Lines end at '\n';
+ * every '\r' on a sequence line is dropped; the last line may lack its '\n'.  bases/offsets may be NULL (count only).
+ * Returns KMO_E_ARG if the text does not start with '@' (FASTQ) / '>' (FASTA). */
+int kmo_fastx_parse(const uint8_t *text, size_t n, unsigned format, uint8_t *bases, uint64_t *offsets,
+                    size_t *n_reads, size_t *n_bases);
 /* synthetic reads: word w of the stream = splitmix64(seed + w); base j of the 32 in it = "ACGT"[(z>>2j)&3] */
 uint64_t kmo_splitmix64(uint64_t x);
 void kmo_gen_reads(uint64_t seed, uint64_t first_byte, uint8_t *out, size_t nbytes);

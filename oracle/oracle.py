@@ -176,6 +176,8 @@ def _bind(lib):
         "kmo_mmiter_new": (C.c_int, [C.POINTER(MMIter), C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
         "kmo_mmiter_next": (C.c_int, [C.POINTER(MMIter), u64p, C.POINTER(C.c_size_t)]),
         "kmo_seqvec_minimizers": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+        "kmo_fastx_parse": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_size_t)]),
         "kmo_splitmix64": (C.c_uint64, [C.c_uint64]),
         "kmo_gen_reads": (None, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]),
         "kmo_bucket_of": (C.c_uint64, [C.c_uint64, C.c_uint]),
@@ -383,6 +385,52 @@ def seqvec_minimizers(sv: "SeqVector", n_reads: int, read_len: int, k: int, w: i
     if st != 0:
         raise OracleError(st, "seqvec_minimizers")
     return words, pos
+
+
+def fastx_parse(text: bytes, fmt: int = 0):
+    """FASTA/FASTQ record splitting (BUILD-DEFINED, the reference has no parser): returns
+    (bases u8[n_bases], offsets u64[n_reads+1]), read r = bases[offsets[r]:offsets[r+1]].  fmt 1 = FASTQ (line i is a
+    read iff i % 4 == 1), 2 = FASTA ('>' lines start a record; the other lines up to the next '>' are its sequence),
+    0 = by the first byte.  Lines end at '\\n', every '\\r' on a sequence line is dropped, the last line may lack its '\\n'.
+    Written with bytes.split -- a different algorithm from kmo_fastx_parse, which it is tested against."""
+    text = bytes(text)
+    if not text:
+        return np.zeros(0, np.uint8), np.zeros(1, np.uint64)
+    if fmt == 0:
+        fmt = 1 if text[:1] == b"@" else 2 if text[:1] == b">" else 3
+    if fmt not in (1, 2) or text[:1] != (b"@" if fmt == 1 else b">"):
+        raise ValueError("not a FASTA/FASTQ text")
+    lines = text.split(b"\n")
+    if text.endswith(b"\n"):
+        lines.pop()          # what follows the last newline is not a line
+    reads = []
+    if fmt == 1:
+        reads = [ln.replace(b"\r", b"") for ln in lines[1::4]]
+    else:
+        for ln in lines:
+            if ln[:1] == b">":
+                reads.append([])
+            else:
+                reads[-1].append(ln.replace(b"\r", b""))
+        reads = [b"".join(r) for r in reads]
+    offsets = np.zeros(len(reads) + 1, np.uint64)
+    if reads:
+        offsets[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+    return np.frombuffer(b"".join(reads), dtype=np.uint8).copy(), offsets
+
+
+def fastx_parse_c(text: bytes, fmt: int = 0):
+    """kmo_fastx_parse (the C state machine): same result as fastx_parse"""
+    text = bytes(text)
+    buf = np.frombuffer(text, dtype=np.uint8)
+    nr, nb = C.c_size_t(0), C.c_size_t(0)
+    p = buf.ctypes.data if len(buf) else None
+    if lib().kmo_fastx_parse(p, len(buf), fmt, None, None, C.byref(nr), C.byref(nb)) != 0:
+        raise ValueError("not a FASTA/FASTQ text")
+    bases = np.zeros(max(nb.value, 1), np.uint8)
+    offsets = np.zeros(nr.value + 1, np.uint64)
+    lib().kmo_fastx_parse(p, len(buf), fmt, bases.ctypes.data, offsets.ctypes.data, C.byref(nr), C.byref(nb))
+    return bases[:nb.value], offsets
 
 
 def gen_reads(seed: int, first_byte: int, nbytes: int) -> np.ndarray:

@@ -227,6 +227,25 @@ int main() {
         (void)naive;
         (void)canon;
     }
+    // ---- FASTA / FASTQ ingestion (build-defined): file image -> ragged reads -> the streaming loop
+    {
+        FastxReads fq(std::string("@r1\nACGTTGCA\n+\nIIIIIIII\n@r2 x\nGGNACGT\n+r2\n@@@@@@@\n"));
+        CHECK(fq.len() == 2 && fq.n_bases() == 15);
+        CHECK(fq.read(0) == "ACGTTGCA" && fq.read(1) == "GGNACGT");
+        CHECK((fq.offsets() == std::vector<uint64_t>{0, 8, 15}));
+        kmx_summary s = canonical_reduce(Context::instance(), fq.reads(), 3);
+        size_t n = 0;
+        uint64_t sum = 0;
+        for (const std::string r : {"ACGTTGCA", "GGNACGT"})
+            for (auto it = CanonicalKmerIterator::from_u8_slice(reinterpret_cast<const uint8_t*>(r.data()), r.size(), 3); !it.exhausted(); it.inc()) {
+                n += 1;
+                sum += it.get().km.get_canonical_word();
+            }
+        CHECK(s.n_valid == n && s.sum_canon == sum && n == 6 + 2);
+        FastxReads fa(std::string(">s1 d\nACG\nTTA\n\n>s2\n>s3\r\nNN\r\nA"));
+        CHECK(fa.len() == 3 && fa.read(0) == "ACGTTA" && fa.read(1).empty() && fa.read(2) == "NNA");
+        CHECK(panics([] { FastxReads bad(std::string("ACGT\n")); }));
+    }
     std::printf(fails ? "%d check(s) FAILED\n" : "all C++ host-layer checks passed\n", fails);
     return fails ? 1 : 0;
 }

@@ -1,0 +1,89 @@
+"""GPU parity of kmx_fastx_parse (build-defined semantics, see tests/test_oracle_fastx.py) against
+the CPU oracle, and of the whole chain file image -> reads -> canonical k-mer summary."""
+import numpy as np
+import pytest
+
+from fastx_cases import EDGE_TEXTS, fasta_text, fastq_text
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from kmers_amd.api import Context
+
+    c = Context()
+    yield c
+    c.close()
+
+
+def _check(ctx, orc, text, fmt=0):
+    from kmers_amd.api import u64_numpy
+
+    eb, eo = orc.fastx_parse(text, fmt)
+    bases, offsets = ctx.fastx_parse(ctx.to_device(text) if len(text) else ctx.empty(0, __import__("torch").uint8), fmt)
+    assert np.array_equal(u64_numpy(offsets), eo)
+    assert np.array_equal(bases.cpu().numpy(), eb)
+    return bases, offsets, eb, eo
+
+
+@pytest.mark.parametrize("i", range(len(EDGE_TEXTS)))
+def test_edge_texts(ctx, orc, i):
+    _check(ctx, orc, EDGE_TEXTS[i])
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+@pytest.mark.parametrize("trail", [False, True])
+def test_random_fastq(ctx, orc, crlf, trail):
+    rng = np.random.default_rng(21 + 2 * crlf + trail)
+    for n, lo, hi in ((1, 0, 50), (9, 0, 10), (3000, 0, 200), (2000, 140, 160), (40, 3000, 9000)):
+        _check(ctx, orc, fastq_text(rng, n, lo, hi, crlf=crlf, trail=trail))
+        _check(ctx, orc, fastq_text(rng, n, lo, hi, crlf=crlf, trail=trail), 1)
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+@pytest.mark.parametrize("trail", [False, True])
+def test_random_fasta(ctx, orc, crlf, trail):
+    rng = np.random.default_rng(31 + 2 * crlf + trail)
+    for n, lo, hi, width in ((1, 0, 50, 60), (9, 0, 10, 3), (3000, 0, 400, 60), (500, 0, 400, 1), (30, 20000, 90000, 80), (3, 300000, 400000, 1 << 30), (120, 30000, 60000, 70)):
+        _check(ctx, orc, fasta_text(rng, n, lo, hi, width=width, crlf=crlf, trail=trail))
+        _check(ctx, orc, fasta_text(rng, n, lo, hi, width=width, crlf=crlf, trail=trail), 2)
+
+
+def test_chunk_boundaries(ctx, orc):
+    """line starts, '>' and the record structure right at the 16-byte lane, 4 KiB row and 128 KiB chunk boundaries"""
+    rng = np.random.default_rng(5)
+    for boundary in (16, 4096, 131072, 262144):
+        for delta in range(-3, 4):
+            head = b">" + b"h" * (boundary + delta - 2) + b"\n"          # the newline lands at boundary + delta - 1
+            _check(ctx, orc, head + b"ACGT\n>b\nGG\n")
+            seq = b">a\n" + b"A" * (boundary + delta - 4) + b"\n"         # a sequence line ends there, a header follows
+            _check(ctx, orc, seq + b">b\nCC\n" + seq)
+            fq = b"@" + b"h" * (boundary + delta - 2) + b"\n" + b"ACGT\n+\nIIII\n"
+            _check(ctx, orc, fq + fastq_text(rng, 5))
+
+
+def test_wrong_format(ctx):
+    from kmers_amd._lib import KmxError
+
+    with pytest.raises(KmxError):
+        ctx.fastx_parse(ctx.to_device(b"ACGT\nACGT\n"))
+    with pytest.raises(KmxError):
+        ctx.fastx_parse(ctx.to_device(b">x\nACGT\n"), 1)
+
+
+@pytest.mark.parametrize("k", [21, 31])
+def test_file_image_to_summary(ctx, orc, k):
+    """the chain a caller runs on real data: FASTQ image -> kmx_fastx_parse -> kmx_canonical_reduce (ragged reads)"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(k)
+    text = fastq_text(rng, 20000, 30, 160)
+    bases, offsets, eb, eo = _check(ctx, orc, text)
+    n = len(eo) - 1
+    g = ctx.canonical_reduce(bases, n, 160, k, _lib.HASH_LEX, k, 0, offsets=offsets)
+    o = orc.canonical_reduce(eb, n, 0, k, hasher_k=k, offsets=eo)
+    assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
