@@ -1,3 +1,4 @@
+"""dev check (not collected by pytest): ragged-read summaries of the GPU path against the oracle, case by case"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
