@@ -118,7 +118,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 chunks = 4u * L + (RAGGED ? 1u : 0u);          // 16-byte chunks a tile may span (ragged: +1 for its unaligned start)
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
     const u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
-    u32* P = lds + wib * (ldsw + 4u * PLANES + 64u * NV);
+    u32* P = lds + wib * (ldsw + 4u * PLANES + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u));
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
     const u64 n_full = n_reads >> 6;
@@ -156,10 +156,15 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
     for (int g = 0; g < NW; ++g) TOT[half * PLANES + 32u * g + p] = 0;
     u32* VAL = TOT + 2u * PLANES;       // ragged: [2][32*NV] validity planes of the current tile
-    u32 qt[NE > 0 ? NE : 1];            // ragged: running popcount of this lane's plane of the read-end words
+    // ragged, per lane, kept in LDS (registers are what caps this variant's occupancy): QT[e][lane] = running popcount of the
+    // lane's plane of the read-end words, NVR[lane] = windows of the lane's reads in bit-sliced tiles
+    u32* QT = VAL + 64u * NV;
+    u64* NVR = reinterpret_cast<u64*>(QT + 64u * NE);
+    if constexpr (RAGGED) {
 #pragma unroll
-    for (int e = 0; e < (NE > 0 ? NE : 1); ++e) qt[e] = 0;
-    u64 nvr = 0;                        // ragged: windows of this lane's reads in bit-sliced tiles
+        for (int e = 0; e < NE; ++e) QT[e * 64 + lane] = 0;
+        NVR[lane] = 0;
+    }
     const u64 total_bytes = RAGGED ? offsets[n_reads] : 0;
     // ragged: per-tile geometry of the current and of the next tile (rel/len per lane, the rest wave-uniform)
     struct TileMeta { u32 rel = 0, len = 0, n_ch = 0; u64 base = 0; bool fits = true; };
@@ -186,8 +191,33 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     u32 n_bs_tiles = 0;
     // word-domain accumulators of the fallback path (tiles with invalid bytes, the final partial tile)
-    struct { u64 n = 0, s0 = 0, s1 = 0, x0 = 0, x1 = 0, fw = 0; } fb;
-    auto fallback_read = [&](u64 read) {
+#ifndef KMX_BS_FB_FLUSH
+#define KMX_BS_FB_FLUSH 1   // 1: the fallback path adds its sums to the output per tile (12 registers less across the main loop: +1.7 % at k=31)
+#endif
+    struct FbAcc { u64 n = 0, s0 = 0, s1 = 0, x0 = 0, x1 = 0, fw = 0; };
+    auto emit_sums = [&](u64 n, u64 r0, u64 r1, u64 h0, u64 h1, u64 f) {   // wave-uniform values, one set of atomics
+        if (lane == 0) {
+            if constexpr (K <= 32) {
+                kmx_summary* o = static_cast<kmx_summary*>(out);
+                atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
+                atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)r0);
+                if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)h0);
+                if (want_sumfw) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
+            } else {
+                kmx_summary2* o = static_cast<kmx_summary2*>(out);
+                atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
+                atomicAdd((unsigned long long*)&o->sum_lo, (unsigned long long)r0);
+                atomicAdd((unsigned long long*)&o->sum_hi, (unsigned long long)r1);
+                if (want_hash) {
+                    atomicXor((unsigned long long*)&o->xor_lo, (unsigned long long)h0);
+                    atomicXor((unsigned long long*)&o->xor_hi, (unsigned long long)h1);
+                }
+            }
+        }
+    };
+    constexpr bool FB_FLUSH = KMX_BS_FB_FLUSH && K <= 32;   // (two-word k-mers: the per-tile sums then live in scratch, 0.46 -> 0.37 of the roofline at k=63)
+    FbAcc fb_all;                                             // !FB_FLUSH: summed over the whole run of the wave
+    auto fallback_read_acc = [&](u64 read, FbAcc& fb) {
         const uint8_t* s = bases + read * (u64)L;
         if constexpr (RAGGED) {
             const u64 o0 = offsets[read];
@@ -225,6 +255,16 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 fb.x0 ^= h.lo;
                 fb.x1 ^= h.hi;
             });
+        }
+    };
+    // one tile (or the final partial one) on the per-lane path; `mine`: this lane has a read
+    auto fallback_read = [&](u64 read, bool mine) {
+        if constexpr (FB_FLUSH) {
+            FbAcc fb;
+            if (mine) fallback_read_acc(read, fb);
+            emit_sums(wave_sum(fb.n), wave_sum(fb.s0), wave_sum(fb.s1), wave_xor(fb.x0), wave_xor(fb.x1), wave_sum(fb.fw));
+        } else {
+            if (mine) fallback_read_acc(read, fb_all);
         }
     };
 
@@ -432,7 +472,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
             for (int j = 0; j < NV; ++j)
                 F[NW + NE + j] = wr >= 32u * (j + 1) ? ~0u : (wr > 32u * j ? (1u << (wr - 32u * j)) - 1u : 0u);
-            nvr += wr;
+            atomicAdd(reinterpret_cast<unsigned long long*>(&NVR[lane]), (unsigned long long)wr);   // ds_add_u64, no return
         }
         // ---- C. transpose each 32 reads x 32 bits block across the 32 lanes of the half-wave, entirely in
         //      the VALU (no LDS round trips): butterfly stage d exchanges with lane^d and keeps/merges the
@@ -504,7 +544,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
             for (int g = 0; g < NW; ++g) atomicAdd(&TOT[half * PLANES + 32u * g + p], Y[g]);
 #pragma unroll
-            for (int e = 0; e < NE; ++e) qt[e] += Y[NW + e];                                     // ragged: read-end planes, totals only
+            for (int e = 0; e < NE; ++e) atomicAdd(&QT[e * 64 + lane], Y[NW + e]);               // ragged: read-end planes, totals only
 #undef KMX_HRUN_BEGIN
 #undef KMX_HRUN_END
         }
@@ -790,10 +830,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         lds_fence();
         KMX_T(1)
         if (bad_tile) {
-#ifdef KMX_DBG_FB
-            if constexpr (RAGGED) { if (lane == 0) fb.n += cur_m.fits ? (1ull << 40) : (1ull << 52); }
-#endif
-            fallback_read(tile * 64u + lane);
+            fallback_read(tile * 64u + lane, true);
         } else if (!(KMX_BS_ABLATE & 32)) {
             phase_BC();
             KMX_T(3)
@@ -824,7 +861,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 
     // ---- final partial tile: per-lane rolling
     const u32 rem = (u32)(n_reads & 63u);
-    if (rem != 0u && wave_id == 0 && lane < rem) fallback_read(n_full * 64u + lane);
+    if (rem != 0u && wave_id == 0) fallback_read(n_full * 64u + lane, lane < rem);
 
     // ---- combine the bit-sliced counters into word-domain results (once per wave; wave-uniform branch)
     // Number of set bits of canonical bit (t,b) over all k-mers of the wave:
@@ -836,7 +873,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u64 bs_n = 0, bs_s0 = 0, bs_s1 = 0, bs_x0 = 0, bs_x1 = 0, bs_fw = 0;
     if (n_bs_tiles != 0u) {
         // k-mers handled bit-sliced by this wave
-        const u64 nk = RAGGED ? wave_sum(nvr) : (u64)n_bs_tiles * 64u * (u64)W;
+        const u64 nk = RAGGED ? wave_sum(NVR[lane]) : (u64)n_bs_tiles * 64u * (u64)W;
         bs_n = nk;
         u64 fwall = 0;
         u32 tot[NW];
@@ -867,7 +904,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         u32* QE = VAL;   // (the validity planes are dead by now; the plane area right after the totals holds the counter sums)
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const u32 both = qt[e] + __shfl_xor(qt[e], 32, WAVE);
+            const u32 qte = QT[e * 64 + lane];
+            const u32 both = qte + __shfl_xor(qte, 32, WAVE);
             if (half == 0) QE[32u * e + p] = both;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -902,28 +940,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     }
 
     // ---- one set of atomics per wave
-    const u64 n = wave_sum(fb.n) + bs_n;
-    const u64 r0 = wave_sum(fb.s0) + bs_s0, r1 = wave_sum(fb.s1) + bs_s1;
-    const u64 h0 = wave_xor(fb.x0) ^ bs_x0, h1 = wave_xor(fb.x1) ^ bs_x1;
-    const u64 f = wave_sum(fb.fw) + bs_fw;
-    if (lane == 0) {
-        if constexpr (K <= 32) {
-            kmx_summary* o = static_cast<kmx_summary*>(out);
-            atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
-            atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)r0);
-            if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)h0);
-            if (want_sumfw) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
-        } else {
-            kmx_summary2* o = static_cast<kmx_summary2*>(out);
-            atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
-            atomicAdd((unsigned long long*)&o->sum_lo, (unsigned long long)r0);
-            atomicAdd((unsigned long long*)&o->sum_hi, (unsigned long long)r1);
-            if (want_hash) {
-                atomicXor((unsigned long long*)&o->xor_lo, (unsigned long long)h0);
-                atomicXor((unsigned long long*)&o->xor_hi, (unsigned long long)h1);
-            }
-        }
-    }
+    if constexpr (FB_FLUSH)
+        emit_sums(bs_n, bs_s0, bs_s1, bs_x0, bs_x1, bs_fw);
+    else
+        emit_sums(wave_sum(fb_all.n) + bs_n, wave_sum(fb_all.s0) + bs_s0, wave_sum(fb_all.s1) + bs_s1, wave_xor(fb_all.x0) ^ bs_x0,
+                  wave_xor(fb_all.x1) ^ bs_x1, wave_sum(fb_all.fw) + bs_fw);
 }
 
 // ------------------------------------------------------------------ launcher
@@ -935,7 +956,8 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     const u32 chunks = 4u * L + (RAGGED ? 1u : 0u);
     const u32 ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
     constexpr u32 NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;
-    size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u) + 64u * NV) * 4u * 4u;
+    constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
+    size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u) + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u)) * 4u * 4u;
     if (const char* e = getenv("KMX_BS_EXTRA_LDS")) lds_bytes += (size_t)atol(e);   // dev knob: caps blocks per CU
     static int bpc = 0;
     static size_t bpc_lds = 0;
