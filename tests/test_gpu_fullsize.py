@@ -122,3 +122,56 @@ def test_full_size_histogram_totals_and_linearity(ctx, big, b):
     parts = ctx.histogram(big[: h * L], h, L, k, _lib.HASH_LEX, k, b)
     parts = ctx.histogram(big[h * L: n * L], n - h, L, k, _lib.HASH_LEX, k, b, counts=parts)
     assert torch.equal(parts, whole)
+
+
+@pytest.mark.parametrize("k", [31, 21, 27])
+def test_full_size_ragged_offsets_past_4gib(ctx, big, k):
+    """the same 15 GB behind an offsets array (offsets run past 2^31 and 2^32: the tile bounds are 64-bit end to end)
+    give the uniform-layout summary -- bit-sliced ragged kernel (k = 31, 21) and word-domain ragged kernel (k = 27)"""
+    import torch
+
+    from kmers_amd import _lib
+
+    uni = ctx.canonical_reduce(big, N_FULL, L, k, _lib.HASH_LEX, k)
+    offsets = torch.arange(N_FULL + 1, dtype=torch.int64, device=big.device) * L
+    for hint in (160, 0):
+        rag = ctx.canonical_reduce(big, N_FULL, hint, k, _lib.HASH_LEX, k, 0, offsets=offsets)
+        assert (rag.n_valid, rag.sum_canon, rag.xor_hash) == (uni.n_valid, uni.sum_canon, uni.xor_hash)
+    # reads of two lengths: dropping the last 30 bases of every other read = the summary of the two strided halves
+    lens = torch.full((N_FULL,), L, dtype=torch.int64, device=big.device)
+    lens[1::2] = L - 30
+    # (a ragged batch is contiguous: compare on a compacted copy of a prefix, built pair by pair -- 150 + 120 bases)
+    n = min(N_FULL, 20_000_000) & ~1
+    view = big[:n * L].view(n, L)
+    packed = torch.cat([view[0::2], view[1::2, :L - 30]], dim=1).contiguous().view(-1)
+    off = torch.zeros(n + 1, dtype=torch.int64, device=big.device)
+    off[1:] = torch.cumsum(lens[:n], 0)
+    rag = ctx.canonical_reduce(packed, n, 160, k, _lib.HASH_LEX, k, 0, offsets=off)
+    a = ctx.canonical_reduce(view[0::2].contiguous().view(-1), (n + 1) // 2, L, k, _lib.HASH_LEX, k)
+    b = ctx.canonical_reduce(view[1::2, :L - 30].contiguous().view(-1), n // 2, L - 30, k, _lib.HASH_LEX, k)
+    assert rag.n_valid == a.n_valid + b.n_valid
+    assert rag.sum_canon == (a.sum_canon + b.sum_canon) & M64
+    assert rag.xor_hash == a.xor_hash ^ b.xor_hash
+
+
+def test_full_size_fastq_image_roundtrip(ctx):
+    """a multi-GB FASTQ image built on the device from the synthetic reads: kmx_fastx_parse must give the reads back
+    (size-independent property: format -> parse is the identity on bases and offsets)"""
+    import torch
+
+    n = min(N_FULL, 16_000_000)
+    bases = ctx.gen_reads(n * L).view(n, L)
+    hdr = torch.tensor(list(b"@r\n"), dtype=torch.uint8, device=bases.device)
+    mid = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device=bases.device)
+    rec = torch.empty((n, 3 + L + 3 + L + 1), dtype=torch.uint8, device=bases.device)   # "@r\n" seq "\n+\n" qual "\n"
+    rec[:, 0:3] = hdr
+    rec[:, 3:3 + L] = bases
+    rec[:, 3 + L:6 + L] = mid
+    rec[:, 6 + L:6 + 2 * L] = ord("@")       # a quality string made of header characters
+    rec[:, 6 + 2 * L] = ord("\n")
+    text = rec.view(-1)
+    assert text.numel() > 2**32
+    out, offsets = ctx.fastx_parse(text)
+    assert offsets.numel() == n + 1
+    assert torch.equal(offsets, torch.arange(n + 1, dtype=torch.int64, device=bases.device) * L)
+    assert torch.equal(out, bases.view(-1))
