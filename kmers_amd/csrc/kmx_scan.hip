@@ -328,18 +328,54 @@ struct WindowsParams {
 // Fast path: the 16 windows of a block are staged through LDS (lane-major, pitch 17) and written back transposed,
 // so every store instruction covers 128-byte contiguous runs (16 windows of one read) instead of 64 scattered
 // 8-byte words at a stride of W*8 bytes.
-struct SinkWindows {
+template <bool ALIGNED>
+struct SinkWindowsT {
     static constexpr u32 PITCH = 17;                        // u64 per lane row (16 + 1 pad: conflict-free both ways)
-    static constexpr u32 kLdsDwordsPerWave = 3u * 64u * PITCH * 2u + 64u * 16u / 4u;   // 3 u64 planes + flag bytes
+    static constexpr u32 PLANE = 64u * PITCH * 2u;          // dwords of one staged u64 array of a wave
+    // staging sized by what the caller asked for (with all three u64 planes a block holds 108 KB = one block per CU and one
+    // wave per SIMD; canonical words alone: 9 KB per wave, three blocks per CU)
+#ifndef KMX_WIN_WAVES
+#define KMX_WIN_WAVES 3
+#endif
+    // store latency is all this sink waits for: occupancy over registers (the line-aligned variant spills at 168 registers
+    // and its 17 KB ring per wave caps a CU at two blocks anyway)
+    static constexpr int kWaves = ALIGNED ? 2 : KMX_WIN_WAVES;
+    static constexpr u32 kLdsDwordsPerWave = 0;
+    // One u64 array and no flags (the usual call: the canonical words): write-back in units of whole, 128-byte ALIGNED
+    // lines of the output.  The lines of read r are shifted by a = r*W mod 16 slots against its windows, so the windows
+    // of two passes sit in a 32-slot ring per read and pass j writes windows [16j - a, 16j + 16 - a).  (Writing windows
+    // [16j, 16j+16) as they come leaves every line half-written until the next pass, and the chip's write rate drops to
+    // 2.9 TB/s at W = 120 (64-byte aligned runs) and 2.1 TB/s at W = 130 (16-byte aligned), against 4.6 TB/s at W = 128;
+    // line by line: 3.5 and 3.3 TB/s.)
+    static constexpr u32 RPITCH = 33;
+    static __host__ __device__ bool line_aligned(const WindowsParams& p) {
+        return ALIGNED;
+    }
+    // the caller's side of ALIGNED: one u64 array, no flags (W a multiple of 16: the plain write-back is aligned already)
+    static bool wants_aligned(const WindowsParams& p, u32 W) {
+        return ((p.fw ? 1u : 0u) + (p.rc ? 1u : 0u) + (p.canon ? 1u : 0u)) == 1u && !p.flags && (W & 15u) != 0u;
+    }
+    static __host__ __device__ u32 wave_dwords(const WindowsParams& p) {
+        if (line_aligned(p)) return 64u * RPITCH * 2u;
+        return ((p.fw ? 1u : 0u) + (p.rc ? 1u : 0u) + (p.canon ? 1u : 0u)) * PLANE + (p.flags ? 64u * 16u / 4u : 0u);
+    }
+    static u32 block_lds_dwords(const WindowsParams& p) { return 4u * wave_dwords(p); }
     WindowsParams p;
-    u64* T;        // [3][64][PITCH] staging (fw, rc, canon)
-    uint8_t* TF;   // [64][16] flags
+    u64 *Tfw, *Trc, *Tcn;   // [64][PITCH] staging of the arrays that are wanted
+    uint8_t* TF;            // [64][16] flags
+    u64* out1;              // line-aligned mode: the one output array (nullptr: staged mode)
     u64 base;      // slot of window 0 of the current read (slow path)
     u32 W, next, lane;
     static constexpr bool kRagged = false;   // the transposed write-back assumes one window count per read
-    static u32 block_lds_dwords(const WindowsParams&) { return 0; }
-    __device__ SinkWindows(const WindowsParams& p_, u32, u32 W_, u32* lds, u32 lane_, u32*, u32)
-        : p(p_), T(reinterpret_cast<u64*>(lds)), TF(reinterpret_cast<uint8_t*>(lds + 3u * 64u * PITCH * 2u)), base(0), W(W_), next(0), lane(lane_) {}
+    __device__ SinkWindowsT(const WindowsParams& p_, u32, u32 W_, u32*, u32 lane_, u32* block_lds, u32 tid)
+        : p(p_), base(0), W(W_), next(0), lane(lane_) {
+        u32* mine = block_lds + (tid >> 6) * wave_dwords(p_);
+        Tfw = reinterpret_cast<u64*>(mine);
+        Trc = Tfw + (p_.fw ? PLANE / 2u : 0u);
+        Tcn = Trc + (p_.rc ? PLANE / 2u : 0u);
+        TF = reinterpret_cast<uint8_t*>(Tcn + (p_.canon ? PLANE / 2u : 0u));
+        out1 = line_aligned(p_) ? (p_.fw ? p_.fw : p_.rc ? p_.rc : p_.canon) : nullptr;
+    }
     __device__ __forceinline__ void store(u64 slot, u64 fw, u64 rc) {
         const bool lt = fw < rc;
         if (p.fw) p.fw[slot] = fw;
@@ -357,11 +393,15 @@ struct SinkWindows {
         }
     }
     __device__ __forceinline__ void fast(u32 o, u64 fw, u64 rc) {
-        const u32 s = o & 15u, at = lane * PITCH + s;
         const bool lt = fw < rc;
-        if (p.fw) T[at] = fw;
-        if (p.rc) T[64u * PITCH + at] = rc;
-        if (p.canon) T[2u * 64u * PITCH + at] = lt ? fw : rc;
+        if (out1) {
+            Tfw[lane * RPITCH + (o & 31u)] = p.fw ? fw : p.rc ? rc : (lt ? fw : rc);
+            return;
+        }
+        const u32 s = o & 15u, at = lane * PITCH + s;
+        if (p.fw) Tfw[at] = fw;
+        if (p.rc) Trc[at] = rc;
+        if (p.canon) Tcn[at] = lt ? fw : rc;
         if (p.flags) TF[lane * 16u + s] = (uint8_t)(KMX_WIN_VALID | (lt ? KMX_WIN_FW_CANONICAL : 0u));
     }
     // all 64 lanes have staged windows [o0, o0+cnt) of reads [read0, read0+64): write them out coalesced
@@ -369,15 +409,34 @@ struct SinkWindows {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (out1) {
+            const bool last = o0 + cnt == W;      // the last pass also writes what is left of each read (< 32 windows)
+            for (u32 sub = 0; sub < (last ? 2u : 1u); ++sub) {
+#pragma unroll 4
+                for (u32 it = 0; it < 16u; ++it) {
+                    const u32 idx = it * 64u + lane, r = idx >> 4, s = idx & 15u;
+                    const u64 read = read0 + r;
+                    const u32 a = ((u32)(read & 15u) * (W & 15u)) & 15u;   // read*W mod 16
+                    const u32 lo = o0 > a ? o0 - a : 0u;
+                    const u32 hi = last ? W : o0 + 16u - a;
+                    const u32 o = lo + 16u * sub + s;
+                    if (o < hi) out1[read * W + o] = Tfw[r * RPITCH + (o & 31u)];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            return;
+        }
 #pragma unroll 4
         for (u32 it = 0; it < 16u; ++it) {
             const u32 idx = it * 64u + lane, r = idx >> 4, sw = idx & 15u;
             if (sw < cnt) {
                 const u64 slot = (read0 + r) * W + o0 + sw;
                 const u32 at = r * PITCH + sw;
-                if (p.fw) p.fw[slot] = T[at];
-                if (p.rc) p.rc[slot] = T[64u * PITCH + at];
-                if (p.canon) p.canon[slot] = T[2u * 64u * PITCH + at];
+                if (p.fw) p.fw[slot] = Tfw[at];
+                if (p.rc) p.rc[slot] = Trc[at];
+                if (p.canon) p.canon[slot] = Tcn[at];
                 if (p.flags) p.flags[slot] = TF[r * 16u + sw];
             }
         }
@@ -413,8 +472,12 @@ struct SinkWindows {
 #ifndef KMX_SCAN_WAVES
 #define KMX_SCAN_WAVES 1   // waves per SIMD the register allocation is sized for (hipcc otherwise spends up to 256 VGPRs on hoisting)
 #endif
+// a sink may ask for a register budget of its own (static constexpr int kWaves)
+template <typename S, typename = void> struct SinkWaves { static constexpr int value = KMX_SCAN_WAVES; };
+template <typename S> struct SinkWaves<S, decltype((void)S::kWaves)> { static constexpr int value = S::kWaves; };
+template <typename S, int NW> constexpr int sink_waves() { return NW <= 10 ? SinkWaves<S>::value : KMX_SCAN_WAVES; }   // (the 16-word frame would spill 1 KB)
 template <int NW, int V, int DW, typename Sink, typename Params, bool RAGGED = false>
-__global__ void __launch_bounds__(256, KMX_SCAN_WAVES)
+__global__ void __launch_bounds__(256, (sink_waves<Sink, NW>()))
 scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, Params params,
                     unsigned long long* __restrict__ queue, const u64* __restrict__ offsets) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -789,7 +852,8 @@ hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 
     *handled = scan_domain(bases, n_reads, L, k);
     if (!*handled) return hipSuccess;
     const WindowsParams p{fw, rc, canon, flags};
-    return dispatch<SinkWindows>(bases, n_reads, L, k, p, queue, n_cu, stream);
+    if (SinkWindowsT<true>::wants_aligned(p, L - k + 1u)) return dispatch<SinkWindowsT<true>>(bases, n_reads, L, k, p, queue, n_cu, stream);
+    return dispatch<SinkWindowsT<false>>(bases, n_reads, L, k, p, queue, n_cu, stream);
 }
 
 }  // namespace kmx

@@ -289,6 +289,22 @@ def test_windows_uniform(ctx, orc, k, p_bad):
     assert (only["canon"].cpu().numpy().view(np.uint64) == canon).all()
 
 
+@pytest.mark.parametrize("L,k", [(150, 31), (150, 21), (158, 31), (100, 31), (160, 27), (47, 31), (64, 17), (151, 2), (250, 31), (33, 18), (31, 31)])
+def test_windows_single_array_line_aligned_writeback(ctx, orc, L, k):
+    """one u64 array requested: the write-back goes out in whole 128-byte lines of the output, shifted per read by
+    read*W mod 16 slots (W = L-k+1 of every residue here), with the head and tail of each read written separately"""
+    rng = np.random.default_rng(L * 100 + k)
+    n = 64 * 5 + 17
+    host = _dirty(rng, n * L, 0.002)
+    bases = ctx.to_device(host)
+    fw, rc, canon, flags = orc.canonical_windows(host, n, L, k)
+    for name, exp in (("canon", canon), ("fw", fw), ("rc", rc)):
+        got = ctx.canonical_windows(bases, n, L, k, want=(name,))[name].cpu().numpy().view(np.uint64)
+        assert (got == exp).all(), (name, int((got != exp).sum()))
+    two = ctx.canonical_windows(bases, n, L, k, want=("canon", "flags"))
+    assert (two["canon"].cpu().numpy().view(np.uint64) == canon).all() and (two["flags"].cpu().numpy() == flags).all()
+
+
 def test_reference_iterator_kats_on_gpu(ctx, orc, kats):
     """canonical_kmer_iterator.rs:123-206 through the HIP path: the iterator state after init/inc/inc_by
     is the (fw, rc) of the n-th valid slot."""
