@@ -22,6 +22,9 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
                                void* (*get_scratch)(void*, size_t), void* user, size_t scratch_budget, const u64* offsets);
 hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon,
                                   uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+hipError_t launch_windows_ragged(const uint8_t* bases, const u64* offsets, const u64* win_offsets, u64 n_reads, u32 L, u32 k,
+                                 u64* fw, u64* rc, u64* canon, uint8_t* flags, unsigned long long* queue, int n_cu,
+                                 hipStream_t stream, bool* handled);
 // kmx_bitslice.hip
 hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
@@ -357,6 +360,13 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
         KMX_HIP(ctx, kmx::launch_windows_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, d_fw, d_rc, d_canon,
                                                  d_flags, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+        if (handled) return KMX_OK;
+    }
+    if (reads->d_offsets && d_win_offsets) {     // ragged reads: the tiled word-domain kernel (read_len = optional length bound)
+        bool handled = false;
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+        KMX_HIP(ctx, kmx::launch_windows_ragged(reads->d_bases, reads->d_offsets, d_win_offsets, reads->n_reads, reads->read_len, k,
+                                                d_fw, d_rc, d_canon, d_flags, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
     }
     KMX_HIP(ctx, kmx::launch_windows_generic(reads, d_win_offsets, k, d_fw, d_rc, d_canon, d_flags, ctx->n_cu, ctx->stream));

@@ -323,6 +323,7 @@ hist_part_reduce_kernel(const uint16_t* __restrict__ stream, const u32* __restri
 struct WindowsParams {
     u64 *fw, *rc, *canon;
     uint8_t* flags;
+    const u64* win_offsets;   // ragged reads: slot of window 0 of read r (n_reads+1 entries); nullptr: r*W
 };
 // dense per-window outputs, slot(read, pos) = read*W + pos.  Write-bound by construction (8 B per array per k-mer).
 // Fast path: the 16 windows of a block are staged through LDS (lane-major, pitch 17) and written back transposed,
@@ -357,16 +358,19 @@ struct SinkWindowsT {
     }
     static __host__ __device__ u32 wave_dwords(const WindowsParams& p) {
         if (line_aligned(p)) return 64u * RPITCH * 2u;
-        return ((p.fw ? 1u : 0u) + (p.rc ? 1u : 0u) + (p.canon ? 1u : 0u)) * PLANE + (p.flags ? 64u * 16u / 4u : 0u);
+        return ((p.fw ? 1u : 0u) + (p.rc ? 1u : 0u) + (p.canon ? 1u : 0u)) * PLANE + (p.flags ? 64u * 16u / 4u : 0u) +
+               (p.win_offsets ? 64u * 3u : 0u);   // ragged: first slot and window count of the tile's 64 reads
     }
     static u32 block_lds_dwords(const WindowsParams& p) { return 4u * wave_dwords(p); }
     WindowsParams p;
     u64 *Tfw, *Trc, *Tcn;   // [64][PITCH] staging of the arrays that are wanted
     uint8_t* TF;            // [64][16] flags
     u64* out1;              // line-aligned mode: the one output array (nullptr: staged mode)
-    u64 base;      // slot of window 0 of the current read (slow path)
-    u32 W, next, lane;
-    static constexpr bool kRagged = false;   // the transposed write-back assumes one window count per read
+    u64* WOL;               // ragged: [64] slot of window 0 of the tile's reads
+    u32* NWL;               // ragged: [64] their window counts
+    u64 base;      // slot of window 0 of the current read
+    u32 W, nwr, next, lane; // W: windows per read (uniform layout); nwr: windows of this lane's read
+    static constexpr bool kRagged = !ALIGNED;   // (the line-aligned write-back assumes one window count per read)
     __device__ SinkWindowsT(const WindowsParams& p_, u32, u32 W_, u32*, u32 lane_, u32* block_lds, u32 tid)
         : p(p_), base(0), W(W_), next(0), lane(lane_) {
         u32* mine = block_lds + (tid >> 6) * wave_dwords(p_);
@@ -374,6 +378,9 @@ struct SinkWindowsT {
         Trc = Tfw + (p_.fw ? PLANE / 2u : 0u);
         Tcn = Trc + (p_.rc ? PLANE / 2u : 0u);
         TF = reinterpret_cast<uint8_t*>(Tcn + (p_.canon ? PLANE / 2u : 0u));
+        WOL = reinterpret_cast<u64*>(TF + (p_.flags ? 64u * 16u : 0u));
+        NWL = reinterpret_cast<u32*>(WOL + 64);
+        nwr = W_;
         out1 = line_aligned(p_) ? (p_.fw ? p_.fw : p_.rc ? p_.rc : p_.canon) : nullptr;
     }
     __device__ __forceinline__ void store(u64 slot, u64 fw, u64 rc) {
@@ -431,8 +438,8 @@ struct SinkWindowsT {
 #pragma unroll 4
         for (u32 it = 0; it < 16u; ++it) {
             const u32 idx = it * 64u + lane, r = idx >> 4, sw = idx & 15u;
-            if (sw < cnt) {
-                const u64 slot = (read0 + r) * W + o0 + sw;
+            if (sw < cnt && (!p.win_offsets || o0 + sw < NWL[r])) {
+                const u64 slot = (p.win_offsets ? WOL[r] : (read0 + r) * W) + o0 + sw;
                 const u32 at = r * PITCH + sw;
                 if (p.fw) p.fw[slot] = Tfw[at];
                 if (p.rc) p.rc[slot] = Trc[at];
@@ -449,8 +456,17 @@ struct SinkWindowsT {
         store(base + pos, fw, rc);
         next = pos + 1u;
     }
-    __device__ __forceinline__ void begin_read(u64 read) { base = read * W; next = 0; }
-    __device__ __forceinline__ void end_read() { zero_to(W); }
+    __device__ __forceinline__ void begin_read(u64 read) {
+        if (p.win_offsets) {
+            base = p.win_offsets[read];
+            nwr = (u32)(p.win_offsets[read + 1u] - base);
+            if (!ALIGNED) { WOL[lane] = base; NWL[lane] = nwr; }   // for the transposed write-back (block_done starts with a wave barrier)
+        } else {
+            base = read * W;
+        }
+        next = 0;
+    }
+    __device__ __forceinline__ void end_read() { zero_to(nwr); }
     __device__ __forceinline__ void tile_fast_done(u32) {}
     __device__ __forceinline__ void finish(const WindowsParams&) {}
 };
@@ -851,9 +867,19 @@ hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 
                                   uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = scan_domain(bases, n_reads, L, k);
     if (!*handled) return hipSuccess;
-    const WindowsParams p{fw, rc, canon, flags};
+    const WindowsParams p{fw, rc, canon, flags, nullptr};
     if (SinkWindowsT<true>::wants_aligned(p, L - k + 1u)) return dispatch<SinkWindowsT<true>>(bases, n_reads, L, k, p, queue, n_cu, stream);
     return dispatch<SinkWindowsT<false>>(bases, n_reads, L, k, p, queue, n_cu, stream);
+}
+
+// ragged reads: win_offsets[r] = slot of window 0 of read r (n_reads+1 entries); L = optional bound of the read lengths
+hipError_t launch_windows_ragged(const uint8_t* bases, const u64* offsets, const u64* win_offsets, u64 n_reads, u32 L, u32 k,
+                                 u64* fw, u64* rc, u64* canon, uint8_t* flags, unsigned long long* queue, int n_cu,
+                                 hipStream_t stream, bool* handled) {
+    *handled = offsets && win_offsets && scan_domain_ragged(bases, L, k);
+    if (!*handled) return hipSuccess;
+    const WindowsParams p{fw, rc, canon, flags, win_offsets};
+    return dispatch<SinkWindowsT<false>>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
 }
 
 }  // namespace kmx

@@ -225,6 +225,28 @@ def test_reduce_and_windows_ragged(ctx, orc):
     assert (outs["flags"].cpu().numpy() == flags).all()
 
 
+@pytest.mark.parametrize("k", [31, 21, 16, 5])
+@pytest.mark.parametrize("hint", [0, 160, 256])
+def test_windows_ragged_tiled_kernel(ctx, orc, k, hint):
+    """materialise mode for ragged reads on the tiled kernel: per-read slot bases and window counts from win_offsets,
+    reads shorter than k (no windows), empty reads, reads longer than the frame (exact path), N bytes"""
+    rng = np.random.default_rng(100 * k + hint)
+    lens = rng.integers(100, 161, size=64 * 9 + 21)
+    lens[rng.integers(0, len(lens), 12)] = rng.choice([0, 1, k - 1, k, k + 1, 40], 12)
+    lens[5] = 300 if hint != 256 else 200
+    lens[64 * 4:64 * 5] = 150
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]), 0.0008)
+    bases, d_off = ctx.to_device(host), ctx.to_device(offsets)
+    fw, rc, canon, flags = orc.canonical_windows(host, len(lens), 0, k, offsets=offsets)
+    outs = ctx.canonical_windows(bases, len(lens), hint, k, offsets=d_off, host_offsets=offsets)
+    for name, exp in (("fw", fw), ("rc", rc), ("canon", canon)):
+        assert (outs[name].cpu().numpy().view(np.uint64) == exp).all(), name
+    assert (outs["flags"].cpu().numpy() == flags).all()
+    only = ctx.canonical_windows(bases, len(lens), hint, k, offsets=d_off, host_offsets=offsets, want=("canon",))
+    assert (only["canon"].cpu().numpy().view(np.uint64) == canon).all()
+
+
 @pytest.mark.parametrize("k", [31, 21, 11, 5])
 @pytest.mark.parametrize("hint", [0, 160, 256])
 def test_reduce_ragged_tiled_kernel(ctx, orc, k, hint):

@@ -26,3 +26,17 @@ for k in (31, 21):
     ms_a = t(lambda: ctx._ck(ctx.lib.kmx_canonical_windows(ctx._h, C.byref(r), None, k, _ptr(fw), _ptr(rc), _ptr(canon), _ptr(fl))))
     print(f"k={k}: fw+rc+canon+flags {ms_a:7.3f} ms = {25*tot/ms_a/1e6:6.0f} GB/s written")
     del canon, fw, rc, fl
+# ragged reads (offsets + win_offsets): the same reads behind an offsets array, and a 100..160 bp mix
+import numpy as np
+k = 31
+for name, lens in (("all 150", np.full(n, 150)), ("100..160", np.random.default_rng(1).integers(100, 161, n))):
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    wo = np.concatenate([[0], np.cumsum(np.maximum(lens - k + 1, 0))]).astype(np.uint64)
+    rb = ctx.gen_reads(int(off[-1]))
+    d_off, d_wo = ctx.to_device(off), ctx.to_device(wo)
+    tot = int(wo[-1])
+    canon = ctx.empty(tot, torch.int64)
+    r = ctx._reads(rb, n, 160, d_off)
+    ms = t(lambda: ctx._ck(ctx.lib.kmx_canonical_windows(ctx._h, C.byref(r), _ptr(d_wo), k, None, None, _ptr(canon), None)))
+    print(f"ragged {name}: canon only {ms:7.3f} ms = {8*tot/ms/1e6:6.0f} GB/s written, {tot/ms/1e6:6.1f} G k-mers/s")
+    del rb, canon
