@@ -188,6 +188,56 @@ seqvec_minimizers_lds_kernel(const u64* __restrict__ words, u64 n_reads, u32 L, 
     }
 }
 
+// The same function as a sliding-window minimum (hashes of at most 56 bits, L <= 256): every l-mer becomes the key
+// (hash << 8) | position -- the minimum of keys is the leftmost minimum-hash l-mer, minimizers.rs:71 -- and the
+// minimum over the k-w+1 keys of a window is min(M[i], M[i + span - len]) with M = minima over len = 2^J <= span
+// consecutive keys, built by J doubling passes over the block's reads in LDS (ping-pong buffers).  log2(span) + 1
+// passes instead of span compares per k-mer: 17 -> 5 at k = 31, w = 15.
+template <int THREADS, int RB>
+__global__ void __launch_bounds__(THREADS)
+seqvec_minimizers_slide_kernel(const u64* __restrict__ words, u64 n_reads, u32 L, u32 k, u32 w, u32 hasher, u32 hk,
+                               u64* __restrict__ out_word, u32* __restrict__ out_pos) {
+    static_assert(THREADS == 16 * RB, "16 threads per read");
+    extern __shared__ __attribute__((aligned(16))) u64 hs[];   // [2][RB][NL]
+    const u32 NL = L - w + 1u, W = L - k + 1u, span = k - w + 1u;
+    const u64 n_words = (n_reads * (u64)L + 31u) >> 5;
+    const u32 r = threadIdx.x >> 4, j16 = threadIdx.x & 15u;
+    const u32 recipW = ((1u << 24) + W - 1u) / W;               // e / W for e < RB*W <= 2^12 (e * W < 2^24)
+    for (u64 r0 = (u64)blockIdx.x * RB; r0 < n_reads; r0 += (u64)gridDim.x * RB) {
+        const u32 nr = (u32)(n_reads - r0 < RB ? n_reads - r0 : RB);
+        u64* A = hs;
+        u64* B = hs + RB * NL;
+        if (r < nr) {
+            for (u32 p = j16; p < NL; p += 16u)
+                A[r * NL + p] = (mm_hash(seqvec_field(words, n_words, (r0 + r) * (u64)L + p, w), hasher, hk) << 8) | p;
+        }
+        __syncthreads();
+        u32 len = 1;
+        while (2u * len <= span) {
+            if (r < nr) {
+                for (u32 p = j16; p < NL; p += 16u) {
+                    const u64 a = A[r * NL + p];
+                    const u64 b = p + len < NL ? A[r * NL + p + len] : a;
+                    B[r * NL + p] = a < b ? a : b;
+                }
+            }
+            __syncthreads();
+            u64* t = A; A = B; B = t;
+            len *= 2u;
+        }
+        const u32 second = span - len;      // the window [i, i+span) = [i, i+len) u [i+second, i+second+len)
+        for (u32 e = threadIdx.x; e < nr * W; e += THREADS) {
+            const u32 rr = (u32)(((u64)e * recipW) >> 24), i = e - rr * W;
+            const u64 a = A[rr * NL + i], b = A[rr * NL + i + second];
+            const u32 pos = (u32)((a < b ? a : b) & 0xFFu);
+            const u64 slot = (r0 + rr) * (u64)W + i;
+            out_word[slot] = seqvec_field(words, n_words, (r0 + rr) * (u64)L + pos, w);
+            out_pos[slot] = pos;
+        }
+        __syncthreads();
+    }
+}
+
 static inline unsigned sgrid(u64 n, int n_cu) {
     u64 g = (n + 255u) / 256u;
     const u64 cap = (u64)n_cu * 16u;
@@ -229,6 +279,16 @@ hipError_t launch_minimizer_words(const u64* in, u64 n, u32 k, u32 w, u32 hasher
 hipError_t launch_seqvec_minimizers(const u64* words, u64 n_reads, u32 L, u32 k, u32 w, u32 hasher, u32 hk, u64* out_word,
                                     u32* out_pos, int n_cu, hipStream_t st) {
     const u32 NL = L - w + 1u;
+    const u32 hash_bits = hasher == KMX_HASH_LEX ? 2u * hk : 2u * w;
+    if (hash_bits <= 56u && L <= 256u && k > w) {   // (hash, position) keys fit a u64: sliding-window minimum
+        constexpr int RB = 16;
+        u64 grid = (n_reads + RB - 1u) / RB;
+        const u64 cap = (u64)n_cu * 8u;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL((seqvec_minimizers_slide_kernel<256, RB>), dim3((unsigned)(grid ? grid : 1)), dim3(256), (size_t)2u * RB * NL * 8u, st,
+                           words, n_reads, L, k, w, hasher, hk, out_word, out_pos);
+        return hipGetLastError();
+    }
     if ((size_t)NL * 8u <= 48u * 1024u) {   // the staged hashes of at least one read fit: LDS-shared kernel
         u32 rb = (48u * 1024u) / (NL * 8u);
         if (rb > 16u) rb = 16u;

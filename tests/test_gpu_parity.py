@@ -698,6 +698,26 @@ def test_seqvec_minimizers_vs_oracle(ctx, orc, k, w, hk):
     assert (mp.cpu().numpy().view(np.uint32) == op).all()
 
 
+@pytest.mark.parametrize("L,k,w,hk", [(150, 31, 28, 28), (150, 31, 29, 29), (150, 31, 15, 6), (150, 31, 15, 0), (256, 31, 15, 15),
+                                      (257, 31, 15, 15), (100, 21, 20, 20), (64, 33, 2, 1), (150, 32, 16, 16), (40, 40, 32, 3), (150, 31, 5, 5)])
+def test_seqvec_minimizers_sliding_minimum(ctx, orc, L, k, w, hk):
+    """the sliding-window-minimum kernel ((hash << 8) | position keys, doubling passes) and its limits: 56-bit hashes,
+    L = 256, hashers shorter than the l-mer (many equal hashes: the leftmost must win), low-complexity reads"""
+    from kmers_amd import _lib
+    rng = np.random.default_rng(L * 1000 + k * 10 + w)
+    n = 16 * 7 + 5
+    host = _acgt(rng, n * L)
+    host[: 20 * L] = np.frombuffer(b"ACAC", np.uint8)[rng.integers(0, 2, 20 * L) * 2]   # two-letter reads: ties everywhere
+    host[20 * L: 24 * L] = ord("A")
+    sv = orc.SeqVector(host.tobytes())
+    words = ctx.seqvec_from_bytes(ctx.to_device(host))
+    hasher = _lib.HASH_LEX if hk else _lib.HASH_IDENTITY
+    mw, mp = ctx.seqvec_minimizers(words, n, L, k, w, hasher, hk)
+    ow, op = orc.seqvec_minimizers(sv, n, L, k, w, hk)
+    assert (mw.cpu().numpy().view(np.uint64) == ow).all()
+    assert (mp.cpu().numpy().view(np.uint32) == op).all()
+
+
 def test_minimizer_words_vs_oracle(ctx, orc):
     from kmers_amd import _lib
     rng = np.random.default_rng(77)
