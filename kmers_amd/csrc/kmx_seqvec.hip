@@ -193,13 +193,26 @@ seqvec_minimizers_lds_kernel(const u64* __restrict__ words, u64 n_reads, u32 L, 
 // minimum over the k-w+1 keys of a window is min(M[i], M[i + span - len]) with M = minima over len = 2^J <= span
 // consecutive keys, built by J doubling passes over the block's reads in LDS (ping-pong buffers).  log2(span) + 1
 // passes instead of span compares per k-mer: 17 -> 5 at k = 31, w = 15.
-template <int THREADS, int RB>
+// The reads themselves are staged too, realigned to bit 0 (FW) and -- for LexHasher(w) on w-base l-mers, whose hash is
+// the l-mer with its bases in reverse order -- base-reversed (RV): an l-mer and its hash are then two bit-field reads
+// from LDS instead of two unaligned fetches from global memory and five 64-bit swap stages.
+// MODE 0: identity hasher, 1: LexHasher(hk == w), 2: LexHasher(any hk).
+__device__ __forceinline__ u64 lds_field(const u32* __restrict__ a, u32 bitoff, u32 nbits /* <= 56 */) {
+    const u32 q = bitoff >> 5, sh = bitoff & 31u;
+    const u64 lo = (u64)a[q] | ((u64)a[q + 1u] << 32);
+    const u64 v = sh ? ((lo >> sh) | ((u64)a[q + 2u] << (64u - sh))) : lo;
+    return v & ((1ull << nbits) - 1ull);
+}
+template <int THREADS, int RB, int MODE>
 __global__ void __launch_bounds__(THREADS)
-seqvec_minimizers_slide_kernel(const u64* __restrict__ words, u64 n_reads, u32 L, u32 k, u32 w, u32 hasher, u32 hk,
+seqvec_minimizers_slide_kernel(const u64* __restrict__ words, u64 n_reads, u32 L, u32 k, u32 w, u32 hk,
                                u64* __restrict__ out_word, u32* __restrict__ out_pos) {
     static_assert(THREADS == 16 * RB, "16 threads per read");
-    extern __shared__ __attribute__((aligned(16))) u64 hs[];   // [2][RB][NL]
+    extern __shared__ __attribute__((aligned(16))) u64 hs[];   // keys [2][RB][NL], then FW [RB][ND], RV [RB][ND] (u32)
     const u32 NL = L - w + 1u, W = L - k + 1u, span = k - w + 1u;
+    const u32 ND = ((2u * L + 31u) >> 5) + 2u;                  // dwords of a staged read (+2: the field reads look ahead)
+    u32* FW = reinterpret_cast<u32*>(hs + 2u * RB * NL);
+    u32* RV = FW + RB * ND;
     const u64 n_words = (n_reads * (u64)L + 31u) >> 5;
     const u32 r = threadIdx.x >> 4, j16 = threadIdx.x & 15u;
     const u32 recipW = ((1u << 24) + W - 1u) / W;               // e / W for e < RB*W <= 2^12 (e * W < 2^24)
@@ -207,9 +220,40 @@ seqvec_minimizers_slide_kernel(const u64* __restrict__ words, u64 n_reads, u32 L
         const u32 nr = (u32)(n_reads - r0 < RB ? n_reads - r0 : RB);
         u64* A = hs;
         u64* B = hs + RB * NL;
+        // the read, realigned: dword d = its bits [32d, 32d+32) (whatever follows the read in the vector comes along: never looked at)
         if (r < nr) {
-            for (u32 p = j16; p < NL; p += 16u)
-                A[r * NL + p] = (mm_hash(seqvec_field(words, n_words, (r0 + r) * (u64)L + p, w), hasher, hk) << 8) | p;
+            const u64 bit0 = 2u * (r0 + r) * (u64)L;
+            for (u32 d = j16; d < ND; d += 16u) {
+                const u64 b = bit0 + 32u * d;
+                const u64 q = b >> 6;
+                const u32 sh = (u32)(b & 63u);
+                const u64 lo = q < n_words ? words[q] : 0ull, hi = (sh && q + 1u < n_words) ? words[q + 1u] : 0ull;
+                FW[r * ND + d] = (u32)(sh ? ((lo >> sh) | (hi << (64u - sh))) : lo);
+            }
+        }
+        __syncthreads();
+        if (MODE == 1 && r < nr) {
+            // base-reversed copy: dword d holds bases L-1-16d-j (j = 0..15) = the 32 bits at base offset L-16d-16, group-reversed
+            for (u32 d = j16; d < ND; d += 16u) {
+                const int off = (int)L - 16 * (int)d - 16;      // may be negative: the read has fewer bases left
+                u32 x;
+                if (off >= 0) x = (u32)lds_field(FW + r * ND, 2u * (u32)off, 32u);
+                else x = off > -16 ? FW[r * ND] << (2u * (u32)(-off)) : 0u;
+                x = __builtin_bitreverse32(x);
+                RV[r * ND + d] = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);   // bit-reversed pairs back in order
+            }
+        }
+        if (MODE == 1) __syncthreads();
+        if (r < nr) {
+            for (u32 p = j16; p < NL; p += 16u) {
+                u64 h;
+                if (MODE == 1) h = lds_field(RV + r * ND, 2u * (L - p - w), 2u * w);
+                else {
+                    const u64 lm = lds_field(FW + r * ND, 2u * p, 2u * w);
+                    h = MODE == 0 ? lm : lex_hash(lm, hk);
+                }
+                A[r * NL + p] = (h << 8) | p;
+            }
         }
         __syncthreads();
         u32 len = 1;
@@ -231,7 +275,7 @@ seqvec_minimizers_slide_kernel(const u64* __restrict__ words, u64 n_reads, u32 L
             const u64 a = A[rr * NL + i], b = A[rr * NL + i + second];
             const u32 pos = (u32)((a < b ? a : b) & 0xFFu);
             const u64 slot = (r0 + rr) * (u64)W + i;
-            out_word[slot] = seqvec_field(words, n_words, (r0 + rr) * (u64)L + pos, w);
+            out_word[slot] = lds_field(FW + rr * ND, 2u * pos, 2u * w);
             out_pos[slot] = pos;
         }
         __syncthreads();
@@ -280,13 +324,23 @@ hipError_t launch_seqvec_minimizers(const u64* words, u64 n_reads, u32 L, u32 k,
                                     u32* out_pos, int n_cu, hipStream_t st) {
     const u32 NL = L - w + 1u;
     const u32 hash_bits = hasher == KMX_HASH_LEX ? 2u * hk : 2u * w;
-    if (hash_bits <= 56u && L <= 256u && k > w) {   // (hash, position) keys fit a u64: sliding-window minimum
+    if (hash_bits <= 56u && w <= 28u && L <= 256u && k > w) {   // (hash, position) keys fit a u64: sliding-window minimum
         constexpr int RB = 16;
         u64 grid = (n_reads + RB - 1u) / RB;
         const u64 cap = (u64)n_cu * 8u;
         if (grid > cap) grid = cap;
-        hipLaunchKernelGGL((seqvec_minimizers_slide_kernel<256, RB>), dim3((unsigned)(grid ? grid : 1)), dim3(256), (size_t)2u * RB * NL * 8u, st,
-                           words, n_reads, L, k, w, hasher, hk, out_word, out_pos);
+        const u32 ND = ((2u * L + 31u) >> 5) + 2u;
+        const size_t lds = (size_t)2u * RB * NL * 8u + (size_t)2u * RB * ND * 4u;
+        const int mode = hasher != KMX_HASH_LEX ? 0 : (hk == w ? 1 : 2);
+        auto k0 = seqvec_minimizers_slide_kernel<256, RB, 0>;
+        auto k1 = seqvec_minimizers_slide_kernel<256, RB, 1>;
+        auto k2 = seqvec_minimizers_slide_kernel<256, RB, 2>;
+        auto kern = mode == 0 ? k0 : mode == 1 ? k1 : k2;
+        if (lds > 64u * 1024u) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)(grid ? grid : 1)), dim3(256), lds, st, words, n_reads, L, k, w, hk, out_word, out_pos);
         return hipGetLastError();
     }
     if ((size_t)NL * 8u <= 48u * 1024u) {   // the staged hashes of at least one read fit: LDS-shared kernel
