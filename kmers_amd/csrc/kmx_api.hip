@@ -91,6 +91,9 @@ struct kmx_ctx {
     unsigned long long* d_scratch;  // 8 KiB: [0] first_bad, [16..] tile-queue heads
     void* d_big;                    // grow-only work buffer of the partitioned histogram (bucket-id streams)
     size_t big_bytes;
+    unsigned long long dirty_desc;      // address of the dirty-tile flags as last written behind the queue heads
+    uint8_t* d_flags;                   // one byte per tile, all zero between calls
+    size_t flags_bytes;
     char last_error[256];
 };
 
@@ -106,6 +109,45 @@ int fail_hip(kmx_ctx* ctx, hipError_t e, const char* where) {
         hipError_t e__ = (expr);                             \
         if (e__ != hipSuccess) return fail_hip(ctx, e__, #expr); \
     } while (0)
+
+void* big_scratch(void* user, size_t bytes);
+
+// The bit-sliced scan flags the tiles that hold an invalid byte (one byte per tile) for its second pass
+// (kmx_bitslice_kernel.h, "reads with an invalid byte").  The flags are the context's own grow-only array, zeroed when
+// it is allocated; the second pass clears every flag it consumes, so it is all-zero again when a call ends and nothing
+// has to be cleared per call.  Its address sits behind the 32 tile-queue heads (d_scratch[16 + 515]), rewritten only
+// when it changes.  No array: 0, and such tiles take the per-lane path as a whole, as they do for k without a second pass.
+int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k) {
+    const uint64_t n_tiles = n_reads >> 6;
+    uint8_t* buf = nullptr;
+    if (n_tiles && (k == 31 || k == 21)) {
+        if (n_tiles > ctx->flags_bytes) {
+            if (ctx->d_flags) {
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipFree(ctx->d_flags);
+                ctx->d_flags = nullptr;
+                ctx->flags_bytes = 0;
+            }
+            const size_t want_bytes = (size_t)(n_tiles + n_tiles / 4u + 4096u);
+            void* q = nullptr;
+            if (hipMalloc(&q, want_bytes) == hipSuccess && hipMemset(q, 0, want_bytes) == hipSuccess) {
+                ctx->d_flags = static_cast<uint8_t*>(q);
+                ctx->flags_bytes = want_bytes;
+            } else {
+                (void)hipGetLastError();
+                if (q) (void)hipFree(q);
+            }
+        }
+        buf = n_tiles <= ctx->flags_bytes ? ctx->d_flags : nullptr;
+    }
+    const unsigned long long want = (unsigned long long)reinterpret_cast<uintptr_t>(buf);
+    if (want != ctx->dirty_desc) {
+        ctx->dirty_desc = want;
+        hipError_t e = hipMemcpyAsync(ctx->d_scratch + 16 + 515, &ctx->dirty_desc, 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return fail_hip(ctx, e, "dirty-tile flags");
+    }
+    return KMX_OK;
+}
 
 // work buffer of the partitioned histogram: grown on demand (hipFree/hipMalloc synchronise, so only when it must grow),
 // kept until the context is destroyed; nullptr => the caller falls back to the global-atomic kernel
@@ -233,6 +275,7 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, kmx_ctx*
     hipError_t e = g.ok ? hipGetDeviceProperties(&prop, device) : hipErrorInvalidDevice;
     if (e == hipSuccess && owns) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_scratch), 8192);
+    if (e == hipSuccess) e = hipMemset(c->d_scratch, 0, 8192);   // (the dirty-list descriptor behind the queue heads starts as "no list")
     if (e != hipSuccess) {
         delete c;
         return KMX_E_HIP;
@@ -252,6 +295,7 @@ void kmx_ctx_destroy(kmx_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_big) (void)hipFree(ctx->d_big);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -328,8 +372,9 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
     const bool lex_same_k = hasher == KMX_HASH_LEX && hasher_k == k;
     if (hasher == KMX_HASH_NONE || lex_same_k) {
         bool handled = false;
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));  // 32 tile-queue heads, 128 B apart
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 8, ctx->stream));  // 32 tile-queue heads, 128 B apart, + the "a tile was flagged" word
         if (!reads->d_offsets) {
+            if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
             KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
                                                     d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
             if (handled) return KMX_OK;

@@ -26,6 +26,7 @@
 #pragma once
 #include "kmx_device.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -97,8 +98,13 @@ __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, 
 //     a read instead of stopping t bases before ITS end, and these per-base totals take the excess back out.
 // A tile whose span or longest read leaves the frame, or that would load past the end of the buffer, and tiles with
 // an invalid byte, take the per-lane rolling path as before.
-template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
-__global__ void __launch_bounds__(256, ((NW > 10 || K > 32) ? 2 : RAGGED ? KMX_BSR_WAVES : PACKED ? KMX_BSP_WAVES : KMX_BS_WAVES))   // 64 prefetch registers at NW=16; 2x counters at K>32
+// PASS = 1: the second pass over the tiles that hold an invalid byte (see "reads with an invalid byte" below).
+#ifndef KMX_BS_DIRTY
+#define KMX_BS_DIRTY 1
+#endif
+template <int K> constexpr bool bs_has_dirty_pass() { return KMX_BS_DIRTY && (K == 31 || K == 21); }   // (one more kernel per frame and k)
+template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, int PASS = 0>
+__global__ void __launch_bounds__(256, ((NW > 10 || K > 32 || PASS == 1) ? 2 : RAGGED ? KMX_BSR_WAVES : PACKED ? KMX_BSP_WAVES : KMX_BS_WAVES))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets) {
@@ -121,7 +127,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 chunks = 4u * L + (RAGGED ? 1u : 0u);          // 16-byte chunks a tile may span (ragged: +1 for its unaligned start)
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
     const u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
-    u32* P = lds + wib * (ldsw + 4u * PLANES + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u));
+    u32* P = lds + wib * (ldsw + 4u * PLANES + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u) + (PASS == 1 ? 128u : 0u));
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
     const u64 n_full = n_reads >> 6;
@@ -193,6 +199,29 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         m.fits = nch <= (u64)chunks && nch <= 64u * NW && wave_max_u32(m.len) <= L && m.base + 16u * nch <= total_bytes;
     };
     u32 n_bs_tiles = 0;
+    // ---- reads with an invalid byte (ASCII input, uniform layout; k with a second-pass kernel).  A tile that holds one
+    // used to go to the per-lane path as a whole -- 64 reads rolled at 6.5x the cost of a bit-sliced tile, so 0.5 % of reads
+    // with an N (27 % of the tiles) made the scan 3.4x slower.  Now the main pass (PASS 0) only flags such a tile (one byte
+    // per tile, all zero between calls) and moves on; the second pass (PASS 1: this kernel again, with room for the extra
+    // state at 2 waves/SIMD) walks the flags, runs the flagged tiles bit-sliced with the offending reads blanked out --
+    // bases zeroed, windows masked out of m, nk counting the others only -- and collects those reads in a 64-entry buffer
+    // per wave that is rolled, one lane per read, whenever it is full: no list in memory, no atomics (one counter could
+    // take 25 M appends a second, less than the tiles a dirty input produces).  Doing all of this in the main pass cost it
+    // 6 % on clean input: the kernel sits at its register budget.
+    // queue[515] (behind the 32 tile-queue heads) = the flag array, 0 = none: such tiles then roll as a whole in PASS 0;
+    // queue[512] = "some tile was flagged" (lets the second pass return at once on clean input).
+    constexpr bool DIRTY_LIST = !PACKED && !RAGGED && bs_has_dirty_pass<K>();
+    static_assert(PASS == 0 || DIRTY_LIST, "second pass: ASCII, uniform layout");
+    u64 valid_reads = ~0ull;                      // PASS 1: reads of the current tile that are not blanked (bit = lane = read)
+    u32 n_blanked = 0;                            // PASS 1: reads blanked in this wave's tiles
+    u32 n_set_aside = 0;                          // PASS 1: reads waiting in the wave's buffer
+    uint8_t* const tile_flags = PASS == 1 ? reinterpret_cast<uint8_t*>(queue[515]) : nullptr;
+    if constexpr (PASS == 1) {
+        if (tile_flags == nullptr || queue[512] == 0) return;   // queue[512]: "a tile was flagged" (zeroed by the caller with the heads)
+    }
+    u64 flag_group = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);   // PASS 1: 64 flags at a time, groups strided over the waves
+    u64 flag_bits = 0;                                             //         flagged tiles of the current group not yet handed out
+    u64 flag_base = 0;
     // word-domain accumulators of the fallback path (tiles with invalid bytes, the final partial tile)
 #ifndef KMX_BS_FB_FLUSH
 #define KMX_BS_FB_FLUSH 1   // 1: the fallback path adds its sums to the output per tile (12 registers less across the main loop: +1.7 % at k=31)
@@ -218,7 +247,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
         }
     };
-    constexpr bool FB_FLUSH = KMX_BS_FB_FLUSH && K <= 32;   // (two-word k-mers: the per-tile sums then live in scratch, 0.46 -> 0.37 of the roofline at k=63)
+    constexpr bool FB_FLUSH = KMX_BS_FB_FLUSH && K <= 32 && PASS == 0;   // (the second pass rolls reads in batches into fb_all)   // (two-word k-mers: the per-tile sums then live in scratch, 0.46 -> 0.37 of the roofline at k=63)
     FbAcc fb_all;                                             // !FB_FLUSH: summed over the whole run of the wave
     auto fallback_read_acc = [&](u64 read, FbAcc& fb) {
         const uint8_t* s = bases + read * (u64)L;
@@ -259,6 +288,18 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 fb.x1 ^= h.hi;
             });
         }
+    };
+    // PASS 1: the reads set aside by the bit-sliced tiles, 64 at a time, one lane per read
+    u64* const SET_ASIDE = reinterpret_cast<u64*>(P + ldsw + 4u * PLANES + 64u * NV);
+    auto roll_set_aside = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < n_set_aside) fallback_read_acc(SET_ASIDE[lane], fb_all);
+        n_set_aside = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     // one tile (or the final partial one) on the per-lane path; `mine`: this lane has a read
     auto fallback_read = [&](u64 read, bool mine) {
@@ -301,11 +342,17 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     auto issue_loads = [&](u64 tile) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
+        // The per-row offsets are derived afresh from an opaque copy of the lane offset: left to itself hipcc hoists all
+        // NLD of them out of the tile loop as zero-extended 64-bit values (24 registers at NLD = 10, and a 64-bit add per
+        // row per tile); recomputed they are one 32-bit op each and the loads take the SGPR-base + VGPR-offset form
+        // (168 -> 152 registers at k = 31, 240 -> 220 at k = 63; same speed).
+        u32 l16 = lane16;
+        asm volatile("" : "+v"(l16));
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             // lanes past the tile end re-read its last chunk: no branch, so all loads of a tile sit in
             // one basic block and stay in flight together (a guarded load would be fenced by vmcnt(0))
-            u32 off = lane16 + (u32)it * 1024u;
+            u32 off = l16 + (u32)it * 1024u;
             if (it == NLD - 1 || short_rows) off = off < last_off ? off : last_off;
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb + off));  // streamed once
@@ -324,6 +371,21 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u32 qid = (blockIdx.x & 255u) >> 3;
     u32 heads_left = NQ;                                // heads this wave has not yet seen exhausted
     auto dequeue = [&]() -> u64 {
+        if constexpr (PASS == 1) {   // the next flagged tile of this wave's groups of 64 flags
+            const u64 n_groups = (n_full + 63u) >> 6;
+            while (flag_bits == 0) {
+                if (flag_group >= n_groups) return ~0ull;
+                flag_base = flag_group * 64u;
+                const u64 t = flag_base + lane;
+                const bool flagged = t < n_full && tile_flags[t] != 0;
+                if (flagged) tile_flags[t] = 0;     // the array goes back to all-zero: the caller never clears it
+                flag_bits = __ballot(flagged);
+                flag_group += (u64)gridDim.x * 4u;
+            }
+            const u32 bit = (u32)__builtin_ctzll(flag_bits);
+            flag_bits &= flag_bits - 1ull;
+            return flag_base + bit;
+        }
         while (heads_left != 0u) {
             unsigned long long v = 0;
             if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);   // heads are 128 bytes apart
@@ -340,10 +402,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     unsigned long long pend = 0;
     u32 pend_qid = 0;
     auto ticket_issue = [&]() {
+        if constexpr (PASS == 1) return;   // (no tickets: dequeue() walks the flags)
         pend_qid = qid;
         if (heads_left != 0u && lane == 0) pend = atomicAdd(queue + qid * 16u, 1ull);
     };
     auto ticket_take = [&]() -> u64 {
+        if constexpr (PASS == 1) return dequeue();
         if (heads_left == 0u) return ~0ull;
         const u32 lo = __builtin_amdgcn_readfirstlane((u32)pend), hi = __builtin_amdgcn_readfirstlane((u32)(pend >> 32));
         const u64 t = (((u64)hi << 32) | lo) * NQ + pend_qid;
@@ -409,6 +473,24 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             return false;
         } else {
+        if constexpr (PASS == 1) {
+            // second pass: also a bitmap of the bad 16-byte chunks, one ballot per row, parked in the plane area (free between
+            // phase D of the last tile and phase C of this one)
+            u64* BM = reinterpret_cast<u64*>(PL);
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const u32 c = it * 64u + lane;
+                u32 rb = 0;
+                const u32 code = encode16(w[it], rb);
+                if (c < chunks) P[1u + c] = code;
+                const bool cb = c < chunks && chunk_has_invalid(rb);
+                const u64 row = __ballot(cb);
+                if (lane == 0) BM[it] = row;
+                bad |= cb ? 1u : 0u;
+            }
+            if (lane == 0) { BM[NW] = 0; BM[NW + 1] = 0; }
+            return __any(bad != 0u);
+        }
         if (KMX_BS_PRIO && !(KMX_BS_ABLATE & 24) && chunks >= 64u * (NW - 1)) {
             // wave-uniform: only the last row of chunks is partial (L = 150: 600 = 9*64 + 24)
 #pragma unroll
@@ -451,6 +533,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
             for (int g = 0; g < NW; ++g) F[g] = alignbit(R[g + 1], R[g], aF);
             if (KMX_BS_PRIO >= 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
+        }
+        if constexpr (PASS == 1) {
+            if (valid_reads != ~0ull) {
+                const bool blank = ((valid_reads >> lane) & 1ull) == 0ull;
+#pragma unroll
+                for (int g = 0; g < NW; ++g) F[g] = blank ? 0u : F[g];
+            }
         }
         if constexpr (RAGGED) {
             const u32 len = cur_m.len >= (u32)K ? cur_m.len : 0u;   // a read shorter than k owns no window: it is blanked out entirely
@@ -699,6 +788,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 } else {
                     m[w] = ((u32)w < nwin) ? lt[w] : 0u;
                 }
+                if constexpr (PASS == 1) m[w] &= set ? (u32)(valid_reads >> 32) : (u32)valid_reads;   // blanked reads own no window
                 pc_acc(mcnt, m[w]);
             }
             asm volatile("" ::: "memory");   // pass 2 re-reads the planes instead of keeping 2K+6 registers live
@@ -832,8 +922,42 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
         lds_fence();
         KMX_T(1)
+        if constexpr (PASS == 1) {
+            valid_reads = ~0ull;
+            if (bad_tile) {
+                // which reads?  a read is set aside if any chunk it touches is bad (a chunk shared by two reads sets both aside:
+                // they are rolled exactly anyway)
+                const u64* BM = reinterpret_cast<const u64*>(PL);
+                const u32 c0 = (lane * L) >> 4, c1 = (lane * L + L - 1u) >> 4;
+                const u32 q0 = c0 >> 6, b0 = c0 & 63u;
+                const u64 lo = BM[q0], hi = BM[q0 + 1u];
+                const u64 bits = b0 ? ((lo >> b0) | (hi << (64u - b0))) : lo;
+                const bool dirty = (bits & ((1ull << (c1 - c0 + 1u)) - 1ull)) != 0ull;
+                const u64 dm = __ballot(dirty);
+                const u32 nd = (u32)__builtin_popcountll(dm);
+                const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(dm >> 32), __builtin_amdgcn_mbcnt_lo((u32)dm, 0u));
+                if (n_set_aside + nd > 64u) roll_set_aside();
+                if (dirty) SET_ASIDE[n_set_aside + rank] = tile * 64u + lane;
+                n_set_aside += nd;
+                bad_tile = false;
+                valid_reads = ~dm;
+                n_blanked += nd;
+                lds_fence();
+            }
+        }
         if (bad_tile) {
-            fallback_read(tile * 64u + lane, true);
+            bool flagged = false;
+            if constexpr (PASS == 0 && DIRTY_LIST) {     // flag the tile for the second pass
+                uint8_t* const flags = reinterpret_cast<uint8_t*>(queue[515]);
+                if (flags != nullptr) {
+                    if (lane == 0) {
+                        flags[tile] = 1;
+                        queue[512] = 1;
+                    }
+                    flagged = true;
+                }
+            }
+            if (!flagged) fallback_read(tile * 64u + lane, true);
         } else if (!(KMX_BS_ABLATE & 32)) {
             phase_BC();
             KMX_T(3)
@@ -864,7 +988,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 
     // ---- final partial tile: per-lane rolling
     const u32 rem = (u32)(n_reads & 63u);
-    if (rem != 0u && wave_id == 0) fallback_read(n_full * 64u + lane, lane < rem);
+    if (PASS == 0 && rem != 0u && wave_id == 0) fallback_read(n_full * 64u + lane, lane < rem);
+    if constexpr (PASS == 1) {
+        if (n_bs_tiles == 0) return;          // nothing flagged in this wave's share: no sums, no atomics
+        if (n_set_aside) roll_set_aside();
+    }
 
     // ---- combine the bit-sliced counters into word-domain results (once per wave; wave-uniform branch)
     // Number of set bits of canonical bit (t,b) over all k-mers of the wave:
@@ -876,7 +1004,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u64 bs_n = 0, bs_s0 = 0, bs_s1 = 0, bs_x0 = 0, bs_x1 = 0, bs_fw = 0;
     if (n_bs_tiles != 0u) {
         // k-mers handled bit-sliced by this wave
-        const u64 nk = RAGGED ? wave_sum(NVR[lane]) : (u64)n_bs_tiles * 64u * (u64)W;
+        const u64 nk = RAGGED ? wave_sum(NVR[lane]) : ((u64)n_bs_tiles * 64u - n_blanked) * (u64)W;
         bs_n = nk;
         u64 fwall = 0;
         u32 tot[NW];
@@ -970,6 +1098,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
         if (e != hipSuccess) return e;
         bpc = b > 0 ? b : 1;
         bpc_lds = lds_bytes;
+        if (getenv("KMX_BS_PRINT_BPC")) fprintf(stderr, "kmx: bit-sliced K=%d NW=%d WPL=%d: %d blocks per CU, %zu B of LDS each\n", K, NW, WPL, bpc, lds_bytes);
     }
     const u64 n_tiles = (n_reads + 63u) >> 6;
     u64 grid = (u64)n_cu * (u64)bpc;
@@ -977,6 +1106,14 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets);
+    if constexpr (!PACKED && !RAGGED && bs_has_dirty_pass<K>()) {
+        // second pass over the tiles the main pass flagged (none on clean input: a wave reads its share of the flags and returns)
+        auto kern1 = scan_bitsliced_kernel<K, NW, WPL, false, false, 1>;
+        u64 grid1 = (u64)n_cu * 2u;
+        if (grid1 > need) grid1 = need;
+        hipLaunchKernelGGL(kern1, dim3((unsigned)(grid1 ? grid1 : 1)), dim3(256), lds_bytes + 128u * 4u * 4u, stream, bases, n_reads, L, want_hash,
+                           want_sumfw, out, queue, offsets);
+    }
     return hipGetLastError();
 }
 

@@ -76,6 +76,34 @@ __device__ __forceinline__ u32 encode16(uint4 w, u32& bad) {
 
 __device__ __forceinline__ bool chunk_has_invalid(u32 bad) { return (bad & 0xDFDFDFDFu) != 0u; }
 
+// does the read s[0, len) hold a byte outside ACGTacgt?  (same accept set as encode16.)  All the 16-byte chunks of the
+// aligned span around the read -- at most MAXV, the caller guarantees that span is readable, as it is inside a tile of the
+// scan kernels -- are requested before the first is looked at: one memory round trip, not one per chunk.
+template <int MAXV>
+__device__ __forceinline__ bool read_has_invalid(const uint8_t* __restrict__ s, u32 len) {
+    constexpr u32 TBL_LO = 0x00430041u, TBL_HI = 0x00470054u;   // as in encode16
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(s), a1 = a0 + len, base = a0 & ~(uintptr_t)15;
+    const u32 nch = (u32)((a1 - base + 15u) >> 4);
+    if (len == 0u) return false;
+    uint4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) v[i] = *reinterpret_cast<const uint4*>(base + 16u * ((u32)i < nch ? (u32)i : nch - 1u));
+    u32 acc = 0;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const u32 wv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uintptr_t a = base + 16u * i + 4u * j;
+            u32 m = ((u32)i < nch && a < a1 && a + 4 > a0) ? ~0u : 0u;
+            if (a < a0) m &= ~0u << (8u * (u32)(a0 - a));            // bytes before the read (1..3 here: a + 4 > a0)
+            if (a + 4 > a1 && a < a1) m &= ~0u >> (8u * (u32)(a + 4 - a1));   // bytes after it
+            acc |= (wv[j] ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, wv[j] & 0x06060606u)) & 0xDFDFDFDFu & m;
+        }
+    }
+    return acc != 0u;
+}
+
 // reverse the 16 2-bit groups of a dword (v_bfrev_b32 + swap the two bits of each pair)
 __device__ __forceinline__ u32 revgroups32(u32 x) {
     const u32 y = __builtin_bitreverse32(x);

@@ -202,6 +202,39 @@ def test_oracle_shows_the_k32_quirk(orc):
     assert (rc == 0).all() and (canon == 0).all() and flags.all()
 
 
+@pytest.mark.parametrize("k", [31, 21])
+@pytest.mark.parametrize("L", [150, 100, 250])
+def test_reduce_reads_with_invalid_bytes_second_pass(ctx, orc, k, L):
+    """tiles with an invalid byte: flagged by the main pass, run by the second pass with the offending reads blanked out
+    and rolled 64 at a time.  Every read of a tile dirty (buffer flushes), one dirty read per tile, N as the last byte of a
+    read / the first of the next (they share a 16-byte chunk), runs of N, clean tiles in between, a partial last tile."""
+    from kmers_amd import _lib
+    rng = np.random.default_rng(1000 * k + L)
+    n = 64 * 40 + 23
+    host = np.frombuffer(b"ACGTacgt", np.uint8)[rng.integers(0, 8, n * L)].copy()
+    reads = host.reshape(n, L)
+    reads[0:64, rng.integers(0, L, 64)] = ord("N")                 # tile 0: every read dirty (a column per read, many hits)
+    reads[64:128, :][np.arange(64), rng.integers(0, L, 64)] = ord("N")   # tile 1: one N per read
+    reads[64 * 3 + 5, L - 1] = ord("N")                             # tile 3: last byte of a read
+    reads[64 * 3 + 6, 0] = ord("n")                                 #         first byte of the next
+    reads[64 * 5 + 63, L // 2: L // 2 + 40] = ord("N")              # tile 5: a run of N in its last read
+    reads[64 * 6, :] = ord("N")                                     # tile 6: a read of N only
+    for t in range(8, 40, 3):                                       # scattered
+        reads[64 * t + int(rng.integers(0, 64)), int(rng.integers(0, L))] = int(rng.integers(0, 256))
+    reads[n - 3, 7] = ord("-")                                      # the partial last tile
+    bases = ctx.to_device(host)
+    for hasher, flags in ((_lib.HASH_LEX, _lib.REDUCE_SUM_FW), (_lib.HASH_NONE, 0)):
+        g = ctx.canonical_reduce(bases, n, L, k, hasher, k if hasher else 0, flags)
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        _cmp_summary(g, o, hasher != 0, flags != 0)
+    # twice in a row on the same context: the flags must be back to zero after a call
+    g2 = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _cmp_summary(g2, orc.canonical_reduce(host, n, L, k, hasher_k=k), True, True)
+    clean = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * L)].copy()
+    g3 = ctx.canonical_reduce(ctx.to_device(clean), n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _cmp_summary(g3, orc.canonical_reduce(clean, n, L, k, hasher_k=k), True, True)
+
+
 # --------------------------------------------------------------- ragged reads
 
 def test_reduce_and_windows_ragged(ctx, orc):

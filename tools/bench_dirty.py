@@ -1,0 +1,25 @@
+"""dev tool: kmx_canonical_reduce (k=31, 150 bp) when a fraction of the reads holds an N"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from kmers_amd.api import Context
+
+ctx = Context(0)
+n, L, k = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000, 150, 31
+for frac in (0.0, 0.001, 0.005, 0.02, 0.1):
+    bases = ctx.gen_reads(n * L)
+    nd = int(n * frac)
+    if nd:
+        g = torch.Generator(device="cuda"); g.manual_seed(1)
+        rd = torch.randperm(n, device="cuda", generator=g)[:nd]
+        pos = torch.randint(0, L, (nd,), device="cuda", generator=g)
+        bases[rd * L + pos] = ord("N")
+    out = ctx.canonical_reduce(bases, n, L, k)
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); ctx.canonical_reduce_async(bases, n, L, k); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = sorted(ts)[2]
+    print(f"{100*frac:5.1f} % of the reads hold an N: {ms:7.3f} ms  {n*L/ms/1e6:6.0f} GB/s   n_valid {out.n_valid}")
+    del bases
