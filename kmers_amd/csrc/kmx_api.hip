@@ -120,7 +120,7 @@ void* big_scratch(void* user, size_t bytes);
 int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k) {
     const uint64_t n_tiles = n_reads >> 6;
     uint8_t* buf = nullptr;
-    if (n_tiles && (k == 31 || k == 21)) {
+    if (n_tiles && k >= 13 && k <= 31) {   // the k with a bit-sliced kernel (and so a second pass)
         if (n_tiles > ctx->flags_bytes) {
             if (ctx->d_flags) {
                 (void)hipStreamSynchronize(ctx->stream);

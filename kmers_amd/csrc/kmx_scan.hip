@@ -524,7 +524,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
 
     Sink sink(params, k, nwin, P + ldsw, lane, lds + 4u * (ldsw + Sink::kLdsDwordsPerWave), threadIdx.x);
 
-    u32 nwin_min = nwin;        // ragged: the shortest read of the tile (blocks of windows below it need no per-lane mask)
+    [[maybe_unused]] u32 nwin_min = nwin;   // ragged: the shortest read of the tile (blocks of windows below it need no per-lane mask)
     auto window = [&](u32 o, u32 f0, u32 f1, u32 f2, u32 g0, u32 g1, u32 g2, u32 sf, u32 sr, bool guard = RAGGED) {
         if (guard && o >= nwin) return;   // past the end of this lane's (shorter) read
         if (DW == 2) {

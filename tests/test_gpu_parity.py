@@ -202,7 +202,7 @@ def test_oracle_shows_the_k32_quirk(orc):
     assert (rc == 0).all() and (canon == 0).all() and flags.all()
 
 
-@pytest.mark.parametrize("k", [31, 21])
+@pytest.mark.parametrize("k", [31, 21, 13, 16, 24, 30])
 @pytest.mark.parametrize("L", [150, 100, 250])
 def test_reduce_reads_with_invalid_bytes_second_pass(ctx, orc, k, L):
     """tiles with an invalid byte: flagged by the main pass, run by the second pass with the offending reads blanked out
