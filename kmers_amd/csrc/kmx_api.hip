@@ -380,6 +380,7 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
             if (handled) return KMX_OK;
         }
         if (reads->d_offsets && !want_sumfw) {   // ragged reads on the bit-sliced kernel (k in {21, 31}; read_len = optional length bound)
+            if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
             KMX_HIP(ctx, kmx::launch_scan_bitsliced_ragged(reads->d_bases, reads->d_offsets, reads->n_reads, reads->read_len, k,
                                                            lex_same_k, d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
             if (handled) return KMX_OK;

@@ -199,7 +199,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         m.fits = nch <= (u64)chunks && nch <= 64u * NW && wave_max_u32(m.len) <= L && m.base + 16u * nch <= total_bytes;
     };
     u32 n_bs_tiles = 0;
-    // ---- reads with an invalid byte (ASCII input, uniform layout; k with a second-pass kernel).  A tile that holds one
+    // ---- reads with an invalid byte (ASCII input, uniform or ragged; k with a second-pass kernel).  A tile that holds one
     // used to go to the per-lane path as a whole -- 64 reads rolled at 6.5x the cost of a bit-sliced tile, so 0.5 % of reads
     // with an N (27 % of the tiles) made the scan 3.4x slower.  Now the main pass (PASS 0) only flags such a tile (one byte
     // per tile, all zero between calls) and moves on; the second pass (PASS 1: this kernel again, with room for the extra
@@ -210,8 +210,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // 6 % on clean input: the kernel sits at its register budget.
     // queue[515] (behind the 32 tile-queue heads) = the flag array, 0 = none: such tiles then roll as a whole in PASS 0;
     // queue[512] = "some tile was flagged" (lets the second pass return at once on clean input).
-    constexpr bool DIRTY_LIST = !PACKED && !RAGGED && bs_has_dirty_pass<K>();
-    static_assert(PASS == 0 || DIRTY_LIST, "second pass: ASCII, uniform layout");
+    constexpr bool DIRTY_LIST = !PACKED && bs_has_dirty_pass<K>();
+    static_assert(PASS == 0 || DIRTY_LIST, "second pass: ASCII input");
     u64 valid_reads = ~0ull;                      // PASS 1: reads of the current tile that are not blanked (bit = lane = read)
     u32 n_blanked = 0;                            // PASS 1: reads blanked in this wave's tiles
     u32 n_set_aside = 0;                          // PASS 1: reads waiting in the wave's buffer
@@ -290,7 +290,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
     };
     // PASS 1: the reads set aside by the bit-sliced tiles, 64 at a time, one lane per read
-    u64* const SET_ASIDE = reinterpret_cast<u64*>(P + ldsw + 4u * PLANES + 64u * NV);
+    u64* const SET_ASIDE = reinterpret_cast<u64*>(P + ldsw + 4u * PLANES + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u));
     auto roll_set_aside = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -459,6 +459,22 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     auto phase_A = [&]() -> bool {   // pack + validate the tile sitting in w[] into the packed LDS buffer
         u32 bad = 0;
         if constexpr (RAGGED) {      // the tile spans cur_m.n_ch chunks from its aligned start (neighbouring tiles' bytes at both ends)
+            if constexpr (PASS == 1) {   // second pass: also the bitmap of bad chunks (see the uniform branch below)
+                u64* BM = reinterpret_cast<u64*>(PL);
+#pragma unroll
+                for (int it = 0; it < NW; ++it) {
+                    const u32 c = it * 64u + lane;
+                    u32 rb = 0;
+                    const u32 code = encode16(w[it], rb);
+                    if (c < cur_m.n_ch) P[1u + c] = code;
+                    const bool cb = c < cur_m.n_ch && chunk_has_invalid(rb);
+                    const u64 row = __ballot(cb);
+                    if (lane == 0) BM[it] = row;
+                    bad |= cb ? 1u : 0u;
+                }
+                if (lane == 0) { BM[NW] = 0; BM[NW + 1] = 0; }
+                return __any(bad != 0u);
+            }
 #pragma unroll
             for (int it = 0; it < NW; ++it) {
                 const u32 c = it * 64u + lane;
@@ -542,7 +558,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
         }
         if constexpr (RAGGED) {
-            const u32 len = cur_m.len >= (u32)K ? cur_m.len : 0u;   // a read shorter than k owns no window: it is blanked out entirely
+            const bool set_aside = PASS == 1 && ((valid_reads >> lane) & 1ull) == 0ull;   // second pass: a read with an invalid byte
+            const u32 len = (cur_m.len >= (u32)K && !set_aside) ? cur_m.len : 0u;   // a read shorter than k owns no window: it is blanked out entirely
             // bases past the end of the read belong to the next read: zero them
 #pragma unroll
             for (int g = 0; g < NW; ++g) {
@@ -924,15 +941,19 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         KMX_T(1)
         if constexpr (PASS == 1) {
             valid_reads = ~0ull;
-            if (bad_tile) {
+            bool have_bitmap = bad_tile;
+            if constexpr (RAGGED) have_bitmap = bad_tile && cur_m.fits;   // (a tile outside the frame was never packed: it rolls as a whole)
+            if (have_bitmap) {
                 // which reads?  a read is set aside if any chunk it touches is bad (a chunk shared by two reads sets both aside:
                 // they are rolled exactly anyway)
                 const u64* BM = reinterpret_cast<const u64*>(PL);
-                const u32 c0 = (lane * L) >> 4, c1 = (lane * L + L - 1u) >> 4;
+                u32 rd_off = lane * L, rd_len = L;           // the read's bytes, relative to the tile's aligned start
+                if constexpr (RAGGED) { rd_off = cur_m.rel; rd_len = cur_m.len; }
+                const u32 c0 = rd_off >> 4, c1 = rd_len ? (rd_off + rd_len - 1u) >> 4 : c0;
                 const u32 q0 = c0 >> 6, b0 = c0 & 63u;
                 const u64 lo = BM[q0], hi = BM[q0 + 1u];
                 const u64 bits = b0 ? ((lo >> b0) | (hi << (64u - b0))) : lo;
-                const bool dirty = (bits & ((1ull << (c1 - c0 + 1u)) - 1ull)) != 0ull;
+                const bool dirty = rd_len != 0u && (bits & ((1ull << (c1 - c0 + 1u)) - 1ull)) != 0ull;
                 const u64 dm = __ballot(dirty);
                 const u32 nd = (u32)__builtin_popcountll(dm);
                 const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(dm >> 32), __builtin_amdgcn_mbcnt_lo((u32)dm, 0u));
@@ -949,7 +970,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             bool flagged = false;
             if constexpr (PASS == 0 && DIRTY_LIST) {     // flag the tile for the second pass
                 uint8_t* const flags = reinterpret_cast<uint8_t*>(queue[515]);
-                if (flags != nullptr) {
+                bool can = flags != nullptr;
+                if constexpr (RAGGED) can = can && cur_m.fits;   // (tiles outside the frame roll as a whole)
+                if (can) {
                     if (lane == 0) {
                         flags[tile] = 1;
                         queue[512] = 1;
@@ -1106,9 +1129,9 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets);
-    if constexpr (!PACKED && !RAGGED && bs_has_dirty_pass<K>()) {
+    if constexpr (!PACKED && bs_has_dirty_pass<K>()) {
         // second pass over the tiles the main pass flagged (none on clean input: a wave reads its share of the flags and returns)
-        auto kern1 = scan_bitsliced_kernel<K, NW, WPL, false, false, 1>;
+        auto kern1 = scan_bitsliced_kernel<K, NW, WPL, false, RAGGED, 1>;
         u64 grid1 = (u64)n_cu * 2u;
         if (grid1 > need) grid1 = need;
         hipLaunchKernelGGL(kern1, dim3((unsigned)(grid1 ? grid1 : 1)), dim3(256), lds_bytes + 128u * 4u * 4u, stream, bases, n_reads, L, want_hash,

@@ -235,6 +235,32 @@ def test_reduce_reads_with_invalid_bytes_second_pass(ctx, orc, k, L):
     _cmp_summary(g3, orc.canonical_reduce(clean, n, L, k, hasher_k=k), True, True)
 
 
+@pytest.mark.parametrize("k", [31, 21])
+@pytest.mark.parametrize("hint", [160, 0])
+def test_reduce_ragged_reads_with_invalid_bytes_second_pass(ctx, orc, k, hint):
+    """the second pass on ragged reads: a set-aside read counts as an empty one (no bases, no windows), N at read ends that
+    share a chunk with the neighbour, empty reads and reads shorter than k next to dirty ones, a tile outside the frame"""
+    from kmers_amd import _lib
+    rng = np.random.default_rng(77 * k + hint)
+    lens = rng.integers(100, 161, size=64 * 30 + 11)
+    lens[rng.integers(0, len(lens), 40)] = rng.choice([0, 1, k - 1, k, 45], 40)
+    lens[64 * 7 + 3] = 400                                           # tile 7 leaves the frame: rolls as a whole
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = np.frombuffer(b"ACGTacgt", np.uint8)[rng.integers(0, 8, int(offsets[-1]))].copy()
+    for r in rng.integers(0, len(lens), 300):                        # ~1 dirty read in 6, many tiles hit
+        if lens[r]:
+            host[int(offsets[r]) + int(rng.integers(0, lens[r]))] = ord("N")
+    for r in range(0, 64):                                           # tile 0: every non-empty read dirty, at its last byte
+        if lens[r]:
+            host[int(offsets[r + 1]) - 1] = ord("N")
+    host[int(offsets[64 * 7 + 5])] = ord("N") if lens[64 * 7 + 5] else host[int(offsets[64 * 7 + 5])]
+    bases, d_off = ctx.to_device(host), ctx.to_device(offsets)
+    o = orc.canonical_reduce(host, len(lens), 0, k, hasher_k=k, offsets=offsets)
+    for _ in range(2):
+        g = ctx.canonical_reduce(bases, len(lens), hint, k, _lib.HASH_LEX, k, 0, offsets=d_off)
+        _cmp_summary(g, o, True, False)
+
+
 # --------------------------------------------------------------- ragged reads
 
 def test_reduce_and_windows_ragged(ctx, orc):

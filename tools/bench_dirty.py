@@ -23,3 +23,23 @@ for frac in (0.0, 0.001, 0.005, 0.02, 0.1):
     ms = sorted(ts)[2]
     print(f"{100*frac:5.1f} % of the reads hold an N: {ms:7.3f} ms  {n*L/ms/1e6:6.0f} GB/s   n_valid {out.n_valid}")
     del bases
+# the same through the ragged layout (an offsets array, frame 160)
+import numpy as np
+d_off = ctx.to_device((np.arange(n + 1, dtype=np.uint64) * np.uint64(L)))
+for frac in (0.0, 0.005, 0.02):
+    bases = ctx.gen_reads(n * L)
+    nd = int(n * frac)
+    if nd:
+        g = torch.Generator(device="cuda"); g.manual_seed(1)
+        rd = torch.randperm(n, device="cuda", generator=g)[:nd]
+        pos = torch.randint(0, L, (nd,), device="cuda", generator=g)
+        bases[rd * L + pos] = ord("N")
+    out = ctx.canonical_reduce(bases, n, 160, k, offsets=d_off)
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); ctx.canonical_reduce_async(bases, n, 160, k, 0, 0, 0, d_off); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = sorted(ts)[2]
+    print(f"ragged, {100*frac:5.1f} % of the reads hold an N: {ms:7.3f} ms  {n*L/ms/1e6:6.0f} GB/s   n_valid {out.n_valid}")
+    del bases
