@@ -33,6 +33,9 @@
 #ifndef KMX_BS_PREFETCH
 #define KMX_BS_PREFETCH 1   // 1: next tile loaded into registers one tile ahead; 0: loads at tile start (fewer VGPRs, more waves)
 #endif
+#ifndef KMX_BS_WAVES16
+#define KMX_BS_WAVES16 3   // waves per SIMD of the 16-word frame (reads of 161..256 bases; 64 prefetch registers, 64 B of spills: +1..3 % over 2 waves)
+#endif
 #ifndef KMX_BSP_WAVES
 #define KMX_BSP_WAVES 3   // waves per SIMD of the packed-input variant
 #endif
@@ -104,7 +107,7 @@ __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, 
 #endif
 template <int K> constexpr bool bs_has_dirty_pass() { return KMX_BS_DIRTY && K <= 32; }   // (one more kernel per frame and k; two-word k keep the whole-tile path)
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, int PASS = 0>
-__global__ void __launch_bounds__(256, ((NW > 10 || K > 32 || PASS == 1) ? 2 : RAGGED ? KMX_BSR_WAVES : PACKED ? KMX_BSP_WAVES : KMX_BS_WAVES))   // 64 prefetch registers at NW=16; 2x counters at K>32
+__global__ void __launch_bounds__(256, ((K > 32 || PASS == 1) ? 2 : RAGGED ? KMX_BSR_WAVES : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : KMX_BS_WAVES))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets) {
