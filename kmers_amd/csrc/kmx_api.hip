@@ -139,6 +139,10 @@ int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k) {
             }
         }
         buf = n_tiles <= ctx->flags_bytes ? ctx->d_flags : nullptr;
+        if (!buf) {   // one byte per 64 reads: if even that cannot be had, nothing else will work either
+            std::snprintf(ctx->last_error, sizeof ctx->last_error, "kmx: no memory for %llu tile flags", (unsigned long long)n_tiles);
+            return KMX_E_NOMEM;
+        }
     }
     const unsigned long long want = (unsigned long long)reinterpret_cast<uintptr_t>(buf);
     if (want != ctx->dirty_desc) {
