@@ -332,8 +332,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 last_off = PACKED ? (L - 1u) * 16u : (chunks - 1u) * 16u;
     const bool short_rows = PACKED || chunks < 64u * (NW - 1);   // whole rows of the load grid may lie past the tile
     auto issue_loads_ragged = [&](const TileMeta& m) {
-        const uint8_t* __restrict__ tb = bases + m.base;
-        const u32 lo = (m.n_ch - 1u) * 16u;
+        // unconditional (a tile outside the frame reads 16 bytes of the queue block instead, and rolls per lane): loads under a
+        // branch make hipcc wait with vmcnt(0) where phase A would count them down
+        const uint8_t* __restrict__ tb = m.fits ? bases + m.base : reinterpret_cast<const uint8_t*>(queue);
+        const u32 lo = m.fits ? (m.n_ch - 1u) * 16u : 0u;
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             u32 off = lane16 + (u32)it * 1024u;
@@ -915,7 +917,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         if (tile < n_full) {
             meta_issue(tile);
             meta_finish(cur_m);
-            if (cur_m.fits) issue_loads_ragged(cur_m);
+            issue_loads_ragged(cur_m);
         }
         if (next_tile < n_full) meta_issue(next_tile);
     } else {
@@ -953,7 +955,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             __builtin_amdgcn_sched_barrier(0);
             if (next_tile < n_full) {
                 meta_finish(nx_m);            // offsets requested a whole iteration ago
-                if (nx_m.fits) issue_loads_ragged(nx_m);
+                issue_loads_ragged(nx_m);
             }
             __builtin_amdgcn_sched_barrier(0);
         } else {
