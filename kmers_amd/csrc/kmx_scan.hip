@@ -72,6 +72,7 @@ struct SinkReduce {
         }
     }
     __device__ __forceinline__ void begin_read(u64) {}
+    __device__ __forceinline__ void slow_step() {}   // every 16 bases of a rolled tile, wave converged
     __device__ __forceinline__ void end_read() {}
     __device__ __forceinline__ void tile_fast_done(u32 nwin) { acc.n_valid += nwin; }
     __device__ __forceinline__ void finish(const ReduceParams& p) { flush_acc(acc, p.out, FULL && p.want_hash, FULL && p.want_sumfw); }
@@ -104,6 +105,7 @@ struct SinkHist {
     __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void begin_read(u64) {}
+    __device__ __forceinline__ void slow_step() {}   // every 16 bases of a rolled tile, wave converged
     __device__ __forceinline__ void end_read() {}
     __device__ __forceinline__ void tile_fast_done(u32) {}
     __device__ __forceinline__ void finish(const HistParams&) {}
@@ -136,6 +138,7 @@ struct SinkHistLds {
     __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void begin_read(u64) {}
+    __device__ __forceinline__ void slow_step() {}   // every 16 bases of a rolled tile, wave converged
     __device__ __forceinline__ void end_read() {}
     __device__ __forceinline__ void tile_fast_done(u32) {}
     __device__ __forceinline__ void finish(const HistParams&) {
@@ -255,6 +258,7 @@ struct SinkHistPart {
     __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void begin_read(u64) {}
+    __device__ __forceinline__ void slow_step() { flush_rows(); }   // every 16 bases of a rolled tile, wave converged: drain the rings
     // slow path: up to W ids per lane since the last flush (what does not fit the rings went to the global table).
     // The final partial tile calls this with some lanes masked off; flush_rows needs the whole wave, so it waits.
     __device__ __forceinline__ void end_read() {
@@ -466,6 +470,7 @@ struct SinkWindowsT {
         }
         next = 0;
     }
+    __device__ __forceinline__ void slow_step() {}
     __device__ __forceinline__ void end_read() { zero_to(nwr); }
     __device__ __forceinline__ void tile_fast_done(u32) {}
     __device__ __forceinline__ void finish(const WindowsParams&) {}
@@ -628,7 +633,10 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         if (!tile_fits || __any(chunk_has_invalid(bad))) {
             // ---- rare: a non-ACGTacgt byte somewhere in this tile (or a ragged tile outside the frame) -> exact iterator semantics
             sink.begin_read(read);
-            roll_read(RAGGED ? bases + my_off : bases + read * (u64)L, RAGGED ? my_len : L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
+            u32 roll_max = L;
+            if constexpr (RAGGED) roll_max = (u32)wave_max_u32(my_len);
+            roll_read_stepped(RAGGED ? bases + my_off : bases + read * (u64)L, RAGGED ? my_len : L, roll_max, k,
+                              [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); }, [&]() { sink.slow_step(); });
             sink.end_read();
             continue;
         }
