@@ -120,7 +120,7 @@ void* big_scratch(void* user, size_t bytes);
 int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k) {
     const uint64_t n_tiles = n_reads >> 6;
     uint8_t* buf = nullptr;
-    if (n_tiles && k >= 13 && k <= 31) {   // the k with a bit-sliced kernel (and so a second pass)
+    if (n_tiles && ((k >= 13 && k <= 31) || (k >= 33 && k <= 63 && (k & 1u)))) {   // the k with a bit-sliced kernel (and so a second pass)
         if (n_tiles > ctx->flags_bytes) {
             if (ctx->d_flags) {
                 (void)hipStreamSynchronize(ctx->stream);
@@ -431,7 +431,8 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
     if (reads->n_reads == 0) return KMX_OK;
     if (!reads->d_offsets) {
         bool handled = false;
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 8, ctx->stream));   // queue heads + the "a tile was flagged" word
+        if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
         KMX_HIP(ctx, kmx::launch_scan_bitsliced2(reads->d_bases, reads->n_reads, reads->read_len, k, with_hash != 0, d_out,
                                                  ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;

@@ -105,7 +105,7 @@ __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, 
 #ifndef KMX_BS_DIRTY
 #define KMX_BS_DIRTY 1
 #endif
-template <int K> constexpr bool bs_has_dirty_pass() { return KMX_BS_DIRTY && K <= 32; }   // (one more kernel per frame and k; two-word k keep the whole-tile path)
+template <int K> constexpr bool bs_has_dirty_pass() { return KMX_BS_DIRTY != 0; }   // (one more kernel per frame and k)
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, int PASS = 0>
 __global__ void __launch_bounds__(256, ((K > 32 || PASS == 1) ? 2 : RAGGED ? KMX_BSR_WAVES : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : KMX_BS_WAVES))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,

@@ -261,6 +261,27 @@ def test_reduce_ragged_reads_with_invalid_bytes_second_pass(ctx, orc, k, hint):
         _cmp_summary(g, o, True, False)
 
 
+@pytest.mark.parametrize("k", [63, 33, 47])
+def test_reduce2_reads_with_invalid_bytes_second_pass(ctx, orc, k):
+    """[u64;2] k-mers: the second pass for tiles with invalid bytes (every read of a tile dirty, scattered, read ends)"""
+    rng = np.random.default_rng(k)
+    L, n = 150, 64 * 20 + 9
+    host = np.frombuffer(b"ACGTacgt", np.uint8)[rng.integers(0, 8, n * L)].copy()
+    reads = host.reshape(n, L)
+    reads[0:64, :][np.arange(64), rng.integers(0, L, 64)] = ord("N")
+    reads[64 * 2 + 5, L - 1] = ord("N")
+    reads[64 * 2 + 6, 0] = ord("n")
+    for t in range(4, 20, 2):
+        reads[64 * t + int(rng.integers(0, 64)), int(rng.integers(0, L))] = int(rng.integers(0, 256))
+    reads[n - 2, 70] = ord("N")
+    bases = ctx.to_device(host)
+    for with_hash in (True, False):
+        o = orc.canonical_reduce2(host, n, L, k, with_hash)
+        for _ in range(2):
+            g = ctx.canonical_reduce2(bases, n, L, k, with_hash)
+            assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+
 # --------------------------------------------------------------- ragged reads
 
 def test_reduce_and_windows_ragged(ctx, orc):
