@@ -218,38 +218,39 @@ __device__ __forceinline__ void roll_read(const uint8_t* __restrict__ s, u32 len
     for (; l < len; ++l) step(s[l], l);
 }
 
-// The same walk for a whole wave in lockstep: every lane rolls its own read, and after every 16 bases -- a point all lanes
-// reach together, `maxlen` = the longest read of the wave -- `every16()` runs with the wave converged (the partitioned
-// histogram drains its LDS rings there; without that a rolled tile overflows them and falls back to global atomics).
-template <typename Emit, typename Every>
-__device__ __forceinline__ void roll_read_stepped(const uint8_t* __restrict__ s, u32 len, u32 maxlen, u32 k, Emit&& emit, Every&& every16) {
+// The same walk for a whole wave in lockstep: every lane rolls its own read, and `block(wb)` runs with the wave converged
+// each time the 16 windows [16 wb, 16 wb + 16) are complete in every lane (after base k-1 + 16 (wb+1)); `maxlen` = the
+// longest read of the wave.  The partitioned histogram drains its LDS rings there (without that a rolled tile overflows
+// them and falls back to global atomics); materialise mode writes the block out as it does on its fast path.
+template <typename Emit, typename Block>
+__device__ __forceinline__ void roll_read_stepped(const uint8_t* __restrict__ s, u32 len, u32 maxlen, u32 k, Emit&& emit, Block&& block) {
     const u64 mask = mask2k(k);
     const u32 top = 2u * k - 2u;
     u64 fw = 0, rc = ~0ull;
     int last_invalid = -1;
-    auto step = [&](u32 c, u32 l) {
-        const u32 b = encode_base(c);
-        if (b < 4u) {
-            fw = (fw >> 2) | ((u64)b << top);
-            rc = mask & ((rc << 2) | (u64)(3u - b));
-            if ((int)l - last_invalid >= (int)k) emit(l + 1u - k, fw, rc);
-        } else {
-            last_invalid = (int)l;
-        }
-    };
-    for (u32 l0 = 0; l0 < maxlen; l0 += 16u) {
-        if (l0 + 16u <= len) {
-            u64 v0, v1;
-            __builtin_memcpy(&v0, s + l0, 8);
-            __builtin_memcpy(&v1, s + l0 + 8u, 8);
+    u32 l = 0;
+    for (u32 wb = 0;; ++wb) {
+        const u32 lend = k - 1u + 16u * (wb + 1u);
+        const u32 stop = lend < len ? lend : len;
+        auto step = [&](u32 c, u32 at) {
+            const u32 b = encode_base(c);
+            if (b < 4u) {
+                fw = (fw >> 2) | ((u64)b << top);
+                rc = mask & ((rc << 2) | (u64)(3u - b));
+                if ((int)at - last_invalid >= (int)k) emit(at + 1u - k, fw, rc);
+            } else {
+                last_invalid = (int)at;
+            }
+        };
+        for (; l + 8u <= stop; l += 8u) {   // 8 bases per (unaligned) global_load_dwordx2
+            u64 v;
+            __builtin_memcpy(&v, s + l, 8);
 #pragma unroll
-            for (u32 j = 0; j < 8u; ++j) step((u32)(v0 >> (8u * j)) & 0xFFu, l0 + j);
-#pragma unroll
-            for (u32 j = 0; j < 8u; ++j) step((u32)(v1 >> (8u * j)) & 0xFFu, l0 + 8u + j);
-        } else {
-            for (u32 l = l0; l < len && l < l0 + 16u; ++l) step(s[l], l);
+            for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
         }
-        every16();
+        for (; l < stop; ++l) step(s[l], l);
+        block(wb);
+        if (lend >= maxlen) break;
     }
 }
 

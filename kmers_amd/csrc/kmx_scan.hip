@@ -72,7 +72,10 @@ struct SinkReduce {
         }
     }
     __device__ __forceinline__ void begin_read(u64) {}
-    __device__ __forceinline__ void slow_step() {}   // every 16 bases of a rolled tile, wave converged
+    __device__ __forceinline__ void slow_block(u32) {}   // a rolled tile: the wave has completed 16 more windows per read
+    __device__ __forceinline__ void tile_slow_begin(u64 read) { begin_read(read); }
+    __device__ __forceinline__ void tile_slow_emit(u32 pos, u64 fw, u64 rc) { slow(pos, fw, rc); }
+    __device__ __forceinline__ void tile_slow_end() { end_read(); }
     __device__ __forceinline__ void end_read() {}
     __device__ __forceinline__ void tile_fast_done(u32 nwin) { acc.n_valid += nwin; }
     __device__ __forceinline__ void finish(const ReduceParams& p) { flush_acc(acc, p.out, FULL && p.want_hash, FULL && p.want_sumfw); }
@@ -105,7 +108,10 @@ struct SinkHist {
     __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void begin_read(u64) {}
-    __device__ __forceinline__ void slow_step() {}   // every 16 bases of a rolled tile, wave converged
+    __device__ __forceinline__ void slow_block(u32) {}   // a rolled tile: the wave has completed 16 more windows per read
+    __device__ __forceinline__ void tile_slow_begin(u64 read) { begin_read(read); }
+    __device__ __forceinline__ void tile_slow_emit(u32 pos, u64 fw, u64 rc) { slow(pos, fw, rc); }
+    __device__ __forceinline__ void tile_slow_end() { end_read(); }
     __device__ __forceinline__ void end_read() {}
     __device__ __forceinline__ void tile_fast_done(u32) {}
     __device__ __forceinline__ void finish(const HistParams&) {}
@@ -138,7 +144,10 @@ struct SinkHistLds {
     __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void begin_read(u64) {}
-    __device__ __forceinline__ void slow_step() {}   // every 16 bases of a rolled tile, wave converged
+    __device__ __forceinline__ void slow_block(u32) {}   // a rolled tile: the wave has completed 16 more windows per read
+    __device__ __forceinline__ void tile_slow_begin(u64 read) { begin_read(read); }
+    __device__ __forceinline__ void tile_slow_emit(u32 pos, u64 fw, u64 rc) { slow(pos, fw, rc); }
+    __device__ __forceinline__ void tile_slow_end() { end_read(); }
     __device__ __forceinline__ void end_read() {}
     __device__ __forceinline__ void tile_fast_done(u32) {}
     __device__ __forceinline__ void finish(const HistParams&) {
@@ -258,7 +267,10 @@ struct SinkHistPart {
     __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void begin_read(u64) {}
-    __device__ __forceinline__ void slow_step() { flush_rows(); }   // every 16 bases of a rolled tile, wave converged: drain the rings
+    __device__ __forceinline__ void slow_block(u32) { flush_rows(); }   // a rolled tile: 16 more windows per read, wave converged: drain the rings
+    __device__ __forceinline__ void tile_slow_begin(u64 read) { begin_read(read); }
+    __device__ __forceinline__ void tile_slow_emit(u32 pos, u64 fw, u64 rc) { slow(pos, fw, rc); }
+    __device__ __forceinline__ void tile_slow_end() { end_read(); }
     // slow path: up to W ids per lane since the last flush (what does not fit the rings went to the global table).
     // The final partial tile calls this with some lanes masked off; flush_rows needs the whole wave, so it waits.
     __device__ __forceinline__ void end_read() {
@@ -470,7 +482,39 @@ struct SinkWindowsT {
         }
         next = 0;
     }
-    __device__ __forceinline__ void slow_step() {}
+    // A tile rolled per lane (an invalid byte in it) is staged and written back like a fast one -- skipped windows stay the
+    // zeros the slots are pre-filled with -- instead of 8-byte stores 1 KB apart: tile_slow_* are the hooks of that path
+    // (begin_read / slow / end_read remain the direct-store path of the final partial tile).
+    u64 slow_read0;
+    bool slow_staged;
+    __device__ __forceinline__ void prefill(u32 o0) {     // zero the staging slots of windows [o0, o0+16)
+#pragma unroll 4
+        for (u32 sI = 0; sI < 16u; ++sI) {
+            const u32 o = o0 + sI;
+            if (out1) Tfw[lane * RPITCH + (o & 31u)] = 0;
+            else {
+                const u32 at = lane * PITCH + (o & 15u);
+                if (p.fw) Tfw[at] = 0;
+                if (p.rc) Trc[at] = 0;
+                if (p.canon) Tcn[at] = 0;
+                if (p.flags) TF[lane * 16u + (o & 15u)] = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ void tile_slow_begin(u64 read) {
+        begin_read(read);
+        slow_read0 = read - lane;
+        prefill(0);
+    }
+    __device__ __forceinline__ void tile_slow_emit(u32 pos, u64 fw, u64 rc) { fast(pos, fw, rc); }
+    __device__ __forceinline__ void slow_block(u32 wb) {
+        const u32 o0 = 16u * wb;
+        if (p.win_offsets == nullptr && o0 >= W) return;            // (uniform layout: past the last window block)
+        const u32 cnt = p.win_offsets ? 16u : (W - o0 < 16u ? W - o0 : 16u);
+        block_done(slow_read0, o0, cnt);
+        prefill(o0 + 16u);
+    }
+    __device__ __forceinline__ void tile_slow_end() {}
     __device__ __forceinline__ void end_read() { zero_to(nwr); }
     __device__ __forceinline__ void tile_fast_done(u32) {}
     __device__ __forceinline__ void finish(const WindowsParams&) {}
@@ -632,12 +676,12 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
 
         if (!tile_fits || __any(chunk_has_invalid(bad))) {
             // ---- rare: a non-ACGTacgt byte somewhere in this tile (or a ragged tile outside the frame) -> exact iterator semantics
-            sink.begin_read(read);
+            sink.tile_slow_begin(read);
             u32 roll_max = L;
             if constexpr (RAGGED) roll_max = (u32)wave_max_u32(my_len);
             roll_read_stepped(RAGGED ? bases + my_off : bases + read * (u64)L, RAGGED ? my_len : L, roll_max, k,
-                              [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); }, [&]() { sink.slow_step(); });
-            sink.end_read();
+                              [&](u32 pos, u64 fw, u64 rc) { sink.tile_slow_emit(pos, fw, rc); }, [&](u32 wb) { sink.slow_block(wb); });
+            sink.tile_slow_end();
             continue;
         }
 
