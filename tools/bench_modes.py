@@ -36,6 +36,6 @@ for k in (31, 21):
         counts = torch.zeros(1 << b, dtype=torch.int64, device="cuda")
         timeit(f"histogram k={k} lex b={b}", lambda: ctx.histogram(bases, n, L, k, _lib.HASH_LEX, k, b, counts=counts), n * L, tot)
 k = 63
-timeit("reduce2 k=63 ([u64;2], generic kernel)", lambda: ctx.canonical_reduce2(bases, n, L, k, True), n * L, n * (L - k + 1))
+timeit("reduce2 k=63 ([u64;2], bit-sliced)", lambda: ctx.canonical_reduce2(bases, n, L, k, True), n * L, n * (L - k + 1))
 off = ctx.to_device(np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
-timeit("reduce k=31 ragged offsets (generic kernel)", lambda: ctx.canonical_reduce(bases, n, 0, 31, offsets=off), n * L, n * 120)
+timeit("reduce k=31 ragged offsets (bit-sliced)", lambda: ctx.canonical_reduce(bases, n, 0, 31, offsets=off), n * L, n * 120)
