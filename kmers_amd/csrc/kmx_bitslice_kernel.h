@@ -21,8 +21,9 @@
 //      lane p of each half-wave ends with plane p -> LDS plane array of the half's 32 reads
 //   D. the 64 lanes split the 2*(L-k+1) (set, window) items; each item = 2k plane loads
 //      (ds_read_b64), a k-step v_bitop3 ripple and 2k masked popcounts.
-// A tile with any non-ACGTacgt byte, and the final partial tile, take roll_read (exact iterator
-// semantics, canonical_kmer_iterator.rs:42-70) exactly like the word-domain kernel.
+// The final partial tile takes roll_read (exact iterator semantics, canonical_kmer_iterator.rs:42-70).  A tile with a
+// non-ACGTacgt byte is flagged and run by a second pass of this kernel (PASS = 1) with the offending reads blanked out
+// and rolled separately, 64 at a time -- see "reads with an invalid byte" in the kernel.
 #pragma once
 #include "kmx_device.h"
 
@@ -30,9 +31,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef KMX_BS_PREFETCH
-#define KMX_BS_PREFETCH 1   // 1: next tile loaded into registers one tile ahead; 0: loads at tile start (fewer VGPRs, more waves)
-#endif
 #ifndef KMX_BS_WAVES16
 #define KMX_BS_WAVES16 3   // waves per SIMD of the 16-word frame (reads of 161..256 bases; 64 prefetch registers, 64 B of spills: +1..3 % over 2 waves)
 #endif
