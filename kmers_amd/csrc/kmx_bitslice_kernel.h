@@ -46,6 +46,9 @@
 #ifndef KMX_BS_P1D
 #define KMX_BS_P1D 2      // pass 1: ripple steps between the LDS request of a plane and its use
 #endif
+#ifndef KMX_BS_RUNR
+#define KMX_BS_RUNR 2      // pass 2: planes per run when KMX_BS_RUN2 (3 and 4 measured 0.3 % slower)
+#endif
 #ifndef KMX_BS_RUN2
 #define KMX_BS_RUN2 1      // pass 2: two planes per (v_and run, v_bcnt run) pair when WPL <= 4
 #endif
@@ -815,25 +818,31 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             constexpr int NPL = (KMX_BS_ABLATE & 1) ? 1 : K + WPL - 1;
 #if KMX_BS_PRIO
             if constexpr (KMX_BS_RUN2 && WPL <= 4) {
-            // two planes per run (4*WPL v_and, then 4*WPL v_bcnt at raised priority): 0.8 % over one plane per run
-            u64 vcur = KMX_PLANE(0), vcur2 = KMX_PLANE(NPL > 1 ? 1 : 0);
+            // R planes per run (2*R*WPL v_and, then 2*R*WPL v_bcnt at raised priority): two planes are 0.8 % over one
+            constexpr int R = KMX_BS_RUNR;
+            u64 vcur[R];
 #pragma unroll
-            for (int i = 0; i < NPL; i += 2) {
-                // (requesting the planes two pairs ahead instead of one changed nothing: pass 2 does not wait on LDS)
-                const u64 vnext = KMX_PLANE(i + 2 < NPL ? i + 2 : i), vnext2 = KMX_PLANE(i + 3 < NPL ? i + 3 : i);
+            for (int h = 0; h < R; ++h) vcur[h] = KMX_PLANE(h < NPL ? h : 0);
+#pragma unroll
+            for (int i = 0; i < NPL; i += R) {
+                // (requesting the planes two runs ahead instead of one changed nothing: pass 2 does not wait on LDS)
+                u64 vnext[R];
+#pragma unroll
+                for (int h = 0; h < R; ++h) vnext[h] = KMX_PLANE(i + R + h < NPL ? i + R + h : i);
                 __builtin_amdgcn_sched_barrier(0);
-                u32 x[4 * WPL];
+                u32 x[2 * R * WPL];
 #pragma unroll
-                for (int w = 0; w < WPL; ++w) {
-                    x[2 * w] = m[w] & (u32)vcur;
-                    x[2 * w + 1] = m[w] & (u32)(vcur >> 32);
-                    x[2 * WPL + 2 * w] = m[w] & (u32)vcur2;
-                    x[2 * WPL + 2 * w + 1] = m[w] & (u32)(vcur2 >> 32);
+                for (int h = 0; h < R; ++h) {
+#pragma unroll
+                    for (int w = 0; w < WPL; ++w) {
+                        x[2 * WPL * h + 2 * w] = m[w] & (u32)vcur[h];
+                        x[2 * WPL * h + 2 * w + 1] = m[w] & (u32)(vcur[h] >> 32);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < R; ++h) {
                     if (i + h >= NPL) continue;
 #pragma unroll
                     for (int w = 0; w < WPL; ++w) {
@@ -846,8 +855,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(0);
-                vcur = vnext;
-                vcur2 = vnext2;
+#pragma unroll
+                for (int h = 0; h < R; ++h) vcur[h] = vnext[h];
             }
             } else
 #endif
