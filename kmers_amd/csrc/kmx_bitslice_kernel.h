@@ -107,8 +107,18 @@ __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, 
 #define KMX_BS_DIRTY 1
 #endif
 template <int K> constexpr bool bs_has_dirty_pass() { return KMX_BS_DIRTY != 0; }   // (one more kernel per frame and k)
+// Waves per SIMD of the ASCII kernel on the 10-word frame.  The counters D[] grow with k: up to k = 23 (k = 25 with
+// <= 4 windows per lane) the kernel fits 128 registers with at most 16 bytes of spills and a 4th wave pays (k = 21: 65 ->
+// 69 % of the roofline, k = 23 / 25: +4 %); at k = 31 the 56 bytes it would spill sit in the main loop (-15 %).
+template <int K, int WPL> constexpr int bs_waves_ascii() {
+#ifdef KMX_BS_WAVES_FORCE
+    return KMX_BS_WAVES_FORCE;
+#else
+    return (K <= 23 || (K <= 25 && WPL <= 4)) ? 4 : KMX_BS_WAVES;
+#endif
+}
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, int PASS = 0>
-__global__ void __launch_bounds__(256, ((K > 32 || PASS == 1) ? 2 : RAGGED ? KMX_BSR_WAVES : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : KMX_BS_WAVES))   // 64 prefetch registers at NW=16; 2x counters at K>32
+__global__ void __launch_bounds__(256, ((K > 32 || PASS == 1) ? 2 : RAGGED ? KMX_BSR_WAVES : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets) {
