@@ -107,14 +107,15 @@ __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, 
 #define KMX_BS_DIRTY 1
 #endif
 template <int K> constexpr bool bs_has_dirty_pass() { return KMX_BS_DIRTY != 0; }   // (one more kernel per frame and k)
-// Waves per SIMD of the ASCII kernel on the 10-word frame.  The counters D[] grow with k: up to k = 23 (k = 25 with
+// Waves per SIMD of the ASCII kernel on the 10-word frame.  The counters D[] grow with k: up to k = 23 (k = 26 with
 // <= 4 windows per lane) the kernel fits 128 registers with at most 16 bytes of spills and a 4th wave pays (k = 21: 65 ->
-// 69 % of the roofline, k = 23 / 25: +4 %); at k = 31 the 56 bytes it would spill sit in the main loop (-15 %).
+// 69 % of the roofline, k = 23 / 25 / 26: +4 %); k = 27 / 28 are neutral (24 B), k = 29 / 30 lose 3-6 % (40 B), and at
+// k = 31 the 56 bytes it would spill include a row of the prefetch (-15 %).
 template <int K, int WPL> constexpr int bs_waves_ascii() {
 #ifdef KMX_BS_WAVES_FORCE
     return KMX_BS_WAVES_FORCE;
 #else
-    return (K <= 23 || (K <= 25 && WPL <= 4)) ? 4 : KMX_BS_WAVES;
+    return (K <= 23 || (K <= 26 && WPL <= 4)) ? 4 : KMX_BS_WAVES;
 #endif
 }
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, int PASS = 0>
