@@ -348,9 +348,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         // branch make hipcc wait with vmcnt(0) where phase A would count them down
         const uint8_t* __restrict__ tb = m.fits ? bases + m.base : reinterpret_cast<const uint8_t*>(queue);
         const u32 lo = m.fits ? (m.n_ch - 1u) * 16u : 0u;
+        u32 l16 = lane16;                       // (opaque copy: see issue_loads)
+        asm volatile("" : "+v"(l16));
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            u32 off = lane16 + (u32)it * 1024u;
+            u32 off = l16 + (u32)it * 1024u;
             off = off < lo ? off : lo;
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb + off));

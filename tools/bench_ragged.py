@@ -6,7 +6,7 @@ from kmers_amd.api import Context
 
 ctx = Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
-k = 31
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 31
 rng = np.random.default_rng(1)
 for name, lens, hint in (("all 150 (hint 160)", np.full(n, 150), 160), ("all 150 (no hint)", np.full(n, 150), 0),
                          ("uniform 100..160 (hint 160)", rng.integers(100, 161, n), 160),
