@@ -1,12 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- canonical k-mers/s at k=31 on 150 bp reads (BASELINE.json metric), MI355X.
 
-One "step" = one pass of the hot path (kmx_canonical_reduce: encode + sliding window + reverse
-complement + canonical min + wrapping-sum reduce) over this rank's shard of synthetic reads,
-already resident in HBM.  N=1 workload = BASELINE configs[1]: 1e8 x 150 bp reads, k=31
-(15.0 GB in, 1.2e10 canonical k-mers per step).  N>1: reads shard embarrassingly, one process
-per GPU, the same 1e8 reads per GPU (weak scaling), no data-path collective; torch.distributed
-(RCCL) is used only for the barrier / max-over-ranks timing and the checksum combine.
+One "step" = one pass of the hot path over this rank's shard of synthetic reads, already resident in HBM:
+kmx_canonical_reduce (encode + sliding window + reverse complement + canonical min + wrapping-sum reduce), or, for
+--config 4, kmx_histogram + the RCCL all-reduce of the bucket counters.
+
+  --config 1    (default) BASELINE configs[1]: k=31, 1e8 x 150 bp per GPU (15.0 GB in, 1.2e10 canonical k-mers per step)
+  --config 2    BASELINE configs[2]: k=21 or k=63 (-k 21 | -k 63; [u64;1] vs [u64;2] storage), 1e8 x 150 bp
+  --config 3    BASELINE configs[3]: k=31 + LexHasher word hash folded in, 1.25e8 reads per GPU (1e9 over 8 GPUs)
+  --config 4    BASELINE configs[4]: k=31 bucket histogram (2^20 buckets) per GPU, then all-reduce over RCCL/xGMI,
+                scan and all-reduce timed separately
+
+N > 1: reads shard embarrassingly, one process per GPU, the same number of reads per GPU (weak scaling), no data-path
+collective; torch.distributed (backend "nccl" = RCCL) carries the barrier, the max-over-ranks timing and the checksum
+combine; the histogram all-reduce goes through libkmx's own RCCL communicator (kmx_comm_*, include/kmx.h) when it can be
+created, through torch.distributed otherwise (stated in the line).  A bare `python bench.py --gpus N` (no torchrun)
+starts the N ranks itself as fresh child processes; under torchrun (WORLD_SIZE set) it is one of the ranks.
+Every line states `rccl_ranks` = the number of ranks a real all-reduce saw, and the run fails if that is not --gpus.
 
 Prints ONE JSON line on rank 0.
 """
@@ -15,7 +25,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -38,22 +51,41 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(host_sample, n_reads, L, k, seconds_target=20.0):
-    """Time the CPU oracle (plain-C port of the reference's naive_impl streaming iterator,
-    canonical_kmer_iterator.rs:42-116) on this box's host cores: 1 thread and all threads."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+
+def cpu_baseline(host_sample, n_reads, L, k, seconds_target=24.0):
+    """Time the CPU oracle (plain-C port of the reference's naive_impl path) on this box's host cores.
+    Three consumer shapes, each at 1 thread and at all usable threads:
+      (ii)  streaming CanonicalKmerIterator + canonical word sum (canonical_kmer_iterator.rs:42-116) -- `value`
+      (i)   per-window Kmer::from + sum == compute_naive (benches/simple_benchmark.rs:14-22)
+      (iii) (ii) + hash_one(LexHasherState::new(k)) folded in (hash.rs:10-20,60-71)"""
+    import ctypes as C
+
     import numpy as np
     from oracle import oracle
 
     lib = oracle.lib(native=True)
     cores = usable_cores()
+    per = L - k + 1
 
-    def run(nthreads, reads_each, reps=1):
+    def run_iter(hk):
+        def one(lo, reads_each):
+            return oracle.canonical_reduce(host_sample[lo * L:(lo + reads_each) * L], reads_each, L, k, hasher_k=hk, native_lib=lib).n_valid
+        return one
+
+    def run_naive(lo, reads_each):   # compute_naive over the same bytes taken as one string (the bench's own shape: one long string)
+        seg = host_sample[lo * L:(lo + reads_each) * L]
+        out = C.c_uint64()
+        lib.kmo_compute_naive(seg.ctypes.data_as(C.POINTER(C.c_uint8)), seg.size, k, C.byref(out))
+        return seg.size - k + 1
+
+    def timed(fn, nthreads, reads_each, reps=1):
         outs = [0] * nthreads
 
         def work(i):
             lo = (i * reads_each) % max(n_reads - reads_each + 1, 1)
             for _ in range(reps):   # the sample is re-scanned when it is smaller than the time budget
-                outs[i] += oracle.canonical_reduce(host_sample[lo * L:(lo + reads_each) * L], reads_each, L, k, native_lib=lib).n_valid
+                outs[i] += fn(lo, reads_each)
 
         ts = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
         t0 = time.perf_counter()
@@ -64,18 +96,23 @@ def cpu_baseline(host_sample, n_reads, L, k, seconds_target=20.0):
         dt = time.perf_counter() - t0
         return sum(outs) / dt, dt
 
-    # calibrate each leg on a small slice, then size its sample for ~seconds_target/2 of wall time
-    per = L - k + 1
-    rate1, _ = run(1, min(n_reads, 20_000))
-    want_1t = max(20_000, rate1 * (seconds_target / 2) / per)
-    reads_1t = int(min(n_reads, want_1t))
-    reps_1t = max(1, int(round(want_1t / reads_1t)))
-    rate1, dt1 = run(1, reads_1t, reps_1t)
-    rate_mt, _ = run(cores, min(n_reads, 20_000))
-    want_mt = max(20_000, rate_mt / cores * (seconds_target / 2) / per)
-    reads_mt = int(min(n_reads // cores if n_reads >= cores * 20_000 else n_reads, want_mt))
-    reps_mt = max(1, int(round(want_mt / reads_mt)))
-    rate_mt, dt_mt = run(cores, reads_mt, reps_mt)
+    def leg(fn, nthreads, seconds):
+        """calibrate on a small slice, then size the sample for ~`seconds` of wall time"""
+        rate, _ = timed(fn, nthreads, min(n_reads, 20_000))
+        want = max(20_000, rate / nthreads * seconds / per)
+        reads = int(min(n_reads // nthreads if n_reads >= nthreads * 20_000 else n_reads, want))
+        reps = max(1, int(round(want / reads)))
+        rate, dt = timed(fn, nthreads, reads, reps)
+        return rate, dt, reads, reps
+
+    s = seconds_target / 8.0
+    it0, itk = run_iter(0), run_iter(k)
+    r_mt, dt_mt, reads_mt, reps_mt = leg(it0, cores, 2 * s)
+    r_1t, dt_1t, reads_1t, reps_1t = leg(it0, 1, 2 * s)
+    n_mt, dtn_mt, _, _ = leg(run_naive, cores, s)
+    n_1t, dtn_1t, _, _ = leg(run_naive, 1, s)
+    h_mt, dth_mt, _, _ = leg(itk, cores, s)
+    h_1t, dth_1t, _, _ = leg(itk, 1, s)
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -86,56 +123,221 @@ def cpu_baseline(host_sample, n_reads, L, k, seconds_target=20.0):
     except OSError:
         pass
     return {
-        "value": rate_mt, "unit": "canonical k-mers/s", "cores": cores, "kind": "port",
-        "value_1thread": rate1,
+        "value": r_mt, "unit": "canonical k-mers/s", "cores": cores, "kind": "port",
+        "value_1thread": r_1t,
+        "variants": {
+            "streaming_iterator": {"all_threads": r_mt, "one_thread": r_1t, "ref": "canonical_kmer_iterator.rs:42-116"},
+            "per_window_compute_naive": {"all_threads": n_mt, "one_thread": n_1t, "unit": "k-mers/s (not canonicalised)",
+                                         "ref": "benches/simple_benchmark.rs:14-22"},
+            "streaming_iterator_lex_hash": {"all_threads": h_mt, "one_thread": h_1t, "ref": "hash.rs:10-20,60-71"},
+        },
         "sample": f"{cores} threads x {reads_mt} reads x {reps_mt} passes x {L} bp (same synthetic stream as the GPU run), k={k}, "
-                  f"{dt_mt:.1f}s; 1 thread x {reads_1t} reads x {reps_1t} passes {dt1:.1f}s; oracle = plain-C port of "
-                  f"naive_impl CanonicalKmerIterator, gcc -O3 -march=native",
+                  f"{dt_mt:.1f}s; 1 thread x {reads_1t} reads x {reps_1t} passes {dt_1t:.1f}s; per-window and lex-hash variants "
+                  f"{dtn_mt + dtn_1t + dth_mt + dth_1t:.1f}s more; oracle = plain-C port of naive_impl, gcc -O3 -march=native",
         "cpu_model": model,
     }
 
 
-def main():
+# ------------------------------------------------------------------------------------------------ launch of N ranks
+
+def passthrough_args(argv):
+    return [a for a in argv]
+
+
+def spawn_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` without torchrun: start N fresh child processes, one per GPU.  This parent never
+    touches the GPU (and never execs): it only waits.  Rank 0's stdout is ours, so its JSON line is the output."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "KMX_BENCH_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = set(range(args.gpus))
+    while alive:
+        for r in list(alive):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            alive.discard(r)
+            if c != 0 and rc == 0:
+                rc = c
+                sys.stderr.write(f"bench.py: rank {r} exited with {c}; stopping the other ranks\n")
+                for o in alive:
+                    procs[o].terminate()   # exactly the processes started above
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ HBM traffic (PMC)
+
+def measure_traffic(argv, log=sys.stderr):
+    """HBM bytes per launch of the scan kernel from the TCC counters, measured in THIS run: two child processes of
+    this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need separate passes, and no tracing flag is mixed
+    in), each launching the calibration stream (kmx_calib_stream_read: a known byte count in the scan's own access
+    pattern) and the scan.  Read correction = known bytes / counted bytes of the calibration kernel in the same pass
+    (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half of a wide coalesced read).  None if rocprofv3 is absent
+    or a pass fails -- the bench line then carries traffic: null."""
+    import csv
+    import glob
+
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not prof:
+        return None, "rocprofv3 not found"
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="kmx_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--",
+                   sys.executable, os.path.abspath(__file__), *argv, "--pmc-child"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} exited with {r.returncode}: {r.stderr[-300:]}"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {ctr}: no counter csv"
+            per = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != ctr:
+                        continue
+                    name = row["Kernel_Name"]
+                    key = "calib" if "calib_stream_read_kernel" in name else ("scan" if ("scan_" in name or "reduce" in name or "hist" in name) else None)
+                    if key:
+                        per.setdefault(key, {}).setdefault(name, []).append(float(row["Counter_Value"]))
+            res[ctr] = per
+        return res, None
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def traffic_from_counters(res, algo_read_bytes, n_step_launch_sets):
+    """counter csv digest -> bytes per step.  Counter values are KiB.  All kernels of a step are summed
+    (main pass + second pass of the bit-sliced scan; the passes of the partitioned histogram)."""
+    fetch, write = res["FETCH_SIZE"], res["WRITE_SIZE"]
+    if "calib" not in fetch or "scan" not in fetch:
+        return None
+    calib_counts = [v for vs in fetch["calib"].values() for v in vs]
+    calib_kib = sum(calib_counts) / len(calib_counts)
+    corr = algo_read_bytes / (calib_kib * 1024.0)
+    fetch_kib = sum(sum(vs) for vs in fetch["scan"].values()) / n_step_launch_sets
+    write_kib = sum(sum(vs) for vs in write.get("scan", {}).values()) / n_step_launch_sets
+    return {
+        "bytes_per_step": fetch_kib * 1024.0 * corr + write_kib * 1024.0,
+        "FETCH_SIZE_KiB_per_step": fetch_kib, "WRITE_SIZE_KiB_per_step": write_kib,
+        "read_correction": corr,
+        "read_correction_from": f"kmx_calib_stream_read over the same buffer in the same pass: {algo_read_bytes:.0f} B known / {calib_kib * 1024.0:.0f} B counted",
+        "write_correction": 1.0,
+    }
+
+
+# ------------------------------------------------------------------------------------------------ the bench itself
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads-per-gpu", type=int, default=100_000_000)
+    ap.add_argument("--config", default="1", choices=["1", "2", "3", "4"], help="BASELINE.json configs[N] (see the module docstring)")
+    ap.add_argument("--reads-per-gpu", type=int, default=None)
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("-k", type=int, default=31)
+    ap.add_argument("-k", type=int, default=None)
     ap.add_argument("--hash", action="store_true", help="also fold the LexHasher(k) word hash (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
+    ap.add_argument("--sustain-steps", type=int, default=1000,
+                    help="after the timed region: this many more back-to-back steps, timed as one interval (the package reaches its "
+                         "power cap within ~1 s, so a 20-step window flatters the kernel); reported in 'sustained'")
     ap.add_argument("--packed", action="store_true",
                     help="reads held as a 2-bit SeqVector (kmx_seqvec_canonical_reduce): 0.25 B per base from HBM (SURVEY 8f row f1; not the metric)")
     ap.add_argument("--histogram", type=int, default=0, metavar="LOG2_BUCKETS",
-                    help="also time the bucket histogram + RCCL all-reduce (BASELINE configs[4]); reported in 'histogram'")
-    args = ap.parse_args()
+                    help="config 1-3: additionally time one bucket histogram + all-reduce after the timed region")
+    ap.add_argument("--dist-single", action="store_true", help="create the nccl process group even for one rank (exercises RCCL on a 1-GPU box)")
+    ap.add_argument("--spawn-selftest", action="store_true", help=argparse.SUPPRESS)   # tests: ranks only rendezvous (gloo, no GPU) and count themselves
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)        # internal: the run under rocprofv3 --pmc
+    args = ap.parse_args(argv)
+    if args.config == "2":
+        args.k = args.k or 21
+        if args.k not in (21, 63):
+            ap.error("--config 2 is k=21 or k=63")
+    if args.config in ("3", "4"):
+        args.k = args.k or 31
+        args.reads_per_gpu = args.reads_per_gpu or 125_000_000
+        args.hash = args.hash or args.config == "3"
+    args.k = args.k or 31
+    args.reads_per_gpu = args.reads_per_gpu or 100_000_000
+    if args.config == "4" and not args.histogram:
+        args.histogram = 20
+    return args
 
+
+def selftest_worker(args):
+    """ranks rendezvous over gloo and count themselves (CPU only: the launch logic, not the GPU path)"""
+    import torch.distributed as dist
+
+    from kmers_amd import dist as kd
+
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ranks = kd.rccl_rank_count()
+    ok = ranks == args.gpus == world
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "rccl_ranks": ranks, "backend": "gloo",
+                          "spawned_by_bench": os.environ.get("KMX_BENCH_SPAWNED") == "1"}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok else 4
+
+
+def worker(args, traffic_raw=None, traffic_err=None):
     import numpy as np
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: n_gpus would be misreported")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the kmx path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_single:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from kmers_amd import _lib
-    from kmers_amd.api import SEED_DEFAULT, Context
+    from kmers_amd import dist as kd
+    from kmers_amd.api import SEED_DEFAULT, Comm, Context
 
     ctx = Context(local_rank)
+    # ranks that a real RCCL all-reduce sees: must be what the line will claim as n_gpus
+    rccl_ranks = kd.rccl_rank_count(ctx.device)
+    if rccl_ranks != args.gpus:
+        sys.stderr.write(f"bench.py: all-reduce saw {rccl_ranks} ranks, --gpus {args.gpus}\n")
+        if dist is not None:
+            dist.destroy_process_group()
+        sys.exit(4)
+
     L, k, n = args.read_len, args.k, args.reads_per_gpu
     nbytes = n * L
     hasher, hk = (_lib.HASH_LEX, k) if args.hash else (_lib.HASH_NONE, 0)
+    hist_mode = args.config == "4"
 
     # synthetic reads generated on the device; rank r owns stream bytes [r*nbytes, (r+1)*nbytes)
     bases = ctx.gen_reads(nbytes, SEED_DEFAULT, rank * nbytes)
@@ -156,16 +358,65 @@ def main():
         words = ctx.seqvec_from_bytes(bases)
         torch.cuda.synchronize()
 
+    # the histogram exchange: libkmx's own RCCL communicator (the C ABI a Rust / C++ host would use), torch.distributed otherwise
+    comm, collective = None, "none (1 rank)"
+    counts = None
+    if args.histogram:
+        counts = torch.zeros(1 << args.histogram, dtype=torch.int64, device=ctx.device)
+        if dist is not None:
+            try:
+                comm = Comm(ctx, world, rank)
+                collective = "kmx_histogram_allreduce: ncclAllReduce(ncclUint64, ncclSum) on libkmx's RCCL communicator"
+            except Exception as e:   # noqa: BLE001 -- keep the run alive: the fallback is RCCL as well
+                comm = None
+                collective = f"torch.distributed all_reduce (nccl = RCCL); kmx_comm_create failed: {e}"
+            flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=ctx.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # all ranks take the same route
+            if int(flag.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
+                collective = "torch.distributed all_reduce (nccl = RCCL); kmx_comm_create failed on another rank"
+
+    def hist_scan():
+        ctx.histogram(bases, n, L, k, _lib.HASH_LEX, k, args.histogram, counts=counts)
+
+    def hist_exchange():
+        if comm is not None:
+            comm.histogram_allreduce(counts)
+        elif dist is not None:
+            with torch.cuda.stream(ctx.stream):
+                kd.allreduce_histogram(counts)
+
+    ev_mid = []
+
     def step():
-        if words is not None:
+        if hist_mode:
+            counts.zero_()
+            hist_scan()
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(ctx.stream)
+            ev_mid.append(e)
+            hist_exchange()
+        elif words is not None:
             ctx.seqvec_canonical_reduce(words, n, L, k, hasher, hk, 0, out=out, sync=False)
         elif two_word:
             ctx._ck(ctx.lib.kmx_canonical_reduce2(ctx._h, C.byref(rd), k, int(args.hash), C.c_void_p(out.data_ptr())))
         else:
             ctx.canonical_reduce_async(bases, n, L, k, hasher, hk, 0, out=out)
 
-    for _ in range(args.warmup):
-        step()
+    if args.pmc_child:   # under rocprofv3 --pmc: the calibration kernel (known bytes) and the step, nothing else
+        cal = ctx.empty(1, torch.int64)
+        for _ in range(3):
+            ctx.calib_stream_read(bases, out=cal)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        return 0
+
+    with torch.cuda.stream(ctx.stream):
+        for _ in range(args.warmup):
+            step()
+    ev_mid.clear()
 
     def barrier():
         torch.cuda.synchronize()
@@ -176,56 +427,102 @@ def main():
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
-    for a, b in evs:
-        a.record(ctx.stream)
-        step()
-        b.record(ctx.stream)
+    with torch.cuda.stream(ctx.stream):
+        for a, b in evs:
+            a.record(ctx.stream)
+            step()
+            b.record(ctx.stream)
     barrier()
     elapsed = time.perf_counter() - t0
 
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-    summ = out.cpu().numpy().view(np.uint64)
-    n_valid, sum_canon = int(summ[0]), int(summ[1])
-
-    from kmers_amd import dist as kd
+    scan_ms = [a.elapsed_time(m) for (a, _), m in zip(evs, ev_mid)] if hist_mode else kernel_ms
+    xchg_ms = [m.elapsed_time(b) for (_, b), m in zip(evs, ev_mid)] if hist_mode else []
+    avg_scan_ms = sum(scan_ms) / len(scan_ms)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
-    tot = kd.combine_summaries({"n_valid": n_valid, "sum_canon": sum_canon, "xor_hash": int(summ[2]) if not two_word else 0, "sum_fw": 0},
-                               device=ctx.device)   # wrapping add / xor of the per-shard summaries
-    total_kmers_per_step = tot["n_valid"]
+
+    if hist_mode:
+        total_count = int(counts.sum().item())            # after the all-reduce: k-mers of ALL ranks
+        total_kmers_per_step = total_count
+        tot = {"sum_canon": int(counts[: 1 << 10].sum().item())}
+        n_valid_local = n * max(L - k + 1, 0)
+    else:
+        summ = out.cpu().numpy().view(np.uint64)
+        n_valid_local, sum_canon = int(summ[0]), int(summ[1])
+        tot = kd.combine_summaries({"n_valid": n_valid_local, "sum_canon": sum_canon, "xor_hash": int(summ[2]) if not two_word else 0, "sum_fw": 0},
+                                   device=ctx.device)   # wrapping add / xor of the per-shard summaries
+        total_kmers_per_step = tot["n_valid"]
+
+    # ---- outside the timed region: sustained run, same-run read ceiling, optional histogram, parity, CPU baseline
+    sustained = None
+    if args.sustain_steps > 0:
+        ev_mid.clear()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        with torch.cuda.stream(ctx.stream):
+            a.record(ctx.stream)
+            for _ in range(args.sustain_steps):
+                step()
+            b.record(ctx.stream)
+        barrier()
+        ev_mid.clear()
+        sus_ms = a.elapsed_time(b) / args.sustain_steps
+        sustained = {"steps": args.sustain_steps, "ms_per_step": sus_ms}
+
+    cal = ctx.empty(1, torch.int64)
+    cal_buf = bases
+    for _ in range(2):
+        ctx.calib_stream_read(cal_buf, out=cal)
+    cevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    with torch.cuda.stream(ctx.stream):
+        for a, b in cevs:
+            a.record(ctx.stream)
+            ctx.calib_stream_read(cal_buf, out=cal)
+            b.record(ctx.stream)
+    torch.cuda.synchronize()
+    stream_ms = sorted(a.elapsed_time(b) for a, b in cevs)[len(cevs) // 2]
+    stream_gbps = float(nbytes) / (stream_ms * 1e-3) / 1e9
 
     hist_info = None
-    if args.histogram:
-        b = args.histogram
-        counts = torch.zeros(1 << b, dtype=torch.int64, device=ctx.device)
-        ctx.histogram(bases, n, L, k, _lib.HASH_LEX, k, b, counts=counts)   # warm-up
+    if args.histogram and not hist_mode:
+        b_ = args.histogram
+        hist_scan()   # warm-up (grows the work buffer)
         counts.zero_()
         barrier()
-        t0 = time.perf_counter()
-        ctx.histogram(bases, n, L, k, _lib.HASH_LEX, k, b, counts=counts)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(ctx.stream):
+            e0.record(ctx.stream)
+            hist_scan()
+            e1.record(ctx.stream)
+            hist_exchange()
+            e2.record(ctx.stream)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        kd.allreduce_histogram(counts)       # the path's only real collective: all-reduce(sum, int64) over RCCL/xGMI
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        hist_info = {"log2_buckets": b, "scan_ms": (t1 - t0) * 1e3, "allreduce_ms": (t2 - t1) * 1e3,
-                     "total_count": int(counts.sum().item()), "expect": total_kmers_per_step}
+        hist_info = {"log2_buckets": b_, "scan_ms": e0.elapsed_time(e1), "allreduce_ms": e1.elapsed_time(e2),
+                     "total_count": int(counts.sum().item()), "expect": total_kmers_per_step, "collective": collective}
 
+    parity = True
+    res = None
     if rank == 0:
+        from oracle import oracle
+
         value = total_kmers_per_step * args.steps / elapsed_max
         # algorithmic bytes per launch: L bytes read per read (L/4 when the reads are 2-bit packed), writes negligible
         algo_bytes = float(nbytes) / (4.0 if args.packed else 1.0)
-        achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        achieved = algo_bytes / (avg_scan_ms * 1e-3) / 1e9
         # parity spot-check against the CPU oracle on the head of this rank's shard (outside the timed region)
-        from oracle import oracle
-
         n_chk = min(n, 200_000)
         host = bases[: n_chk * L].cpu().numpy()
-        if two_word:
+        if hist_mode:
+            n_h = min(n, 20_000)
+            o = oracle.histogram(host[: n_h * L], n_h, L, k, k, args.histogram)
+            g = ctx.histogram(bases[: n_h * L], n_h, L, k, _lib.HASH_LEX, k, args.histogram).cpu().numpy().view(np.uint64)
+            parity = bool((g == o).all()) and total_count == world * n * max(L - k + 1, 0)
+        elif two_word:
             o = oracle.canonical_reduce2(host, n_chk, L, k, with_hash=args.hash)
             g = ctx.canonical_reduce2(bases[: n_chk * L], n_chk, L, k, with_hash=args.hash)
             parity = tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
@@ -233,20 +530,28 @@ def main():
             o = oracle.canonical_reduce(host, n_chk, L, k, hasher_k=hk)
             g = ctx.canonical_reduce(bases[: n_chk * L], n_chk, L, k, hasher, hk, 0)
             parity = (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash if args.hash else 0)
-        parity = parity and n_valid == n * max(L - k + 1, 0)
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (same kernel, same workload only)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pt = json.load(f)
-            if (k, L, n, args.hash, args.packed) == (31, 150, 100_000_000, False, False):
-                traffic = pt["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        parity = parity and n_valid_local == n * max(L - k + 1, 0)
+        traffic, traffic_detail = None, traffic_err
+        if traffic_raw is not None:
+            td = traffic_from_counters(traffic_raw, float(nbytes), 3)
+            if td is not None:
+                traffic, traffic_detail = td["bytes_per_step"], td
+        bs_kernel = (13 <= k <= 31 or (33 <= k <= 63 and L <= 160)) and L <= 256
+        if hist_mode:
+            kernel_name = "kmx::scan_uniform_kernel<SinkHist*> (partition pass + per-partition tables)"
+        elif bs_kernel:
+            kernel_name = "kmx::scan_bitsliced_kernel<%d,%d,*>" % (k, 10 if L <= 160 else 16)
+        else:
+            kernel_name = "kmx::scan_uniform_kernel" if k <= 31 else "kmx::reduce2_generic_kernel"
+        cfg_names = {"1": "BASELINE configs[1]", "2": "BASELINE configs[2]", "3": "BASELINE configs[3]", "4": "BASELINE configs[4]"}
+        what = ("distinct-k-mer bucket histogram (2^%d buckets, LexHasher) + RCCL all-reduce" % args.histogram) if hist_mode else \
+               ("canonicalize from a 2-bit SeqVector" if args.packed else "encode+canonicalize") + ("+lex-hash" if args.hash else "") + " (reduce mode)"
         res = {
             "metric": "canonical k-mers/sec at k=31, 150 bp reads; HBM GB/s vs peak",
             "value": value,
             "unit": "canonical k-mers/s",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
@@ -256,33 +561,62 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": f"k={k} {'canonicalize from a 2-bit SeqVector' if args.packed else 'encode+canonicalize'}{'+lex-hash' if args.hash else ''} (reduce mode), "
-                            f"{n} x {L} bp synthetic reads per GPU" + ("" if args.packed else " (BASELINE configs[1])"),
+                "workload": f"k={k} {what}, {n} x {L} bp synthetic reads per GPU" + ("" if args.packed else f" ({cfg_names[args.config]})"),
                 "reads_per_gpu": n, "read_len": L, "k": k, "parallelism": f"shard{world}",
-                "bytes_per_gpu": nbytes,
+                "bytes_per_gpu": nbytes, "launched_by": "bench.py (self-spawned ranks)" if os.environ.get("KMX_BENCH_SPAWNED") == "1" else ("torchrun" if world > 1 else "single process"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": ("kmx::scan_bitsliced_kernel<%d,%d,*>" % (k, 10 if L <= 160 else 16)) if (13 <= k <= 31 or (33 <= k <= 63 and k % 2 == 1 and L <= 160)) and L <= 256 else ("kmx::scan_uniform_kernel" if k <= 31 else "kmx::reduce2_generic_kernel"),
-                "avg_kernel_ms": avg_kernel_ms, "min_kernel_ms": min(kernel_ms),
-                "median_kernel_ms": sorted(kernel_ms)[len(kernel_ms) // 2], "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel": kernel_name,
+                "avg_kernel_ms": avg_scan_ms, "min_kernel_ms": min(scan_ms),
+                "median_kernel_ms": sorted(scan_ms)[len(scan_ms) // 2], "algorithmic_bytes_per_launch": algo_bytes,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
+                "same_run_stream_read_GBps": stream_gbps, "frac_of_same_run_stream_read": achieved / stream_gbps,
+                "traffic_detail": traffic_detail,
             },
             "parity_vs_oracle": "ok" if parity else "MISMATCH",
             "checksum": f"{tot['sum_canon']:#018x}",
         }
-        if hist_info is not None:
+        if sustained is not None:
+            sustained["achieved_GBps"] = algo_bytes / (sustained["ms_per_step"] * 1e-3) / 1e9 if not hist_mode else None
+            sustained["frac"] = sustained["achieved_GBps"] / HBM_PEAK_GBPS if not hist_mode else None
+            sustained["value"] = total_kmers_per_step / (sustained["ms_per_step"] * 1e-3)
+            res["sustained"] = sustained
+        if hist_mode:
+            res["histogram"] = {"log2_buckets": args.histogram, "scan_ms": avg_scan_ms, "allreduce_ms": sum(xchg_ms) / len(xchg_ms),
+                                "total_count": total_count, "expect": world * n * max(L - k + 1, 0), "collective": collective}
+        elif hist_info is not None:
             res["histogram"] = hist_info
         if world == 1 and not args.no_cpu_baseline and not two_word:
             n_s = min(n, 4_000_000)
             res["cpu_baseline"] = cpu_baseline(bases[: n_s * L].cpu().numpy(), n_s, L, k)
         print(json.dumps(res), flush=True)
-        if not parity:
-            sys.exit(3)
+    # every rank learns the verdict and leaves together (a lone sys.exit on rank 0 would strand the others in a collective)
     if dist is not None:
+        v = torch.tensor([1 if parity else 0], dtype=torch.int64, device=ctx.device)
+        dist.broadcast(v, src=0)
+        parity = bool(int(v.item()))
+        if comm is not None:
+            comm.close()
         dist.barrier()
         dist.destroy_process_group()
+    return 0 if parity else 3
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    have_world = "WORLD_SIZE" in os.environ
+    if not have_world and args.gpus > 1:
+        sys.exit(spawn_ranks(args, argv))       # before anything touches the GPU; children are fresh processes
+    if args.spawn_selftest:
+        sys.exit(selftest_worker(args))
+    traffic_raw, traffic_err = None, "not measured (--no-traffic, N > 1, or a child of another run)"
+    if not have_world and args.gpus == 1 and not args.no_traffic and not args.pmc_child and not args.dist_single:
+        # two short child runs under rocprofv3 --pmc, BEFORE this process initialises the GPU
+        traffic_raw, traffic_err = measure_traffic([a for a in argv if a not in ("--no-cpu-baseline",)] + ["--no-cpu-baseline", "--no-traffic"])
+    sys.exit(worker(args, traffic_raw, traffic_err))
 
 
 if __name__ == "__main__":

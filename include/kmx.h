@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KMX_VERSION 1
+#define KMX_VERSION 2
 
 /* ---- status codes (reference panics become codes; SURVEY 8b "Errors") ---- */
 #define KMX_OK 0
@@ -195,6 +195,31 @@ int kmx_encoding_rev_comp(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint32
 int kmx_encoding_decode(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint8_t enc_byte, uint32_t words_per_kmer,
                         uint8_t *d_seqs);
 
+/* ---------------------------------------------------------------- decode / display direction ---- */
+/* Kmer::sub_kmer_word(word, k, pos, width) (src/naive_impl/kmer.rs:156-162) for n words: (word >> 2*pos) & MASK_TABLE[width].
+ * The reference asserts pos < k and pos + width <= k: KMX_E_ARG otherwise.  1 <= k <= 32 (width 32 would meet
+ * MASK_TABLE[32] == 0, kmer.rs:617, and give 0 like the reference). */
+int kmx_sub_kmer_words(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n, uint32_t k, uint32_t pos, uint32_t width,
+                       uint64_t *d_out);
+/* String::from(Kmer) (src/naive_impl/kmer.rs:196-207, BASE_TABLE :24): n words -> n*k LOWER-case letters, base 0 first. */
+int kmx_kmers_to_strings(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n, uint32_t k, uint8_t *d_out);
+/* kmer::bitmer_to_bytes(mer, len) (src/kmer.rs:71-91): n words -> n*len UPPER-case letters, base 0 first.  len <= 32. */
+int kmx_bitmers_to_bytes(kmx_ctx *ctx, const uint64_t *d_mers, uint64_t n, uint32_t len, uint8_t *d_out);
+
+/* ---------------------------------------------------------------- Encoding<P, B> for every utils::Data word type ----
+ * src/utils.rs:4-24 implements Data for u8, u16, u32, u64 and u128; encoding::Naive is generic over it
+ * (src/encoding/naive.rs:112-154; Xor10 == Naive::ACTG for u64 / u128, xor10.rs:50).  bit_field's BitArray puts flat bit i
+ * into word i / BITS, bit i % BITS, so the little-endian byte image of a [P; B] is the same flat bit string for every P:
+ * the arrays are passed as bytes, word_bits * words_per_kmer / 8 per k-mer, and P only decides the capacity
+ * (KMX_E_TOO_LONG where bit_field would panic) and the number of letters decode() emits (word_bits * words_per_kmer / 2).
+ * word_bits in {8, 16, 32, 64, 128}; at most 64 bytes per k-mer. */
+int kmx_encode_kmers_p(kmx_ctx *ctx, const uint8_t *d_seqs, uint64_t n, uint32_t seq_len, uint8_t enc_byte,
+                       uint32_t word_bits, uint32_t words_per_kmer, void *d_arrays);
+int kmx_encoding_rev_comp_p(kmx_ctx *ctx, const void *d_in, uint64_t n, uint32_t K, uint8_t enc_byte, uint32_t word_bits,
+                            uint32_t words_per_kmer, void *d_out);
+int kmx_encoding_decode_p(kmx_ctx *ctx, const void *d_in, uint64_t n, uint8_t enc_byte, uint32_t word_bits,
+                          uint32_t words_per_kmer, uint8_t *d_seqs);
+
 /* ----------------------------------------------------------------------------------------------------------------
  * SeqVector -- the reference's 2-bit packed sequence container (src/naive_impl/seq_vector.rs).
  * Layout: base i at flat bits [2i, 2i+1] of a little-endian u64 word array, codes A0 C1 G2 T3 (it is built from
@@ -254,6 +279,33 @@ int kmx_seqvec_minimizers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_read
 #define KMX_FASTX_FASTA 2
 int kmx_fastx_parse(kmx_ctx *ctx, const uint8_t *d_text, uint64_t n_bytes, uint32_t format, uint8_t *d_bases,
                     uint64_t *d_offsets, uint64_t max_reads, uint64_t *h_n_reads, uint64_t *h_n_bases);
+
+/* ---------------------------------------------------------------- multi-GPU exchange ----
+ * The reference has no distributed code; reads shard embarrassingly (k-mers never span reads,
+ * canonical_kmer_iterator.rs:72-83), so the scans need no collective.  What is exchanged is the optional bucket
+ * histogram -- ncclAllReduce(ncclUint64, ncclSum) over RCCL/xGMI -- and the 32-byte summaries.  One kmx_comm per
+ * kmx_ctx (one process or thread per GPU); the collectives run on the context's stream.
+ * Bootstrap: rank 0 calls kmx_comm_get_unique_id and hands the KMX_COMM_ID_BYTES bytes to the other ranks by any
+ * means (file, environment, socket, MPI, a torch.distributed broadcast); then every rank calls kmx_comm_create. */
+#define KMX_COMM_ID_BYTES 128
+typedef struct kmx_comm kmx_comm;
+int kmx_comm_get_unique_id(uint8_t *h_id /* KMX_COMM_ID_BYTES, host */);
+int kmx_comm_create(kmx_ctx *ctx, const uint8_t *h_id, int n_ranks, int rank, kmx_comm **out); /* collective over the ranks */
+void kmx_comm_destroy(kmx_comm *comm);
+int kmx_comm_size(const kmx_comm *comm);
+int kmx_comm_rank(const kmx_comm *comm);
+/* d_counts[i] = sum over ranks of d_counts[i], in place, n_counts u64 (2^log2_buckets of kmx_histogram) */
+int kmx_histogram_allreduce(kmx_comm *comm, uint64_t *d_counts, uint64_t n_counts);
+/* the per-shard kmx_summary of every rank combined in place: wrapping sums of n_valid / sum_canon / sum_fw, xor of xor_hash */
+int kmx_summary_allreduce(kmx_comm *comm, kmx_summary *d_summary);
+
+/* ---------------------------------------------------------------- measurement helper ----
+ * Read-only pass over [d_buf, d_buf + nbytes) with the load shape of the scan kernels (16 bytes per lane, non-temporal,
+ * one 9600-byte tile = 64 reads x 150 bytes per wave and step, the next tile requested before the current one is
+ * consumed), xor-folded into *d_out (8 bytes, overwritten): the same-run ceiling of the HBM read stream next to which
+ * bench.py reports kmx_canonical_reduce, and the known-byte-count kernel the FETCH_SIZE counter is calibrated on.
+ * d_buf 16-byte aligned. */
+int kmx_calib_stream_read(kmx_ctx *ctx, const uint8_t *d_buf, uint64_t nbytes, uint64_t *d_out);
 
 #ifdef __cplusplus
 }

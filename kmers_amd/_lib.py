@@ -10,7 +10,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmx.so")
+# KMX_LIB_VARIANT=<name> (development only): load kmers_amd/libkmx_<name>.so, a build of the same sources with extra -D
+# switches (kmers_amd/build.py); the default library is never overwritten by such builds
+_VARIANT = os.environ.get("KMX_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, f"libkmx_{_VARIANT}.so" if _VARIANT else "libkmx.so")
+COMM_ID_BYTES = 128
 
 # status codes (include/kmx.h)
 OK, E_ARG, E_K_RANGE, E_HIP, E_INVALID_BASE, E_TOO_LONG, E_NOMEM = range(7)
@@ -82,6 +86,20 @@ SIGNATURES = {
     "kmx_minimizer_words": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _vp]),
     "kmx_seqvec_minimizers": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "kmx_fastx_parse": (_int, [_vp, _vp, _u64, _u32, _vp, _vp, _u64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "kmx_sub_kmer_words": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp]),
+    "kmx_kmers_to_strings": (_int, [_vp, _vp, _u64, _u32, _vp]),
+    "kmx_bitmers_to_bytes": (_int, [_vp, _vp, _u64, _u32, _vp]),
+    "kmx_encode_kmers_p": (_int, [_vp, _vp, _u64, _u32, _u8, _u32, _u32, _vp]),
+    "kmx_encoding_rev_comp_p": (_int, [_vp, _vp, _u64, _u32, _u8, _u32, _u32, _vp]),
+    "kmx_encoding_decode_p": (_int, [_vp, _vp, _u64, _u8, _u32, _u32, _vp]),
+    "kmx_comm_get_unique_id": (_int, [_vp]),
+    "kmx_comm_create": (_int, [_vp, _vp, _int, _int, C.POINTER(_vp)]),
+    "kmx_comm_destroy": (None, [_vp]),
+    "kmx_comm_size": (_int, [_vp]),
+    "kmx_comm_rank": (_int, [_vp]),
+    "kmx_histogram_allreduce": (_int, [_vp, _vp, _u64]),
+    "kmx_summary_allreduce": (_int, [_vp, _vp]),
+    "kmx_calib_stream_read": (_int, [_vp, _vp, _u64, _vp]),
 }
 
 FASTX_AUTO, FASTX_FASTQ, FASTX_FASTA = 0, 1, 2

@@ -2,11 +2,18 @@
 
 torch is plumbing here (device memory, streams, torch.distributed); every computation is a
 hand-written HIP kernel behind include/kmx.h.  All functions run on `Context.stream` (by
-default torch's current stream of the device) and are asynchronous like any torch CUDA op.
+default torch's current stream of the device at construction) and are asynchronous like any torch CUDA op.
+
+Stream discipline: kmx kernels are enqueued on `Context.stream`.  Every method makes that stream torch's current
+stream for its whole body, so the buffers it allocates, the launch and the device-to-host read-back are ordered on ONE
+stream -- also when the context was built on a side stream, or is used inside `with torch.cuda.stream(other)`.  Tensors
+handed IN by the caller must be ready on `Context.stream` (produced there, or after a `wait_stream`): they are marked
+with `record_stream` so the caching allocator does not recycle them under a running kmx kernel.
 """
 from __future__ import annotations
 
 import ctypes as C
+import functools
 
 import numpy as np
 import torch
@@ -30,6 +37,21 @@ def _ptr(t):
 def u64_numpy(t: torch.Tensor) -> np.ndarray:
     """int64 CUDA tensor holding u64 words -> numpy uint64 (host)."""
     return t.detach().cpu().numpy().view(np.uint64)
+
+
+def _on_ctx_stream(fn):
+    """Run a Context method with Context.stream as torch's current stream (see "Stream discipline" above)."""
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream == self.stream.cuda_stream:
+            return fn(self, *args, **kwargs)
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                a.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            return fn(self, *args, **kwargs)
+    return wrapped
 
 
 class Context:
@@ -67,9 +89,11 @@ class Context:
         self._ck(self.lib.kmx_ctx_synchronize(self._h))
 
     # ------------------------------------------------------------- helpers
+    @_on_ctx_stream
     def empty(self, n, dtype):
         return torch.empty(int(n), dtype=dtype, device=self.device)
 
+    @_on_ctx_stream
     def to_device(self, a) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
             return a.to(self.device).contiguous()
@@ -85,6 +109,7 @@ class Context:
                      _ptr(offsets))
 
     # ------------------------------------------------------------ hot path
+    @_on_ctx_stream
     def gen_reads(self, nbytes: int, seed: int = SEED_DEFAULT, first_byte: int = 0, out: torch.Tensor | None = None):
         """Deterministic synthetic ACGT stream (kmx_gen_reads)."""
         if out is None:
@@ -92,6 +117,7 @@ class Context:
         self._ck(self.lib.kmx_gen_reads(self._h, seed & (2**64 - 1), first_byte, _ptr(out), int(nbytes)))
         return out
 
+    @_on_ctx_stream
     def canonical_reduce_async(self, bases, n_reads, read_len, k, hasher=HASH_NONE, hasher_k=0, flags=0, offsets=None,
                                out: torch.Tensor | None = None) -> torch.Tensor:
         """kmx_canonical_reduce; returns the device-resident summary (4 x int64 viewable as u64)."""
@@ -101,6 +127,7 @@ class Context:
         self._ck(self.lib.kmx_canonical_reduce(self._h, C.byref(r), k, hasher, hasher_k, flags, _ptr(out)))
         return out
 
+    @_on_ctx_stream
     def canonical_reduce(self, bases, n_reads, read_len, k, hasher=HASH_NONE, hasher_k=0, flags=0, offsets=None) -> Summary:
         out = self.canonical_reduce_async(bases, n_reads, read_len, k, hasher, hasher_k, flags, offsets)
         v = u64_numpy(out)
@@ -113,6 +140,7 @@ class Context:
         lens = np.diff(np.asarray(offsets).astype(np.int64))
         return np.concatenate([[0], np.cumsum(np.maximum(lens - k + 1, 0))]).astype(np.uint64)
 
+    @_on_ctx_stream
     def canonical_windows(self, bases, n_reads, read_len, k, offsets=None, host_offsets=None, want=("fw", "rc", "canon", "flags")):
         """kmx_canonical_windows -> dict of device tensors (u64 words as int64, flags uint8)."""
         wo_host = self.win_offsets(n_reads, read_len, k, host_offsets)
@@ -124,6 +152,7 @@ class Context:
                                                 _ptr(outs.get("canon")), _ptr(outs.get("flags"))))
         return outs
 
+    @_on_ctx_stream
     def canonical_reduce2(self, bases, n_reads, read_len, k, with_hash=False, offsets=None) -> Summary2:
         out = self.empty(5, torch.int64)
         r = self._reads(bases, n_reads, read_len, offsets)
@@ -131,6 +160,7 @@ class Context:
         v = u64_numpy(out)
         return Summary2(*[int(x) for x in v])
 
+    @_on_ctx_stream
     def canonical_windows2(self, bases, n_reads, read_len, k, offsets=None, host_offsets=None):
         wo_host = self.win_offsets(n_reads, read_len, k, host_offsets)
         total = int(wo_host[-1])
@@ -142,6 +172,7 @@ class Context:
                                                  _ptr(outs["canon"]), _ptr(outs["flags"])))
         return outs
 
+    @_on_ctx_stream
     def histogram(self, bases, n_reads, read_len, k, hasher, hasher_k, log2_buckets, offsets=None,
                   counts: torch.Tensor | None = None) -> torch.Tensor:
         if counts is None:
@@ -151,6 +182,7 @@ class Context:
         return counts
 
     # --------------------------------------------------------- element-wise
+    @_on_ctx_stream
     def kmers_from_bytes(self, seqs: torch.Tensor, n: int, k: int) -> torch.Tensor:
         out = self.empty(n, torch.int64)
         bad = C.c_uint64()
@@ -162,39 +194,46 @@ class Context:
         self._ck(st)
         return out
 
+    @_on_ctx_stream
     def revcomp_words(self, words: torch.Tensor, k: int) -> torch.Tensor:
         out = torch.empty_like(words)
         self._ck(self.lib.kmx_revcomp_words(self._h, _ptr(words), words.numel(), k, _ptr(out)))
         return out
 
+    @_on_ctx_stream
     def canonical_words(self, words: torch.Tensor, k: int):
         canon = torch.empty_like(words)
         isc = self.empty(words.numel(), torch.uint8)
         self._ck(self.lib.kmx_canonical_words(self._h, _ptr(words), words.numel(), k, _ptr(canon), _ptr(isc)))
         return canon, isc
 
+    @_on_ctx_stream
     def hash_words(self, words: torch.Tensor, hasher: int, hasher_k: int) -> torch.Tensor:
         out = torch.empty_like(words)
         self._ck(self.lib.kmx_hash_words(self._h, _ptr(words), words.numel(), hasher, hasher_k, _ptr(out)))
         return out
 
+    @_on_ctx_stream
     def match_words(self, fw, rc, other) -> torch.Tensor:
         out = self.empty(fw.numel(), torch.uint8)
         self._ck(self.lib.kmx_match_words(self._h, _ptr(fw), _ptr(rc), _ptr(other), fw.numel(), _ptr(out)))
         return out
 
+    @_on_ctx_stream
     def ck_shift(self, fw, rc, bases, k, append=True) -> torch.Tensor:
         dropped = self.empty(fw.numel(), torch.uint8)
         fn = self.lib.kmx_ck_append_bases if append else self.lib.kmx_ck_prepend_bases
         self._ck(fn(self._h, _ptr(fw), _ptr(rc), _ptr(bases), fw.numel(), k, _ptr(dropped)))
         return dropped
 
+    @_on_ctx_stream
     def encode_kmers(self, seqs: torch.Tensor, n: int, seq_len: int, enc_byte: int, words_per_kmer: int) -> torch.Tensor:
         out = self.empty(n * words_per_kmer, torch.int64)
         self._ck(self.lib.kmx_encode_kmers(self._h, _ptr(seqs) if seqs.numel() else None, n, seq_len, enc_byte,
                                            words_per_kmer, _ptr(out)))
         return out
 
+    @_on_ctx_stream
     def encode_windows(self, bases, n_reads, read_len, k, enc_byte, words_per_kmer) -> torch.Tensor:
         nwin = max(read_len - k + 1, 0)
         out = self.empty(n_reads * nwin * words_per_kmer, torch.int64)
@@ -202,6 +241,7 @@ class Context:
         self._ck(self.lib.kmx_encode_windows(self._h, C.byref(r), k, enc_byte, words_per_kmer, _ptr(out)))
         return out
 
+    @_on_ctx_stream
     def encoding_rev_comp(self, words: torch.Tensor, K: int, enc_byte: int, words_per_kmer: int) -> torch.Tensor:
         out = torch.empty_like(words)
         self._ck(self.lib.kmx_encoding_rev_comp(self._h, _ptr(words), words.numel() // words_per_kmer, K, enc_byte,
@@ -209,12 +249,14 @@ class Context:
         return out
 
     # ---- SeqVector (src/naive_impl/seq_vector.rs): 2-bit packed sequences on the device
+    @_on_ctx_stream
     def seqvec_from_bytes(self, data: torch.Tensor, n: int | None = None) -> torch.Tensor:
         """SeqVector::from(&[u8]) (seq_vector.rs:346-358): ceil(n/32) u64 words (as int64 tensor), base i at bits [2i,2i+1]"""
         n = data.numel() if n is None else n
         words = torch.zeros((n + 31) // 32 + 2, dtype=torch.int64, device=self.device)[: (n + 31) // 32]
         return self.seqvec_push_chars(words, 0, data, n)
 
+    @_on_ctx_stream
     def seqvec_push_chars(self, words: torch.Tensor, n_before: int, data: torch.Tensor, n: int | None = None) -> torch.Tensor:
         """SeqVector::push_chars (seq_vector.rs:241-262): append n ASCII bases after the n_before already stored"""
         n = data.numel() if n is None else n
@@ -227,17 +269,20 @@ class Context:
         self._ck(st)
         return words
 
+    @_on_ctx_stream
     def seqvec_to_bytes(self, words: torch.Tensor, n_bases: int) -> torch.Tensor:
         out = self.empty(n_bases, torch.uint8)
         self._ck(self.lib.kmx_seqvec_to_bytes(self._h, _ptr(words) if n_bases else None, n_bases, _ptr(out) if n_bases else None))
         return out
 
+    @_on_ctx_stream
     def seqvec_get_kmers(self, words: torch.Tensor, n_bases: int, pos: torch.Tensor, k: int) -> torch.Tensor:
         out = self.empty(pos.numel(), torch.int64)
         n = pos.numel()
         self._ck(self.lib.kmx_seqvec_get_kmers(self._h, _ptr(words) if n else None, n_bases, _ptr(pos) if n else None, n, k, _ptr(out) if n else None))
         return out
 
+    @_on_ctx_stream
     def seqvec_iter_kmers(self, words: torch.Tensor, n_bases: int, k: int, start: int = 0, end: int | None = None) -> torch.Tensor:
         end = n_bases if end is None else end
         cnt = max(0, end - start - k + 1)
@@ -245,6 +290,7 @@ class Context:
         self._ck(self.lib.kmx_seqvec_iter_kmers(self._h, _ptr(words), n_bases, start, end, k, _ptr(out) if cnt else None))
         return out
 
+    @_on_ctx_stream
     def seqvec_canonical_reduce(self, words: torch.Tensor, n_reads: int, read_len: int, k: int, hasher: int = 0, hasher_k: int = 0,
                                 flags: int = 0, out: torch.Tensor | None = None, sync: bool = True):
         """canonical k-mer scan of the reads stored back to back in a SeqVector (read r = slice [r*L, (r+1)*L))"""
@@ -256,6 +302,7 @@ class Context:
         return Summary(int(v[0]), int(v[1]), int(v[2]), int(v[3]))
 
     # ---- minimizers
+    @_on_ctx_stream
     def minimizer_words(self, words: torch.Tensor, k: int, width: int, hasher: int, hasher_k: int = 0):
         """Kmer::minimizer_word (kmer.rs:170-192) per k-mer word -> (mmer words int64, offsets int32)"""
         n = words.numel()
@@ -264,6 +311,7 @@ class Context:
                                               _ptr(mm) if n else None, _ptr(off) if n else None))
         return mm, off
 
+    @_on_ctx_stream
     def seqvec_minimizers(self, words: torch.Tensor, n_reads: int, read_len: int, k: int, w: int, hasher: int, hasher_k: int = 0):
         """SeqVecMinimizerIter over every read slice -> (word int64, pos int32), slot r*(L-k+1)+i"""
         tot = n_reads * max(read_len - k + 1, 0)
@@ -272,6 +320,7 @@ class Context:
                                                 _ptr(mw) if tot else None, _ptr(mp) if tot else None))
         return mw, mp
 
+    @_on_ctx_stream
     def fastx_parse(self, text: torch.Tensor, fmt: int = 0):
         """kmx_fastx_parse: FASTA/FASTQ file image (uint8, on the device) -> (bases uint8[n_bases], offsets int64[n_reads+1]).
         Two calls: the counts, then the emit into exactly sized buffers."""
@@ -284,8 +333,126 @@ class Context:
                                           C.byref(nr), C.byref(nb)))
         return bases[:nb.value], offsets
 
+    @_on_ctx_stream
     def encoding_decode(self, words: torch.Tensor, enc_byte: int, words_per_kmer: int) -> torch.Tensor:
         n = words.numel() // words_per_kmer
         out = self.empty(n * 32 * words_per_kmer, torch.uint8)
         self._ck(self.lib.kmx_encoding_decode(self._h, _ptr(words), n, enc_byte, words_per_kmer, _ptr(out)))
         return out
+
+    # ---- decode / display direction
+    @_on_ctx_stream
+    def sub_kmer_words(self, words: torch.Tensor, k: int, pos: int, width: int) -> torch.Tensor:
+        """Kmer::sub_kmer_word (kmer.rs:156-162) per word"""
+        out = torch.empty_like(words)
+        n = words.numel()
+        self._ck(self.lib.kmx_sub_kmer_words(self._h, _ptr(words) if n else None, n, k, pos, width, _ptr(out) if n else None))
+        return out
+
+    @_on_ctx_stream
+    def kmers_to_strings(self, words: torch.Tensor, k: int) -> torch.Tensor:
+        """String::from(Kmer) (kmer.rs:196-207): uint8[n*k], lower case"""
+        n = words.numel()
+        out = self.empty(n * k, torch.uint8)
+        self._ck(self.lib.kmx_kmers_to_strings(self._h, _ptr(words) if n else None, n, k, _ptr(out) if n * k else None))
+        return out
+
+    @_on_ctx_stream
+    def bitmers_to_bytes(self, mers: torch.Tensor, length: int) -> torch.Tensor:
+        """kmer::bitmer_to_bytes (src/kmer.rs:71-91): uint8[n*len], upper case"""
+        n = mers.numel()
+        out = self.empty(n * length, torch.uint8)
+        self._ck(self.lib.kmx_bitmers_to_bytes(self._h, _ptr(mers) if n else None, n, length, _ptr(out) if n * length else None))
+        return out
+
+    # ---- Encoding<P, B> for any utils::Data word type (byte image of [P; B])
+    @_on_ctx_stream
+    def encode_kmers_p(self, seqs: torch.Tensor, n: int, seq_len: int, enc_byte: int, word_bits: int, words_per_kmer: int) -> torch.Tensor:
+        out = self.empty(n * (word_bits // 8) * words_per_kmer, torch.uint8)
+        self._ck(self.lib.kmx_encode_kmers_p(self._h, _ptr(seqs) if seqs.numel() else None, n, seq_len, enc_byte, word_bits,
+                                             words_per_kmer, _ptr(out) if out.numel() else None))
+        return out
+
+    @_on_ctx_stream
+    def encoding_rev_comp_p(self, arrays: torch.Tensor, K: int, enc_byte: int, word_bits: int, words_per_kmer: int) -> torch.Tensor:
+        out = torch.empty_like(arrays)
+        n = arrays.numel() // ((word_bits // 8) * words_per_kmer)
+        self._ck(self.lib.kmx_encoding_rev_comp_p(self._h, _ptr(arrays) if n else None, n, K, enc_byte, word_bits, words_per_kmer,
+                                                  _ptr(out) if n else None))
+        return out
+
+    @_on_ctx_stream
+    def encoding_decode_p(self, arrays: torch.Tensor, enc_byte: int, word_bits: int, words_per_kmer: int) -> torch.Tensor:
+        n = arrays.numel() // ((word_bits // 8) * words_per_kmer)
+        out = self.empty(arrays.numel() * 4, torch.uint8)
+        self._ck(self.lib.kmx_encoding_decode_p(self._h, _ptr(arrays) if n else None, n, enc_byte, word_bits, words_per_kmer,
+                                                _ptr(out) if n else None))
+        return out
+
+    # ---- measurement helper
+    @_on_ctx_stream
+    def calib_stream_read(self, buf: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """kmx_calib_stream_read: read-only pass over `buf` with the scan's load shape (async; returns the 1-word xor fold)"""
+        out = self.empty(1, torch.int64) if out is None else out
+        self._ck(self.lib.kmx_calib_stream_read(self._h, _ptr(buf) if buf.numel() else None, buf.numel() * buf.element_size(), _ptr(out)))
+        return out
+
+
+class Comm:
+    """kmx_comm: the RCCL communicator behind the C ABI (include/kmx.h, "multi-GPU exchange").  One per Context.
+
+    `exchange_id(id_bytes_or_None) -> bytes` hands rank 0's unique id to the other ranks; with torch.distributed
+    initialised the default does it with one broadcast."""
+
+    def __init__(self, ctx: Context, n_ranks: int, rank: int, exchange_id=None):
+        self.ctx = ctx
+        lib = ctx.lib
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        if rank == 0:
+            _lib.check(lib, None, lib.kmx_comm_get_unique_id(buf))
+        if n_ranks > 1:
+            if exchange_id is None:
+                exchange_id = self._torch_broadcast
+            raw = exchange_id(bytes(buf) if rank == 0 else None)
+            buf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(raw)
+        h = C.c_void_p()
+        ctx._ck(lib.kmx_comm_create(ctx._h, buf, n_ranks, rank, C.byref(h)))
+        self._h = h
+        self.n_ranks, self.rank = n_ranks, rank
+
+    def _torch_broadcast(self, raw):
+        import torch.distributed as dist
+
+        t = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+        if raw is not None:
+            t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+        if dist.get_backend() == "nccl":
+            t = t.to(self.ctx.device)
+        dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx.lib.kmx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self) -> int:
+        return self.ctx.lib.kmx_comm_size(self._h)
+
+    def histogram_allreduce(self, counts: torch.Tensor) -> torch.Tensor:
+        """in-place sum over ranks of the 2^b u64 counters (ncclAllReduce, ncclUint64/ncclSum) on the context's stream"""
+        counts.record_stream(self.ctx.stream)
+        self.ctx._ck(self.ctx.lib.kmx_histogram_allreduce(self._h, _ptr(counts), counts.numel()))
+        return counts
+
+    def summary_allreduce(self, summary: torch.Tensor) -> torch.Tensor:
+        """in-place combine of the device-resident 32-byte kmx_summary of every rank"""
+        summary.record_stream(self.ctx.stream)
+        self.ctx._ck(self.ctx.lib.kmx_summary_allreduce(self._h, _ptr(summary)))
+        return summary

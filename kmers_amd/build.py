@@ -2,6 +2,11 @@
 
 The .so is written next to this file (kmers_amd/libkmx.so): it is git-ignored but travels
 to the GPU box with the repo snapshot, so nothing is compiled there.
+
+Development variants (`-D` switches of the kernels) never touch the default library: they are built
+into their own object directory and `libkmx_<variant>.so`, selected at load time by the environment
+variable KMX_LIB_VARIANT (kmers_amd/_lib.py).  The default build records its flags in a stamp file, so
+a library left behind by different flags is rebuilt instead of being taken for current.
 """
 from __future__ import annotations
 
@@ -17,11 +22,14 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libkmx.so")
 SOURCES = ["kmx_bitslice.hip", "kmx_bitslice_k21.hip", "kmx_bitslice_k13_17.hip", "kmx_bitslice_k18_23.hip", "kmx_bitslice_k24_27.hip",
            "kmx_bitslice_k28_30.hip", "kmx_bitslice_k33_39.hip", "kmx_bitslice_k41_47.hip", "kmx_bitslice_k49_55.hip",
-           "kmx_bitslice_k57_61.hip", "kmx_bitslice_ragged.hip", "kmx_scan.hip", "kmx_generic.hip", "kmx_elem.hip", "kmx_seqvec.hip", "kmx_fastx.hip", "kmx_api.hip"]
-HEADERS = [os.path.join(CSRC, "kmx_device.h"), os.path.join(CSRC, "kmx_bitslice_kernel.h"), os.path.join(HERE, "..", "include", "kmx.h")]
+           "kmx_bitslice_k57_61.hip", "kmx_bitslice_ragged.hip", "kmx_scan.hip", "kmx_generic.hip", "kmx_elem.hip", "kmx_seqvec.hip", "kmx_fastx.hip",
+           "kmx_comm.hip", "kmx_api.hip"]
+HEADERS = [os.path.join(CSRC, "kmx_device.h"), os.path.join(CSRC, "kmx_bitslice_kernel.h"), os.path.join(CSRC, "kmx_internal.h"),
+           os.path.join(HERE, "..", "include", "kmx.h")]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-fno-gpu-rdc", "-munsafe-fp-atomics"]
+JOBS = int(os.environ.get("KMX_BUILD_JOBS", "4"))
 
 
 def hipcc() -> str:
@@ -31,6 +39,10 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: libkmx is HIP-only (gfx950) and has no other build")
 
 
+def lib_path(variant: str | None = None) -> str:
+    return LIB if not variant else os.path.join(HERE, f"libkmx_{variant}.so")
+
+
 def _stale(target: str, deps: list[str]) -> bool:
     if not os.path.exists(target):
         return True
@@ -38,10 +50,10 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src: str, force: bool, extra: list[str]) -> str:
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+def _compile(src: str, obj_dir: str, force: bool, extra: list[str]) -> str:
+    obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
-    if force or _stale(obj, [path] + HEADERS):
+    if force or _stale(obj, [path] + [h for h in HEADERS if os.path.exists(h)]):
         cmd = [hipcc(), *CXXFLAGS, *extra, "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -51,19 +63,51 @@ def _compile(src: str, force: bool, extra: list[str]) -> str:
     return obj
 
 
-def build(force: bool = False, extra: list[str] | None = None) -> str:
+def build(force: bool = False, extra: list[str] | None = None, variant: str | None = None, only: list[str] | None = None) -> str:
+    """Build the default library, or -- with `variant` -- a development variant compiled with the `extra` flags.
+    `only`: the sources the extra flags apply to (the other objects are shared with the default build)."""
+    extra = list(extra or [])
+    if extra and not variant:
+        raise ValueError("extra flags build a named variant (variant=...): the default libkmx.so is always the default build")
     os.makedirs(OBJ, exist_ok=True)
-    extra = extra or []
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, extra), SOURCES))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs,
-               "-Wl,-rpath,/opt/rocm/lib", "-Wl,-soname,libkmx.so"]
+    obj_dir = OBJ if not variant else os.path.join(CSRC, f"_obj_{variant}")
+    os.makedirs(obj_dir, exist_ok=True)
+    stamp = os.path.join(obj_dir, "flags.txt")
+    flags_now = " ".join(CXXFLAGS + extra)
+    try:
+        with open(stamp) as f:
+            if f.read() != flags_now:
+                force = True
+    except OSError:
+        force = True   # objects of unknown provenance (e.g. left by an older build script)
+    lib = lib_path(variant)
+
+    def one(s: str) -> str:
+        if variant and only is not None and s not in only:
+            return _compile(s, OBJ, False, [])
+        return _compile(s, obj_dir, force, extra)
+
+    with ThreadPoolExecutor(max_workers=JOBS) as ex:
+        objs = list(ex.map(one, SOURCES))
+    with open(stamp, "w") as f:
+        f.write(flags_now)
+    if force or _stale(lib, objs):
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs,
+               "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lrccl", f"-Wl,-soname,{os.path.basename(lib)}"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    if args:   # python -m kmers_amd.build VARIANT [--only a.hip,b.hip] -DX=1 ...
+        only = None
+        if "--only" in args:
+            i = args.index("--only")
+            only = args[i + 1].split(",")
+            del args[i:i + 2]
+        print(build(force="--force" in sys.argv, extra=args[1:], variant=args[0], only=only))
+    else:
+        print(build(force="--force" in sys.argv))

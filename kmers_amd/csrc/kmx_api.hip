@@ -8,7 +8,7 @@
 #include <cstring>
 #include <new>
 
-#include "../../include/kmx.h"
+#include "kmx_internal.h"
 
 namespace kmx {
 typedef uint32_t u32;
@@ -78,37 +78,27 @@ hipError_t launch_encode_windows(const uint8_t* bases, u64 n_reads, u32 L, u32 k
                                  hipStream_t st);
 hipError_t launch_encoding_rev_comp(const u64* in, u64 n, u32 K, u32 comp_lut, u32 B, u64* out, int n_cu, hipStream_t st);
 hipError_t launch_encoding_decode(const u64* in, u64 n, u32 nuc_lut, u32 B, uint8_t* seqs, int n_cu, hipStream_t st);
+hipError_t launch_sub_kmer_words(const u64* in, u64 n, u32 pos, u32 width, u64* out, int n_cu, hipStream_t st);
+hipError_t launch_kmers_to_bytes(const u64* in, u64 n, u32 k, bool upper, uint8_t* out, int n_cu, hipStream_t st);
+hipError_t launch_encode_kmers_bytes(const uint8_t* seqs, u64 n, u32 seq_len, u32 enc, u32 nb, uint8_t* arrays, int n_cu, hipStream_t st);
+hipError_t launch_encoding_rev_comp_bytes(const uint8_t* in, u64 n, u32 K, u32 comp_lut, u32 nb, uint8_t* out, int n_cu, hipStream_t st);
+hipError_t launch_encoding_decode_bytes(const uint8_t* in, u64 total_bytes, u32 nuc_lut, uint8_t* seqs, int n_cu, hipStream_t st);
+hipError_t launch_calib_stream_read(const uint8_t* buf, u64 nbytes, unsigned long long* out, int n_cu, hipStream_t st);
 }  // namespace kmx
 
 using kmx::u32;
 using kmx::u64;
 
-struct kmx_ctx {
-    int device;
-    hipStream_t stream;
-    bool owns_stream;
-    int n_cu;
-    unsigned long long* d_scratch;  // 8 KiB: [0] first_bad, [16..] tile-queue heads
-    void* d_big;                    // grow-only work buffer of the partitioned histogram (bucket-id streams)
-    size_t big_bytes;
-    unsigned long long dirty_desc;      // address of the dirty-tile flags as last written behind the queue heads
-    uint8_t* d_flags;                   // one byte per tile, all zero between calls
-    size_t flags_bytes;
-    char last_error[256];
-};
-
-namespace {
-
+namespace kmx {
 int fail_hip(kmx_ctx* ctx, hipError_t e, const char* where) {
     if (ctx) std::snprintf(ctx->last_error, sizeof ctx->last_error, "%s: %s", where, hipGetErrorString(e));
     return KMX_E_HIP;
 }
+}  // namespace kmx
+using kmx::DeviceGuard;
+using kmx::fail_hip;
 
-#define KMX_HIP(ctx, expr)                                   \
-    do {                                                     \
-        hipError_t e__ = (expr);                             \
-        if (e__ != hipSuccess) return fail_hip(ctx, e__, #expr); \
-    } while (0)
+namespace {
 
 void* big_scratch(void* user, size_t bytes);
 
@@ -130,7 +120,8 @@ int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k) {
             }
             const size_t want_bytes = (size_t)(n_tiles + n_tiles / 4u + 4096u);
             void* q = nullptr;
-            if (hipMalloc(&q, want_bytes) == hipSuccess && hipMemset(q, 0, want_bytes) == hipSuccess) {
+            // (cleared on the context's stream: a non-blocking stream is not ordered against the null stream hipMemset runs on)
+            if (hipMalloc(&q, want_bytes) == hipSuccess && hipMemsetAsync(q, 0, want_bytes, ctx->stream) == hipSuccess) {
                 ctx->d_flags = static_cast<uint8_t*>(q);
                 ctx->flags_bytes = want_bytes;
             } else {
@@ -182,19 +173,6 @@ size_t hist_scratch_budget() {
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && budget > free_b / 2) budget = free_b / 2;
     return budget;
 }
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        int cur = -1;
-        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
-    }
-};
 
 bool reads_ok(const kmx_reads* r) {
     if (!r) return false;
@@ -273,14 +251,22 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, kmx_ctx*
     c->d_scratch = nullptr;
     c->d_big = nullptr;
     c->big_bytes = 0;
+    c->dirty_desc = 0;
+    c->d_flags = nullptr;
+    c->flags_bytes = 0;
     c->last_error[0] = 0;
     DeviceGuard g(device);
     hipDeviceProp_t prop;
     hipError_t e = g.ok ? hipGetDeviceProperties(&prop, device) : hipErrorInvalidDevice;
     if (e == hipSuccess && owns) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_scratch), 8192);
-    if (e == hipSuccess) e = hipMemset(c->d_scratch, 0, 8192);   // (the dirty-list descriptor behind the queue heads starts as "no list")
+    // (the dirty-list descriptor behind the queue heads starts as "no list"; cleared on the context's own stream so that
+    // the clear is ordered before every kernel the context launches)
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_scratch, 0, 8192, c->stream);
     if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        if (owns && c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return KMX_E_HIP;
     }
@@ -602,6 +588,101 @@ int kmx_encoding_decode(kmx_ctx* ctx, const uint64_t* d_in, uint64_t n, uint8_t 
     if (n == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
     KMX_HIP(ctx, kmx::launch_encoding_decode(d_in, n, nuc_lut_for(enc_byte), words_per_kmer, d_seqs, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+/* ------------------------------------------------ decode / display (f3) ---- */
+
+int kmx_sub_kmer_words(kmx_ctx* ctx, const uint64_t* d_words, uint64_t n, uint32_t k, uint32_t pos, uint32_t width,
+                       uint64_t* d_out) {
+    if (!ctx || (n && (!d_words || !d_out))) return KMX_E_ARG;
+    if (k < 1 || k > 32) return KMX_E_K_RANGE;
+    if (!(pos < k) || !(pos + width <= k)) return KMX_E_ARG;   // the reference's two asserts (kmer.rs:157-158)
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_sub_kmer_words(d_words, n, pos, width, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_kmers_to_strings(kmx_ctx* ctx, const uint64_t* d_words, uint64_t n, uint32_t k, uint8_t* d_out) {
+    if (!ctx || (n && k && (!d_words || !d_out))) return KMX_E_ARG;
+    if (k > 32) return KMX_E_K_RANGE;
+    if (n == 0 || k == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_kmers_to_bytes(d_words, n, k, false, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_bitmers_to_bytes(kmx_ctx* ctx, const uint64_t* d_mers, uint64_t n, uint32_t len, uint8_t* d_out) {
+    if (!ctx || (n && len && (!d_mers || !d_out))) return KMX_E_ARG;
+    if (len > 32) return KMX_E_K_RANGE;
+    if (n == 0 || len == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_kmers_to_bytes(d_mers, n, len, true, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+/* ------------------------------------------------ Encoding<P, B>, any utils::Data P ---- */
+
+static int p_shape_ok(uint32_t word_bits, uint32_t words_per_kmer, uint32_t* nb) {
+    if (word_bits != 8 && word_bits != 16 && word_bits != 32 && word_bits != 64 && word_bits != 128) return KMX_E_ARG;
+    if (words_per_kmer < 1) return KMX_E_ARG;
+    const uint64_t bytes = (uint64_t)(word_bits / 8u) * words_per_kmer;
+    if (bytes > 64) return KMX_E_ARG;
+    *nb = (uint32_t)bytes;
+    return KMX_OK;
+}
+
+int kmx_encode_kmers_p(kmx_ctx* ctx, const uint8_t* d_seqs, uint64_t n, uint32_t seq_len, uint8_t enc_byte, uint32_t word_bits,
+                       uint32_t words_per_kmer, void* d_arrays) {
+    uint32_t nb = 0;
+    if (!ctx || (n && ((seq_len && !d_seqs) || !d_arrays))) return KMX_E_ARG;
+    if (!enc_ok(enc_byte)) return KMX_E_ARG;
+    if (int st = p_shape_ok(word_bits, words_per_kmer, &nb)) return st;
+    if (seq_len > 4u * nb) return KMX_E_TOO_LONG;   // bit_field set_bits would panic (naive.rs:120)
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_encode_kmers_bytes(d_seqs, n, seq_len, enc_byte, nb, static_cast<uint8_t*>(d_arrays), ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_encoding_rev_comp_p(kmx_ctx* ctx, const void* d_in, uint64_t n, uint32_t K, uint8_t enc_byte, uint32_t word_bits,
+                            uint32_t words_per_kmer, void* d_out) {
+    uint32_t nb = 0;
+    if (!ctx || (n && (!d_in || !d_out))) return KMX_E_ARG;
+    if (!enc_ok(enc_byte)) return KMX_E_ARG;
+    if (int st = p_shape_ok(word_bits, words_per_kmer, &nb)) return st;
+    if (K < 2 || K > 4u * nb) return KMX_E_K_RANGE;   // K=1 underflows usize in the reference (naive.rs:140,150)
+    if (n == 0) return KMX_OK;
+    if (d_in == d_out) return KMX_E_ARG;              // base i reads base K-1-i of the input
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_encoding_rev_comp_bytes(static_cast<const uint8_t*>(d_in), n, K, comp_lut_for(enc_byte), nb,
+                                                     static_cast<uint8_t*>(d_out), ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_encoding_decode_p(kmx_ctx* ctx, const void* d_in, uint64_t n, uint8_t enc_byte, uint32_t word_bits,
+                          uint32_t words_per_kmer, uint8_t* d_seqs) {
+    uint32_t nb = 0;
+    if (!ctx || (n && (!d_in || !d_seqs))) return KMX_E_ARG;
+    if (!enc_ok(enc_byte)) return KMX_E_ARG;
+    if (int st = p_shape_ok(word_bits, words_per_kmer, &nb)) return st;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_encoding_decode_bytes(static_cast<const uint8_t*>(d_in), n * (uint64_t)nb, nuc_lut_for(enc_byte), d_seqs,
+                                                   ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+/* ------------------------------------------------ measurement helper ---- */
+
+int kmx_calib_stream_read(kmx_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* d_out) {
+    if (!ctx || !d_out || (nbytes && !d_buf)) return KMX_E_ARG;
+    if (reinterpret_cast<uintptr_t>(d_buf) & 15u) return KMX_E_ARG;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, hipMemsetAsync(d_out, 0, 8, ctx->stream));
+    if (nbytes < 16) return KMX_OK;
+    KMX_HIP(ctx, kmx::launch_calib_stream_read(d_buf, nbytes, reinterpret_cast<unsigned long long*>(d_out), ctx->n_cu, ctx->stream));
     return KMX_OK;
 }
 

@@ -1150,9 +1150,14 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
     size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u) + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u)) * 4u * 4u;
     if (const char* e = getenv("KMX_BS_EXTRA_LDS")) lds_bytes += (size_t)atol(e);   // dev knob: caps blocks per CU
-    static int bpc = 0;
-    static size_t bpc_lds = 0;
-    if (bpc == 0 || bpc_lds != lds_bytes) {
+    // blocks per CU, cached per host thread and device (one thread per context / GPU is the ABI's model: a plain static
+    // would be shared, and written, by all of them)
+    static thread_local int bpc = 0, bpc_dev = -1;
+    static thread_local size_t bpc_lds = 0;
+    int dev_now = -1;
+    (void)hipGetDevice(&dev_now);
+    if (bpc == 0 || bpc_lds != lds_bytes || bpc_dev != dev_now) {
+        bpc_dev = dev_now;
         int b = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, 256, lds_bytes);
         if (e != hipSuccess) return e;

@@ -198,6 +198,134 @@ encoding_decode_kernel(const u64* __restrict__ in, u64 n, u32 nuc_lut, u32 B, ui
     }
 }
 
+// ------------------------------------------------- decode / display direction
+
+// Kmer::sub_kmer_word (src/naive_impl/kmer.rs:156-162): (word >> 2*pos) & MASK_TABLE[width]  (MASK_TABLE[32] == 0, :617)
+__global__ void __launch_bounds__(256)
+sub_kmer_words_kernel(const u64* __restrict__ in, u64 n, u32 pos, u32 width, u64* __restrict__ out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 mask = width >= 32u ? 0ull : ((1ull << (2u * width)) - 1ull);
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) out[e] = (in[e] >> (2u * pos)) & mask;
+}
+
+// String::from(Kmer) (kmer.rs:196-207, lower case) / bitmer_to_bytes (src/kmer.rs:71-91, upper case): letter i = table[(w >> 2i) & 3].
+// One thread per 4 letters (one dword store when the output is aligned, bytes otherwise).
+__global__ void __launch_bounds__(256)
+kmers_to_bytes_kernel(const u64* __restrict__ in, u64 n, u32 k, u32 letters /* 4 bytes indexed by code */, uint8_t* __restrict__ out) {
+    const u32 q = (k + 3u) >> 2;                 // groups of 4 letters per k-mer
+    const u64 total = n * (u64)q;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const u64 e = t / q;
+        const u32 g = (u32)(t - e * q);
+        const u32 bits = (u32)(in[e] >> (8u * g)) & 0xFFu;
+        const u32 sel = (bits & 0x03u) | ((bits & 0x0Cu) << 6) | ((bits & 0x30u) << 12) | ((bits & 0xC0u) << 18);
+        const u32 four = __builtin_amdgcn_perm(0u, letters, sel);
+        uint8_t* o = out + e * (u64)k + 4u * g;
+        const u32 cnt = k - 4u * g < 4u ? k - 4u * g : 4u;
+        if (cnt == 4u && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
+            *reinterpret_cast<u32*>(o) = four;
+        } else {
+            for (u32 i = 0; i < cnt; ++i) o[i] = (uint8_t)(four >> (8u * i));
+        }
+    }
+}
+
+// ------------------------------------------------- Encoding<P, B> on the byte image of [P; B] (utils::Data: u8 .. u128)
+// flat bit i of a [P; B] = byte i / 8, bit i % 8 of its little-endian image, whatever P (bit_field BitArray)
+
+// Encoding::encode (naive.rs:116-124): nb = B * size_of::<P>() bytes per k-mer, unused high bits zero
+__global__ void __launch_bounds__(256)
+encode_kmers_bytes_kernel(const uint8_t* __restrict__ seqs, u64 n, u32 seq_len, u32 enc, u32 nb, uint8_t* __restrict__ arrays) {
+    const u64 total = n * (u64)nb;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const u64 e = t / nb;
+        const u32 by = (u32)(t - e * nb);
+        const uint8_t* s = seqs + e * (u64)seq_len + 4u * by;
+        u32 v = 0;
+        for (u32 i = 0; i < 4u && 4u * by + i < seq_len; ++i) v |= nuc2bits(enc, s[i]) << (2u * i);
+        arrays[t] = (uint8_t)v;
+    }
+}
+
+// Encoding::rev_comp::<K> (naive.rs:138-154): out base i = complement(in base K-1-i) for i < K, bits >= 2K unchanged
+__global__ void __launch_bounds__(256)
+encoding_rev_comp_bytes_kernel(const uint8_t* __restrict__ in, u64 n, u32 K, u32 comp_lut, u32 nb, uint8_t* __restrict__ out) {
+    const u64 total = n * (u64)nb;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const u64 e = t / nb;
+        const u32 by = (u32)(t - e * nb);
+        const uint8_t* a = in + e * (u64)nb;
+        u32 v = a[by];
+        for (u32 i = 0; i < 4u; ++i) {
+            const u32 b = 4u * by + i;
+            if (b >= K) break;
+            const u32 j = K - 1u - b;
+            const u32 c = ((u32)a[j >> 2] >> (2u * (j & 3u))) & 3u;
+            v = (v & ~(3u << (2u * i))) | (((comp_lut >> (2u * c)) & 3u) << (2u * i));
+        }
+        out[t] = (uint8_t)v;
+    }
+}
+
+// Encoding::decode (naive.rs:126-136): ALL 4 * nb letters
+__global__ void __launch_bounds__(256)
+encoding_decode_bytes_kernel(const uint8_t* __restrict__ in, u64 total_bytes, u32 nuc_lut, uint8_t* __restrict__ seqs) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total_bytes; t += stride) {
+        const u32 bits = in[t];
+        const u32 sel = (bits & 0x03u) | ((bits & 0x0Cu) << 6) | ((bits & 0x30u) << 12) | ((bits & 0xC0u) << 18);
+        const u32 four = __builtin_amdgcn_perm(0u, nuc_lut, sel);
+        uint8_t* o = seqs + 4u * t;
+        if ((reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
+            *reinterpret_cast<u32*>(o) = four;
+        } else {
+            for (u32 i = 0; i < 4u; ++i) o[i] = (uint8_t)(four >> (8u * i));
+        }
+    }
+}
+
+// ------------------------------------------------- measurement helper: read-only stream with the scan's load shape
+// each wave streams whole 9600-byte tiles (600 16-byte chunks), tiles striped over the waves, next tile requested before
+// the current one is folded
+__global__ void __launch_bounds__(256) calib_stream_read_kernel(const uint8_t* __restrict__ buf, u64 n_tiles, u64 tail_chunks,
+                                                                unsigned long long* __restrict__ out) {
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int TILE16 = 600, IT = (TILE16 + 63) / 64;
+    const u32x4* __restrict__ p = reinterpret_cast<const u32x4*>(buf);
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = (u64)blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = (u64)gridDim.x * 4u;
+    u32 acc = 0;
+    u32x4 w[IT];
+    auto issue = [&](u64 t) {
+        const u32x4* tb = p + t * TILE16;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            u32 c = it * 64u + lane;
+            c = c < TILE16 ? c : TILE16 - 1;
+            w[it] = __builtin_nontemporal_load(tb + c);
+        }
+    };
+    if (wave < n_tiles) issue(wave);
+    for (u64 t = wave; t < n_tiles; t += n_waves) {
+        u32 a = 0;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) a ^= w[it].x ^ w[it].y ^ w[it].z ^ w[it].w;
+        acc ^= a;
+        issue(t + n_waves < n_tiles ? t + n_waves : t);
+    }
+    if (wave == 0) {   // the chunks behind the last whole tile
+        for (u64 c = lane; c < tail_chunks; c += 64u) {
+            const u32x4 v = p[n_tiles * TILE16 + c];
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
+    acc = (u32)wave_xor((u64)acc);
+    if (lane == 0 && acc != 0u) atomicXor(out, (unsigned long long)acc);
+}
+
 // ------------------------------------------------------------------ launchers
 
 static inline unsigned egrid(u64 n, int n_cu) {
@@ -269,6 +397,35 @@ hipError_t launch_encoding_rev_comp(const u64* in, u64 n, u32 K, u32 comp_lut, u
 }
 hipError_t launch_encoding_decode(const u64* in, u64 n, u32 nuc_lut, u32 B, uint8_t* seqs, int n_cu, hipStream_t st) {
     hipLaunchKernelGGL(encoding_decode_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, in, n, nuc_lut, B, seqs);
+    return hipGetLastError();
+}
+
+hipError_t launch_sub_kmer_words(const u64* in, u64 n, u32 pos, u32 width, u64* out, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(sub_kmer_words_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, in, n, pos, width, out);
+    return hipGetLastError();
+}
+hipError_t launch_kmers_to_bytes(const u64* in, u64 n, u32 k, bool upper, uint8_t* out, int n_cu, hipStream_t st) {
+    const u32 letters = upper ? 0x54474341u /* A C G T */ : 0x74676361u /* a c g t */;
+    hipLaunchKernelGGL(kmers_to_bytes_kernel, dim3(egrid(n * (u64)((k + 3u) >> 2), n_cu)), dim3(256), 0, st, in, n, k, letters, out);
+    return hipGetLastError();
+}
+hipError_t launch_encode_kmers_bytes(const uint8_t* seqs, u64 n, u32 seq_len, u32 enc, u32 nb, uint8_t* arrays, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(encode_kmers_bytes_kernel, dim3(egrid(n * (u64)nb, n_cu)), dim3(256), 0, st, seqs, n, seq_len, enc, nb, arrays);
+    return hipGetLastError();
+}
+hipError_t launch_encoding_rev_comp_bytes(const uint8_t* in, u64 n, u32 K, u32 comp_lut, u32 nb, uint8_t* out, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(encoding_rev_comp_bytes_kernel, dim3(egrid(n * (u64)nb, n_cu)), dim3(256), 0, st, in, n, K, comp_lut, nb, out);
+    return hipGetLastError();
+}
+hipError_t launch_encoding_decode_bytes(const uint8_t* in, u64 total_bytes, u32 nuc_lut, uint8_t* seqs, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(encoding_decode_bytes_kernel, dim3(egrid(total_bytes, n_cu)), dim3(256), 0, st, in, total_bytes, nuc_lut, seqs);
+    return hipGetLastError();
+}
+hipError_t launch_calib_stream_read(const uint8_t* buf, u64 nbytes, unsigned long long* out, int n_cu, hipStream_t st) {
+    const u64 n_tiles = nbytes / 9600u, tail_chunks = (nbytes - n_tiles * 9600u) >> 4;
+    u64 grid = (u64)n_cu * 3u;   // the scan's 3 blocks per CU
+    if (grid > (n_tiles + 3u) / 4u) grid = (n_tiles + 3u) / 4u;
+    hipLaunchKernelGGL(calib_stream_read_kernel, dim3((unsigned)(grid ? grid : 1)), dim3(256), 0, st, buf, n_tiles, tail_chunks, out);
     return hipGetLastError();
 }
 

@@ -1,0 +1,46 @@
+// kmx_internal.h -- host-side state shared by the translation units behind include/kmx.h
+// (kmx_api.hip: entry points; kmx_comm.hip: the RCCL communicator).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/kmx.h"
+
+struct kmx_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+    int n_cu;
+    unsigned long long* d_scratch;  // 8 KiB: [0] first_bad, [2..3] fastx totals, [16..] tile-queue heads
+    void* d_big;                    // grow-only work buffer of the partitioned histogram (bucket-id streams)
+    size_t big_bytes;
+    unsigned long long dirty_desc;  // address of the dirty-tile flags as last written behind the queue heads
+    uint8_t* d_flags;               // one byte per tile, all zero between calls
+    size_t flags_bytes;
+    char last_error[256];
+};
+
+namespace kmx {
+int fail_hip(kmx_ctx* ctx, hipError_t e, const char* where);
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+}  // namespace kmx
+
+#define KMX_HIP(ctx, expr)                                            \
+    do {                                                              \
+        hipError_t e__ = (expr);                                      \
+        if (e__ != hipSuccess) return kmx::fail_hip(ctx, e__, #expr); \
+    } while (0)

@@ -767,9 +767,14 @@ static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Pa
     const u32 chunks = RAGGED ? 64u * NW : 4u * L;
     const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
     const size_t lds_bytes = (size_t)(ldsw + Sink::kLdsDwordsPerWave) * 4u * 4u + (size_t)Sink::block_lds_dwords(params) * 4u;
-    static int bpc = 0;
-    static size_t bpc_lds = 0;
-    if (bpc == 0 || bpc_lds != lds_bytes) {
+    // blocks per CU, cached per host thread and device (the ABI's model is one thread per context / GPU: a plain static
+    // would be written by all of them at once, and the function attribute below is a per-device setting)
+    static thread_local int bpc = 0, bpc_dev = -1;
+    static thread_local size_t bpc_lds = 0;
+    int dev_now = -1;
+    (void)hipGetDevice(&dev_now);
+    if (bpc == 0 || bpc_lds != lds_bytes || bpc_dev != dev_now) {
+        bpc_dev = dev_now;
         if (lds_bytes > 64u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return e;

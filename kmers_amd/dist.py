@@ -24,6 +24,16 @@ def shard_range(n_reads: int, rank: int, world: int) -> tuple[int, int]:
     return start, base + (1 if rank < extra else 0)
 
 
+def rccl_rank_count(device=None, group=None) -> int:
+    """Ranks that really take part in a collective: all-reduce(sum) of a one.  bench.py asserts it equals the
+    number of GPUs it claims (a process group that silently has one rank would otherwise measure one GPU)."""
+    if not dist.is_initialized():
+        return 1
+    one = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
+    return int(one.item())
+
+
 def _split(v: int) -> tuple[int, int]:
     return v & 0xFFFFFFFF, (v >> 32) & 0xFFFFFFFF
 

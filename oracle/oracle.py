@@ -511,3 +511,19 @@ def words(arr: np.ndarray, p_bits: int) -> list[int]:
     b = _u8(arr).tobytes()
     n = p_bits // 8
     return [int.from_bytes(b[i:i + n], "little") for i in range(0, len(b), n)]
+
+
+def sub_kmer_word(word: int, k: int, pos: int, width: int) -> int:
+    """Kmer::sub_kmer_word (kmer.rs:156-162); the reference's asserts surface as OracleError"""
+    out = C.c_uint64()
+    st = lib().kmo_sub_kmer_word(word, k, pos, width, C.byref(out))
+    if st != OK:
+        raise OracleError(st, "sub_kmer_word")
+    return out.value
+
+
+def bitmer_to_bytes(mer: int, length: int) -> bytes:
+    """kmer::bitmer_to_bytes (src/kmer.rs:71-91)"""
+    out = np.zeros(max(length, 1), np.uint8)
+    lib().kmo_bitmer_to_bytes(mer, length, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out[:length].tobytes()

@@ -31,7 +31,7 @@ def test_version_and_strerror():
     from kmers_amd import _lib
 
     lib = _lib.load()
-    assert lib.kmx_version() == 1
+    assert lib.kmx_version() == 2
     for st in range(0, 8):
         assert lib.kmx_strerror(st)
     assert lib.kmx_strerror(_lib.E_K_RANGE).decode().startswith("k outside")

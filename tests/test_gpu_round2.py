@@ -1,0 +1,274 @@
+"""GPU parity tests of the entry points added in round 2 (all through the libkmx C ABI, against the CPU oracle):
+decode / display direction, Encoding<P, B> for every utils::Data word type (row a18),
+the RCCL communicator behind the ABI (row e; one rank: a GPU box has one GPU), stream discipline of the
+torch-facing layer, the calibration kernel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M64 = 2**64 - 1
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from kmers_amd.api import Context
+
+    c = Context()
+    yield c
+    c.close()
+
+
+def _words(rng, n, k):
+    w = rng.integers(0, 2**63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    if k < 32:
+        w &= np.uint64((1 << (2 * k)) - 1)
+    return w
+
+
+# ------------------------------------------------------------------ f3: sub_kmer_word / String::from / bitmer_to_bytes
+
+@pytest.mark.parametrize("k,pos,width", [(31, 0, 31), (31, 5, 12), (31, 30, 1), (32, 0, 32), (32, 1, 31), (21, 7, 14), (1, 0, 1),
+                                         (13, 12, 0)])
+def test_sub_kmer_words(ctx, orc, k, pos, width):
+    rng = np.random.default_rng(k * 1000 + pos * 37 + width)
+    w = _words(rng, 1000 + k, k)
+    g = ctx.sub_kmer_words(ctx.to_device(w), k, pos, width).cpu().numpy().view(np.uint64)
+    exp = np.array([orc.sub_kmer_word(int(x), k, pos, width) for x in w], dtype=np.uint64)
+    assert (g == exp).all()
+
+
+def test_sub_kmer_words_asserts_become_codes(ctx):
+    from kmers_amd import _lib
+
+    import torch
+    w = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+    for k, pos, width in [(31, 31, 0), (31, 20, 12), (31, 40, 1)]:      # kmer.rs:157-158
+        with pytest.raises(_lib.KmxError) as e:
+            ctx.sub_kmer_words(w, k, pos, width)
+        assert e.value.status == _lib.E_ARG
+    with pytest.raises(_lib.KmxError) as e:
+        ctx.sub_kmer_words(w, 33, 0, 1)
+    assert e.value.status == _lib.E_K_RANGE
+
+
+def test_sub_kmer_reference_kat(ctx, kats):
+    """src/naive_impl/kmer.rs:529-542 (sub_kmer of "ACTTGAT" == Kmer::from of the substring), every (pos, width)"""
+    from oracle import oracle
+
+    s = kats["sub_kmer"]["seq"].encode()
+    km = oracle.kmer_from_bytes(s)
+    w = ctx.to_device(np.array([km.data], dtype=np.uint64))
+    for pos in range(len(s)):
+        for width in range(1, len(s) - pos + 1):
+            got = int(ctx.sub_kmer_words(w, len(s), pos, width).cpu().numpy().view(np.uint64)[0])
+            assert got == oracle.kmer_from_bytes(s[pos:pos + width]).data
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 13, 21, 31, 32])
+def test_kmers_to_strings_and_bitmer_to_bytes(ctx, orc, k):
+    rng = np.random.default_rng(k)
+    n = 777
+    w = _words(rng, n, k)
+    d = ctx.to_device(w)
+    low = ctx.kmers_to_strings(d, k).cpu().numpy().tobytes()
+    up = ctx.bitmers_to_bytes(d, k).cpu().numpy().tobytes()
+    for i in range(n):
+        exp = orc.bitmer_to_bytes(int(w[i]), k)                          # src/kmer.rs:71-91
+        assert up[i * k:(i + 1) * k] == exp
+        assert low[i * k:(i + 1) * k] == exp.lower()                       # kmer.rs:196-207 (BASE_TABLE is lower case)
+    assert orc.kmer_to_string(orc.Kmer(k, int(w[0]))).encode() == low[:k]
+
+
+def test_kmer_string_round_trip(ctx, orc):
+    """Kmer::from(&str) -> String::from(Kmer) is the identity on lower-case ACGT (kmer.rs:260-271 round trips)"""
+    rng = np.random.default_rng(5)
+    k, n = 27, 500
+    seqs = np.frombuffer(b"acgt", np.uint8)[rng.integers(0, 4, n * k)]
+    words = ctx.kmers_from_bytes(ctx.to_device(seqs), n, k)
+    back = ctx.kmers_to_strings(words, k).cpu().numpy()
+    assert (back == seqs).all()
+
+
+# ------------------------------------------------------------------ a18: Encoding<P, B> for u8 / u16 / u32 / u64 / u128
+
+P_SHAPES = [(8, 1), (8, 3), (8, 8), (16, 1), (16, 2), (16, 5), (32, 1), (32, 3), (64, 1), (64, 2), (128, 1), (128, 2), (128, 4)]
+ENCS = [0x1E, 0x1B, 0xE4, 0x27, 0x4B, 0xD8]   # ACGT, ACTG (= Xor10), TGCA, ... (naive.rs:48-74 discriminants)
+
+
+@pytest.mark.parametrize("word_bits,B", P_SHAPES)
+def test_encoding_p_encode_decode_revcomp(ctx, orc, word_bits, B):
+    rng = np.random.default_rng(word_bits * 100 + B)
+    nb = word_bits // 8 * B
+    cap = 4 * nb
+    n = 300
+    for enc in ENCS:
+        for seq_len in sorted({1, 2, cap // 2, cap - 1, cap} - {0}):
+            seqs = rng.integers(0, 256, n * seq_len, dtype=np.uint8)      # no validity check: every byte maps (naive.rs:14-16)
+            arr = ctx.encode_kmers_p(ctx.to_device(seqs), n, seq_len, enc, word_bits, B)
+            got = arr.cpu().numpy().reshape(n, nb)
+            for i in (0, 1, n // 2, n - 1):
+                exp = orc.naive_encode(enc, seqs[i * seq_len:(i + 1) * seq_len].tobytes(), nb)
+                assert (got[i] == exp).all(), (enc, seq_len, i)
+            dec = ctx.encoding_decode_p(arr, enc, word_bits, B).cpu().numpy().reshape(n, cap)
+            for i in (0, n - 1):
+                assert dec[i].tobytes() == orc.naive_decode(enc, got[i])
+            if seq_len >= 2:
+                rc = ctx.encoding_rev_comp_p(arr, seq_len, enc, word_bits, B).cpu().numpy().reshape(n, nb)
+                for i in (0, 2, n - 1):
+                    assert (rc[i] == orc.naive_rev_comp(enc, seq_len, got[i])).all(), (enc, seq_len, i)
+
+
+def test_encoding_p_reference_kats(ctx, kats, orc):
+    """the exact-word KATs of src/encoding/naive.rs:297-445 (P = u8, u16, u32, u64, u128) through the GPU:
+    encode words, decode, and decode of rev_comp"""
+    encs = kats["naive_encodings"]["enc_bytes"]
+    cases = kats["naive_encode_kats"]["cases"]
+    assert {c["p_bits"] for c in cases} >= {8, 16, 32, 64}
+    for c in cases:
+        enc, p_bits, B, K = encs[c["enc"]], c["p_bits"], c["B"], c["K"]
+        seq = np.frombuffer(c["seq"].encode(), np.uint8)
+        arr = ctx.encode_kmers_p(ctx.to_device(seq), 1, len(seq), enc, p_bits, B)
+        assert orc.words(arr.cpu().numpy(), p_bits) == [int(w) for w in c["words"]], c["name"]
+        assert ctx.encoding_decode_p(arr, enc, p_bits, B).cpu().numpy().tobytes() == c["decode"].encode(), c["name"]
+        rc = ctx.encoding_rev_comp_p(arr, K, enc, p_bits, B)
+        assert ctx.encoding_decode_p(rc, enc, p_bits, B).cpu().numpy().tobytes() == c["decode_rev_comp"].encode(), c["name"]
+
+
+def test_encoding_p_matches_u64_entry_points(ctx):
+    rng = np.random.default_rng(9)
+    n, K = 500, 45
+    seqs = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * K)]
+    d = ctx.to_device(seqs)
+    a = ctx.encode_kmers(d, n, K, 0x1E, 2).cpu().numpy().view(np.uint8)
+    b = ctx.encode_kmers_p(d, n, K, 0x1E, 64, 2).cpu().numpy()
+    assert (a == b).all()
+    c = ctx.encode_kmers_p(d, n, K, 0x1E, 16, 8).cpu().numpy()
+    assert (a == c).all()          # same flat bit string whatever P
+
+
+def test_encoding_p_capacity_is_a_code(ctx):
+    from kmers_amd import _lib
+
+    import torch
+    s = torch.zeros(100, dtype=torch.uint8, device=ctx.device)
+    with pytest.raises(_lib.KmxError) as e:
+        ctx.encode_kmers_p(s, 1, 5, 0x1E, 8, 1)       # 5 bases into a [u8; 1]: bit_field panics
+    assert e.value.status == _lib.E_TOO_LONG
+    with pytest.raises(_lib.KmxError) as e:
+        ctx.encode_kmers_p(s, 1, 4, 0x1E, 24, 1)
+    assert e.value.status == _lib.E_ARG
+
+
+# ------------------------------------------------------------------ RCCL communicator behind the ABI (one rank)
+
+def test_kmx_comm_single_rank(ctx, orc):
+    import torch
+
+    from kmers_amd.api import Comm
+
+    comm = Comm(ctx, 1, 0)
+    assert comm.size() == 1
+    counts = torch.arange(1 << 12, dtype=torch.int64, device=ctx.device) * 3
+    before = counts.clone()
+    comm.histogram_allreduce(counts)
+    ctx.synchronize()
+    assert torch.equal(counts, before)
+    n, L, k = 1000, 150, 31
+    bases = ctx.gen_reads(n * L)
+    from kmers_amd import _lib
+    s = ctx.canonical_reduce_async(bases, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    ref = s.clone()
+    comm.summary_allreduce(s)
+    ctx.synchronize()
+    assert torch.equal(s, ref)
+    comm.close()
+
+
+def test_torch_nccl_single_rank_on_device(ctx, orc):
+    """kmers_amd.dist on a real nccl (= RCCL) process group of one rank, device tensors"""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from kmers_amd import dist as kd
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=ctx.device)
+    try:
+        assert kd.rccl_rank_count(ctx.device) == 1
+        local = {"n_valid": 123, "sum_canon": M64 - 5, "xor_hash": 0x8000000000000001, "sum_fw": 77}
+        assert kd.combine_summaries(local, device=ctx.device) == local
+        counts = torch.ones(1 << 10, dtype=torch.int64, device=ctx.device)
+        kd.allreduce_histogram(counts)
+        assert int(counts.sum().item()) == 1 << 10
+    finally:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ stream discipline (api.py:46)
+
+def test_context_on_side_stream(orc):
+    import torch
+
+    from kmers_amd import _lib
+    from kmers_amd.api import Context
+
+    side = torch.cuda.Stream()
+    c = Context(stream=side)
+    n, L, k = 20_000, 150, 31
+    for it in range(5):
+        bases = c.gen_reads(n * L, first_byte=it * 1000)
+        g = c.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, 0)
+        host = bases.cpu().numpy()   # default stream: order it behind the side stream first
+        side.synchronize()
+        host = bases.cpu().numpy()
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+        outs = c.canonical_windows(bases, 256, L, k, want=("canon",))
+        side.synchronize()
+        _, _, canon, _ = orc.canonical_windows(host, 256, L, k)
+        assert (outs["canon"].cpu().numpy().view(np.uint64) == canon).all()
+    c.close()
+
+
+def test_default_context_used_inside_other_stream(orc):
+    import torch
+
+    from kmers_amd.api import Context
+
+    c = Context()
+    other = torch.cuda.Stream()
+    n, L, k = 10_000, 150, 21
+    bases = c.gen_reads(n * L)
+    torch.cuda.synchronize()
+    host = bases.cpu().numpy()
+    o = orc.canonical_reduce(host, n, L, k)
+    with torch.cuda.stream(other):
+        for _ in range(10):
+            g = c.canonical_reduce(bases, n, L, k)
+            assert (g.n_valid, g.sum_canon) == (o.n_valid, o.sum_canon)
+    c.close()
+
+
+# ------------------------------------------------------------------ calibration kernel
+
+@pytest.mark.parametrize("nbytes", [0, 16, 9600, 9600 * 7 + 160, 150 * 64 * 1000 + 48])
+def test_calib_stream_read_folds_every_chunk(ctx, nbytes):
+    import torch
+
+    rng = np.random.default_rng(nbytes + 1)
+    host = rng.integers(0, 256, max(nbytes, 16), dtype=np.uint8)[:nbytes]
+    buf = ctx.to_device(host) if nbytes else torch.zeros(16, dtype=torch.uint8, device=ctx.device)[:0]
+    out = ctx.calib_stream_read(buf)
+    got = int(out.cpu().numpy().view(np.uint64)[0])
+    words = host[: nbytes // 16 * 16].view(np.uint32)
+    exp = int(np.bitwise_xor.reduce(words)) if words.size else 0
+    assert got == exp
