@@ -58,6 +58,22 @@
 #ifndef KMX_BS_SWZ
 #define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
 #endif
+#ifndef KMX_BS_P1TIE
+#define KMX_BS_P1TIE 2   // pass 1: how a plane request is tied to the ripple step it belongs to (1: opaque copy of the LDS address, a v_mov per step; 2: compiler fence, no instruction)
+#endif
+#ifndef KMX_BS_RELANE
+#define KMX_BS_RELANE 0   // 1: every phase derives its lane-dependent indices and LDS addresses afresh from an opaque copy of the lane id (a few VALU per tile) instead of keeping ~10 of them in registers across the tile loop
+#endif
+#ifndef KMX_BS_TRC_LDS
+#define KMX_BS_TRC_LDS 0   // 1: the eight per-lane constants of the transposes (phase C) live in a 1 KB table in LDS, fetched per tile, instead of in registers across the loop
+#endif
+#ifndef KMX_BS_LATE_ROWS
+// uniform ASCII main pass on the 10-word frame: this many of the NW prefetch rows are requested between pass 1 and pass 2
+// of phase D instead of right after phase A -- their 4 registers each are free until then, and with half of the tile's
+// rows out of the way every k from 13 to 31 fits 128 registers without a spill: 4 waves/SIMD (k = 31: 0.648 -> 0.676 of the
+// roofline; 5 or 6 late rows measure the same, 3 or 4 need more help and lose what they gain)
+#define KMX_BS_LATE_ROWS 5
+#endif
 #ifndef KMX_BS_ABLATE
 #define KMX_BS_ABLATE 0   // dev: bitmask of phases to skip (timing experiments only; results become wrong)
 #endif
@@ -77,6 +93,12 @@ __device__ __forceinline__ void plane_weights(u32 i, u32 L, u32 k, u64& wf, u64&
     wf = ((1ull << (2u * (e_hi + 1u))) - (1ull << (2u * e_lo))) / 3ull;
     const u32 f_lo = k - 1u - e_hi, f_hi = k - 1u - e_lo;
     wr = ((1ull << (2u * (f_hi + 1u))) - (1ull << (2u * f_lo))) / 3ull;
+}
+
+// a wave-uniform 64-bit value, pinned to scalar registers
+__device__ __forceinline__ u64 uniform_u64(u64 v) {
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
 }
 
 // one step of the fw<rc ripple: lt' = (~a & ~q) | ((a ^ q) & lt) as a single v_bitop3_b32
@@ -107,15 +129,15 @@ __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, 
 #define KMX_BS_DIRTY 1
 #endif
 template <int K> constexpr bool bs_has_dirty_pass() { return KMX_BS_DIRTY != 0; }   // (one more kernel per frame and k)
-// Waves per SIMD of the ASCII kernel on the 10-word frame.  The counters D[] grow with k: up to k = 23 (k = 26 with
-// <= 4 windows per lane) the kernel fits 128 registers with at most 16 bytes of spills and a 4th wave pays (k = 21: 65 ->
-// 69 % of the roofline, k = 23 / 25 / 26: +4 %); k = 27 / 28 are neutral (24 B), k = 29 / 30 lose 3-6 % (40 B), and at
-// k = 31 the 56 bytes it would spill include a row of the prefetch (-15 %).
+// Waves per SIMD of the ASCII kernel on the 10-word frame: 4 for every k now that half of the prefetch rows are requested
+// late (KMX_BS_LATE_ROWS).  Before that the counters D[] decided: up to k = 23 (k = 26 with <= 4 windows per lane) the
+// kernel fit 128 registers with at most 16 bytes of spills, k = 27 / 28 were neutral, k = 29 / 30 lost 3-6 % and k = 31
+// spilled a row of the prefetch (-15 %).
 template <int K, int WPL> constexpr int bs_waves_ascii() {
 #ifdef KMX_BS_WAVES_FORCE
     return KMX_BS_WAVES_FORCE;
 #else
-    return (K <= 23 || (K <= 26 && WPL <= 4)) ? 4 : KMX_BS_WAVES;
+    return (KMX_BS_LATE_ROWS >= 5 || K <= 23 || (K <= 26 && WPL <= 4)) ? 4 : KMX_BS_WAVES;
 #endif
 }
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, int PASS = 0>
@@ -138,11 +160,18 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     constexpr int PLANES = 8 * S2;       // dwords per set (>= 32*NW)
     const u32 lane = threadIdx.x & 63u;
     const u32 half = lane >> 5, p = lane & 31u;
-    const u32 wib = threadIdx.x >> 6;
+    const u32 wib = KMX_BS_RELANE ? (u32)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (threadIdx.x >> 6);
+    // KMX_BS_RELANE: an opaque copy of the lane id; what a phase derives from it cannot be hoisted out of the tile loop
+    auto relane = [&]() -> u32 {
+        u32 v = lane;
+        if (KMX_BS_RELANE) asm volatile("" : "+v"(v));
+        return v;
+    };
     const u32 chunks = 4u * L + (RAGGED ? 1u : 0u);          // 16-byte chunks a tile may span (ragged: +1 for its unaligned start)
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
     const u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
-    u32* P = lds + wib * (ldsw + 4u * PLANES + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u) + (PASS == 1 ? 128u : 0u));
+    constexpr u32 TRC_DW = KMX_BS_TRC_LDS ? 256u : 0u;     // [32 lanes of a half-wave][8] transpose constants, shared by the block
+    u32* P = lds + TRC_DW + wib * (ldsw + 4u * PLANES + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u) + (PASS == 1 ? 128u : 0u));
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
     const u64 n_full = n_reads >> 6;
@@ -170,15 +199,26 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // v_perm_b32 selectors of the byte-granular stages ({S0=y: bytes 4-7, S1=x: bytes 0-3})
     const u32 tr_sel16 = (p & 16u) ? 0x03020706u : 0x05040100u;   // keep x.hi, take y.hi>>16  |  keep x.lo, take y.lo<<16
     const u32 tr_sel8 = (p & 8u) ? 0x03070105u : 0x06020400u;     // odd bytes kept, even from y.odd | even kept, odd from y.even
+    if constexpr (KMX_BS_TRC_LDS) {
+        // every wave writes the same values (no block barrier needed: a wave reads them after its own, fenced, writes)
+        if (half == 0) {
+            uint4* t = reinterpret_cast<uint4*>(lds + 8u * p);
+            t[0] = make_uint4(tr_sh[2], tr_sh[3], tr_sh[4], tr_sel16);
+            t[1] = make_uint4(tr_keep[2], tr_keep[3], tr_keep[4], tr_sel8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     u32 D[2 * NT];
 #pragma unroll
     for (int q = 0; q < 2 * NT; ++q) D[q] = 0;
     u32 mcnt = 0;                       // sum popcount(m)
-    // per-plane popcount totals of the planes this lane produces live in LDS (TOT[half][32g+p]); only this
+    // per-plane popcount totals of the planes this lane produces live in LDS (TOT[g][lane]); only this
     // lane ever touches its own slots, so plain read-modify-write is enough
     u32* TOT = PL + 2u * PLANES;
 #pragma unroll
-    for (int g = 0; g < NW; ++g) TOT[half * PLANES + 32u * g + p] = 0;
+    for (int g = 0; g < NW; ++g) TOT[64u * g + lane] = 0;   // (indexed [group][lane]: one address register, a compile-time offset per group)
     u32* VAL = TOT + 2u * PLANES;       // ragged: [2][32*NV] validity planes of the current tile
     // ragged, per lane, kept in LDS (registers are what caps this variant's occupancy): QT[e][lane] = running popcount of the
     // lane's plane of the read-end words, NVR[lane] = windows of the lane's reads in bit-sliced tiles
@@ -359,20 +399,25 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             w[it] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    auto issue_loads = [&](u64 tile) {
+    constexpr int LATE = (!PACKED && !RAGGED && PASS == 0 && K <= 32 && NW == 10) ? KMX_BS_LATE_ROWS : 0;   // rows of the prefetch requested late
+    u64 tile = ~0ull, next_tile = ~0ull;
+    auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
         // The per-row offsets are derived afresh from an opaque copy of the lane offset: left to itself hipcc hoists all
         // NLD of them out of the tile loop as zero-extended 64-bit values (24 registers at NLD = 10, and a 64-bit add per
         // row per tile); recomputed they are one 32-bit op each and the loads take the SGPR-base + VGPR-offset form
         // (168 -> 152 registers at k = 31, 240 -> 220 at k = 63; same speed).
-        u32 l16 = lane16;
+        u32 l16 = KMX_BS_RELANE ? relane() * 16u : lane16;
         asm volatile("" : "+v"(l16));
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
+            if (it < row0 || it >= row1) continue;
             // lanes past the tile end re-read its last chunk: no branch, so all loads of a tile sit in
             // one basic block and stay in flight together (a guarded load would be fenced by vmcnt(0))
             u32 off = l16 + (u32)it * 1024u;
-            if (it == NLD - 1 || short_rows) off = off < last_off ? off : last_off;
+            // (the bound of a row that cannot leave the tile is ~0: one v_min per row, the choice is made on the scalar side)
+            const u32 row_bound = (it == NLD - 1 || short_rows) ? last_off : 0xFFFFFFFFu;
+            off = off < row_bound ? off : row_bound;
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb + off));  // streamed once
             w[it] = make_uint4(v.x, v.y, v.z, v.w);
@@ -418,22 +463,32 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     // The ticket for tile t+2 is requested at the end of iteration t and only looked at an iteration later: reading the
     // atomic's return value right away (as dequeue() does) stalled every wave for a device-atomic round trip per tile.
-    unsigned long long pend = 0;
+    u32 pend = 0;            // (the low word: a head hands out fewer than 2^32 tickets -- launch_bs checks the tile count)
     u32 pend_qid = 0;
     auto ticket_issue = [&]() {
         if constexpr (PASS == 1) return;   // (no tickets: dequeue() walks the flags)
         pend_qid = qid;
-        if (heads_left != 0u && lane == 0) pend = atomicAdd(queue + qid * 16u, 1ull);
+        if (heads_left != 0u && lane == 0) {
+            unsigned long long one = 1ull;   // (made here: hoisted, the constant holds a register pair across the tile loop)
+            asm volatile("" : "+v"(one));
+            pend = (u32)atomicAdd(queue + qid * 16u, one);
+        }
     };
     auto ticket_take = [&]() -> u64 {
         if constexpr (PASS == 1) return dequeue();
         if (heads_left == 0u) return ~0ull;
-        const u32 lo = __builtin_amdgcn_readfirstlane((u32)pend), hi = __builtin_amdgcn_readfirstlane((u32)(pend >> 32));
-        const u64 t = (((u64)hi << 32) | lo) * NQ + pend_qid;
+        const u32 lo = __builtin_amdgcn_readfirstlane(pend);
+        const u64 t = (u64)lo * NQ + pend_qid;
         if (t < n_full) return t;
         qid = (pend_qid + 1u) & (NQ - 1u);   // that head is drained: move on, synchronously (rare)
         heads_left -= 1u;
         return dequeue();
+    };
+    auto prefetch = [&](u64 t, u64 fallback_t, int row0 = 0, int row1 = 64) {   // clamped => unconditional, one basic block, pinned by sched barriers
+        const u64 nxt = t < n_full ? t : fallback_t;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(KMX_BS_ABLATE & 128)) issue_loads(nxt, row0, row1);   // (dev) 128: compute-only
+        __builtin_amdgcn_sched_barrier(0);
     };
     // ---- per-tile phases
     // encode16, hand-scheduled for the VALU co-issue rule of gfx950 (see phase D, pass 2): the half-rate instructions
@@ -453,12 +508,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                      "s_setprio 0"
                      : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
                      : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(TBL_HI), "v"(TBL_LO));
-        e0 ^= wv.x;
-        e1 ^= wv.y;
-        e2 ^= wv.z;
-        e3 ^= wv.w;
-        bad = __builtin_amdgcn_bitop3_b32(bad, e0, e1, 0xFE);
-        bad = __builtin_amdgcn_bitop3_b32(bad, e2, e3, 0xFE);
+        // bad |= expected ^ actual, one v_bitop3_b32 per dword (S0 | (S1 ^ S2) = 0xF6) instead of 4 v_xor + 2 three-input ORs
+        bad = __builtin_amdgcn_bitop3_b32(bad, e0, wv.x, 0xF6);
+        bad = __builtin_amdgcn_bitop3_b32(bad, e1, wv.y, 0xF6);
+        bad = __builtin_amdgcn_bitop3_b32(bad, e2, wv.z, 0xF6);
+        bad = __builtin_amdgcn_bitop3_b32(bad, e3, wv.w, 0xF6);
         // 2 * (4 bases in 8 bits) per dword, merged to 16 bases in 32 bits: ((d0 | d1<<8 | d2<<16) >> 1) | d3<<23
         asm volatile("s_setprio 3\n\t"
                      "v_dot4_u32_u8 %0, %0, %4, 0\n\t"
@@ -476,6 +530,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         return __builtin_amdgcn_bitop3_b32(t0 >> 1, t0, k55, 0x6c);   // internal (ACTG) -> naive_impl (ACGT) codes
     };
     auto phase_A = [&]() -> bool {   // pack + validate the tile sitting in w[] into the packed LDS buffer
+        const u32 ln_ = relane();
+        const u32 lane = ln_;
         u32 bad = 0;
         if constexpr (RAGGED) {      // the tile spans cur_m.n_ch chunks from its aligned start (neighbouring tiles' bytes at both ends)
             if constexpr (PASS == 1) {   // second pass: also the bitmap of bad chunks (see the uniform branch below)
@@ -532,6 +588,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
             const u32 c = (NW - 1) * 64u + lane;
             if (c < chunks) P[1u + c] = encode_prio(w[NW - 1], bad);
+
         } else if (chunks >= 64u * (NW - 1)) {
 #pragma unroll
             for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode16(w[it], bad);
@@ -553,10 +610,16 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     auto phase_BC = [&]() {
+        const u32 ln_ = relane();
+        const u32 lane = ln_, half = ln_ >> 5, p = ln_ & 31u;
         // ---- B. this lane's read, realigned: F[g] = bases [16g, 16g+16)
         u32 F[NXT];
         if constexpr (RAGGED) {
             posF = cur_m.rel + 16u * PAD;
+            qF = posF >> 4;
+            aF = 2u * (posF & 15u);
+        } else if constexpr (KMX_BS_RELANE != 0) {
+            posF = lane * L + 16u * PAD;
             qF = posF >> 4;
             aF = 2u * (posF & 15u);
         }
@@ -614,28 +677,36 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         // (v_perm_b32 / v_alignbit_b32 / DPP moves) as one raised-priority run and its full-rate bit selects after it.
         {
             u32 Y[NXT];
+            u32 c_sh2 = tr_sh[2], c_sh3 = tr_sh[3], c_sh4 = tr_sh[4], c_sel16 = tr_sel16;
+            u32 c_keep2 = tr_keep[2], c_keep3 = tr_keep[3], c_keep4 = tr_keep[4], c_sel8 = tr_sel8;
+            if constexpr (KMX_BS_TRC_LDS) {
+                const uint4* t = reinterpret_cast<const uint4*>(lds + 8u * p);
+                const uint4 a = t[0], b = t[1];
+                c_sh2 = a.x; c_sh3 = a.y; c_sh4 = a.z; c_sel16 = a.w;
+                c_keep2 = b.x; c_keep3 = b.y; c_keep4 = b.z; c_sel8 = b.w;
+            }
 #define KMX_HRUN_BEGIN __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3);
 #define KMX_HRUN_END __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int g = 0; g < NXT; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (16 << 10) | 0x1f);
             KMX_HRUN_BEGIN
 #pragma unroll
-            for (int g = 0; g < NXT; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], tr_sel16);
+            for (int g = 0; g < NXT; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], c_sel16);
             KMX_HRUN_END
 #pragma unroll
             for (int g = 0; g < NXT; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (8 << 10) | 0x1f);
             KMX_HRUN_BEGIN
 #pragma unroll
-            for (int g = 0; g < NXT; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], tr_sel8);
+            for (int g = 0; g < NXT; ++g) F[g] = __builtin_amdgcn_perm(Y[g], F[g], c_sel8);
             KMX_HRUN_END
 #pragma unroll
             for (int g = 0; g < NXT; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (4 << 10) | 0x1f);
             KMX_HRUN_BEGIN
 #pragma unroll
-            for (int g = 0; g < NXT; ++g) Y[g] = alignbit(Y[g], Y[g], tr_sh[2]);
+            for (int g = 0; g < NXT; ++g) Y[g] = alignbit(Y[g], Y[g], c_sh2);
             KMX_HRUN_END
 #pragma unroll
-            for (int g = 0; g < NXT; ++g) F[g] = bitsel(F[g], Y[g], tr_keep[2]);
+            for (int g = 0; g < NXT; ++g) F[g] = bitsel(F[g], Y[g], c_keep2);
 #pragma unroll
             for (int st = 3; st < 5; ++st) {
 #if KMX_BS_SWZ == 2
@@ -652,16 +723,20 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                                    : (u32)__builtin_amdgcn_update_dpp(0, (int)F[g], 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
 #endif
 #pragma unroll
-                for (int g = 0; g < NXT; ++g) Y[g] = alignbit(Y[g], Y[g], tr_sh[st]);
+                for (int g = 0; g < NXT; ++g) Y[g] = alignbit(Y[g], Y[g], st == 3 ? c_sh3 : c_sh4);
                 KMX_HRUN_END
 #pragma unroll
-                for (int g = 0; g < NXT; ++g) F[g] = bitsel(F[g], Y[g], tr_keep[st]);
+                for (int g = 0; g < NXT; ++g) F[g] = bitsel(F[g], Y[g], st == 3 ? c_keep3 : c_keep4);
             }
+            {
+                // plane q = 32g + p  <->  base beta = 16g + p/2, bit p & 1.  One lane-dependent base and a compile-time offset per
+                // group (indexing PL[] with the whole expression costs an address register per group: the u32 sum could wrap, so
+                // hipcc cannot split it into register + immediate offset)
+                const u32 b0 = p >> 1;
+                const u32 slot0 = (WPL == 4) ? (b0 & 3u) * S2 + (b0 >> 2) : b0;
+                u32* const pst = PL + (half * PLANES + 2u * slot0 + (p & 1u));
 #pragma unroll
-            for (int g = 0; g < NW; ++g) {
-                const u32 beta = 16u * g + (p >> 1);
-                const u32 slot = (WPL == 4) ? (beta & 3u) * S2 + (beta >> 2) : beta;
-                PL[half * PLANES + 2u * slot + (p & 1u)] = F[g];
+                for (int g = 0; g < NW; ++g) pst[(WPL == 4) ? 8 * g : 32 * g] = F[g];
             }
 #pragma unroll
             for (int j = 0; j < NV; ++j) VAL[half * 32u * NV + 32u * j + p] = F[NW + NE + j];   // ragged: plane V_(32j+p) of this set
@@ -669,8 +744,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
             for (int g = 0; g < NW + NE; ++g) Y[g] = (u32)__builtin_popcount(F[g]);
             KMX_HRUN_END
+            {
+                u32* const tot_l = TOT + lane;
 #pragma unroll
-            for (int g = 0; g < NW; ++g) atomicAdd(&TOT[half * PLANES + 32u * g + p], Y[g]);
+                for (int g = 0; g < NW; ++g) atomicAdd(tot_l + 64 * g, Y[g]);
+            }
 #pragma unroll
             for (int e = 0; e < NE; ++e) atomicAdd(&QT[e * 64 + lane], Y[NW + e]);               // ragged: read-end planes, totals only
 #undef KMX_HRUN_BEGIN
@@ -728,18 +806,29 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 const u32 slot = (WPL == 4) ? (beta & 3u) * S2 + (beta >> 2) : beta;
                 PL[half * PLANES + 2u * slot + (p & 1u)] = x;
             }
-            atomicAdd(&TOT[half * PLANES + 32u * g + p], (u32)__builtin_popcount(x));   // ds_add_u32, no return: no LDS round trip
+            atomicAdd(&TOT[64u * g + lane], (u32)__builtin_popcount(x));   // ds_add_u32, no return: no LDS round trip
         }
 #endif
         lds_fence();
 
     };
-    auto phase_D = [&]() {
+    auto phase_D = [&](const bool run) {
         // ---- D. a lane handles the WPL windows o..o+WPL-1 of one set (o = WPL*group): they share the planes of
         //      bases o..o+K+WPL-2, streamed twice from LDS as u64 (2 planes per base):
         //      pass 1 = four interleaved fw<rc ripples, pass 2 = masked popcounts.
+        // `run` (wave-uniform) = false: a tile that is not scanned here (flagged for the second pass); with LATE > 0 the call
+        // is still made, for the ONE static site of the late prefetch rows between the passes (a second site in another
+        // branch gets its own registers and is hoisted above the branch).
+        // The launchers pick WPL so that the 2 * NG (set, group) items of a tile fit the 64 lanes: ONE round, always
+        // (launch_bs checks it).  LATE > 0 relies on it: with a compile-time single trip the late prefetch rows have one
+        // definition on every path.  Otherwise the round loop stays a real loop (runtime bound): as straight-line code hipcc
+        // hoists the plane requests of pass 1 across phase C and the kernels gain 20-60 registers.
+        const u32 n_rounds = LATE > 0 ? 1u : (run ? rounds : 0u);
+        const u32 ln_ = relane();
+        const u32 lane = ln_;
 #pragma unroll 1
-        for (u32 r = 0; r < ((KMX_BS_ABLATE & 64) ? 0u : rounds); ++r) {
+        for (u32 r = 0; LATE > 0 ? r < 1u : r < n_rounds; ++r) {
+            if (KMX_BS_ABLATE & 64) break;
             const u32 gidx = r * 64u + lane;
             const bool active = gidx < 2u * NG;
             const u32 set = (gidx >= NG && active) ? 1u : 0u;
@@ -751,7 +840,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             u32 lt[WPL];
 #pragma unroll
             for (int w = 0; w < WPL; ++w) lt[w] = 0u;
-            {
+            if (run) {
 #if KMX_BS_P1D == 0
                 // (dev) plane loads left to the compiler
                 u64 Pv[K + WPL - 1];
@@ -794,11 +883,20 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     // an (empty) asm ties the address to the ripple state of the previous step, so the two requests are
                     // issued here and not hoisted to the top of the unrolled loop (34 planes live = spills)
                     // (an index, not the pointer: an opaque pointer would lose its LDS address space and turn the reads into flat loads)
-                    u32 z = 0;
-                    asm volatile("" : "+v"(z) : "v"(lt[0]));
-                    const u64* sj = src + z;
+                    // (the LDS byte address itself goes through the asm and comes back as an address-space-3 pointer: a zero
+                    // offset added to `src` costs a v_mov and a v_lshl_add per step, 30 VALU instructions a tile)
+#if KMX_BS_P1TIE == 2
+                    asm volatile("" : : "v"(lt[0]) : "memory");   // a compiler-level fence only: no instruction, no copy
+                    Pv[j] = KMX_PLANE_AT(src, j);
+                    Pv[K - 1 - j + WPL - 1] = KMX_PLANE_AT(src, K - 1 - j + WPL - 1);
+#else
+                    typedef const u64 __attribute__((address_space(3))) * lds_cu64p;
+                    u32 a = (u32)(uintptr_t)(lds_cu64p)src;
+                    asm volatile("" : "+v"(a) : "v"(lt[0]));
+                    const lds_cu64p sj = (lds_cu64p)(uintptr_t)a;
                     Pv[j] = KMX_PLANE_AT(sj, j);
                     Pv[K - 1 - j + WPL - 1] = KMX_PLANE_AT(sj, K - 1 - j + WPL - 1);
+#endif
                 };
 #pragma unroll
                 for (int j = J0; j >= JEND; --j) {
@@ -825,8 +923,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     m[w] = ((u32)w < nwin) ? lt[w] : 0u;
                 }
                 if constexpr (PASS == 1) m[w] &= set ? (u32)(valid_reads >> 32) : (u32)valid_reads;   // blanked reads own no window
-                pc_acc(mcnt, m[w]);
+                pc_acc(mcnt, m[w]);   // (a tile that is not scanned: lt == 0, nothing is added)
             }
+            if constexpr (LATE > 0) {   // the rest of the next tile's rows: the registers of pass 1's plane window are free now
+                if (r == 0) prefetch(next_tile, tile, NLD - LATE, NLD);
+            }
+            if (!run) break;
             asm volatile("" ::: "memory");   // pass 2 re-reads the planes instead of keeping 2K+6 registers live
             constexpr int NPL = (KMX_BS_ABLATE & 1) ? 1 : K + WPL - 1;
 #if KMX_BS_PRIO
@@ -920,18 +1022,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
 #undef KMX_PLANE
 #undef KMX_PLANE_AT
-        n_bs_tiles += 1;
-    };
-    auto prefetch = [&](u64 t, u64 fallback_t) {   // clamped => unconditional, one basic block, pinned by sched barriers
-        const u64 nxt = t < n_full ? t : fallback_t;
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(KMX_BS_ABLATE & 128)) issue_loads(nxt);   // (dev) 128: compute-only
-        __builtin_amdgcn_sched_barrier(0);
+        if (run) n_bs_tiles += 1;
     };
 
     // Pipeline order 1: [A of tile t] [issue loads of tile t+1] [B,C,D of tile t]
-    u64 tile = dequeue();
-    u64 next_tile = dequeue();
+    tile = uniform_u64(dequeue());
+    next_tile = uniform_u64(dequeue());
     ticket_issue();
     if constexpr (RAGGED) {
         if (tile < n_full) {
@@ -961,8 +1057,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 return;
             }
             if (lane == 0) {
-                flags[tile] = 1;
-                queue[512] = 1;
+                u32 one = 1u;   // (made here: hoisted out of the tile loop these constants each hold a register for good)
+                asm volatile("" : "+v"(one));
+                flags[tile] = (uint8_t)one;
+                queue[512] = one;
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (as an instruction the waitcnt pass sees, not inline asm)
             flagged = true;
@@ -980,10 +1078,15 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             __builtin_amdgcn_sched_barrier(0);
         } else {
             bad_tile = phase_A();
+            // LATE > 0: the waits for the rows' loads sit under branches of phase A (lanes past the tile skip their chunk), so
+            // for hipcc a row may still be in flight afterwards, and the first write to one of its registers -- they are free
+            // until the late rows go out -- would cost an s_waitcnt vmcnt(0) with the next tile's loads already out.  Here, on
+            // every path, the wait is free: the wave has just used all of them.
+            if constexpr (LATE > 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             if constexpr (PASS == 0 && DIRTY_LIST) {
                 if (bad_tile) flag_tile();
             }
-            prefetch(next_tile, tile);
+            prefetch(next_tile, tile, 0, NLD - LATE);
         }
         lds_fence();
         KMX_T(1)
@@ -1018,16 +1121,17 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             if constexpr (!(PASS == 0 && DIRTY_LIST && !RAGGED)) {   // (the uniform main pass never rolls a full tile itself)
                 if (!flagged) fallback_read(tile * 64u + lane, true);
             }
-        } else if (!(KMX_BS_ABLATE & 32)) {
-            phase_BC();
+        }
+        {
+            const bool run = !bad_tile && !(KMX_BS_ABLATE & 32);
+            if (run) phase_BC();
             KMX_T(3)
-            phase_D();
+            if (run || LATE > 0) phase_D(run);
             KMX_T(4)
-        } else {
-            n_bs_tiles += 1;
+            if (!bad_tile && (KMX_BS_ABLATE & 32)) n_bs_tiles += 1;
         }
         tile = next_tile;
-        next_tile = ticket_take();     // requested one whole iteration ago
+        next_tile = uniform_u64(ticket_take());     // requested one whole iteration ago (kept in scalar registers)
         ticket_issue();
         if constexpr (RAGGED) {
             cur_m = nx_m;
@@ -1071,7 +1175,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
         for (int g = 0; g < NW; ++g) {
             const u32 qidx = 32u * g + p;
-            const u32 pcq = TOT[half * PLANES + qidx];     // per-plane totals of this half's set
+            const u32 pcq = TOT[64u * g + lane];           // per-plane totals of this half's set
             if constexpr (K <= 32 && !RAGGED) {
                 u64 wf, wr;
                 plane_weights(qidx >> 1, L, (u32)K, wf, wr);
@@ -1149,6 +1253,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     constexpr u32 NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;
     constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
     size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u) + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u)) * 4u * 4u;
+    if (KMX_BS_TRC_LDS) lds_bytes += 1024u;
     if (const char* e = getenv("KMX_BS_EXTRA_LDS")) lds_bytes += (size_t)atol(e);   // dev knob: caps blocks per CU
     // blocks per CU, cached per host thread and device (one thread per context / GPU is the ABI's model: a plain static
     // would be shared, and written, by all of them)
@@ -1165,6 +1270,8 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
         bpc_lds = lds_bytes;
         if (getenv("KMX_BS_PRINT_BPC")) fprintf(stderr, "kmx: bit-sliced K=%d NW=%d WPL=%d: %d blocks per CU, %zu B of LDS each\n", K, NW, WPL, bpc, lds_bytes);
     }
+    if (L < (u32)K || 2u * ((L - (u32)K + 1u + (u32)WPL - 1u) / (u32)WPL) > 64u) return hipErrorInvalidValue;   // phase D runs ONE round of 64 items
+    if ((n_reads >> 6) >= (1ull << 36)) return hipErrorInvalidValue;   // tickets are kept as 32-bit values (32 heads x 2^32 tiles; 2^42 reads is far past any HBM)
     const u64 n_tiles = (n_reads + 63u) >> 6;
     u64 grid = (u64)n_cu * (u64)bpc;
     const u64 need = (n_tiles + 3u) / 4u;
