@@ -58,6 +58,12 @@
 #ifndef KMX_BS_SWZ
 #define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
 #endif
+#ifndef KMX_BS_WAVES2
+#define KMX_BS_WAVES2 2   // waves per SIMD the two-word kernels (k = 33..63) are compiled for
+#endif
+#ifndef KMX_BS_LATE2
+#define KMX_BS_LATE2 5   // late prefetch rows of the two-word k (33..63): k = 33 then fits 128 registers (4 waves/SIMD), k = 45..53 fit 168 (3 waves instead of 2)
+#endif
 #ifndef KMX_BS_P1TIE
 #define KMX_BS_P1TIE 2   // pass 1: how a plane request is tied to the ripple step it belongs to (1: opaque copy of the LDS address, a v_mov per step; 2: compiler fence, no instruction)
 #endif
@@ -141,7 +147,7 @@ template <int K, int WPL> constexpr int bs_waves_ascii() {
 #endif
 }
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, int PASS = 0>
-__global__ void __launch_bounds__(256, ((K > 32 || PASS == 1) ? 2 : RAGGED ? KMX_BSR_WAVES : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
+__global__ void __launch_bounds__(256, (PASS == 1 ? 2 : K > 32 ? KMX_BS_WAVES2 : RAGGED ? KMX_BSR_WAVES : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets) {
@@ -399,7 +405,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             w[it] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    constexpr int LATE = (!PACKED && !RAGGED && PASS == 0 && K <= 32 && NW == 10) ? KMX_BS_LATE_ROWS : 0;   // rows of the prefetch requested late
+    constexpr int LATE = (!PACKED && !RAGGED && PASS == 0 && NW == 10) ? (K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2) : 0;   // rows of the prefetch requested late
     u64 tile = ~0ull, next_tile = ~0ull;
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
