@@ -22,14 +22,15 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libkmx.so")
 SOURCES = ["kmx_bitslice.hip", "kmx_bitslice_k21.hip", "kmx_bitslice_k13_17.hip", "kmx_bitslice_k18_23.hip", "kmx_bitslice_k24_27.hip",
            "kmx_bitslice_k28_30.hip", "kmx_bitslice_k33_39.hip", "kmx_bitslice_k41_47.hip", "kmx_bitslice_k49_55.hip",
-           "kmx_bitslice_k57_61.hip", "kmx_bitslice_ragged.hip", "kmx_scan.hip", "kmx_generic.hip", "kmx_elem.hip", "kmx_seqvec.hip", "kmx_fastx.hip",
+           "kmx_bitslice_k57_61.hip", "kmx_bitslice_k34_40.hip", "kmx_bitslice_k42_48.hip", "kmx_bitslice_k50_56.hip", "kmx_bitslice_k58_64.hip",
+           "kmx_bitslice_ragged.hip", "kmx_scan.hip", "kmx_generic.hip", "kmx_elem.hip", "kmx_seqvec.hip", "kmx_fastx.hip",
            "kmx_comm.hip", "kmx_api.hip"]
 HEADERS = [os.path.join(CSRC, "kmx_device.h"), os.path.join(CSRC, "kmx_bitslice_kernel.h"), os.path.join(CSRC, "kmx_internal.h"),
            os.path.join(HERE, "..", "include", "kmx.h")]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-fno-gpu-rdc", "-munsafe-fp-atomics"]
-JOBS = int(os.environ.get("KMX_BUILD_JOBS", "4"))
+JOBS = int(os.environ.get("KMX_BUILD_JOBS", str(min(8, os.cpu_count() or 4))))
 
 
 def hipcc() -> str:

@@ -84,6 +84,7 @@ hipError_t launch_encode_kmers_bytes(const uint8_t* seqs, u64 n, u32 seq_len, u3
 hipError_t launch_encoding_rev_comp_bytes(const uint8_t* in, u64 n, u32 K, u32 comp_lut, u32 nb, uint8_t* out, int n_cu, hipStream_t st);
 hipError_t launch_encoding_decode_bytes(const uint8_t* in, u64 total_bytes, u32 nuc_lut, uint8_t* seqs, int n_cu, hipStream_t st);
 hipError_t launch_calib_stream_read(const uint8_t* buf, u64 nbytes, unsigned long long* out, int n_cu, hipStream_t st);
+hipError_t launch_fix_hash_fold(kmx_summary* out, u32 k, u32 hasher, u32 hk, hipStream_t st);
 }  // namespace kmx
 
 using kmx::u32;
@@ -110,7 +111,7 @@ void* big_scratch(void* user, size_t bytes);
 int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k) {
     const uint64_t n_tiles = n_reads >> 6;
     uint8_t* buf = nullptr;
-    if (n_tiles && ((k >= 13 && k <= 31) || (k >= 33 && k <= 63 && (k & 1u)))) {   // the k with a bit-sliced kernel (and so a second pass)
+    if (n_tiles && ((k >= 13 && k <= 31) || (k >= 33 && k <= 64))) {   // the k with a bit-sliced kernel (and so a second pass)
         if (n_tiles > ctx->flags_bytes) {
             if (ctx->d_flags) {
                 (void)hipStreamSynchronize(ctx->stream);
@@ -359,26 +360,31 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
     KMX_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(kmx_summary), ctx->stream));
     if (reads->n_reads == 0) return KMX_OK;
     const bool want_sumfw = (flags & KMX_REDUCE_SUM_FW) != 0;
-    const bool lex_same_k = hasher == KMX_HASH_LEX && hasher_k == k;
-    if (hasher == KMX_HASH_NONE || lex_same_k) {
+    // The tiled kernels fold LexHasher(k); the fold under LexHasher(hasher_k != k) or the identity hasher follows from it
+    // (fix_hash_fold_kernel: every hasher offered is linear over GF(2)), so no hasher sends a call to the per-lane kernel.
+    const bool want_fold = hasher != KMX_HASH_NONE;
+    const bool fix_fold = want_fold && !(hasher == KMX_HASH_LEX && hasher_k == k);
+    {
         bool handled = false;
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 8, ctx->stream));  // 32 tile-queue heads, 128 B apart, + the "a tile was flagged" word
         if (!reads->d_offsets) {
             if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
-            KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
+            KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, want_fold, want_sumfw,
                                                     d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
-            if (handled) return KMX_OK;
         }
-        if (reads->d_offsets && !want_sumfw) {   // ragged reads on the bit-sliced kernel (k in {21, 31}; read_len = optional length bound)
+        if (!handled && reads->d_offsets && !want_sumfw) {   // ragged reads on the bit-sliced kernel (read_len = optional length bound)
             if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
             KMX_HIP(ctx, kmx::launch_scan_bitsliced_ragged(reads->d_bases, reads->d_offsets, reads->n_reads, reads->read_len, k,
-                                                           lex_same_k, d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
-            if (handled) return KMX_OK;
+                                                           want_fold, d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         }
         // word-domain kernel: uniform reads of any (k, L) in its domain, and ragged reads (read_len = optional length bound)
-        KMX_HIP(ctx, kmx::launch_scan_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, lex_same_k, want_sumfw,
-                                              d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled, reads->d_offsets));
-        if (handled) return KMX_OK;
+        if (!handled)
+            KMX_HIP(ctx, kmx::launch_scan_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, want_fold, want_sumfw,
+                                                  d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled, reads->d_offsets));
+        if (handled) {
+            if (fix_fold) KMX_HIP(ctx, kmx::launch_fix_hash_fold(d_out, k, hasher, hasher_k, ctx->stream));
+            return KMX_OK;
+        }
     }
     KMX_HIP(ctx, kmx::launch_reduce_generic(reads, k, hasher, hasher_k, want_sumfw ? 1u : 0u, d_out, ctx->n_cu, ctx->stream));
     return KMX_OK;
@@ -747,17 +753,20 @@ int kmx_seqvec_canonical_reduce(kmx_ctx* ctx, const uint64_t* d_words, uint64_t 
                                 uint32_t hasher, uint32_t hasher_k, uint32_t flags, kmx_summary* d_out) {
     if (!ctx || !d_out || (n_reads && !d_words)) return KMX_E_ARG;
     if (k < 1 || k > 31) return KMX_E_K_RANGE;   // rolling with MASK_TABLE[32] == 0 is unusable (kmer.rs:617)
-    if (hasher > KMX_HASH_LEX || (hasher == KMX_HASH_LEX && hasher_k != k)) return KMX_E_ARG;
+    if (hasher > KMX_HASH_IDENTITY) return KMX_E_ARG;
+    if (hasher == KMX_HASH_LEX && (hasher_k < 1 || hasher_k > 32)) return KMX_E_K_RANGE;
     DeviceGuard g(ctx->device);
     KMX_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(kmx_summary), ctx->stream));
     if (n_reads == 0 || read_len < k) return KMX_OK;
-    const bool want_hash = hasher == KMX_HASH_LEX, want_sumfw = (flags & KMX_REDUCE_SUM_FW) != 0;
+    const bool want_hash = hasher != KMX_HASH_NONE, want_sumfw = (flags & KMX_REDUCE_SUM_FW) != 0;
+    const bool fix_fold = want_hash && !(hasher == KMX_HASH_LEX && hasher_k == k);   // (as in kmx_canonical_reduce)
     bool handled = false;
     KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
     KMX_HIP(ctx, kmx::launch_scan_bitsliced_packed(d_words, n_reads, read_len, k, want_hash, want_sumfw, d_out,
                                                    ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
-    if (handled) return KMX_OK;
-    KMX_HIP(ctx, kmx::launch_reduce_packed_generic(d_words, n_reads, read_len, k, want_hash, want_sumfw, d_out, ctx->n_cu, ctx->stream));
+    if (!handled)
+        KMX_HIP(ctx, kmx::launch_reduce_packed_generic(d_words, n_reads, read_len, k, want_hash, want_sumfw, d_out, ctx->n_cu, ctx->stream));
+    if (fix_fold) KMX_HIP(ctx, kmx::launch_fix_hash_fold(d_out, k, hasher, hasher_k, ctx->stream));
     return KMX_OK;
 }
 

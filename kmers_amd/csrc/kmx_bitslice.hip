@@ -6,8 +6,13 @@ namespace kmx {
 
 KMX_BS_DEFINE_K(31, true)
 
-static bool bs_domain(const void* p, u64 n_reads, u32 L, u32 k) {
-    if (L < k || L > 256 || (reinterpret_cast<uintptr_t>(p) & 15u)) return false;
+// `packed`: a SeqVector (16-byte aligned words).  ASCII reads may start anywhere: a base that is not 16-byte aligned costs
+// a tile one more chunk, which the frames hold except for their very longest reads (L = 160 / 256)
+static bool bs_domain(const void* p, u64 n_reads, u32 L, u32 k, bool packed) {
+    if (L < k || L > 256) return false;
+    if (reinterpret_cast<uintptr_t>(p) & 15u) {
+        if (packed || L == 160 || L == 256) return false;
+    }
     return n_reads * (u64)L < (1ull << 62);
 }
 
@@ -21,7 +26,7 @@ static bool bs_domain(const void* p, u64 n_reads, u32 L, u32 k) {
 hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
-    if (!bs_domain(bases, n_reads, L, k)) return hipSuccess;
+    if (!bs_domain(bases, n_reads, L, k, false)) return hipSuccess;
     switch (k) {
         KMX_BS_FOR_EACH_K(KMX_BS_CASE)
         default:
@@ -34,7 +39,7 @@ hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
     const uint8_t* bases = reinterpret_cast<const uint8_t*>(words);
-    if (!bs_domain(bases, n_reads, L, k)) return hipSuccess;
+    if (!bs_domain(bases, n_reads, L, k, true)) return hipSuccess;
 #define KMX_BS_PCASE(K) \
     case K:             \
         *handled = true; \
@@ -71,11 +76,11 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
     }
 }
 
-// [u64;2] k-mers: every odd k from 33 to 63 is instantiated (k = 63 is BASELINE configs[2]); even k take the generic kernel
+// [u64;2] k-mers: every k from 33 to 64 is instantiated (k = 63 is BASELINE configs[2])
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
-    if (L < k || L > 160 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
+    if (L < k || L > 160 || ((reinterpret_cast<uintptr_t>(bases) & 15u) && L == 160)) return hipSuccess;
     if (n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
 #define KMX_BS2_CASE(K) \
     case K:             \

@@ -150,7 +150,10 @@ template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, int 
 __global__ void __launch_bounds__(256, (PASS == 1 ? 2 : K > 32 ? KMX_BS_WAVES2 : RAGGED ? KMX_BSR_WAVES : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
-                      unsigned long long* __restrict__ queue, const u64* __restrict__ offsets) {
+                      unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead) {
+    // `lead` (uniform ASCII input whose first byte is not 16-byte aligned): `bases` is the aligned address below it and
+    // read r starts at byte lead + r*L.  A tile then spans one more chunk (its first holds the tail of the tile before
+    // it), exactly like a ragged tile streamed from its aligned start; 0 for every other input.
     static_assert(!RAGGED || (!PACKED && K <= 32 && KMX_BS_PRIO >= 2), "ragged input: ASCII, single-word k-mers");
     constexpr int NE = RAGGED ? (K - 1 + 15) / 16 : 0;            // dwords holding the last K-1 bases of a read
     constexpr int NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;  // validity words per read (one bit per window of the frame)
@@ -173,7 +176,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         if (KMX_BS_RELANE) asm volatile("" : "+v"(v));
         return v;
     };
-    const u32 chunks = 4u * L + (RAGGED ? 1u : 0u);          // 16-byte chunks a tile may span (ragged: +1 for its unaligned start)
+    const u32 chunks = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);   // 16-byte chunks a tile may span (+1 for an unaligned start)
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
     const u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
     constexpr u32 TRC_DW = KMX_BS_TRC_LDS ? 256u : 0u;     // [32 lanes of a half-wave][8] transpose constants, shared by the block
@@ -183,7 +186,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u64 n_full = n_reads >> 6;
     const u64 wave_id = (u64)blockIdx.x * 4u + wib;
 
-    u32 posF = lane * L + 16u * PAD;    // (ragged: set per tile from the lane's own offset)
+    u32 posF = lane * L + lead + 16u * PAD;    // (ragged: set per tile from the lane's own offset)
     u32 qF = posF >> 4, aF = 2u * (posF & 15u);
     const u32 W = L - (u32)K + 1u;      // windows per read
     const u32 NG = (W + WPL - 1u) / WPL; // groups of WPL adjacent windows per read
@@ -311,7 +314,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     constexpr bool FB_FLUSH = KMX_BS_FB_FLUSH && K <= 32 && PASS == 0;   // (the second pass rolls reads in batches into fb_all)   // (two-word k-mers: the per-tile sums then live in scratch, 0.46 -> 0.37 of the roofline at k=63)
     FbAcc fb_all;                                             // !FB_FLUSH: summed over the whole run of the wave
     auto fallback_read_acc = [&](u64 read, FbAcc& fb) {
-        const uint8_t* s = bases + read * (u64)L;
+        const uint8_t* s = bases + lead + read * (u64)L;
         if constexpr (RAGGED) {
             const u64 o0 = offsets[read];
             roll_read(bases + o0, (u32)(offsets[read + 1u] - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
@@ -625,7 +628,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             qF = posF >> 4;
             aF = 2u * (posF & 15u);
         } else if constexpr (KMX_BS_RELANE != 0) {
-            posF = lane * L + 16u * PAD;
+            posF = lane * L + lead + 16u * PAD;
             qF = posF >> 4;
             aF = 2u * (posF & 15u);
         }
@@ -1104,7 +1107,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 // which reads?  a read is set aside if any chunk it touches is bad (a chunk shared by two reads sets both aside:
                 // they are rolled exactly anyway)
                 const u64* BM = reinterpret_cast<const u64*>(PL);
-                u32 rd_off = lane * L, rd_len = L;           // the read's bytes, relative to the tile's aligned start
+                u32 rd_off = lane * L + lead, rd_len = L;    // the read's bytes, relative to the tile's aligned start
                 if constexpr (RAGGED) { rd_off = cur_m.rel; rd_len = cur_m.len; }
                 const u32 c0 = rd_off >> 4, c1 = rd_len ? (rd_off + rd_len - 1u) >> 4 : c0;
                 const u32 q0 = c0 >> 6, b0 = c0 & 63u;
@@ -1254,7 +1257,14 @@ template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
 static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
                             unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets = nullptr) {
     auto kern = scan_bitsliced_kernel<K, NW, WPL, PACKED, RAGGED>;
-    const u32 chunks = 4u * L + (RAGGED ? 1u : 0u);
+    // uniform ASCII reads from a base that is not 16-byte aligned: the kernel streams from the aligned address below it
+    u32 lead = 0;
+    if constexpr (!PACKED && !RAGGED) {
+        lead = (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
+        bases -= lead;
+        if (lead != 0u && 4u * L + 1u > 64u * (u32)NW) return hipErrorInvalidValue;   // (callers check: the extra chunk must fit the frame)
+    }
+    const u32 chunks = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);
     const u32 ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
     constexpr u32 NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;
     constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
@@ -1283,14 +1293,14 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     const u64 need = (n_tiles + 3u) / 4u;
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets, lead);
     if constexpr (!PACKED && bs_has_dirty_pass<K>()) {
         // second pass over the tiles the main pass flagged (none on clean input: a wave reads its share of the flags and returns)
         auto kern1 = scan_bitsliced_kernel<K, NW, WPL, false, RAGGED, 1>;
         u64 grid1 = (u64)n_cu * 2u;
         if (grid1 > need) grid1 = need;
         hipLaunchKernelGGL(kern1, dim3((unsigned)(grid1 ? grid1 : 1)), dim3(256), lds_bytes + 128u * 4u * 4u, stream, bases, n_reads, L, want_hash,
-                           want_sumfw, out, queue, offsets);
+                           want_sumfw, out, queue, offsets, lead);
     }
     return hipGetLastError();
 }
@@ -1325,8 +1335,9 @@ static hipError_t launch_bs2_any(const uint8_t* bases, u64 n_reads, u32 L, u32 w
                                int n_cu, hipStream_t stream) {                                                               \
         return launch_bs2_any<K>(bases, n_reads, L, want_hash, out, queue, n_cu, stream);                                    \
     }
-// two-word k with a bit-sliced kernel: every odd k from 33 to 63
-#define KMX_BS2_FOR_EACH_K(X) X(33) X(35) X(37) X(39) X(41) X(43) X(45) X(47) X(49) X(51) X(53) X(55) X(57) X(59) X(61) X(63)
+// two-word k with a bit-sliced kernel: every k from 33 to 64
+#define KMX_BS2_FOR_EACH_K(X) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48) \
+    X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) X(64)
 
 // ragged reads: Lf = the frame (longest read a tile may hold; a tile with a longer read rolls per lane)
 template <int K>

@@ -287,6 +287,17 @@ encoding_decode_bytes_kernel(const uint8_t* __restrict__ in, u64 total_bytes, u3
     }
 }
 
+// ------------------------------------------------- hash fold of a reduce pass under another hasher
+// The scan kernels fold xor of LexHasher(k)(canonical word) (for the bit-sliced kernels it is the parity of counters they
+// keep anyway).  Every hasher offered is a GF(2)-linear map of the word -- LexHasher(hk): the 2-bit groups reversed and
+// shifted (hash.rs:60-71); identity: the word itself (hash.rs:4-8) -- so the xor over all k-mers of H(word) is H(xor of
+// the words), and Lex(k) is an involution on k-base words: the fold under any other hasher follows from the Lex(k) fold.
+__global__ void fix_hash_fold_kernel(kmx_summary* __restrict__ out, u32 k, u32 hasher, u32 hk) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const u64 x = lex_hash(out->xor_hash, k);   // xor of the canonical words themselves
+    out->xor_hash = hasher == KMX_HASH_LEX ? lex_hash(x, hk) : x;
+}
+
 // ------------------------------------------------- measurement helper: read-only stream with the scan's load shape
 // each wave streams whole 9600-byte tiles (600 16-byte chunks), tiles striped over the waves, next tile requested before
 // the current one is folded
@@ -419,6 +430,10 @@ hipError_t launch_encoding_rev_comp_bytes(const uint8_t* in, u64 n, u32 K, u32 c
 }
 hipError_t launch_encoding_decode_bytes(const uint8_t* in, u64 total_bytes, u32 nuc_lut, uint8_t* seqs, int n_cu, hipStream_t st) {
     hipLaunchKernelGGL(encoding_decode_bytes_kernel, dim3(egrid(total_bytes, n_cu)), dim3(256), 0, st, in, total_bytes, nuc_lut, seqs);
+    return hipGetLastError();
+}
+hipError_t launch_fix_hash_fold(kmx_summary* out, u32 k, u32 hasher, u32 hk, hipStream_t st) {
+    hipLaunchKernelGGL(fix_hash_fold_kernel, dim3(1), dim3(64), 0, st, out, k, hasher, hk);
     return hipGetLastError();
 }
 hipError_t launch_calib_stream_read(const uint8_t* buf, u64 nbytes, unsigned long long* out, int n_cu, hipStream_t st) {

@@ -544,11 +544,13 @@ template <typename S, int NW> constexpr int sink_waves() { return NW <= 10 ? Sin
 template <int NW, int V, int DW, typename Sink, typename Params, bool RAGGED = false>
 __global__ void __launch_bounds__(256, (sink_waves<Sink, NW>()))
 scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, Params params,
-                    unsigned long long* __restrict__ queue, const u64* __restrict__ offsets) {
+                    unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead) {
+    // `lead` (uniform reads whose first byte is not 16-byte aligned): `bases` is the aligned address below it, read r
+    // starts at byte lead + r*L and a tile spans one more chunk (as a ragged tile streamed from its aligned start does)
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const u32 lane = threadIdx.x & 63u;
     const u32 wib = threadIdx.x >> 6;
-    const u32 chunks_u = RAGGED ? 64u * NW : 4u * L;  // 16-byte chunks per 64-read tile (ragged: the most a tile may span)
+    const u32 chunks_u = RAGGED ? 64u * NW : 4u * L + (lead != 0u ? 1u : 0u);  // 16-byte chunks per 64-read tile (ragged: the most a tile may span)
     const u32 ldsw = (chunks_u + 1u + 6u + 3u) & ~3u; // front pad 1, tail pad >= 6
     u32* P = lds + wib * (ldsw + Sink::kLdsDwordsPerWave);
 
@@ -557,7 +559,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     const u64 total_bytes = RAGGED ? offsets[n_reads] : 0;
 
     // per-lane alignment of this lane's read inside the packed tile (LDS index 1+c holds bases [16c,16c+16))
-    u32 posF = lane * L + 16u;
+    u32 posF = lane * L + lead + 16u;
     u32 qF = posF >> 4, aF = 2u * (posF & 15u);
     const u32 delta = (1u - k) & 15u;  // rc stream pre-offset so that rc sub-shift == 30-2s
     u32 posR = posF - delta;
@@ -679,7 +681,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
             sink.tile_slow_begin(read);
             u32 roll_max = L;
             if constexpr (RAGGED) roll_max = (u32)wave_max_u32(my_len);
-            roll_read_stepped(RAGGED ? bases + my_off : bases + read * (u64)L, RAGGED ? my_len : L, roll_max, k,
+            roll_read_stepped(RAGGED ? bases + my_off : bases + lead + read * (u64)L, RAGGED ? my_len : L, roll_max, k,
                               [&](u32 pos, u64 fw, u64 rc) { sink.tile_slow_emit(pos, fw, rc); }, [&](u32 wb) { sink.slow_block(wb); });
             sink.tile_slow_end();
             continue;
@@ -746,7 +748,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
             const u64 o0 = offsets[read];
             roll_read(bases + o0, (u32)(offsets[read + 1u] - o0), k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
         } else {
-            roll_read(bases + read * (u64)L, L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
+            roll_read(bases + lead + read * (u64)L, L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
         }
         sink.end_read();
     }
@@ -764,7 +766,13 @@ template <int NW, int V, int DW, typename Sink, typename Params, typename Pre = 
 static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Params& params,
                              unsigned long long* queue, int n_cu, hipStream_t stream, Pre pre = Pre(), const u64* offsets = nullptr) {
     auto kern = scan_uniform_kernel<NW, V, DW, Sink, Params, RAGGED>;
-    const u32 chunks = RAGGED ? 64u * NW : 4u * L;
+    u32 lead = 0;   // uniform reads from a base that is not 16-byte aligned: streamed from the aligned address below it
+    if constexpr (!RAGGED) {
+        lead = (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
+        bases -= lead;
+        if (lead != 0u && 4u * L + 1u > 64u * (u32)NW) return hipErrorInvalidValue;   // (scan_domain checks: the extra chunk must fit the frame)
+    }
+    const u32 chunks = RAGGED ? 64u * NW : 4u * L + (lead != 0u ? 1u : 0u);
     const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
     const size_t lds_bytes = (size_t)(ldsw + Sink::kLdsDwordsPerWave) * 4u * 4u + (size_t)Sink::block_lds_dwords(params) * 4u;
     // blocks per CU, cached per host thread and device (the ABI's model is one thread per context / GPU: a plain static
@@ -791,17 +799,18 @@ static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Pa
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
     if (!pre(grid)) return hipErrorOutOfMemory;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, params, queue, offsets);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, params, queue, offsets, lead);
     return hipGetLastError();
 }
 
 static bool scan_domain(const uint8_t* bases, u64 n_reads, u32 L, u32 k) {
-    if (k < 2 || k > 31 || k == 17 || L < k || L > 256 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return false;
+    if (k < 2 || k > 31 || L < k || L > 256) return false;
+    if ((reinterpret_cast<uintptr_t>(bases) & 15u) && (L == 160 || L == 256)) return false;   // the extra chunk of an unaligned start must fit the frame
     return n_reads * (u64)L < (1ull << 62);
 }
 // ragged reads: L is an optional upper bound of the lengths (0 = unknown); reads longer than the frame fall back per tile
 static bool scan_domain_ragged(const uint8_t* bases, u32 L, u32 k) {
-    return !(k < 2 || k > 31 || k == 17 || L > 256 || (reinterpret_cast<uintptr_t>(bases) & 15u));
+    return !(k < 2 || k > 31 || L > 256 || (reinterpret_cast<uintptr_t>(bases) & 15u));
 }
 
 // offsets != nullptr: ragged reads; L is then only an upper bound of the read lengths (0 = unknown) that selects the frame
@@ -816,12 +825,20 @@ static hipError_t dispatch(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Para
             if (big) return launch_one<16, 1, 1, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
             return launch_one<10, 1, 1, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
         }
+        if (k == 17) {   // the one k whose rc window sits at the V = 1 register index while the k-mer needs two dwords
+            if (big) return launch_one<16, 1, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+            return launch_one<10, 1, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+        }
         if (big) return launch_one<16, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
         return launch_one<10, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
     }
     if (k <= 16) {
         if (big) return launch_one<16, 1, 1, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
         return launch_one<10, 1, 1, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+    }
+    if (k == 17) {
+        if (big) return launch_one<16, 1, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+        return launch_one<10, 1, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
     }
     if (big) return launch_one<16, 2, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
     return launch_one<10, 2, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
@@ -834,6 +851,10 @@ static hipError_t dispatch_part(const uint8_t* bases, u64 n_reads, u32 L, u32 k,
     if (k <= 16) {
         if (big) return launch_one<16, 1, 1, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
         return launch_one<10, 1, 1, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+    }
+    if (k == 17) {
+        if (big) return launch_one<16, 1, 2, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+        return launch_one<10, 1, 2, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
     }
     if (big) return launch_one<16, 2, 2, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
     return launch_one<10, 2, 2, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);

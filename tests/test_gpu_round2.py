@@ -272,3 +272,128 @@ def test_calib_stream_read_folds_every_chunk(ctx, nbytes):
     words = host[: nbytes // 16 * 16].view(np.uint32)
     exp = int(np.bitwise_xor.reduce(words)) if words.size else 0
     assert got == exp
+
+
+# ------------------------------------------------------------------ no argument sends a call to the slow kernel
+
+def _dirty(rng, n, p_bad=0.004):
+    alpha = np.frombuffer(b"ACGTacgt", np.uint8)
+    a = alpha[rng.integers(0, 8, n)].copy()
+    bad = rng.random(n) < p_bad
+    a[bad] = rng.integers(0, 256, int(bad.sum()), dtype=np.uint8)
+    return a
+
+
+def _identity_fold(orc, host, n, L, k, offsets=None):
+    """xor of the canonical words of every yielded window = hash fold under the identity hasher (hash.rs:4-8)"""
+    _, _, canon, flags = orc.canonical_windows(host, n, L, k, offsets=offsets)
+    v = canon[(flags & 1) != 0]
+    return int(np.bitwise_xor.reduce(v)) if v.size else 0
+
+
+@pytest.mark.parametrize("k", [5, 12, 13, 21, 27, 31])
+@pytest.mark.parametrize("L,n", [(150, 64 * 40 + 9), (100, 64 * 7), (250, 64 * 5 + 3)])
+def test_reduce_any_hasher(ctx, orc, k, L, n):
+    """LexHasher(hasher_k != k) and the identity hasher on every tiled reduce path (they used to drop to the per-lane kernel)"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(k * 31 + L)
+    host = _dirty(rng, n * L)
+    bases = ctx.to_device(host)
+    for hk in sorted({1, 7, k - 1, k, min(k + 1, 32), 32} - {0}):
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=hk)
+        g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, hk, _lib.REDUCE_SUM_FW)
+        assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw), hk
+    g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_IDENTITY, 0, 0)
+    assert g.xor_hash == _identity_fold(orc, host, n, L, k)
+    # ragged reads
+    lens = rng.integers(0, L + 1, n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    hostr = _dirty(rng, int(off[-1]) + 16)[: int(off[-1])]
+    d_r, d_off = ctx.to_device(np.concatenate([hostr, np.zeros(16, np.uint8)]))[: hostr.size], ctx.to_device(off)
+    for hk in (3, k, 29):
+        o = orc.canonical_reduce(hostr, n, 0, k, hasher_k=hk, offsets=off)
+        g = ctx.canonical_reduce(d_r, n, L, k, _lib.HASH_LEX, hk, 0, offsets=d_off)
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash), hk
+    g = ctx.canonical_reduce(d_r, n, L, k, _lib.HASH_IDENTITY, 0, 0, offsets=d_off)
+    assert g.xor_hash == _identity_fold(orc, hostr, n, 0, k, offsets=off)
+
+
+@pytest.mark.parametrize("k", [9, 21, 31])
+def test_seqvec_reduce_any_hasher(ctx, orc, k):
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(k)
+    L, n = 150, 64 * 20 + 5
+    host = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * L)]
+    words = ctx.seqvec_from_bytes(ctx.to_device(host))
+    for hk in (4, k, 32):
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=hk)
+        g = ctx.seqvec_canonical_reduce(words, n, L, k, _lib.HASH_LEX, hk, 0)
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+    g = ctx.seqvec_canonical_reduce(words, n, L, k, _lib.HASH_IDENTITY, 0, 0)
+    assert g.xor_hash == _identity_fold(orc, host, n, L, k)
+
+
+@pytest.mark.parametrize("k", list(range(34, 65, 2)))
+@pytest.mark.parametrize("L,n,p_bad", [(150, 64 * 30 + 7, 0.0), (150, 64 * 30 + 7, 0.0005), (100, 64 * 12, 0.0), (160, 64 * 9 + 1, 0.0)])
+def test_reduce2_bitsliced_every_even_k(ctx, orc, k, L, n, p_bad):
+    """[u64;2] k-mers: the even k from 34 to 64 on the bit-sliced kernel too (round 1: lane-per-read kernel)"""
+    if L < k:
+        pytest.skip("read shorter than k")
+    rng = np.random.default_rng(k * 7 + L)
+    host = _dirty(rng, n * L, p_bad)
+    for with_hash in (True, False):
+        o = orc.canonical_reduce2(host, n, L, k, with_hash=with_hash)
+        g = ctx.canonical_reduce2(ctx.to_device(host), n, L, k, with_hash=with_hash)
+        assert tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
+
+
+@pytest.mark.parametrize("lead", [1, 2, 3, 6, 8, 13, 15])
+@pytest.mark.parametrize("k,L", [(31, 150), (21, 150), (11, 150), (5, 100), (31, 159), (27, 250), (47, 150), (63, 100), (31, 160), (17, 120)])
+def test_base_pointer_not_16_byte_aligned(ctx, orc, lead, k, L):
+    """reads that start at any byte address (a slice of a larger buffer): reduce, windows and histogram against the oracle.
+    (L = 160 / 256 with an unaligned base does not fit the frame and takes the per-lane kernel: still exact.)"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(lead * 100 + k)
+    n = 64 * 11 + 5
+    host = _dirty(rng, n * L, 0.0008)
+    buf = ctx.to_device(np.concatenate([rng.integers(0, 256, lead, dtype=np.uint8), host, np.zeros(32, np.uint8)]))
+    bases = buf[lead: lead + n * L]
+    assert bases.data_ptr() % 16 == lead
+    if k <= 31:
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
+        _, _, canon, flags = orc.canonical_windows(host, n, L, k)
+        outs = ctx.canonical_windows(bases, n, L, k, want=("canon", "flags"))
+        assert (outs["flags"].cpu().numpy() == flags).all()
+        assert (outs["canon"].cpu().numpy().view(np.uint64) == canon).all()
+        for b in (10, 16):
+            h = ctx.histogram(bases, n, L, k, _lib.HASH_LEX, k, b).cpu().numpy().view(np.uint64)
+            assert (h == orc.histogram(host, n, L, k, k, b)).all()
+    else:
+        o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+        g = ctx.canonical_reduce2(bases, n, L, k, with_hash=True)
+        assert tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
+
+
+@pytest.mark.parametrize("L", [100, 150, 200])
+def test_k17_on_the_tiled_kernels(ctx, orc, L):
+    """k = 17 (two dwords per k-mer at the V = 1 register index) used to be the one single-word k without a tiled
+    materialise / histogram kernel"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(L)
+    n, k = 64 * 9 + 3, 17
+    host = _dirty(rng, n * L, 0.001)
+    bases = ctx.to_device(host)
+    fw, rc, canon, flags = orc.canonical_windows(host, n, L, k)
+    outs = ctx.canonical_windows(bases, n, L, k)
+    assert (outs["flags"].cpu().numpy() == flags).all()
+    for name, exp in (("fw", fw), ("rc", rc), ("canon", canon)):
+        assert (outs[name].cpu().numpy().view(np.uint64) == exp).all(), name
+    for b in (8, 14, 18):
+        h = ctx.histogram(bases, n, L, k, _lib.HASH_LEX, k, b).cpu().numpy().view(np.uint64)
+        assert (h == orc.histogram(host, n, L, k, k, b)).all()
