@@ -32,6 +32,8 @@ hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 L_hint, u32 k, bool want_hash,
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+hipError_t launch_scan_bitsliced_long(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary* out,
+                                      unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 // kmx_fastx.hip
@@ -371,6 +373,12 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
             if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
             KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, want_fold, want_sumfw,
                                                     d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+        }
+        if (!handled && !reads->d_offsets && reads->read_len > 256 && !want_sumfw) {   // long uniform reads: overlapping 160-base segments on the ragged kernel
+            const uint64_t n_seg = reads->n_reads * (((uint64_t)reads->read_len - k + (161u - k)) / (161u - k));
+            if (int st = prepare_dirty_flags(ctx, n_seg, k)) return st;
+            KMX_HIP(ctx, kmx::launch_scan_bitsliced_long(reads->d_bases, reads->n_reads, reads->read_len, k, want_fold, d_out,
+                                                         ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         }
         if (!handled && reads->d_offsets && !want_sumfw) {   // ragged reads on the bit-sliced kernel (read_len = optional length bound)
             if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;

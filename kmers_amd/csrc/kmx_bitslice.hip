@@ -68,7 +68,7 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
 #define KMX_BSR_CASE(K) \
     case K:             \
         *handled = true; \
-        return launch_bs_ragged_k##K(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream);
+        return launch_bs_ragged_k##K(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, 0, 0);
     switch (k) {
         KMX_BSR_FOR_EACH_K(KMX_BSR_CASE)
         default:
@@ -88,6 +88,28 @@ hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 
         return launch_bs2_k##K(bases, n_reads, L, want_hash, out, queue, n_cu, stream);
     switch (k) {
         KMX_BS2_FOR_EACH_K(KMX_BS2_CASE)
+        default:
+            return hipSuccess;
+    }
+}
+
+// Uniform reads too long for a frame (L > 256: long reads, contigs): each read is cut into overlapping segments of
+// T = 161 - k windows (160 bases) that the ragged kernel scans as reads of their own -- neighbouring segments share
+// their k - 1 bases in LDS, HBM is still read once.  k in 13..31, 16-byte aligned base, no sum_fw (as for ragged reads).
+hipError_t launch_scan_bitsliced_long(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary* out,
+                                      unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
+    *handled = false;
+    if (L <= 256 || k < 13 || k > 31 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
+    const u32 T = 161u - k, Lf = 160u;
+    const u64 J = ((u64)L - k + T) / T;             // segments per read
+    if (n_reads > (1ull << 40) / J || n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
+    const u64 n_seg = n_reads * J;
+#define KMX_BSL_CASE(K) \
+    case K:             \
+        *handled = true; \
+        return launch_bs_ragged_k##K(bases, nullptr, n_seg, Lf, want_hash, out, queue, n_cu, stream, T, L);
+    switch (k) {
+        KMX_BSR_FOR_EACH_K(KMX_BSL_CASE)
         default:
             return hipSuccess;
     }

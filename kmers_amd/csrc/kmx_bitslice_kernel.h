@@ -38,7 +38,7 @@
 #define KMX_BSP_WAVES 3   // waves per SIMD of the packed-input variant
 #endif
 #ifndef KMX_BSR_WAVES
-#define KMX_BSR_WAVES 2   // waves per SIMD of the ragged variant
+#define KMX_BSR_WAVES 3   // waves per SIMD of the ragged variant (with its late prefetch rows: 149..162 registers, no spills; 2 before)
 #endif
 #ifndef KMX_BS_WAVES
 #define KMX_BS_WAVES 3      // waves per SIMD the register allocation is sized for
@@ -57,6 +57,9 @@
 #endif
 #ifndef KMX_BS_SWZ
 #define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
+#endif
+#ifndef KMX_BSR_LATE
+#define KMX_BSR_LATE 5   // late prefetch rows of the ragged variant
 #endif
 #ifndef KMX_BS_WAVES2
 #define KMX_BS_WAVES2 2   // waves per SIMD the two-word kernels (k = 33..63) are compiled for
@@ -147,7 +150,7 @@ template <int K, int WPL> constexpr int bs_waves_ascii() {
 #endif
 }
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, int PASS = 0>
-__global__ void __launch_bounds__(256, (PASS == 1 ? 2 : K > 32 ? KMX_BS_WAVES2 : RAGGED ? KMX_BSR_WAVES : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
+__global__ void __launch_bounds__(256, (PASS == 1 ? 2 : K > 32 ? KMX_BS_WAVES2 : RAGGED ? (NW > 10 ? 2 : KMX_BSR_WAVES) : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead) {
@@ -238,15 +241,40 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         for (int e = 0; e < NE; ++e) QT[e * 64 + lane] = 0;
         NVR[lane] = 0;
     }
-    const u64 total_bytes = RAGGED ? offsets[n_reads] : 0;
+    // RAGGED with offsets == nullptr: "reads" are the overlapping SEGMENTS of uniform reads too long for a frame (L > 256):
+    // read i of `seg_L` bases is cut into J segments of seg_T windows each (the last one shorter), segment j = bases
+    // [j*seg_T, j*seg_T + seg_T + K - 1) of the read -- neighbours share K - 1 bases in LDS, nothing is read twice from HBM,
+    // and every window of the read belongs to exactly one segment.  The two parameters ride in arguments this variant does
+    // not use otherwise (lead = seg_T, want_sumfw = seg_L); n_reads counts segments.
+    const bool seg_mode = RAGGED && offsets == nullptr;
+    const u32 seg_T = lead, seg_L = want_sumfw;
+    const u32 seg_J = seg_mode ? (seg_L - (u32)K + seg_T) / seg_T : 1u;      // ceil((seg_L - K + 1) / seg_T)
+    auto seg_bounds = [&](u64 g, u64& o0, u64& o1) {
+        const u64 i = g / seg_J;
+        const u32 j = (u32)(g - i * seg_J);
+        o0 = i * (u64)seg_L + (u64)j * seg_T;
+        const u64 e = o0 + seg_T + (u32)(K - 1), re = (i + 1u) * (u64)seg_L;
+        o1 = e < re ? e : re;
+    };
+    const u64 total_bytes = !RAGGED ? 0 : seg_mode ? (n_reads / seg_J) * (u64)seg_L : offsets[n_reads];
     // ragged: per-tile geometry of the current and of the next tile (rel/len per lane, the rest wave-uniform)
     struct TileMeta { u32 rel = 0, len = 0, n_ch = 0; u64 base = 0; bool fits = true; };
     TileMeta cur_m, nx_m;
     // the two offsets of a lane are requested one iteration before anything looks at them (meta_issue / meta_finish)
     u64 raw_o0 = 0, raw_o1 = 0;
     auto meta_issue = [&](u64 t) {
-        raw_o0 = offsets[t * 64u + lane];
-        raw_o1 = offsets[t * 64u + lane + 1u];
+        if (seg_mode) {
+            // the tile's first segment once (wave-uniform 64-bit division), the lane's own by a 32-bit one
+            const u64 g0 = t * 64u, i0 = g0 / seg_J;
+            const u32 jj = (u32)(g0 - i0 * seg_J) + lane, di = jj / seg_J, j = jj - di * seg_J;
+            const u64 i = i0 + di;
+            raw_o0 = i * (u64)seg_L + (u64)j * seg_T;
+            const u64 e = raw_o0 + seg_T + (u32)(K - 1), re = (i + 1u) * (u64)seg_L;
+            raw_o1 = e < re ? e : re;
+        } else {
+            raw_o0 = offsets[t * 64u + lane];
+            raw_o1 = offsets[t * 64u + lane + 1u];
+        }
     };
     auto meta_finish = [&](TileMeta& m) {
         const u64 o0 = raw_o0, o1 = raw_o1;
@@ -298,7 +326,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
                 atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)r0);
                 if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)h0);
-                if (want_sumfw) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
+                if (want_sumfw && !RAGGED) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);   // (ragged: no sum_fw; the argument carries seg_L)
             } else {
                 kmx_summary2* o = static_cast<kmx_summary2*>(out);
                 atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
@@ -316,8 +344,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     auto fallback_read_acc = [&](u64 read, FbAcc& fb) {
         const uint8_t* s = bases + lead + read * (u64)L;
         if constexpr (RAGGED) {
-            const u64 o0 = offsets[read];
-            roll_read(bases + o0, (u32)(offsets[read + 1u] - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
+            u64 o0, o1;
+            if (seg_mode) seg_bounds(read, o0, o1);
+            else { o0 = offsets[read]; o1 = offsets[read + 1u]; }
+            roll_read(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
                 const u64 canon = fw < rc ? fw : rc;
                 fb.n += 1;
                 fb.s0 += canon;
@@ -392,7 +422,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 lane16 = lane * 16u;
     const u32 last_off = PACKED ? (L - 1u) * 16u : (chunks - 1u) * 16u;
     const bool short_rows = PACKED || chunks < 64u * (NW - 1);   // whole rows of the load grid may lie past the tile
-    auto issue_loads_ragged = [&](const TileMeta& m) {
+    auto issue_loads_ragged = [&](const TileMeta& m, int row0 = 0, int row1 = 64) {
         // unconditional (a tile outside the frame reads 16 bytes of the queue block instead, and rolls per lane): loads under a
         // branch make hipcc wait with vmcnt(0) where phase A would count them down
         const uint8_t* __restrict__ tb = m.fits ? bases + m.base : reinterpret_cast<const uint8_t*>(queue);
@@ -401,6 +431,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         asm volatile("" : "+v"(l16));
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
+            if (it < row0 || it >= row1) continue;
             u32 off = l16 + (u32)it * 1024u;
             off = off < lo ? off : lo;
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
@@ -408,7 +439,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             w[it] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    constexpr int LATE = (!PACKED && !RAGGED && PASS == 0 && NW == 10) ? (K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2) : 0;   // rows of the prefetch requested late
+    constexpr int LATE = (!PACKED && PASS == 0 && NW == 10) ? (RAGGED ? KMX_BSR_LATE : K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2) : 0;   // rows of the prefetch requested late
     u64 tile = ~0ull, next_tile = ~0ull;
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
@@ -935,7 +966,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 pc_acc(mcnt, m[w]);   // (a tile that is not scanned: lt == 0, nothing is added)
             }
             if constexpr (LATE > 0) {   // the rest of the next tile's rows: the registers of pass 1's plane window are free now
-                if (r == 0) prefetch(next_tile, tile, NLD - LATE, NLD);
+                if constexpr (RAGGED) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r == 0 && next_tile < n_full) issue_loads_ragged(nx_m, NLD - LATE, NLD);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    if (r == 0) prefetch(next_tile, tile, NLD - LATE, NLD);
+                }
             }
             if (!run) break;
             asm volatile("" ::: "memory");   // pass 2 re-reads the planes instead of keeping 2K+6 registers live
@@ -1079,10 +1116,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             if constexpr (PASS == 0 && DIRTY_LIST) {
                 if (bad_tile && cur_m.fits) flag_tile();   // (tiles outside the frame roll as a whole)
             }
+            if constexpr (LATE > 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the uniform branch
             __builtin_amdgcn_sched_barrier(0);
             if (next_tile < n_full) {
                 meta_finish(nx_m);            // offsets requested a whole iteration ago
-                issue_loads_ragged(nx_m);
+                issue_loads_ragged(nx_m, 0, NLD - LATE);
             }
             __builtin_amdgcn_sched_barrier(0);
         } else {
@@ -1255,10 +1293,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
 static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
-                            unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets = nullptr) {
+                            unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets = nullptr,
+                            u32 seg_T = 0 /* RAGGED, offsets == nullptr: segments of long uniform reads, see the kernel */) {
     auto kern = scan_bitsliced_kernel<K, NW, WPL, PACKED, RAGGED>;
     // uniform ASCII reads from a base that is not 16-byte aligned: the kernel streams from the aligned address below it
     u32 lead = 0;
+    if constexpr (RAGGED) lead = seg_T;
     if constexpr (!PACKED && !RAGGED) {
         lead = (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
         bases -= lead;
@@ -1340,25 +1380,27 @@ static hipError_t launch_bs2_any(const uint8_t* bases, u64 n_reads, u32 L, u32 w
     X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) X(64)
 
 // ragged reads: Lf = the frame (longest read a tile may hold; a tile with a longer read rolls per lane)
+// offsets == nullptr: segments of uniform reads of seg_L bases, seg_T windows each (n_reads = segments, Lf = seg_T + K - 1)
 template <int K>
 static hipError_t launch_bs_ragged_any(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out,
-                                       unsigned long long* queue, int n_cu, hipStream_t stream) {
+                                       unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L) {
     const u32 W = Lf - (u32)K + 1u;
-    if (Lf > 160) return launch_bs<K, 16, 8, false, true>(bases, n_reads, Lf, want_hash, 0, out, queue, n_cu, stream, offsets);
-    if (W <= 96u) return launch_bs<K, 10, 3, false, true>(bases, n_reads, Lf, want_hash, 0, out, queue, n_cu, stream, offsets);
-    if (W <= 128u) return launch_bs<K, 10, 4, false, true>(bases, n_reads, Lf, want_hash, 0, out, queue, n_cu, stream, offsets);
-    return launch_bs<K, 10, 5, false, true>(bases, n_reads, Lf, want_hash, 0, out, queue, n_cu, stream, offsets);
+    if (Lf > 160) return launch_bs<K, 16, 8, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+    if (W <= 96u) return launch_bs<K, 10, 3, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+    if (W <= 128u) return launch_bs<K, 10, 4, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+    return launch_bs<K, 10, 5, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
 }
 #define KMX_BSR_DECLARE_K(K) \
     hipError_t launch_bs_ragged_k##K(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out, \
-                                     unsigned long long* queue, int n_cu, hipStream_t stream);
+                                     unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L);
 #define KMX_BSR_DEFINE_K(K)                                                                                                  \
     hipError_t launch_bs_ragged_k##K(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out, \
-                                     unsigned long long* queue, int n_cu, hipStream_t stream) {                               \
-        return launch_bs_ragged_any<K>(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream);                     \
+                                     unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L) {         \
+        return launch_bs_ragged_any<K>(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, seg_T, seg_L);       \
     }
-// k with a bit-sliced kernel for ragged reads
-#define KMX_BSR_FOR_EACH_K(X) X(21) X(31)
+// k with a bit-sliced kernel for ragged reads: 13..31, like the uniform kernel
+#define KMX_BSR_FOR_EACH_K(X) \
+    X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
 
 #define KMX_BS_DECLARE_K(K) \
     hipError_t launch_bs_k##K(const uint8_t* bases, u64 n_reads, u32 L, bool packed, u32 want_hash, u32 want_sumfw, void* out, \

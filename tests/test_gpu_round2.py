@@ -397,3 +397,23 @@ def test_k17_on_the_tiled_kernels(ctx, orc, L):
     for b in (8, 14, 18):
         h = ctx.histogram(bases, n, L, k, _lib.HASH_LEX, k, b).cpu().numpy().view(np.uint64)
         assert (h == orc.histogram(host, n, L, k, k, b)).all()
+
+
+@pytest.mark.parametrize("k", [13, 21, 30, 31])
+@pytest.mark.parametrize("L,n", [(257, 64 * 9 + 5), (300, 64 * 6), (1000, 64 * 3 + 1), (5003, 150), (20000, 70)])
+def test_long_uniform_reads_take_the_segmented_bitsliced_path(ctx, orc, k, L, n):
+    """uniform reads longer than the 256-base frame (round 1: lane-per-read kernel at 0.36 TB/s): cut into overlapping
+    160-base segments on the ragged bit-sliced kernel; clean and with invalid bytes, with and without the hash fold"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(k * 1000 + L)
+    for p_bad in (0.0, 0.0004):
+        host = _dirty(rng, n * L, p_bad)
+        bases = ctx.to_device(host)
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, 0)
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash), p_bad
+        g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_NONE, 0, 0)
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, 0)
+        g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)   # sum_fw: the per-lane kernel, still exact
+        assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
