@@ -302,6 +302,12 @@ def selftest_worker(args):
 
 
 def worker(args, traffic_raw=None, traffic_err=None):
+    # stdout carries ONE line, the JSON of rank 0.  Native libraries write there as well (RCCL prints a version banner
+    # when a communicator is created, flushed at exit -- after our line): everything but that line goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -413,6 +419,23 @@ def worker(args, traffic_raw=None, traffic_err=None):
         torch.cuda.synchronize()
         return 0
 
+    # Same-run ceiling of the HBM read stream (kmx_calib_stream_read: the scan's load shape, no compute), measured BEFORE the
+    # timed region: it is part of every line, and ~70 ms of streaming also brings the device out of its idle power state --
+    # from cold the first ten launches of any kernel run up to 40 % slow (tools/step_times.py), which W = 5 warm-up steps
+    # alone do not cover.
+    cal = ctx.empty(1, torch.int64)
+    for _ in range(5):
+        ctx.calib_stream_read(bases, out=cal)
+    cevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(25)]
+    with torch.cuda.stream(ctx.stream):
+        for a, b in cevs:
+            a.record(ctx.stream)
+            ctx.calib_stream_read(bases, out=cal)
+            b.record(ctx.stream)
+    torch.cuda.synchronize()
+    stream_ms = sorted(a.elapsed_time(b) for a, b in cevs)[len(cevs) // 2]
+    stream_gbps = float(nbytes) / (stream_ms * 1e-3) / 1e9
+
     with torch.cuda.stream(ctx.stream):
         for _ in range(args.warmup):
             step()
@@ -473,20 +496,6 @@ def worker(args, traffic_raw=None, traffic_err=None):
         ev_mid.clear()
         sus_ms = a.elapsed_time(b) / args.sustain_steps
         sustained = {"steps": args.sustain_steps, "ms_per_step": sus_ms}
-
-    cal = ctx.empty(1, torch.int64)
-    cal_buf = bases
-    for _ in range(2):
-        ctx.calib_stream_read(cal_buf, out=cal)
-    cevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-    with torch.cuda.stream(ctx.stream):
-        for a, b in cevs:
-            a.record(ctx.stream)
-            ctx.calib_stream_read(cal_buf, out=cal)
-            b.record(ctx.stream)
-    torch.cuda.synchronize()
-    stream_ms = sorted(a.elapsed_time(b) for a, b in cevs)[len(cevs) // 2]
-    stream_gbps = float(nbytes) / (stream_ms * 1e-3) / 1e9
 
     hist_info = None
     if args.histogram and not hist_mode:
@@ -591,7 +600,7 @@ def worker(args, traffic_raw=None, traffic_err=None):
         if world == 1 and not args.no_cpu_baseline and not two_word:
             n_s = min(n, 4_000_000)
             res["cpu_baseline"] = cpu_baseline(bases[: n_s * L].cpu().numpy(), n_s, L, k)
-        print(json.dumps(res), flush=True)
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     # every rank learns the verdict and leaves together (a lone sys.exit on rank 0 would strand the others in a collective)
     if dist is not None:
         v = torch.tensor([1 if parity else 0], dtype=torch.int64, device=ctx.device)

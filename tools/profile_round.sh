@@ -1,19 +1,43 @@
 #!/bin/bash
 # dev tool (run on the GPU box through gpurun): the profile set committed under profiles/ for one round.
-#   tools/profile_round.sh OUTDIR      -> OUTDIR/{trace,pmc_*}/..., OUTDIR/bench_under_trace.json, OUTDIR/ubench*.txt
+#   tools/profile_round.sh OUTDIR      -> OUTDIR/{trace*,pmc_*}/..., OUTDIR/bench_*.json, OUTDIR/*.txt
 # rocprofv3 runs from /tmp; --pmc passes are separate runs without any tracing flags.
 R=$GRAFT_REPO_ROOT
 out=$R/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+B="python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --sustain-steps 0"
+# kernel traces: the headline config and the other BASELINE configs
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $B > $out/bench_under_trace.json 2> $out/trace.err
-for c in FETCH_SIZE WRITE_SIZE "SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_k21 -o t -- $B --config 2 -k 21 > $out/bench_k21_under_trace.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_k63 -o t -- $B --config 2 -k 63 > $out/bench_k63_under_trace.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_hash -o t -- $B --config 3 > $out/bench_hash_under_trace.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_hist20 -o t -- $B --config 4 --steps 5 --warmup 2 > $out/bench_hist20_under_trace.json 2> /dev/null
+# counters (the bench's own two --pmc children cover FETCH_SIZE / WRITE_SIZE with the calibration kernel; these are the SQ sets)
+for c in "SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE SQ_WAIT_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$tag -o t -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $out/pmc_$tag.json 2> $out/pmc_$tag.err
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$tag -o t -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-traffic --sustain-steps 0 > $out/pmc_$tag.json 2> $out/pmc_$tag.err
 done
 cd $R
-for u in ubench3 ubench4 ubench7; do [ -x tools/$u ] && ./tools/$u > $out/$u.txt 2>&1; done
 python3 tools/pmc_summary.py $out > $out/pmc_summary.txt 2>&1
-python3 bench.py --steps 20 --warmup 3 > $out/bench_default.json 2> $out/bench_default.err
+# un-profiled lines: the driver's command (with in-run traffic + CPU baseline), the other configs, the sustained run
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_default.json 2> $out/bench_default.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --sustain-steps 3000 > $out/bench_sustained3000.json 2> /dev/null
+python3 bench.py --config 2 -k 21 --no-traffic > $out/bench_k21.json 2> /dev/null
+python3 bench.py --config 2 -k 63 --no-traffic > $out/bench_k63.json 2> /dev/null
+python3 bench.py --config 3 --no-traffic > $out/bench_hash.json 2> /dev/null
+python3 bench.py --config 4 --no-traffic --no-cpu-baseline --steps 5 --warmup 2 --sustain-steps 20 > $out/bench_hist20.json 2> /dev/null
+python3 bench.py --config 4 --dist-single --no-cpu-baseline --steps 5 --warmup 2 --sustain-steps 0 > $out/bench_hist20_rccl1.json 2> /dev/null
+python3 bench.py --packed --no-cpu-baseline --no-traffic > $out/bench_packed.json 2> /dev/null
+for k in 13 17 25 27 29 33 41 47 51 55; do python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 200 -k $k 2>/dev/null | python3 tools/bench_line.py "k=$k"; done > $out/k_sweep.txt
+for spec in "100 150000000" "250 60000000" "300 50000000" "1000 15000000" "10000 1500000"; do set -- $spec
+  python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len $1 --reads-per-gpu $2 2>/dev/null | python3 tools/bench_line.py "L=$1"; done > $out/len_sweep.txt
+python3 tools/bench_ragged.py 100000000 31 > $out/ragged_bench.txt 2>/dev/null
+python3 tools/bench_ragged.py 100000000 21 >> $out/ragged_bench.txt 2>/dev/null
+python3 tools/bench_dirty.py > $out/dirty_bench.txt 2>/dev/null
+python3 tools/bench_windows.py > $out/windows_bench.txt 2>/dev/null
+python3 tools/bench_hist.py 100000000 12,16,20,22 > $out/hist_bench.txt 2>/dev/null
+python3 tools/bench_minimizers.py > $out/minimizers_bench.txt 2>/dev/null
+python3 tools/bench_fastx.py > $out/fastx_bench.txt 2>/dev/null
+python3 tools/step_times.py > $out/step_times.txt 2>/dev/null
 ls $out
