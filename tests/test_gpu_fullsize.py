@@ -79,16 +79,45 @@ def test_full_size_invalid_byte_accounting(ctx, big):
     assert (again.n_valid, again.sum_canon) == (clean.n_valid, clean.sum_canon)  # restored, idempotent
 
 
-def test_full_size_k63_two_word(ctx, orc, big):
-    """BASELINE configs[2]: k=63 ([u64;2] storage, build-defined order); counts + oracle-checked prefix"""
-    k = 63
-    n = min(N_FULL, 20_000_000)
+@pytest.mark.parametrize("k", [63, 64, 47])
+def test_full_size_two_word_k(ctx, orc, big, k):
+    """BASELINE configs[2]: k=63 ([u64;2] storage, build-defined order) at the full 1e8 reads -- exact count, shard
+    linearity (the word sums and the xor fold of two halves combine to the whole), oracle-checked prefix; and an even k
+    and a 3-waves/SIMD k on the same terms"""
+    n = N_FULL
     g = ctx.canonical_reduce2(big[: n * L], n, L, k, with_hash=True)
     assert g.n_valid == n * (L - k + 1)
+    h = n // 2 + 37
+    a = ctx.canonical_reduce2(big[: h * L], h, L, k, with_hash=True)
+    b = ctx.canonical_reduce2(big[h * L: n * L], n - h, L, k, with_hash=True)
+    M = (1 << 64) - 1   # (kmx_summary2: the low and the high words are summed separately, each wrapping)
+    assert (g.n_valid, g.sum_lo, g.sum_hi) == (a.n_valid + b.n_valid, (a.sum_lo + b.sum_lo) & M, (a.sum_hi + b.sum_hi) & M)
+    assert (g.xor_lo, g.xor_hi) == (a.xor_lo ^ b.xor_lo, a.xor_hi ^ b.xor_hi)
     n_chk = min(n, 300_000)
     o = orc.canonical_reduce2(big[: n_chk * L].cpu().numpy(), n_chk, L, k, with_hash=True)
     gp = ctx.canonical_reduce2(big[: n_chk * L], n_chk, L, k, with_hash=True)
     assert tuple(getattr(gp, f) for f, _ in gp._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
+
+
+def test_full_size_ragged_and_long_reads_agree_with_the_uniform_scan(ctx, big):
+    """the same 15 GB three ways: 1e8 uniform reads; the same reads behind an offsets array (ragged bit-sliced kernel);
+    and, re-cut as 1.5e6 reads of 10 000 bases (overlapping segments on the ragged kernel), the windows that do not
+    straddle an old read boundary -- checked through exact counts and the identity n_valid(long) = n_valid + (k-1)(n - n_long)"""
+    from kmers_amd import _lib
+
+    n, k = N_FULL, 31
+    a = ctx.canonical_reduce(big, n, L, k, _lib.HASH_LEX, k, 0)
+    off = ctx.to_device(np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    r = ctx.canonical_reduce(big, n, 160, k, _lib.HASH_LEX, k, 0, offsets=off)
+    assert (r.n_valid, r.sum_canon, r.xor_hash) == (a.n_valid, a.sum_canon, a.xor_hash)
+    del off
+    Ll = 10_000
+    nl = n * L // Ll
+    g = ctx.canonical_reduce(big[: nl * Ll], nl, Ll, k, _lib.HASH_NONE, 0, 0)
+    assert g.n_valid == nl * (Ll - k + 1)
+    h = nl // 3
+    p, q = ctx.canonical_reduce(big[: h * Ll], h, Ll, k), ctx.canonical_reduce(big[h * Ll: nl * Ll], nl - h, Ll, k)
+    assert (g.n_valid, g.sum_canon) == (p.n_valid + q.n_valid, (p.sum_canon + q.sum_canon) & ((1 << 64) - 1))
 
 
 @pytest.mark.parametrize("k", [31, 27, 17])
