@@ -58,6 +58,9 @@
 #ifndef KMX_BS_SWZ
 #define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
 #endif
+#ifndef KMX_BS_LATE16
+#define KMX_BS_LATE16 8   // late prefetch rows (of 16) of the 16-word frame (uniform ASCII reads of 161..256 bases): 160 registers, no spills (168 with 10 spilled before)
+#endif
 #ifndef KMX_BSR_LATE
 #define KMX_BSR_LATE 5   // late prefetch rows of the ragged variant
 #endif
@@ -439,7 +442,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             w[it] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    constexpr int LATE = (!PACKED && PASS == 0 && NW == 10) ? (RAGGED ? KMX_BSR_LATE : K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2) : 0;   // rows of the prefetch requested late
+    constexpr int LATE = (PACKED || PASS != 0) ? 0 : NW == 10 ? (RAGGED ? KMX_BSR_LATE : K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2) : (RAGGED || K > 32) ? 0 : KMX_BS_LATE16;   // rows of the prefetch requested late
     u64 tile = ~0ull, next_tile = ~0ull;
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;

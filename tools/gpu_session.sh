@@ -1,5 +1,8 @@
 #!/bin/bash
-mkdir -p gpurun_out/s11
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/s11/pytest_full.txt 2>&1
-tail -5 gpurun_out/s11/pytest_full.txt
-python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic > gpurun_out/s11/b.json 2>/dev/null; wc -l gpurun_out/s11/b.json; python3 tools/bench_line.py default < gpurun_out/s11/b.json
+mkdir -p gpurun_out/s12
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/s12/pytest_full.txt 2>&1
+tail -4 gpurun_out/s12/pytest_full.txt
+for spec in "250 60000000" "200 75000000" "170 88000000"; do set -- $spec
+  python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len $1 --reads-per-gpu $2 2>/dev/null | python3 tools/bench_line.py "L=$1"
+  KMX_LIB_VARIANT=r1 python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len $1 --reads-per-gpu $2 2>/dev/null | python3 tools/bench_line.py "r1 L=$1"
+done
