@@ -66,6 +66,12 @@ typedef struct {
     uint32_t read_len;
     const uint64_t *d_offsets;
 } kmx_reads;
+/* Limits: a single read is shorter than 2^31 bases (the iterator's positions are i32 in the reference as well,
+ * canonical_kmer_iterator.rs:15); offsets and totals are 64-bit.  A ragged read of 2^31 bases or more -- e.g. a whole
+ * chromosome out of kmx_fastx_parse's FASTA mode -- is not diagnosed: cut such records into overlapping pieces first
+ * (k - 1 bases of overlap, or hand the bytes over as uniform reads: reads longer than 256 bases are scanned in
+ * 160-base segments).  Uniform reads may start at any byte address; ragged reads need a 16-byte-aligned d_bases for the
+ * tiled kernels (any address is served, by the per-read kernel). */
 
 /* Result of a streaming reduce pass (device-resident, 32 bytes).
  * == what a consumer loop over CanonicalKmerIterator accumulates
