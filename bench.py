@@ -318,6 +318,12 @@ def worker(args, traffic_raw=None, traffic_err=None):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: n_gpus would be misreported")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the kmx path has no CPU fallback")
+    # KMX_BENCH_TEST_SHARED_GPU=1 (tests only, stated in the line): every rank runs on cuda:0 and the process group is gloo --
+    # the whole N > 1 control flow (barriers, summary combine, histogram exchange and its fallback, verdict broadcast) on a
+    # box with ONE GPU.  RCCL refuses two ranks on one device, so this is the only way to run that code on the GPU pool.
+    shared_gpu = os.environ.get("KMX_BENCH_TEST_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.dist_single:
@@ -325,7 +331,11 @@ def worker(args, traffic_raw=None, traffic_err=None):
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    coll_dev = None if shared_gpu else torch.device("cuda", local_rank)   # where the small control-plane tensors live
 
     from kmers_amd import _lib
     from kmers_amd import dist as kd
@@ -333,7 +343,7 @@ def worker(args, traffic_raw=None, traffic_err=None):
 
     ctx = Context(local_rank)
     # ranks that a real RCCL all-reduce sees: must be what the line will claim as n_gpus
-    rccl_ranks = kd.rccl_rank_count(ctx.device)
+    rccl_ranks = kd.rccl_rank_count(coll_dev)
     if rccl_ranks != args.gpus:
         sys.stderr.write(f"bench.py: all-reduce saw {rccl_ranks} ranks, --gpus {args.gpus}\n")
         if dist is not None:
@@ -371,12 +381,14 @@ def worker(args, traffic_raw=None, traffic_err=None):
         counts = torch.zeros(1 << args.histogram, dtype=torch.int64, device=ctx.device)
         if dist is not None:
             try:
+                if shared_gpu:
+                    raise RuntimeError("ranks share one GPU (test mode): RCCL cannot build a communicator")
                 comm = Comm(ctx, world, rank)
                 collective = "kmx_histogram_allreduce: ncclAllReduce(ncclUint64, ncclSum) on libkmx's RCCL communicator"
             except Exception as e:   # noqa: BLE001 -- keep the run alive: the fallback is RCCL as well
                 comm = None
                 collective = f"torch.distributed all_reduce (nccl = RCCL); kmx_comm_create failed: {e}"
-            flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=ctx.device)
+            flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # all ranks take the same route
             if int(flag.item()) == 0 and comm is not None:
                 comm.close()
@@ -389,6 +401,10 @@ def worker(args, traffic_raw=None, traffic_err=None):
     def hist_exchange():
         if comm is not None:
             comm.histogram_allreduce(counts)
+        elif dist is not None and shared_gpu:
+            host = counts.cpu()
+            kd.allreduce_histogram(host)
+            counts.copy_(host)
         elif dist is not None:
             with torch.cuda.stream(ctx.stream):
                 kd.allreduce_histogram(counts)
@@ -464,7 +480,7 @@ def worker(args, traffic_raw=None, traffic_err=None):
     xchg_ms = [m.elapsed_time(b) for (_, b), m in zip(evs, ev_mid)] if hist_mode else []
     avg_scan_ms = sum(scan_ms) / len(scan_ms)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
@@ -478,7 +494,7 @@ def worker(args, traffic_raw=None, traffic_err=None):
         summ = out.cpu().numpy().view(np.uint64)
         n_valid_local, sum_canon = int(summ[0]), int(summ[1])
         tot = kd.combine_summaries({"n_valid": n_valid_local, "sum_canon": sum_canon, "xor_hash": int(summ[2]) if not two_word else 0, "sum_fw": 0},
-                                   device=ctx.device)   # wrapping add / xor of the per-shard summaries
+                                   device=coll_dev)   # wrapping add / xor of the per-shard summaries
         total_kmers_per_step = tot["n_valid"]
 
     # ---- outside the timed region: sustained run, same-run read ceiling, optional histogram, parity, CPU baseline
@@ -572,7 +588,7 @@ def worker(args, traffic_raw=None, traffic_err=None):
             "config": {
                 "workload": f"k={k} {what}, {n} x {L} bp synthetic reads per GPU" + ("" if args.packed else f" ({cfg_names[args.config]})"),
                 "reads_per_gpu": n, "read_len": L, "k": k, "parallelism": f"shard{world}",
-                "bytes_per_gpu": nbytes, "launched_by": "bench.py (self-spawned ranks)" if os.environ.get("KMX_BENCH_SPAWNED") == "1" else ("torchrun" if world > 1 else "single process"),
+                "bytes_per_gpu": nbytes, **({"TEST_MODE": "KMX_BENCH_TEST_SHARED_GPU: all ranks on cuda:0, gloo process group -- not a multi-GPU measurement"} if shared_gpu else {}), "launched_by": "bench.py (self-spawned ranks)" if os.environ.get("KMX_BENCH_SPAWNED") == "1" else ("torchrun" if world > 1 else "single process"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -603,7 +619,7 @@ def worker(args, traffic_raw=None, traffic_err=None):
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     # every rank learns the verdict and leaves together (a lone sys.exit on rank 0 would strand the others in a collective)
     if dist is not None:
-        v = torch.tensor([1 if parity else 0], dtype=torch.int64, device=ctx.device)
+        v = torch.tensor([1 if parity else 0], dtype=torch.int64, device=coll_dev)
         dist.broadcast(v, src=0)
         parity = bool(int(v.item()))
         if comm is not None:

@@ -417,3 +417,38 @@ def test_long_uniform_reads_take_the_segmented_bitsliced_path(ctx, orc, k, L, n)
         assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, 0)
         g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)   # sum_fw: the per-lane kernel, still exact
         assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
+
+
+# ------------------------------------------------------------------ bench.py, N > 1 control flow on one GPU
+
+@pytest.mark.parametrize("cfg", ["1", "3", "4"])
+def test_bench_two_ranks_share_the_gpu(cfg):
+    """`python bench.py --gpus 2` (it starts its own ranks) with both ranks on cuda:0 and a gloo process group
+    (KMX_BENCH_TEST_SHARED_GPU): barriers, shard streams, summary combine, histogram exchange (the torch.distributed
+    route: RCCL cannot put two ranks on one device), verdict broadcast -- everything of the N > 1 path but RCCL itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["KMX_BENCH_TEST_SHARED_GPU"] = "1"
+    n = 2_000_000
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", cfg, "--reads-per-gpu", str(n),
+                        "--steps", "3", "--warmup", "1", "--sustain-steps", "5", "--no-traffic", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]     # stdout is the ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["parity_vs_oracle"] == "ok"
+    assert "TEST_MODE" in d["config"]
+    per_rank = n * (150 - 31 + 1)
+    if cfg == "4":
+        h = d["histogram"]
+        assert h["total_count"] == h["expect"] == 2 * per_rank
+        assert "torch.distributed" in h["collective"]
+    else:
+        # value = k-mers of BOTH ranks per step / time
+        assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * per_rank) < 1e-6 * 2 * per_rank
