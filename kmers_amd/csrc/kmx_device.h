@@ -139,8 +139,17 @@ __device__ __forceinline__ u64 splitmix64(u64 x) {
     return x ^ (x >> 31);
 }
 
+#ifndef KMX_BUCKET_CHEAP
+#define KMX_BUCKET_CHEAP 0
+#endif
 __device__ __forceinline__ u64 bucket_of(u64 h, u32 log2_buckets) {
+#if KMX_BUCKET_CHEAP
+    // (dev) 32-bit Fibonacci hashing of the folded word: one v_mul_lo_u32 instead of the four of a 64-bit product
+    const u32 x = (u32)h ^ (u32)(h >> 31);
+    return log2_buckets ? (u64)((x * 0x9E3779B1u) >> (32u - log2_buckets)) : 0ull;
+#else
     return log2_buckets ? (h * 0x9E3779B97F4A7C15ull) >> (64u - log2_buckets) : 0ull;
+#endif
 }
 
 // max over the 64 lanes, returned wave-uniform: DPP inside the 16-lane rows (no LDS round trips), then 4 v_readlane

@@ -181,7 +181,7 @@ struct SinkHistPart {
 #endif
     static constexpr u32 NP = 64, ROW = KMX_HIST_ROW;   // partitions; ring entries per partition (u16); rows of ROW/2 ids leave together
     static constexpr u32 HALF = ROW / 2u, PER_LANE = HALF / 16u;   // ids per lane of the quarter-wave that writes a row (2 or 4)
-    static constexpr u32 kLdsDwordsPerWave = NP * ROW / 2u + 2u * NP;
+    static constexpr u32 kLdsDwordsPerWave = NP * ROW / 2u + 2u * NP + NP / 4u;   // rings, {appended|written} words, segment cursors, rank -> ring bytes
     static constexpr bool kRagged = false;
     static u32 block_lds_dwords(const HistPartParams&) { return 0; }
     HistPartParams p;
@@ -205,14 +205,17 @@ struct SinkHistPart {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __device__ __forceinline__ void emit(u64 fw, u64 rc) {
+    __device__ __forceinline__ u32 bucket_of_window(u64 fw, u64 rc) const {
         const u64 canon = fw < rc ? fw : rc;
         u64 h;
         if (p.hasher == KMX_HASH_LEX) h = (p.hk == k) ? (maskk ^ fw ^ rc ^ canon) : lex_hash(canon, p.hk);
         else h = canon;
-        const u32 bucket = (u32)bucket_of(h, p.log2_buckets);
+        return (u32)bucket_of(h, p.log2_buckets);
+    }
+    // the slot of an id in its partition's ring: ONE returning LDS atomic
+    __device__ __forceinline__ u32 take_slot(u32 bucket) { return atomicAdd(&word[bucket >> lowbits], 0x10000u); }
+    __device__ __forceinline__ void place(u32 bucket, u32 w) {
         const u32 q = bucket >> lowbits;
-        const u32 w = atomicAdd(&word[q], 0x10000u);
         const u32 slot = w >> 16;
         if (((slot - w) & 0xFFFFu) < ROW) ring[q * ROW + (slot & (ROW - 1u))] = (uint16_t)(bucket & ((1u << lowbits) - 1u));
         else {   // ring full: take the slot back (every slot handed out past the ring is, so the count ends exact) and divert
@@ -220,49 +223,80 @@ struct SinkHistPart {
             atomicAdd((unsigned long long*)&p.counts[bucket], 1ull);
         }
     }
+    __device__ __forceinline__ void emit(u64 fw, u64 rc) {
+        const u32 bucket = bucket_of_window(fw, rc);
+        place(bucket, take_slot(bucket));
+    }
+    // The windows of an unrolled block are consumed NB at a time: their slot requests go out back to back and are
+    // waited for once.  One at a time, every window paid the LDS round trip of its atomic before its ring store could be
+    // addressed (and a branch on the answer keeps hipcc from overlapping them): the waves of pass 1 sat in s_waitcnt for
+    // 47 % of their cycles.
+    static constexpr bool kBatch16 = true;
+    static constexpr int kWaves = 3;   // (LDS allows three blocks per CU: keep the registers inside 168)
+#ifndef KMX_HIST_BATCH
+#define KMX_HIST_BATCH 8
+#endif
+    static constexpr int NB = KMX_HIST_BATCH;   // windows whose slot requests are in flight together (divides 16)
+    u32 pend[NB];
+    __device__ __forceinline__ void fast_slot(int s, u64 fw, u64 rc) {
+        pend[s % NB] = bucket_of_window(fw, rc);
+        if (s % NB == NB - 1) {
+            u32 w[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) w[j] = take_slot(pend[j]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) place(pend[j], w[j]);
+        }
+    }
     // ids staged and not yet written out
     static __device__ __forceinline__ u32 staged(u32 w) { return ((w >> 16) - w) & 0xFFFFu; }
-    // The whole wave: every ring with a full half row (HALF ids) writes it out; quarter-wave j handles one ring per round.
+    // The whole wave: every ring with a full half row (HALF ids) writes it out.  SIXTEEN rings per round, four lanes
+    // (16 bytes each) per ring; which ring a group takes comes from a rank table (ring -> its rank among the rings to
+    // flush, by v_mbcnt; rank -> ring through 64 bytes of LDS), not from a scalar walk over the mask: with ~32 of the 64
+    // rings due after every block of 16 windows, the first version's rounds of four rings -- eight per block, each with its
+    // scalar ctz loop, a quarter-wave busy and a wave_sync -- cost more than the 16 windows they followed
+    // (pass 1 at 2^20 buckets: 22 -> see DESIGN 4.3).
     __device__ __forceinline__ void flush_rows() {
+        static_assert(ROW == 64, "row flush: 32 ids = 64 bytes = 4 lanes x 16 bytes");
         wave_sync();
-        u64 m = __ballot(staged(word[lane]) >= HALF);
-        const u32 quarter = lane >> 4, l16 = lane & 15u;
-        while (m) {
-            u32 q = NP;   // this quarter-wave's ring of the round (NP = none)
-#pragma unroll
-            for (u32 j = 0; j < 4; ++j) {
-                if (m) {
-                    const u32 qq = (u32)__builtin_ctzll(m);
-                    m &= m - 1u;
-                    if (quarter == j) q = qq;
-                }
-            }
-            if (q < NP) {
+        const bool due = staged(word[lane]) >= HALF;
+        const u64 m = __ballot(due);
+        if (m == 0) return;
+        const u32 n_due = (u32)__builtin_popcountll(m);
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+        uint8_t* order = reinterpret_cast<uint8_t*>(cur + NP);   // [NP] ring of rank r
+        if (due) order[rank] = (uint8_t)lane;
+        wave_sync();
+        const u32 grp = lane >> 2, l4 = lane & 3u;
+        for (u32 base = 0; base < n_due; base += 16u) {
+            const u32 r = base + grp;
+            if (r < n_due) {
+                const u32 q = order[r];
                 const u32 w = word[q];
                 const u32 pos = cur[q];
                 const u32 half = w & HALF;   // written-out count is a multiple of HALF: the row starts at ring entry 0 or HALF
-                u32 v[PER_LANE / 2u];
-#pragma unroll
-                for (u32 i = 0; i < PER_LANE / 2u; ++i) v[i] = reinterpret_cast<const u32*>(ring + q * ROW + half + PER_LANE * l16)[i];
+                const uint4 v = *reinterpret_cast<const uint4*>(ring + q * ROW + half + 8u * l4);
                 if (pos + HALF <= p.cap) {
-#pragma unroll
-                    for (u32 i = 0; i < PER_LANE / 2u; ++i) reinterpret_cast<u32*>(seg + (u64)q * p.cap + pos + PER_LANE * l16)[i] = v[i];
+                    *reinterpret_cast<uint4*>(seg + (u64)q * p.cap + pos + 8u * l4) = v;
                 } else {   // segment full: the ids go to the global table
                     const u32 hi = q << lowbits;
+                    const u32 vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                    for (u32 i = 0; i < PER_LANE / 2u; ++i) {
-                        atomicAdd((unsigned long long*)&p.counts[hi | (v[i] & 0xFFFFu)], 1ull);
-                        atomicAdd((unsigned long long*)&p.counts[hi | (v[i] >> 16)], 1ull);
+                    for (u32 i = 0; i < 4; ++i) {
+                        atomicAdd((unsigned long long*)&p.counts[hi | (vv[i] & 0xFFFFu)], 1ull);
+                        atomicAdd((unsigned long long*)&p.counts[hi | (vv[i] >> 16)], 1ull);
                     }
                 }
-                if (l16 == 0) {
+                if (l4 == 0) {
                     if (pos + HALF <= p.cap) cur[q] = pos + HALF;
                     word[q] = (w & 0xFFFF0000u) | ((w + HALF) & 0xFFFFu);
                 }
             }
-            wave_sync();
         }
+        wave_sync();
     }
+    // (a full unrolled block arrives as 16 fast_slot() calls -- uniform reads only, so every lane has all 16; the partial
+    // last block of a read arrives through fast(), one window at a time)
     __device__ __forceinline__ void block_done(u64, u32, u32) { flush_rows(); }
     __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) { emit(fw, rc); }
@@ -540,6 +574,9 @@ struct SinkWindowsT {
 // a sink may ask for a register budget of its own (static constexpr int kWaves)
 template <typename S, typename = void> struct SinkWaves { static constexpr int value = KMX_SCAN_WAVES; };
 template <typename S> struct SinkWaves<S, decltype((void)S::kWaves)> { static constexpr int value = S::kWaves; };
+// a sink may take the 16 windows of an unrolled block together (static constexpr bool kBatch16 = true; fast_slot())
+template <typename S, typename = void> struct SinkBatch16 { static constexpr bool value = false; };
+template <typename S> struct SinkBatch16<S, decltype((void)S::kBatch16)> { static constexpr bool value = S::kBatch16; };
 template <typename S, int NW> constexpr int sink_waves() { return NW <= 10 ? SinkWaves<S>::value : KMX_SCAN_WAVES; }   // (the 16-word frame would spill 1 KB)
 template <int NW, int V, int DW, typename Sink, typename Params, bool RAGGED = false>
 __global__ void __launch_bounds__(256, (sink_waves<Sink, NW>()))
@@ -576,17 +613,29 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     Sink sink(params, k, nwin, P + ldsw, lane, lds + 4u * (ldsw + Sink::kLdsDwordsPerWave), threadIdx.x);
 
     [[maybe_unused]] u32 nwin_min = nwin;   // ragged: the shortest read of the tile (blocks of windows below it need no per-lane mask)
-    auto window = [&](u32 o, u32 f0, u32 f1, u32 f2, u32 g0, u32 g1, u32 g2, u32 sf, u32 sr, bool guard = RAGGED) {
+    // `slot`: position of the window inside a fully unrolled block of 16 (a compile-time value there), -1 elsewhere; a
+    // sink with kBatch16 collects the 16 windows of such a block and consumes them together in block_done()
+    auto window = [&](u32 o, u32 f0, u32 f1, u32 f2, u32 g0, u32 g1, u32 g2, u32 sf, u32 sr, bool guard = RAGGED, int slot = -1) {
         if (guard && o >= nwin) return;   // past the end of this lane's (shorter) read
+        u64 fw, rc;
         if (DW == 2) {
             const u32 fw_lo = alignbit(f1, f0, sf);
             const u32 fw_hi = alignbit(f2, f1, sf) & mhi;
             const u32 rc_lo = alignbit(g1, g0, sr);
             const u32 rc_hi = alignbit(g2, g1, sr) & mhi;
-            sink.fast(o, ((u64)fw_hi << 32) | fw_lo, ((u64)rc_hi << 32) | rc_lo);
+            fw = ((u64)fw_hi << 32) | fw_lo;
+            rc = ((u64)rc_hi << 32) | rc_lo;
         } else {
-            sink.fast(o, (u64)(alignbit(f1, f0, sf) & mlo), (u64)(alignbit(g1, g0, sr) & mlo));
+            fw = (u64)(alignbit(f1, f0, sf) & mlo);
+            rc = (u64)(alignbit(g1, g0, sr) & mlo);
         }
+        if constexpr (SinkBatch16<Sink>::value) {
+            if (slot >= 0) {
+                sink.fast_slot(slot, fw, rc);
+                return;
+            }
+        }
+        sink.fast(o, fw, rc);
     };
 
     // dynamic tile queue (see kmx_bitslice.hip): NQ interleaved heads, one tile per ticket, ticket fetched one
@@ -728,7 +777,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
                 // (a second, unmasked copy of the block for tiles of equal-length reads doubles the code past the
                 //  instruction cache and costs more than the per-window mask it saves)
 #pragma unroll
-                for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, RAGGED && !KMX_SCAN_DEV_NOGUARD);
+                for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, RAGGED && !KMX_SCAN_DEV_NOGUARD, RAGGED ? -1 : s);
 #endif
                 sink.block_done(tile * 64u, 16u * i, 16u);
             } else if ((u32)i == imax) {

@@ -1,4 +1,5 @@
 #!/bin/bash
-mkdir -p gpurun_out/s13
-timeout 1800 python -m pytest tests/test_gpu_round2.py -m gpu -x -q -k "bench_two_ranks" > gpurun_out/s13/pytest.txt 2>&1
-tail -30 gpurun_out/s13/pytest.txt
+for v in default h4 h2 h16; do
+  if [ "$v" == "default" ]; then unset KMX_LIB_VARIANT; else export KMX_LIB_VARIANT=$v; fi
+  echo "== $v"; python3 tools/bench_hist.py 100000000 16,20 2>/dev/null
+done
