@@ -1234,12 +1234,18 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             tot[g] = pcq + __shfl_xor(pcq, 32, WAVE);      // lanes p and p+32 hold the same plane of the two sets
         }
         if constexpr (K <= 32) bs_fw = wave_sum(fwall);
-        const u64 mc = wave_sum((u64)mcnt);
+        u32 mcnt_c;
+        asm volatile("v_mov_b32 %0, %1" : "=&v"(mcnt_c) : "v"(mcnt));
+        const u64 mc = wave_sum((u64)mcnt_c);
         u64* CS = reinterpret_cast<u64*>(PL + PLANES);      // set-1 plane area is free now
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 2 * NT; ++q) {
-            const u64 v = wave_sum((u64)D[q]);
+            // (through an opaque 32-bit copy: zero-extended directly, D[q] becomes the low half of a 64-bit register for its
+            // whole life -- even-aligned on gfx950 -- and the allocator needs ~35 registers more for the same live values)
+            u32 dq;
+            asm volatile("v_mov_b32 %0, %1" : "=&v"(dq) : "v"(D[q]));   // (early clobber: a register of its own)
+            const u64 v = wave_sum((u64)dq);
             if (lane == 0) CS[q] = v;
         }
 #pragma unroll
