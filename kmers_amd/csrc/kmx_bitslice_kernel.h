@@ -1361,7 +1361,14 @@ template <int K, bool PACKED>
 static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
                                 unsigned long long* queue, int n_cu, hipStream_t stream) {
     const u32 W = L - (u32)K + 1u;
-    if (L > 160) return launch_bs<K, 16, 8, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);   // 161..256 bp
+    if (L > 160) {   // 161..256 bp: the 16-word frame, as few windows per lane as keep the 2*ceil(W/WPL) items inside 64 lanes
+        if constexpr (!PACKED) {
+            if (W <= 160u) return launch_bs<K, 16, 5, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+            if (W <= 192u) return launch_bs<K, 16, 6, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+            if (W <= 224u) return launch_bs<K, 16, 7, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        }
+        return launch_bs<K, 16, 8, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+    }
     if (W <= 96u) return launch_bs<K, 10, 3, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
     if (W <= 128u) return launch_bs<K, 10, 4, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
     return launch_bs<K, 10, 5, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
@@ -1394,7 +1401,12 @@ template <int K>
 static hipError_t launch_bs_ragged_any(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out,
                                        unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L) {
     const u32 W = Lf - (u32)K + 1u;
-    if (Lf > 160) return launch_bs<K, 16, 8, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+    if (Lf > 160) {
+        if (W <= 160u) return launch_bs<K, 16, 5, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+        if (W <= 192u) return launch_bs<K, 16, 6, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+        if (W <= 224u) return launch_bs<K, 16, 7, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+        return launch_bs<K, 16, 8, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+    }
     if (W <= 96u) return launch_bs<K, 10, 3, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
     if (W <= 128u) return launch_bs<K, 10, 4, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
     return launch_bs<K, 10, 5, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
