@@ -8,7 +8,8 @@ ctx = Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 31
 rng = np.random.default_rng(1)
-for name, lens, hint in (("all 150 (hint 160)", np.full(n, 150), 160), ("all 150 (no hint)", np.full(n, 150), 0),
+for name, lens, hint in (("all 150 (hint 160)", np.full(n, 150), 160), ("all 150 (hint 150)", np.full(n, 150), 150), ("all 150 (no hint)", np.full(n, 150), 0),
+                         ("150 with 2% trimmed to 36..149 (hint 150)", np.where(rng.random(n) < 0.02, rng.integers(36, 150, n), 150), 150),
                          ("uniform 100..160 (hint 160)", rng.integers(100, 161, n), 160),
                          ("150 with 2% trimmed to 36..149 (hint 160)", np.where(rng.random(n) < 0.02, rng.integers(36, 150, n), 150), 160)):
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
