@@ -61,6 +61,10 @@
 #ifndef KMX_BS_LATE16
 #define KMX_BS_LATE16 8   // late prefetch rows (of 16) of the 16-word frame (uniform ASCII reads of 161..256 bases): 160 registers, no spills (168 with 10 spilled before)
 #endif
+#ifndef KMX_BSR_VAL
+#define KMX_BSR_VAL 1    // ragged: 1 = validity planes from per-read end marks + a prefix-OR across the lanes, bases past a read's end masked out of
+                         // the plane totals only; 0 = (round 1) NV thermometer words per read through the 32x32 transposes, bases zeroed per group
+#endif
 #ifndef KMX_BSR_LATE
 #define KMX_BSR_LATE 5   // late prefetch rows of the ragged variant
 #endif
@@ -161,9 +165,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // read r starts at byte lead + r*L.  A tile then spans one more chunk (its first holds the tail of the tile before
     // it), exactly like a ragged tile streamed from its aligned start; 0 for every other input.
     static_assert(!RAGGED || (!PACKED && K <= 32 && KMX_BS_PRIO >= 2), "ragged input: ASCII, single-word k-mers");
+    static_assert(WPL <= 8, "the zero words behind the validity planes cover a lane's windows");
     constexpr int NE = RAGGED ? (K - 1 + 15) / 16 : 0;            // dwords holding the last K-1 bases of a read
     constexpr int NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;  // validity words per read (one bit per window of the frame)
-    constexpr int NXT = NW + NE + NV;                            // 32x32 transposes per half-wave and tile
+    constexpr u32 VS = RAGGED ? 32u * NV + 8u : 0u;             // validity planes of one set + 8 always-zero words (a lane's windows past the frame, idle lanes)
+    constexpr int NVT = KMX_BSR_VAL ? 0 : NV;                    // validity words that go through the transposes
+    constexpr int NXT = NW + NE + NVT;                           // 32x32 transposes per half-wave and tile
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     // Plane storage of one 32-read set: base beta (2 planes = one u64) lives at u64 index
     // (beta & 3) * S2 + (beta >> 2).  In phase D lane g reads bases 4g+i: consecutive lanes then touch
@@ -186,7 +193,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
     const u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
     constexpr u32 TRC_DW = KMX_BS_TRC_LDS ? 256u : 0u;     // [32 lanes of a half-wave][8] transpose constants, shared by the block
-    u32* P = lds + TRC_DW + wib * (ldsw + 4u * PLANES + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u) + (PASS == 1 ? 128u : 0u));
+    u32* P = lds + TRC_DW + wib * (ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u) + (PASS == 1 ? 128u : 0u));
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
     const u64 n_full = n_reads >> 6;
@@ -237,12 +244,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u32* VAL = TOT + 2u * PLANES;       // ragged: [2][32*NV] validity planes of the current tile
     // ragged, per lane, kept in LDS (registers are what caps this variant's occupancy): QT[e][lane] = running popcount of the
     // lane's plane of the read-end words, NVR[lane] = windows of the lane's reads in bit-sliced tiles
-    u32* QT = VAL + 64u * NV;
+    u32* QT = VAL + 2u * VS;
     u64* NVR = reinterpret_cast<u64*>(QT + 64u * NE);
     if constexpr (RAGGED) {
 #pragma unroll
         for (int e = 0; e < NE; ++e) QT[e * 64 + lane] = 0;
         NVR[lane] = 0;
+        if (lane < 16u) VAL[(lane >> 3) * VS + 32u * NV + (lane & 7u)] = 0;   // the zero words (never written again)
     }
     // RAGGED with offsets == nullptr: "reads" are the overlapping SEGMENTS of uniform reads too long for a frame (L > 256):
     // read i of `seg_L` bases is cut into J segments of seg_T windows each (the last one shorter), segment j = bases
@@ -387,7 +395,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
     };
     // PASS 1: the reads set aside by the bit-sliced tiles, 64 at a time, one lane per read
-    u64* const SET_ASIDE = reinterpret_cast<u64*>(P + ldsw + 4u * PLANES + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u));
+    u64* const SET_ASIDE = reinterpret_cast<u64*>(P + ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u));
     auto roll_set_aside = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -593,10 +601,17 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 if (lane == 0) { BM[NW] = 0; BM[NW + 1] = 0; }
                 return __any(bad != 0u);
             }
+            if (KMX_BSR_VAL && cur_m.n_ch >= 64u * (NW - 1)) {   // wave-uniform: only the last row is partial (64 reads of 150: 600 or 601 chunks)
 #pragma unroll
-            for (int it = 0; it < NW; ++it) {
-                const u32 c = it * 64u + lane;
-                if (c < cur_m.n_ch) P[1u + c] = encode_prio(w[it], bad);
+                for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
+                const u32 c = (NW - 1) * 64u + lane;
+                if (c < cur_m.n_ch) P[1u + c] = encode_prio(w[NW - 1], bad);
+            } else {
+#pragma unroll
+                for (int it = 0; it < NW; ++it) {
+                    const u32 c = it * 64u + lane;
+                    if (c < cur_m.n_ch) P[1u + c] = encode_prio(w[it], bad);
+                }
             }
             return __any(chunk_has_invalid(bad));
         } else if constexpr (PACKED) {      // already 2-bit codes: 16 bytes = 4 packed dwords per lane and load
@@ -685,11 +700,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         if constexpr (RAGGED) {
             const bool set_aside = PASS == 1 && ((valid_reads >> lane) & 1ull) == 0ull;   // second pass: a read with an invalid byte
             const u32 len = (cur_m.len >= (u32)K && !set_aside) ? cur_m.len : 0u;   // a read shorter than k owns no window: it is blanked out entirely
-            // bases past the end of the read belong to the next read: zero them
+            // bases past the end of the read belong to the next read.  KMX_BSR_VAL: they stay -- a window that holds one is masked
+            // out of m by its validity plane, and the plane totals count a plane through the validity plane of its base (below)
+            if constexpr (!KMX_BSR_VAL) {
 #pragma unroll
-            for (int g = 0; g < NW; ++g) {
-                const u32 keep = len > 16u * g ? (len - 16u * g < 16u ? len - 16u * g : 16u) : 0u;
-                F[g] = keep >= 16u ? F[g] : (F[g] & ((1u << (2u * keep)) - 1u));
+                for (int g = 0; g < NW; ++g) {
+                    const u32 keep = len > 16u * g ? (len - 16u * g < 16u ? len - 16u * g : 16u) : 0u;
+                    F[g] = keep >= 16u ? F[g] : (F[g] & ((1u << (2u * keep)) - 1u));
+                }
             }
             // the last K-1 bases of the read, base len-K+1+i at position i of the NE dwords
             const u32 posE = len ? posF + len - (u32)(K - 1) : posF;
@@ -703,10 +721,48 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             // validity: bit o of word o/32 = window o lies inside the read
             const u32 wr = len ? len - (u32)K + 1u : 0u;
-#pragma unroll
-            for (int j = 0; j < NV; ++j)
-                F[NW + NE + j] = wr >= 32u * (j + 1) ? ~0u : (wr > 32u * j ? (1u << (wr - 32u * j)) - 1u : 0u);
             atomicAdd(reinterpret_cast<unsigned long long*>(&NVR[lane]), (unsigned long long)wr);   // ds_add_u64, no return
+            if constexpr (!KMX_BSR_VAL) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    F[NW + NE + j] = wr >= 32u * (j + 1) ? ~0u : (wr > 32u * j ? (1u << (wr - 32u * j)) - 1u : 0u);
+            } else {
+                // Validity planes without transposes: V_o (bit r = read r owns window o <=> wr_r > o) = OR over i > o of E_i,
+                // E_i = the reads with wr == i.  The reads mark E (in the plane area, free until the planes are stored at the end
+                // of this phase); lane p of a half-wave then takes the NV planes o = NV*(31-p) .. +NV-1 -- the lanes below it hold
+                // the higher o -- ORs its own marks downwards and gets the marks of all higher o from a prefix-OR across the lanes
+                // (4 row shifts + the row broadcast).  The reads that share lane 0's wr (all of them, in untrimmed FASTQ) are
+                // marked by ONE lane per half with the whole ballot: 64 atomics on one LDS word would serialise.
+                constexpr u32 EMS = 32u * NV + 4u;      // dwords per half-wave: E_0 .. E_(32 NV)
+                u32* const EM = PL;
+                static_assert(2u * EMS <= 2u * PLANES, "end marks fit the plane area");
+                for (u32 i = 4u * lane; i < 2u * EMS; i += 256u) *reinterpret_cast<uint4*>(EM + i) = make_uint4(0u, 0u, 0u, 0u);
+                lds_fence();
+                const u32 ref = (u32)__builtin_amdgcn_readfirstlane(wr);
+                const bool is_ref = wr == ref;
+                const u64 bref = __ballot(is_ref);
+                u32* const emh = EM + half * EMS;
+                if (!is_ref) atomicOr(emh + wr, 1u << p);
+                if (p == 0u) atomicOr(emh + ref, half ? (u32)(bref >> 32) : (u32)bref);
+                lds_fence();
+                const u32 ob = (u32)NV * (31u - p);
+                u32 e[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) e[j] = emh[ob + 1u + j];
+#pragma unroll
+                for (int j = NV - 2; j >= 0; --j) e[j] |= e[j + 1];
+                u32 x = e[0];
+                x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+                x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+                x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+                x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+                u32 c = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);        // the lanes below, within the row of 16
+                c |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);      // rows 1 and 3: all of the row before
+                u32* const vh = VAL + half * VS + ob;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) vh[j] = e[j] | c;
+                lds_fence();
+            }
         }
         // ---- C. transpose each 32 reads x 32 bits block across the 32 lanes of the half-wave, entirely in
         //      the VALU (no LDS round trips): butterfly stage d exchanges with lane^d and keeps/merges the
@@ -782,11 +838,32 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 for (int g = 0; g < NW; ++g) pst[(WPL == 4) ? 8 * g : 32 * g] = F[g];
             }
 #pragma unroll
-            for (int j = 0; j < NV; ++j) VAL[half * 32u * NV + 32u * j + p] = F[NW + NE + j];   // ragged: plane V_(32j+p) of this set
+            for (int j = 0; j < NVT; ++j) VAL[half * VS + 32u * j + p] = F[NW + NE + j];   // ragged: plane V_(32j+p) of this set
+            if constexpr (RAGGED && KMX_BSR_VAL) {
+                // plane (g, p) holds base beta = 16g + p/2 of the set's reads: only the reads that HAVE a base beta count
+                // (len > beta <=> wr > beta - (K-1): validity plane V_(beta-K+1); below K-1 every read that owns a window at all)
+                const u32* const vh = VAL + half * VS;
+                const u32 b0 = p >> 1;
+#pragma unroll
+                for (int g = 0; g < NW; ++g) {
+                    u32 vm;
+                    if (16 * g + 15 < K - 1) vm = vh[0];
+                    else if (16 * g >= K - 1) vm = (vh + b0)[16 * g - (K - 1)];
+                    else { const u32 beta = 16u * g + b0; vm = vh[beta >= (u32)(K - 1) ? beta - (u32)(K - 1) : 0u]; }
+                    Y[g] = F[g] & vm;
+                }
+                KMX_HRUN_BEGIN
+#pragma unroll
+                for (int g = 0; g < NW; ++g) Y[g] = (u32)__builtin_popcount(Y[g]);
+#pragma unroll
+                for (int g = NW; g < NW + NE; ++g) Y[g] = (u32)__builtin_popcount(F[g]);
+                KMX_HRUN_END
+            } else {
             KMX_HRUN_BEGIN
 #pragma unroll
             for (int g = 0; g < NW + NE; ++g) Y[g] = (u32)__builtin_popcount(F[g]);
             KMX_HRUN_END
+            }
             {
                 u32* const tot_l = TOT + lane;
 #pragma unroll
@@ -960,8 +1037,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
             for (int w = 0; w < WPL; ++w) {
                 if constexpr (RAGGED) {   // only the reads that own window o+w (none of them past the frame)
-                    const u32 ow = o + (u32)w;
-                    m[w] = (active && ow < 32u * NV) ? (lt[w] & VAL[set * 32u * NV + ow]) : 0u;
+                    // (an idle lane and a window past the frame read one of the 8 zero words behind the set's planes)
+                    m[w] = lt[w] & (VAL + set * VS + (active ? o : 32u * NV))[w];
                 } else {
                     m[w] = ((u32)w < nwin) ? lt[w] : 0u;
                 }
@@ -1317,7 +1394,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     const u32 ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
     constexpr u32 NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;
     constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
-    size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u) + 64u * NV + (RAGGED ? 64u * (NE + 2) : 0u)) * 4u * 4u;
+    size_t lds_bytes = (size_t)(ldsw + 4u * 8u * (4u * NW + 1u) + (RAGGED ? 2u * (32u * NV + 8u) : 0u) + (RAGGED ? 64u * (NE + 2) : 0u)) * 4u * 4u;
     if (KMX_BS_TRC_LDS) lds_bytes += 1024u;
     if (const char* e = getenv("KMX_BS_EXTRA_LDS")) lds_bytes += (size_t)atol(e);   // dev knob: caps blocks per CU
     // blocks per CU, cached per host thread and device (one thread per context / GPU is the ABI's model: a plain static
