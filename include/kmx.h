@@ -137,7 +137,8 @@ int kmx_canonical_windows2(kmx_ctx *ctx, const kmx_reads *reads, const uint64_t 
                            uint64_t *d_fw2, uint64_t *d_rc2, uint64_t *d_canon2, uint8_t *d_flags);
 
 /* Per-bucket occupancy of hash(canonical k-mer): d_counts[bucket] += 1 for every yielded window;
- * bucket = (hash * 0x9E3779B97F4A7C15) >> (64 - log2_buckets)  (BUILD-DEFINED bucket function).
+ * bucket = (uint32_t)(lo32(hash) * 0x9E3779B1 + hi32(hash) * 0x85EBCA6B) >> (32 - log2_buckets)  (BUILD-DEFINED bucket
+ * function: the top bits of a 32-bit multiplicative mix of the two halves; log2_buckets <= 30).
  * d_counts (2^log2_buckets device u64) is ACCUMULATED into; the caller zeroes it and, across
  * GPUs, all-reduces it (RCCL ncclSum/uint64).
  * Uniform reads with 2^15..2^21 buckets go through a grow-only work buffer owned by the context (at most 8 GiB or

@@ -607,10 +607,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 const u32 c = (NW - 1) * 64u + lane;
                 if (c < cur_m.n_ch) P[1u + c] = encode_prio(w[NW - 1], bad);
             } else {
+                // (row bound on the scalar side, compared with the lane id: ten per-row chunk indices would sit in registers across the tile loop)
 #pragma unroll
                 for (int it = 0; it < NW; ++it) {
-                    const u32 c = it * 64u + lane;
-                    if (c < cur_m.n_ch) P[1u + c] = encode_prio(w[it], bad);
+                    const int left = (int)cur_m.n_ch - 64 * it;
+                    if ((int)lane < left) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
                 }
             }
             return __any(chunk_has_invalid(bad));

@@ -139,17 +139,13 @@ __device__ __forceinline__ u64 splitmix64(u64 x) {
     return x ^ (x >> 31);
 }
 
-#ifndef KMX_BUCKET_CHEAP
-#define KMX_BUCKET_CHEAP 0
-#endif
+// BUILD-DEFINED bucket of a hash value (include/kmx.h, oracle kmo_bucket_of): the top log2_buckets bits of the 32-bit sum of the
+// two halves, each times its own odd constant.  One v_mul_lo_u32 and one multiply-add: the partition pass of the histogram
+// is bound by VALU issue, and the 64-bit Fibonacci product of round 1 (top bits of h * 0x9E3779B97F4A7C15) cost it 6
+// instructions per k-mer.  Every bit of h reaches the top bits of the sum (a multiplicative hash carries upwards only).
+__device__ __forceinline__ u32 bucket_mix(u32 lo, u32 hi) { return lo * 0x9E3779B1u + hi * 0x85EBCA6Bu; }
 __device__ __forceinline__ u64 bucket_of(u64 h, u32 log2_buckets) {
-#if KMX_BUCKET_CHEAP
-    // (dev) 32-bit Fibonacci hashing of the folded word: one v_mul_lo_u32 instead of the four of a 64-bit product
-    const u32 x = (u32)h ^ (u32)(h >> 31);
-    return log2_buckets ? (u64)((x * 0x9E3779B1u) >> (32u - log2_buckets)) : 0ull;
-#else
-    return log2_buckets ? (h * 0x9E3779B97F4A7C15ull) >> (64u - log2_buckets) : 0ull;
-#endif
+    return log2_buckets ? (u64)(bucket_mix((u32)h, (u32)(h >> 32)) >> (32u - log2_buckets)) : 0ull;
 }
 
 // max over the 64 lanes, returned wave-uniform: DPP inside the 16-lane rows (no LDS round trips), then 4 v_readlane

@@ -175,7 +175,12 @@ struct HistPartParams {
     u32* seg_len;       // [n_waves][64]
     u32 cap;            // entries per (wave, partition) segment, multiple of 64
 };
-struct SinkHistPart {
+// MODE (how the hash of a window comes about, fixed at compile time: three uniform branches per window otherwise):
+//   0 LexHasher with hasher_k == k: hash = the 2k-bit complement of the LARGER of fw / rc (kmx_device.h lex_hash: the
+//     reversed groups of the canonical word are the complement of the other strand) -- no hash arithmetic at all;
+//   1 identity: hash = the smaller of the two;   2 LexHasher with another hasher_k.
+template <int MODE>
+struct SinkHistPartT {
 #ifndef KMX_HIST_ROW
 #define KMX_HIST_ROW 64
 #endif
@@ -191,9 +196,15 @@ struct SinkHistPart {
     uint16_t* seg;     // this wave's [NP][cap] segments
     u64 maskk;
     u32 k, lane, lowbits;
-    __device__ SinkHistPart(const HistPartParams& p_, u32 k_, u32, u32* lds, u32 lane_, u32*, u32)
+    u32 shift_b, shift_q, ring_lds, word_lds;   // 32 - log2_buckets; 26 (top 6 bits of the mix); LDS byte addresses of ring[] and word[]
+    __device__ SinkHistPartT(const HistPartParams& p_, u32 k_, u32, u32* lds, u32 lane_, u32*, u32)
         : p(p_), ring(reinterpret_cast<uint16_t*>(lds)), word(lds + NP * ROW / 2u), cur(lds + NP * ROW / 2u + NP),
           maskk(mask2k(k_)), k(k_), lane(lane_), lowbits(p_.log2_buckets - 6u) {
+        shift_b = 32u - p.log2_buckets;
+        shift_q = 26u;
+        typedef u32 __attribute__((address_space(3))) * lds_u32p;
+        ring_lds = (u32)(uintptr_t)(lds_u32p)lds;
+        word_lds = (u32)(uintptr_t)(lds_u32p)word;
         const u64 wave = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);
         seg = p.stream + wave * NP * (u64)p.cap;
         word[lane] = 0;
@@ -205,13 +216,15 @@ struct SinkHistPart {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __device__ __forceinline__ u32 bucket_of_window(u64 fw, u64 rc) const {
-        const u64 canon = fw < rc ? fw : rc;
+    // the 32-bit mix whose top log2_buckets bits are the bucket (bucket_of, kmx_device.h)
+    __device__ __forceinline__ u32 mix_of_window(u64 fw, u64 rc) const {
         u64 h;
-        if (p.hasher == KMX_HASH_LEX) h = (p.hk == k) ? (maskk ^ fw ^ rc ^ canon) : lex_hash(canon, p.hk);
-        else h = canon;
-        return (u32)bucket_of(h, p.log2_buckets);
+        if constexpr (MODE == 0) h = (fw < rc ? rc : fw) ^ maskk;
+        else if constexpr (MODE == 1) h = fw < rc ? fw : rc;
+        else h = lex_hash(fw < rc ? fw : rc, p.hk);
+        return bucket_mix((u32)h, (u32)(h >> 32));
     }
+    __device__ __forceinline__ u32 bucket_of_window(u64 fw, u64 rc) const { return mix_of_window(fw, rc) >> shift_b; }
     // the slot of an id in its partition's ring: ONE returning LDS atomic
     __device__ __forceinline__ u32 take_slot(u32 bucket) { return atomicAdd(&word[bucket >> lowbits], 0x10000u); }
     __device__ __forceinline__ void place(u32 bucket, u32 w) {
@@ -237,15 +250,37 @@ struct SinkHistPart {
 #define KMX_HIST_BATCH 8
 #endif
     static constexpr int NB = KMX_HIST_BATCH;   // windows whose slot requests are in flight together (divides 16)
-    u32 pend[NB];
+    u32 pend[NB];   // the mixes of the windows collected so far
+    // The returned word is {appended : 16 | written out : 16} with written out in {0, HALF} and appended < 2 ROW + 64 (flush_rows
+    // keeps them small: no 16-bit wrap to mask), so "staged before me" is one sub-dword subtract, the ring byte offset
+    // 2 * (appended mod ROW) is the 7-bit field at bit 15, and ONE test per batch (an OR over the staged counts) tells
+    // whether any of its ids found its ring full -- then, and only then, the batch takes the id-by-id path with the
+    // diversion to the global table.
     __device__ __forceinline__ void fast_slot(int s, u64 fw, u64 rc) {
-        pend[s % NB] = bucket_of_window(fw, rc);
+        static_assert(ROW == 64, "ring addressing below: 64 entries of 2 bytes");
+        pend[s % NB] = mix_of_window(fw, rc);
         if (s % NB == NB - 1) {
+            typedef u32 __attribute__((address_space(3))) * lds_u32p;
+            typedef uint16_t __attribute__((address_space(3))) * lds_u16p;
             u32 w[NB];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) w[j] = take_slot(pend[j]);
+            for (int j = 0; j < NB; ++j) {
+                const u32 a = word_lds + ((pend[j] >> shift_q) << 2);
+                w[j] = __hip_atomic_fetch_add((lds_u32p)(uintptr_t)a, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            u32 over = 0;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) place(pend[j], w[j]);
+            for (int j = 0; j < NB; ++j) over |= (w[j] >> 16) - (w[j] & 0xFFFFu);
+            if (__builtin_expect(__any((over & ~(ROW - 1u)) != 0u), 0)) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) place(pend[j] >> shift_b, w[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const u32 a = ring_lds + ((pend[j] >> shift_q) << 7) + __builtin_amdgcn_ubfe(w[j], 15, 7);
+                    *(lds_u16p)(uintptr_t)a = (uint16_t)(pend[j] >> shift_b);   // (bits lowbits..15 belong to the partition: pass 2 masks them off)
+                }
+            }
         }
     }
     // ids staged and not yet written out
@@ -279,17 +314,18 @@ struct SinkHistPart {
                 if (pos + HALF <= p.cap) {
                     *reinterpret_cast<uint4*>(seg + (u64)q * p.cap + pos + 8u * l4) = v;
                 } else {   // segment full: the ids go to the global table
-                    const u32 hi = q << lowbits;
+                    const u32 hi = q << lowbits, idm = (1u << lowbits) - 1u;
                     const u32 vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (u32 i = 0; i < 4; ++i) {
-                        atomicAdd((unsigned long long*)&p.counts[hi | (vv[i] & 0xFFFFu)], 1ull);
-                        atomicAdd((unsigned long long*)&p.counts[hi | (vv[i] >> 16)], 1ull);
+                        atomicAdd((unsigned long long*)&p.counts[hi | (vv[i] & idm)], 1ull);
+                        atomicAdd((unsigned long long*)&p.counts[hi | ((vv[i] >> 16) & idm)], 1ull);
                     }
                 }
                 if (l4 == 0) {
                     if (pos + HALF <= p.cap) cur[q] = pos + HALF;
-                    word[q] = (w & 0xFFFF0000u) | ((w + HALF) & 0xFFFFu);
+                    // written out: 0 -> HALF; HALF -> 0 with a whole ring taken off the appended count (the same slot mod ROW)
+                    word[q] = half ? w - HALF - (ROW << 16) : w + HALF;
                 }
             }
         }
@@ -324,7 +360,7 @@ struct SinkHistPart {
             if (lane < n) {
                 const uint16_t e = ring[q * ROW + ((w + lane) & (ROW - 1u))];
                 if (pos + n <= p.cap) seg[(u64)q * p.cap + pos + lane] = e;
-                else atomicAdd((unsigned long long*)&p.counts[(q << lowbits) | e], 1ull);
+                else atomicAdd((unsigned long long*)&p.counts[(q << lowbits) | (e & ((1u << lowbits) - 1u))], 1ull);
             }
             wave_sync();
             if (lane == 0 && pos + n <= p.cap) cur[q] = pos + n;
@@ -341,7 +377,7 @@ __global__ void __launch_bounds__(THREADS)
 hist_part_reduce_kernel(const uint16_t* __restrict__ stream, const u32* __restrict__ seg_len, u32 cap, u32 n_waves,
                         u32 log2_buckets, u64* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) u32 tab[];
-    const u32 lowbits = log2_buckets - 6u, nb = 1u << lowbits;
+    const u32 lowbits = log2_buckets - 6u, nb = 1u << lowbits, idm = nb - 1u;
     const u32 q = blockIdx.x;
     for (u32 j = threadIdx.x; j < nb; j += THREADS) tab[j] = 0;
     __syncthreads();
@@ -352,16 +388,17 @@ hist_part_reduce_kernel(const uint16_t* __restrict__ stream, const u32* __restri
         const u32x4* __restrict__ sp8 = reinterpret_cast<const u32x4*>(sp);
         for (u32 i = threadIdx.x; i < len / 8u; i += THREADS) {
             const u32x4 v = __builtin_nontemporal_load(sp8 + i);
-            atomicAdd(&tab[v.x & 0xFFFFu], 1u);
-            atomicAdd(&tab[v.x >> 16], 1u);
-            atomicAdd(&tab[v.y & 0xFFFFu], 1u);
-            atomicAdd(&tab[v.y >> 16], 1u);
-            atomicAdd(&tab[v.z & 0xFFFFu], 1u);
-            atomicAdd(&tab[v.z >> 16], 1u);
-            atomicAdd(&tab[v.w & 0xFFFFu], 1u);
-            atomicAdd(&tab[v.w >> 16], 1u);
+            // (an id carries the low bits of its partition above bit lowbits: the scan writes the bucket's low 16 bits as they are)
+            atomicAdd(&tab[v.x & idm], 1u);
+            atomicAdd(&tab[(v.x >> 16) & idm], 1u);
+            atomicAdd(&tab[v.y & idm], 1u);
+            atomicAdd(&tab[(v.y >> 16) & idm], 1u);
+            atomicAdd(&tab[v.z & idm], 1u);
+            atomicAdd(&tab[(v.z >> 16) & idm], 1u);
+            atomicAdd(&tab[v.w & idm], 1u);
+            atomicAdd(&tab[(v.w >> 16) & idm], 1u);
         }
-        for (u32 i = (len & ~7u) + threadIdx.x; i < len; i += THREADS) atomicAdd(&tab[sp[i]], 1u);
+        for (u32 i = (len & ~7u) + threadIdx.x; i < len; i += THREADS) atomicAdd(&tab[sp[i] & idm], 1u);
     }
     __syncthreads();
     for (u32 j = threadIdx.x; j < nb; j += THREADS) {
@@ -893,9 +930,9 @@ static hipError_t dispatch(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Para
     return launch_one<10, 2, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
 }
 
-template <typename Pre>
-static hipError_t dispatch_part(const uint8_t* bases, u64 n_reads, u32 L, u32 k, HistPartParams& p, unsigned long long* queue,
-                                int n_cu, hipStream_t stream, Pre pre) {
+template <typename SinkHistPart, typename Pre>
+static hipError_t dispatch_part_mode(const uint8_t* bases, u64 n_reads, u32 L, u32 k, HistPartParams& p, unsigned long long* queue,
+                                     int n_cu, hipStream_t stream, Pre pre) {
     const bool big = L > 160;
     if (k <= 16) {
         if (big) return launch_one<16, 1, 1, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
@@ -907,6 +944,14 @@ static hipError_t dispatch_part(const uint8_t* bases, u64 n_reads, u32 L, u32 k,
     }
     if (big) return launch_one<16, 2, 2, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
     return launch_one<10, 2, 2, SinkHistPart, HistPartParams, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+}
+
+template <typename Pre>
+static hipError_t dispatch_part(const uint8_t* bases, u64 n_reads, u32 L, u32 k, HistPartParams& p, unsigned long long* queue,
+                                int n_cu, hipStream_t stream, Pre pre) {
+    if (p.hasher != KMX_HASH_LEX) return dispatch_part_mode<SinkHistPartT<1>, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+    if (p.hk == k) return dispatch_part_mode<SinkHistPartT<0>, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+    return dispatch_part_mode<SinkHistPartT<2>, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
 }
 
 // Each returns hipSuccess and sets *handled=false when (L,k) is outside the fast kernel's domain.

@@ -890,7 +890,8 @@ void kmo_gen_reads(uint64_t seed, uint64_t first_byte, uint8_t *out, size_t nbyt
 
 uint64_t kmo_bucket_of(uint64_t h, unsigned log2_buckets) {
     if (log2_buckets == 0) return 0;
-    return (h * 0x9E3779B97F4A7C15ULL) >> (64 - log2_buckets);
+    uint32_t x = (uint32_t)h * 0x9E3779B1u + (uint32_t)(h >> 32) * 0x85EBCA6Bu;
+    return (uint64_t)(x >> (32 - log2_buckets));
 }
 
 int kmo_histogram(const uint8_t *reads, size_t n_reads, size_t read_len, const uint64_t *offsets,

@@ -219,7 +219,7 @@ int kmo_fastx_parse(const uint8_t *text, size_t n, unsigned format, uint8_t *bas
 /* synthetic reads: word w of the stream = splitmix64(seed + w); base j of the 32 in it = "ACGT"[(z>>2j)&3] */
 uint64_t kmo_splitmix64(uint64_t x);
 void kmo_gen_reads(uint64_t seed, uint64_t first_byte, uint8_t *out, size_t nbytes);
-/* bucket of a hash value: top log2_buckets bits of (h * 0x9E3779B97F4A7C15) */
+/* bucket of a hash value: top log2_buckets bits of the 32-bit sum lo32(h) * 0x9E3779B1 + hi32(h) * 0x85EBCA6B (log2_buckets <= 30) */
 uint64_t kmo_bucket_of(uint64_t h, unsigned log2_buckets);
 int kmo_histogram(const uint8_t *reads, size_t n_reads, size_t read_len, const uint64_t *offsets,
                   uint8_t k, size_t hasher_k, unsigned log2_buckets, uint64_t *counts);

@@ -56,6 +56,26 @@ constexpr int ITER = 4000;
 #define T_BCNT0_2 "v_bcnt_u32_b32 %9, %11, 0\n"
 #define T_MUL24_1 "v_mul_u32_u24 %8, %10, %11\n"
 #define T_MUL24_2 "v_mul_u32_u24 %9, %11, %12\n"
+#define T_MULLO_1 "v_mul_lo_u32 %8, %10, %11\n"
+#define T_MULLO_2 "v_mul_lo_u32 %9, %11, %12\n"
+#define T_MULHI_1 "v_mul_hi_u32 %8, %10, %11\n"
+#define T_MULHI_2 "v_mul_hi_u32 %9, %11, %12\n"
+#define T_MULHI24_1 "v_mul_hi_u32_u24 %8, %10, %11\n"
+#define T_MULHI24_2 "v_mul_hi_u32_u24 %9, %11, %12\n"
+#define T_MAD24_1 "v_mad_u32_u24 %8, %10, %11, %12\n"
+#define T_MAD24_2 "v_mad_u32_u24 %9, %11, %12, %13\n"
+#define T_BFE_1 "v_bfe_u32 %8, %10, 16, 6\n"
+#define T_BFE_2 "v_bfe_u32 %9, %11, 16, 6\n"
+#define T_LSHLADD_1 "v_lshl_add_u32 %8, %10, 7, %11\n"
+#define T_LSHLADD_2 "v_lshl_add_u32 %9, %11, 7, %12\n"
+#define T_SUBSDWA_1 "v_sub_u32_sdwa %8, %10, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n"
+#define T_SUBSDWA_2 "v_sub_u32_sdwa %9, %11, %11 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n"
+#define T_CMP64_1 "v_cmp_lt_u64 vcc, %[p0], %[p1]\n"
+#define T_CMP64_2 "v_cmp_lt_u64 vcc, %[p1], %[p0]\n"
+#define T_CMP16_1 "v_cmp_gt_u16 vcc, 64, %10\n"
+#define T_CMP16_2 "v_cmp_gt_u16 vcc, 64, %11\n"
+#define T_NOT_1 "v_not_b32 %8, %10\n"
+#define T_NOT_2 "v_not_b32 %9, %11\n"
 #define T_PERM_1 "v_perm_b32 %8, %10, %11, %12\n"
 #define T_PERM_2 "v_perm_b32 %9, %11, %12, %13\n"
 template <int WHICH>
@@ -63,6 +83,7 @@ __global__ void __launch_bounds__(768) k_roles(uint32_t* out, uint32_t seed, int
     uint32_t d0=seed,d1=seed+1,d2=seed+2,d3=seed+3,d4=seed+4,d5=seed+5,d6=seed+6,d7=seed+7, t0=0, t1=0;
     uint32_t a = threadIdx.x + seed, b = a * 3u + 1u, c = a ^ 0x55aa55aau, e = b + 7u;
     const uint32_t sg = seed * 0x01010101u;
+    unsigned long long pp0 = ((unsigned long long)a << 32) | b, pp1 = ((unsigned long long)c << 32) | e;
     const int role = threadIdx.x >> 8;
     if (role < nb) {
         asm volatile("s_setprio 3");
@@ -91,6 +112,18 @@ __global__ void __launch_bounds__(768) k_roles(uint32_t* out, uint32_t seed, int
             if (WHICH == 19) ASMV(R32(T_BCNT_1, T_BCNT_2));
             if (WHICH == 20) ASMV(R32(T_BCNT0_1, T_BCNT0_2));
             if (WHICH == 21) ASMV(R32(T_MUL24_1, T_MUL24_2));
+            if (WHICH == 22) ASMV(R32(T_MULLO_1, T_MULLO_2));
+            if (WHICH == 23) ASMV(R32(T_MULHI_1, T_MULHI_2));
+            if (WHICH == 24) ASMV(R32(T_MULHI24_1, T_MULHI24_2));
+            if (WHICH == 25) ASMV(R32(T_MAD24_1, T_MAD24_2));
+            if (WHICH == 26) ASMV(R32(T_BFE_1, T_BFE_2));
+            if (WHICH == 27) ASMV(R32(T_LSHLADD_1, T_LSHLADD_2));
+            if (WHICH == 28) ASMV(R32(T_SUBSDWA_1, T_SUBSDWA_2));
+            if (WHICH == 29) asm volatile(R32(T_CMP64_1, T_CMP64_2) : : [p0] "v"(pp0), [p1] "v"(pp1) : "vcc");
+            if (WHICH == 30) asm volatile(R32(T_CMP16_1, T_CMP16_2) : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7), "+v"(t0), "+v"(t1), "+v"(a), "+v"(b) : : "vcc");
+            if (WHICH == 31) ASMV(R32(T_NOT_1, T_NOT_2));
+            if (WHICH == 32) asm volatile(R16("v_cmp_lt_u64 vcc, %[p0], %[p1]\n v_cndmask_b32 %0, %2, %3, vcc\n", "v_cndmask_b32 %1, %3, %2, vcc\n v_xor_b32 %0, %0, %1\n") : "+v"(d0), "+v"(d1), "+v"(a), "+v"(b) : [p0] "v"(pp0), [p1] "v"(pp1) : "vcc");
+            if (WHICH == 33) asm volatile(R16("v_cmp_lt_u64 s[20:21], %[p0], %[p1]\n v_cndmask_b32 %0, %2, %3, s[20:21]\n", "v_cndmask_b32 %1, %3, %2, s[20:21]\n v_xor_b32 %0, %0, %1\n") : "+v"(d0), "+v"(d1), "+v"(a), "+v"(b) : [p0] "v"(pp0), [p1] "v"(pp1) : "s20", "s21");
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = d0^d1^d2^d3^d4^d5^d6^d7^t0^t1^a^b^c^e;
@@ -113,14 +146,16 @@ int main() {
     uint32_t* out; CHECK(hipMalloc(&out, (size_t)cus * 512 * 4));
     const char* names[] = {"v_and (2 VGPR)", "v_xor (2 VGPR)", "v_bitop3 (3 distinct VGPR)", "v_bitop3 (dst = src0)", "v_bitop3 (2 distinct VGPR)", "v_lshrrev (const, VGPR)",
                            "v_add_u32", "v_and literal", "v_and SGPR", "v_mov", "v_fma_f32 (3 VGPR)", "v_perm", "v_dot4_u32_u8", "v_lshl_or", "v_alignbit", "v_mov_dpp quad_perm", "v_cndmask vcc", "v_min_u32", "v_lshlrev",
-                           "v_bcnt accumulate", "v_bcnt (+0)", "v_mul_u32_u24"};
+                           "v_bcnt accumulate", "v_bcnt (+0)", "v_mul_u32_u24", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_u32_u24", "v_mad_u32_u24", "v_bfe_u32", "v_lshl_add_u32",
+                           "v_sub_u32 sdwa", "v_cmp_lt_u64", "v_cmp_gt_u16", "v_not_b32", "cmp64 + 2 cndmask(vcc) + xor  x8", "cmp64 + 2 cndmask(sgpr) + xor x8"};
     printf("ns per body (32 test instructions; the bcnt wave runs 64): the test wave ALONE | next to a bcnt wave at priority 3 (a bcnt wave alone: see first line)\n");
     printf("%-28s %8.1f\n", "bcnt wave alone", run<0>(out, cus, 1, 0));
 #define ROW(W) printf("%-28s alone %8.1f   with bcnt %8.1f\n", names[W], run<W>(out, cus, 0, 1), run<W>(out, cus, 1, 1));
     ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11)
     ROW(12) ROW(13) ROW(14) ROW(15) ROW(16) ROW(17) ROW(18) ROW(19) ROW(20) ROW(21)
+    ROW(22) ROW(23) ROW(24) ROW(25) ROW(26) ROW(27) ROW(28) ROW(29) ROW(30) ROW(31) ROW(32) ROW(33)
     printf("two test waves per SIMD (no bcnt wave): does a second wave of the same instruction double the time?\n");
 #define ROW2(W) printf("%-28s 1 wave %8.1f   2 waves %8.1f\n", names[W], run<W>(out, cus, 0, 1), run<W>(out, cus, 0, 2));
-    ROW2(0) ROW2(2) ROW2(11) ROW2(12) ROW2(13) ROW2(14) ROW2(15) ROW2(16) ROW2(18) ROW2(19)
+    ROW2(22) ROW2(23) ROW2(29) ROW2(0) ROW2(2) ROW2(11) ROW2(12) ROW2(13) ROW2(14) ROW2(15) ROW2(16) ROW2(18) ROW2(19)
     return 0;
 }
