@@ -25,6 +25,7 @@
 //   A tile that contains any invalid byte (or the final partial tile) takes the reference-shaped
 //   per-lane rolling path instead (roll_read) -- bit-exact with the iterator's skip semantics.
 //   Tiles come from the same interleaved dynamic queue as the bit-sliced kernel.
+#include <cstdlib>
 #include "kmx_device.h"
 
 namespace kmx {
@@ -186,9 +187,13 @@ struct SinkHistPartT {
 #endif
     static constexpr u32 NP = 64, ROW = KMX_HIST_ROW;   // partitions; ring entries per partition (u16); rows of ROW/2 ids leave together
     static constexpr u32 HALF = ROW / 2u, PER_LANE = HALF / 16u;   // ids per lane of the quarter-wave that writes a row (2 or 4)
-    static constexpr u32 kLdsDwordsPerWave = NP * ROW / 2u + 2u * NP + NP / 4u;   // rings, {appended|written} words, segment cursors, rank -> ring bytes
+    // LDS: per wave the {appended|written} words, the segment cursors and the rank -> ring bytes; the rings of the four waves
+    // together at the end of the block's LDS, each wave's 8 KB at a multiple of 8 KB: the ring address of an id is then
+    // (mix >> 26 | base >> 13 << 6) << 7 -- one v_alignbit_b32 with the wave's base in the high word -- plus the slot bytes
+    static constexpr u32 kLdsDwordsPerWave = 2u * NP + NP / 4u;
+    static constexpr u32 kBlockLdsAlign = 2048u;   // dwords (8 KB)
     static constexpr bool kRagged = false;
-    static u32 block_lds_dwords(const HistPartParams&) { return 0; }
+    static u32 block_lds_dwords(const HistPartParams&) { return 4u * NP * ROW / 2u; }
     HistPartParams p;
     uint16_t* ring;    // [NP][ROW]
     u32* word;         // [NP] appended (mod 2^16) << 16 | written out (mod 2^16)
@@ -196,15 +201,16 @@ struct SinkHistPartT {
     uint16_t* seg;     // this wave's [NP][cap] segments
     u64 maskk;
     u32 k, lane, lowbits;
-    u32 shift_b, shift_q, ring_lds, word_lds;   // 32 - log2_buckets; 26 (top 6 bits of the mix); LDS byte addresses of ring[] and word[]
-    __device__ SinkHistPartT(const HistPartParams& p_, u32 k_, u32, u32* lds, u32 lane_, u32*, u32)
-        : p(p_), ring(reinterpret_cast<uint16_t*>(lds)), word(lds + NP * ROW / 2u), cur(lds + NP * ROW / 2u + NP),
+    u32 shift_b, ring_hi, word_rel;   // 32 - log2_buckets; LDS byte address of ring[] >> 13; LDS byte address of word[] minus 4 * (ring_hi << 6)
+    __device__ SinkHistPartT(const HistPartParams& p_, u32 k_, u32, u32* lds, u32 lane_, u32* block_lds, u32 tid)
+        : p(p_), ring(reinterpret_cast<uint16_t*>(block_lds + (tid >> 6) * (NP * ROW / 2u))), word(lds), cur(lds + NP),
           maskk(mask2k(k_)), k(k_), lane(lane_), lowbits(p_.log2_buckets - 6u) {
         shift_b = 32u - p.log2_buckets;
-        shift_q = 26u;
         typedef u32 __attribute__((address_space(3))) * lds_u32p;
-        ring_lds = (u32)(uintptr_t)(lds_u32p)lds;
-        word_lds = (u32)(uintptr_t)(lds_u32p)word;
+        const u32 ring_lds = (u32)(uintptr_t)(lds_u32p) reinterpret_cast<u32*>(ring);
+        if (ring_lds & 8191u) __builtin_trap();   // (the launcher aligns the block region; dynamic LDS starts at 0)
+        ring_hi = (u32)__builtin_amdgcn_readfirstlane(ring_lds >> 13);
+        word_rel = (u32)(uintptr_t)(lds_u32p)word - ((ring_hi << 6) << 2);
         const u64 wave = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);
         seg = p.stream + wave * NP * (u64)p.cap;
         word[lane] = 0;
@@ -216,10 +222,16 @@ struct SinkHistPartT {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    // the 32-bit mix whose top log2_buckets bits are the bucket (bucket_of, kmx_device.h)
+    // MODE 0: the scan kernel hands its windows over COMPLEMENTED (fw ^ mask, rc ^ mask: it builds them from complemented
+    // source words, which costs nothing), and the hash -- the complement of the larger strand -- is the smaller of the two as
+    // they come.  (The rolled paths -- slow(), tile_slow_emit() -- pass the words themselves.)
+    static constexpr bool kComplement = MODE == 0;
+    // the 32-bit mix whose top log2_buckets bits are the bucket (bucket_of, kmx_device.h); COMPL: complemented inputs
+    template <bool COMPL = false>
     __device__ __forceinline__ u32 mix_of_window(u64 fw, u64 rc) const {
         u64 h;
-        if constexpr (MODE == 0) h = (fw < rc ? rc : fw) ^ maskk;
+        if constexpr (MODE == 0 && COMPL) h = fw < rc ? fw : rc;
+        else if constexpr (MODE == 0) h = (fw < rc ? rc : fw) ^ maskk;
         else if constexpr (MODE == 1) h = fw < rc ? fw : rc;
         else h = lex_hash(fw < rc ? fw : rc, p.hk);
         return bucket_mix((u32)h, (u32)(h >> 32));
@@ -258,14 +270,16 @@ struct SinkHistPartT {
     // diversion to the global table.
     __device__ __forceinline__ void fast_slot(int s, u64 fw, u64 rc) {
         static_assert(ROW == 64, "ring addressing below: 64 entries of 2 bytes");
-        pend[s % NB] = mix_of_window(fw, rc);
+        pend[s % NB] = mix_of_window<kComplement>(fw, rc);
         if (s % NB == NB - 1) {
             typedef u32 __attribute__((address_space(3))) * lds_u32p;
             typedef uint16_t __attribute__((address_space(3))) * lds_u16p;
             u32 w[NB];
+            u32 qb[NB];   // ring base >> 7: partition | the wave's 8 KB index << 6
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const u32 a = word_lds + ((pend[j] >> shift_q) << 2);
+                qb[j] = __builtin_amdgcn_alignbit(ring_hi, pend[j], 26);
+                const u32 a = word_rel + (qb[j] << 2);
                 w[j] = __hip_atomic_fetch_add((lds_u32p)(uintptr_t)a, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             u32 over = 0;
@@ -277,7 +291,7 @@ struct SinkHistPartT {
             } else {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const u32 a = ring_lds + ((pend[j] >> shift_q) << 7) + __builtin_amdgcn_ubfe(w[j], 15, 7);
+                    const u32 a = (qb[j] << 7) + __builtin_amdgcn_ubfe(w[j], 15, 7);
                     *(lds_u16p)(uintptr_t)a = (uint16_t)(pend[j] >> shift_b);   // (bits lowbits..15 belong to the partition: pass 2 masks them off)
                 }
             }
@@ -334,7 +348,10 @@ struct SinkHistPartT {
     // (a full unrolled block arrives as 16 fast_slot() calls -- uniform reads only, so every lane has all 16; the partial
     // last block of a read arrives through fast(), one window at a time)
     __device__ __forceinline__ void block_done(u64, u32, u32) { flush_rows(); }
-    __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) { emit(fw, rc); }
+    __device__ __forceinline__ void fast(u32, u64 fw, u64 rc) {   // (from the scan kernel's window(): complemented like fast_slot's)
+        const u32 bucket = mix_of_window<kComplement>(fw, rc) >> shift_b;
+        place(bucket, take_slot(bucket));
+    }
     __device__ __forceinline__ void slow(u32, u64 fw, u64 rc) { emit(fw, rc); }
     __device__ __forceinline__ void begin_read(u64) {}
     __device__ __forceinline__ void slow_block(u32) { flush_rows(); }   // a rolled tile: 16 more windows per read, wave converged: drain the rings
@@ -381,24 +398,44 @@ hist_part_reduce_kernel(const uint16_t* __restrict__ stream, const u32* __restri
     const u32 q = blockIdx.x;
     for (u32 j = threadIdx.x; j < nb; j += THREADS) tab[j] = 0;
     __syncthreads();
-    for (u32 w = blockIdx.y; w < n_waves; w += gridDim.y) {
-        const u32 len = seg_len[(u64)w * 64u + q];
+    // every WAVE of the block walks its own segments (w == its index mod the waves of the partition's blocks): a segment is
+    // ~25 KB, too short for 512 threads to keep several loads each in flight
+    const u32 wv = threadIdx.x >> 6, ln = threadIdx.x & 63u, nwv = THREADS / 64u;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    // (an id carries the low bits of its partition above bit lowbits: the scan writes the bucket's low 16 bits as they are)
+    auto count8 = [&](const u32x4 v) {
+        atomicAdd(&tab[v.x & idm], 1u);
+        atomicAdd(&tab[(v.x >> 16) & idm], 1u);
+        atomicAdd(&tab[v.y & idm], 1u);
+        atomicAdd(&tab[(v.y >> 16) & idm], 1u);
+        atomicAdd(&tab[v.z & idm], 1u);
+        atomicAdd(&tab[(v.z >> 16) & idm], 1u);
+        atomicAdd(&tab[v.w & idm], 1u);
+        atomicAdd(&tab[(v.w >> 16) & idm], 1u);
+    };
+    const u32 w0 = blockIdx.y * nwv + wv, wstep = gridDim.y * nwv;
+    u32 len_next = w0 < n_waves ? seg_len[(u64)w0 * 64u + q] : 0u;
+    for (u32 w = w0; w < n_waves; w += wstep) {
+        const u32 len = len_next;
+        if (w + wstep < n_waves) len_next = seg_len[(u64)(w + wstep) * 64u + q];   // (one segment ahead)
         const uint16_t* __restrict__ sp = stream + ((u64)w * 64u + q) * (u64)cap;   // cap is a multiple of 64: 128-byte aligned
-        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
         const u32x4* __restrict__ sp8 = reinterpret_cast<const u32x4*>(sp);
-        for (u32 i = threadIdx.x; i < len / 8u; i += THREADS) {
-            const u32x4 v = __builtin_nontemporal_load(sp8 + i);
-            // (an id carries the low bits of its partition above bit lowbits: the scan writes the bucket's low 16 bits as they are)
-            atomicAdd(&tab[v.x & idm], 1u);
-            atomicAdd(&tab[(v.x >> 16) & idm], 1u);
-            atomicAdd(&tab[v.y & idm], 1u);
-            atomicAdd(&tab[(v.y >> 16) & idm], 1u);
-            atomicAdd(&tab[v.z & idm], 1u);
-            atomicAdd(&tab[(v.z >> 16) & idm], 1u);
-            atomicAdd(&tab[v.w & idm], 1u);
-            atomicAdd(&tab[(v.w >> 16) & idm], 1u);
+        // four 16-byte loads per lane in flight: with one load per thread the pass ran at the latency of its loads (3.8 TB/s
+        // of ids, the LDS 39 % busy)
+        const u32 n16 = len / 8u;
+        u32 i = ln;
+        for (; i + 192u < n16; i += 256u) {
+            const u32x4 v0 = __builtin_nontemporal_load(sp8 + i);
+            const u32x4 v1 = __builtin_nontemporal_load(sp8 + i + 64u);
+            const u32x4 v2 = __builtin_nontemporal_load(sp8 + i + 128u);
+            const u32x4 v3 = __builtin_nontemporal_load(sp8 + i + 192u);
+            count8(v0);
+            count8(v1);
+            count8(v2);
+            count8(v3);
         }
-        for (u32 i = (len & ~7u) + threadIdx.x; i < len; i += THREADS) atomicAdd(&tab[sp[i] & idm], 1u);
+        for (; i < n16; i += 64u) count8(__builtin_nontemporal_load(sp8 + i));
+        for (u32 j = (len & ~7u) + ln; j < len; j += 64u) atomicAdd(&tab[sp[j] & idm], 1u);
     }
     __syncthreads();
     for (u32 j = threadIdx.x; j < nb; j += THREADS) {
@@ -614,6 +651,12 @@ template <typename S> struct SinkWaves<S, decltype((void)S::kWaves)> { static co
 // a sink may take the 16 windows of an unrolled block together (static constexpr bool kBatch16 = true; fast_slot())
 template <typename S, typename = void> struct SinkBatch16 { static constexpr bool value = false; };
 template <typename S> struct SinkBatch16<S, decltype((void)S::kBatch16)> { static constexpr bool value = S::kBatch16; };
+// a sink may want its block-level LDS region to start at a multiple of kBlockLdsAlign dwords (static constexpr u32)
+template <typename S, typename = void> struct SinkBlockAlign { static constexpr u32 value = 1u; };
+template <typename S> struct SinkBlockAlign<S, decltype((void)S::kBlockLdsAlign)> { static constexpr u32 value = S::kBlockLdsAlign; };
+// a sink may ask for complemented windows (fw ^ mask, rc ^ mask) from the kernel's fast path (static constexpr bool kComplement)
+template <typename S, typename = void> struct SinkComplement { static constexpr bool value = false; };
+template <typename S> struct SinkComplement<S, decltype((void)S::kComplement)> { static constexpr bool value = S::kComplement; };
 template <typename S, int NW> constexpr int sink_waves() { return NW <= 10 ? SinkWaves<S>::value : KMX_SCAN_WAVES; }   // (the 16-word frame would spill 1 KB)
 template <int NW, int V, int DW, typename Sink, typename Params, bool RAGGED = false>
 __global__ void __launch_bounds__(256, (sink_waves<Sink, NW>()))
@@ -647,7 +690,8 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     u32 nwin = omax + 1u;       // windows of this lane's read
     u32 chunks = chunks_u;
 
-    Sink sink(params, k, nwin, P + ldsw, lane, lds + 4u * (ldsw + Sink::kLdsDwordsPerWave), threadIdx.x);
+    constexpr u32 BAL = SinkBlockAlign<Sink>::value;
+    Sink sink(params, k, nwin, P + ldsw, lane, lds + (4u * (ldsw + Sink::kLdsDwordsPerWave) + BAL - 1u) / BAL * BAL, threadIdx.x);
 
     [[maybe_unused]] u32 nwin_min = nwin;   // ragged: the shortest read of the tile (blocks of windows below it need no per-lane mask)
     // `slot`: position of the window inside a fully unrolled block of 16 (a compile-time value there), -1 elsewhere; a
@@ -780,14 +824,15 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
 #pragma unroll
             for (int j = 0; j <= NW; ++j) R[j] = P[qF + j];
 #pragma unroll
-            for (int i = 0; i < NW; ++i) F[i] = alignbit(R[i + 1], R[i], aF);
+            for (int i = 0; i < NW; ++i) F[i] = SinkComplement<Sink>::value ? ~alignbit(R[i + 1], R[i], aF) : alignbit(R[i + 1], R[i], aF);
             F[NW] = 0;
             F[NW + 1] = 0;
             u32 Rr[NW + 2];
 #pragma unroll
             for (int j = 0; j <= NW + 1; ++j) Rr[j] = P[qR + j];
 #pragma unroll
-            for (int m = 0; m <= NW; ++m) G[m] = revgroups32(~alignbit(Rr[NW - m + 1], Rr[NW - m], aR));
+            for (int m = 0; m <= NW; ++m)
+                G[m] = SinkComplement<Sink>::value ? revgroups32(alignbit(Rr[NW - m + 1], Rr[NW - m], aR)) : revgroups32(~alignbit(Rr[NW - m + 1], Rr[NW - m], aR));
             G[NW + 1] = 0;
         }
 
@@ -860,7 +905,8 @@ static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Pa
     }
     const u32 chunks = RAGGED ? 64u * NW : 4u * L + (lead != 0u ? 1u : 0u);
     const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
-    const size_t lds_bytes = (size_t)(ldsw + Sink::kLdsDwordsPerWave) * 4u * 4u + (size_t)Sink::block_lds_dwords(params) * 4u;
+    constexpr u32 BAL = SinkBlockAlign<Sink>::value;
+    const size_t lds_bytes = (size_t)((4u * (ldsw + Sink::kLdsDwordsPerWave) + BAL - 1u) / BAL * BAL) * 4u + (size_t)Sink::block_lds_dwords(params) * 4u;
     // blocks per CU, cached per host thread and device (the ABI's model is one thread per context / GPU: a plain static
     // would be written by all of them at once, and the function attribute below is a per-device setting)
     static thread_local int bpc = 0, bpc_dev = -1;
@@ -881,6 +927,7 @@ static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Pa
     }
     const u64 n_tiles = (n_reads + 63u) >> 6;
     u64 grid = (u64)n_cu * (u64)bpc;
+    if (const char* ov = getenv("KMX_DEV_BPC")) grid = (u64)n_cu * (u64)atoi(ov);   // (dev) blocks per CU
     const u64 need = (n_tiles + 3u) / 4u;
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
