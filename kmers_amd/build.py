@@ -24,9 +24,9 @@ SOURCES = ["kmx_bitslice.hip", "kmx_bitslice_k21.hip", "kmx_bitslice_k13_17.hip"
            "kmx_bitslice_k28_30.hip", "kmx_bitslice_k33_39.hip", "kmx_bitslice_k41_47.hip", "kmx_bitslice_k49_55.hip",
            "kmx_bitslice_k57_61.hip", "kmx_bitslice_k34_40.hip", "kmx_bitslice_k42_48.hip", "kmx_bitslice_k50_56.hip", "kmx_bitslice_k58_64.hip",
            "kmx_bitslice_ragged_k13_16.hip", "kmx_bitslice_ragged_k17_20.hip", "kmx_bitslice_ragged_k21_24.hip", "kmx_bitslice_ragged_k25_28.hip",
-           "kmx_bitslice_ragged_k29_31.hip", "kmx_scan.hip", "kmx_generic.hip", "kmx_elem.hip", "kmx_seqvec.hip", "kmx_fastx.hip",
+           "kmx_bitslice_ragged_k29_31.hip", "kmx_scan.hip", "kmx_hist.hip", "kmx_generic.hip", "kmx_elem.hip", "kmx_seqvec.hip", "kmx_fastx.hip",
            "kmx_comm.hip", "kmx_api.hip"]
-HEADERS = [os.path.join(CSRC, "kmx_device.h"), os.path.join(CSRC, "kmx_bitslice_kernel.h"), os.path.join(CSRC, "kmx_internal.h"),
+HEADERS = [os.path.join(CSRC, "kmx_device.h"), os.path.join(CSRC, "kmx_bitslice_kernel.h"), os.path.join(CSRC, "kmx_internal.h"), os.path.join(CSRC, "kmx_scan_kernel.h"),
            os.path.join(HERE, "..", "include", "kmx.h")]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
@@ -52,10 +52,24 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _headers_of(src: str) -> list[str]:
+    """the headers a source depends on (the two kernel headers are each included by their own few translation units)"""
+    out = []
+    for h in HEADERS:
+        base = os.path.basename(h)
+        if base == "kmx_bitslice_kernel.h" and not src.startswith("kmx_bitslice"):
+            continue
+        if base == "kmx_scan_kernel.h" and src not in ("kmx_scan.hip", "kmx_hist.hip"):
+            continue
+        if os.path.exists(h):
+            out.append(h)
+    return out
+
+
 def _compile(src: str, obj_dir: str, force: bool, extra: list[str]) -> str:
     obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
-    if force or _stale(obj, [path] + [h for h in HEADERS if os.path.exists(h)]):
+    if force or _stale(obj, [path] + _headers_of(src)):
         cmd = [hipcc(), *CXXFLAGS, *extra, "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -1,0 +1,364 @@
+// kmx_scan_kernel.h -- the word-domain scan kernel (scan_uniform_kernel) and its launch plumbing, shared by the translation
+// units that instantiate it with their sinks: kmx_scan.hip (reduce, materialise) and kmx_hist.hip (bucket histograms).
+// See kmx_scan.hip for the design.  Everything here is a template or static: one copy per translation unit.
+#pragma once
+#include <cstdlib>
+#include "kmx_device.h"
+
+namespace kmx {
+
+// ------------------------------------------------------------------------------------------ sinks
+// A sink consumes windows.  fast(o, fw, rc): window o of the lane's read on the all-valid fast path;
+// slow(pos, fw, rc): a window yielded by roll_read (invalid ones are skipped); begin/end bracket one read
+// on the slow path; tile_fast_done(nwin) closes a fast tile.
+
+// ----------------------------------------------------------------------------------------- kernel
+// NW  = packed dwords per read = ceil(L/16) rounded up to an instantiated size (L <= 16*NW)
+// V   = 1: k in [2,17]   2: k in [18,32]   (fixes the static register index of the rc window)
+// DW  = dwords per k-mer (1: k<=16, 2: k>=17)
+// RAGGED: reads of different lengths, read r = bases[offsets[r], offsets[r+1]).  A tile is still 64 consecutive reads =
+// one contiguous byte span, streamed from its 16-byte-aligned start; lanes carry their own start and window count,
+// windows past a lane's read are masked.  A tile whose span or longest read does not fit the NW-word frame, or that
+// would load past the end of the buffer, takes the per-lane rolling path.
+#ifndef KMX_SCAN_RAGGED_2COPY
+#define KMX_SCAN_RAGGED_2COPY 0
+#endif
+#ifndef KMX_SCAN_DEV_NOGUARD
+#define KMX_SCAN_DEV_NOGUARD 0   // dev: drop the per-window length mask of the ragged kernel (wrong for unequal lengths; timing only)
+#endif
+#ifndef KMX_SCAN_WAVES
+#define KMX_SCAN_WAVES 1   // waves per SIMD the register allocation is sized for (hipcc otherwise spends up to 256 VGPRs on hoisting)
+#endif
+// a sink may ask for a register budget of its own (static constexpr int kWaves)
+template <typename S, typename = void> struct SinkWaves { static constexpr int value = KMX_SCAN_WAVES; };
+template <typename S> struct SinkWaves<S, decltype((void)S::kWaves)> { static constexpr int value = S::kWaves; };
+// a sink may take the 16 windows of an unrolled block together (static constexpr bool kBatch16 = true; fast_slot())
+template <typename S, typename = void> struct SinkBatch16 { static constexpr bool value = false; };
+template <typename S> struct SinkBatch16<S, decltype((void)S::kBatch16)> { static constexpr bool value = S::kBatch16; };
+// a sink may want its block-level LDS region to start at a multiple of kBlockLdsAlign dwords (static constexpr u32)
+template <typename S, typename = void> struct SinkBlockAlign { static constexpr u32 value = 1u; };
+template <typename S> struct SinkBlockAlign<S, decltype((void)S::kBlockLdsAlign)> { static constexpr u32 value = S::kBlockLdsAlign; };
+// a sink may ask for complemented windows (fw ^ mask, rc ^ mask) from the kernel's fast path (static constexpr bool kComplement)
+template <typename S, typename = void> struct SinkComplement { static constexpr bool value = false; };
+template <typename S> struct SinkComplement<S, decltype((void)S::kComplement)> { static constexpr bool value = S::kComplement; };
+template <typename S, int NW> constexpr int sink_waves() { return NW <= 10 ? SinkWaves<S>::value : KMX_SCAN_WAVES; }   // (the 16-word frame would spill 1 KB)
+template <int NW, int V, int DW, typename Sink, typename Params, bool RAGGED = false>
+__global__ void __launch_bounds__(256, (sink_waves<Sink, NW>()))
+scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, Params params,
+                    unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead) {
+    // `lead` (uniform reads whose first byte is not 16-byte aligned): `bases` is the aligned address below it, read r
+    // starts at byte lead + r*L and a tile spans one more chunk (as a ragged tile streamed from its aligned start does)
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wib = threadIdx.x >> 6;
+    const u32 chunks_u = RAGGED ? 64u * NW : 4u * L + (lead != 0u ? 1u : 0u);  // 16-byte chunks per 64-read tile (ragged: the most a tile may span)
+    const u32 ldsw = (chunks_u + 1u + 6u + 3u) & ~3u; // front pad 1, tail pad >= 6
+    u32* P = lds + wib * (ldsw + Sink::kLdsDwordsPerWave);
+
+    const u64 n_full = n_reads >> 6;
+    const u64 wave_id = (u64)blockIdx.x * 4u + wib;
+    const u64 total_bytes = RAGGED ? offsets[n_reads] : 0;
+
+    // per-lane alignment of this lane's read inside the packed tile (LDS index 1+c holds bases [16c,16c+16))
+    u32 posF = lane * L + lead + 16u;
+    u32 qF = posF >> 4, aF = 2u * (posF & 15u);
+    const u32 delta = (1u - k) & 15u;  // rc stream pre-offset so that rc sub-shift == 30-2s
+    u32 posR = posF - delta;
+    u32 qR = posR >> 4, aR = 2u * (posR & 15u);
+
+    u32 omax = L - k;  // last window start (uniform: of every read; ragged: the longest read of the tile)
+    u32 imax = omax >> 4, smax = omax & 15u;
+    const u64 maskk = mask2k(k);
+    const u32 mlo = (u32)maskk;
+    const u32 mhi = (u32)(maskk >> 32);
+    u32 nwin = omax + 1u;       // windows of this lane's read
+    u32 chunks = chunks_u;
+
+    constexpr u32 BAL = SinkBlockAlign<Sink>::value;
+    Sink sink(params, k, nwin, P + ldsw, lane, lds + (4u * (ldsw + Sink::kLdsDwordsPerWave) + BAL - 1u) / BAL * BAL, threadIdx.x);
+
+    [[maybe_unused]] u32 nwin_min = nwin;   // ragged: the shortest read of the tile (blocks of windows below it need no per-lane mask)
+    // `slot`: position of the window inside a fully unrolled block of 16 (a compile-time value there), -1 elsewhere; a
+    // sink with kBatch16 collects the 16 windows of such a block and consumes them together in block_done()
+    auto window = [&](u32 o, u32 f0, u32 f1, u32 f2, u32 g0, u32 g1, u32 g2, u32 sf, u32 sr, bool guard = RAGGED, int slot = -1) {
+        if (guard && o >= nwin) return;   // past the end of this lane's (shorter) read
+        u64 fw, rc;
+        if (DW == 2) {
+            const u32 fw_lo = alignbit(f1, f0, sf);
+            const u32 fw_hi = alignbit(f2, f1, sf) & mhi;
+            const u32 rc_lo = alignbit(g1, g0, sr);
+            const u32 rc_hi = alignbit(g2, g1, sr) & mhi;
+            fw = ((u64)fw_hi << 32) | fw_lo;
+            rc = ((u64)rc_hi << 32) | rc_lo;
+        } else {
+            fw = (u64)(alignbit(f1, f0, sf) & mlo);
+            rc = (u64)(alignbit(g1, g0, sr) & mlo);
+        }
+        if constexpr (SinkBatch16<Sink>::value) {
+            if (slot >= 0) {
+                sink.fast_slot(slot, fw, rc);
+                return;
+            }
+        }
+        sink.fast(o, fw, rc);
+    };
+
+    // dynamic tile queue (see kmx_bitslice.hip): NQ interleaved heads, one tile per ticket, ticket fetched one
+    // tile ahead; removes the under-occupied tail that static striding leaves behind
+    constexpr u32 NQ = 32;
+    u32 qid = (blockIdx.x & 255u) >> 3;
+    u32 heads_left = NQ;
+    auto dequeue = [&]() -> u64 {
+        while (heads_left != 0u) {
+            unsigned long long v = 0;
+            if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);
+            const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+            const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
+            if (t < n_full) return t;
+            qid = (qid + 1u) & (NQ - 1u);
+            heads_left -= 1u;
+        }
+        return ~0ull;
+    };
+    u64 next_tile = dequeue();
+    // ragged: this lane's [start, end) of the NEXT tile, fetched one tile ahead so that the tile's byte loads never wait
+    // behind a dependent offsets load
+    u64 nx_off = 0, nx_end = 0;
+    if (RAGGED && next_tile < n_full) {
+        nx_off = offsets[next_tile * 64u + lane];
+        nx_end = offsets[next_tile * 64u + lane + 1u];
+    }
+    for (u64 tile = next_tile; tile < n_full; tile = next_tile) {
+        next_tile = dequeue();
+        const u64 read = tile * 64u + lane;
+        const uint4* __restrict__ tb = reinterpret_cast<const uint4*>(bases + tile * 64u * (u64)L);
+        u64 my_off = 0;
+        u32 my_len = 0;
+        bool tile_fits = true;
+        if constexpr (RAGGED) {
+            my_off = nx_off;
+            my_len = (u32)(nx_end - nx_off);
+            // (the builtins return int: through u32 first, or offsets >= 2^31 get sign-extended into the high word)
+            const u32 t0l = __builtin_amdgcn_readfirstlane((u32)nx_off), t0h = __builtin_amdgcn_readfirstlane((u32)(nx_off >> 32));
+            const u32 t1l = __builtin_amdgcn_readlane((u32)nx_end, 63), t1h = __builtin_amdgcn_readlane((u32)(nx_end >> 32), 63);
+            const u64 t0 = ((u64)t0h << 32) | t0l, t1 = ((u64)t1h << 32) | t1l;
+            if (next_tile < n_full) {
+                nx_off = offsets[next_tile * 64u + lane];
+                nx_end = offsets[next_tile * 64u + lane + 1u];
+            }
+            const u64 base_al = t0 & ~15ull;
+            const u64 n_ch = (t1 - base_al + 15u) >> 4;
+            const u32 max_len = (u32)wave_max_u32(my_len);
+            tile_fits = n_ch <= 64u * NW && max_len <= 16u * NW && base_al + 16u * n_ch <= total_bytes;
+            chunks = (u32)n_ch;
+            tb = reinterpret_cast<const uint4*>(bases + base_al);
+            posF = (u32)(my_off - base_al) + 16u;
+            qF = posF >> 4;
+            aF = 2u * (posF & 15u);
+            posR = posF - delta;
+            qR = posR >> 4;
+            aR = 2u * (posR & 15u);
+            nwin = my_len >= k ? my_len - k + 1u : 0u;
+            nwin_min = ~wave_max_u32(~nwin);
+            omax = max_len >= k ? max_len - k : 0u;
+            imax = omax >> 4;
+            smax = omax & 15u;
+            if (max_len < k) {   // nothing to emit in this tile
+                sink.tile_fast_done(0);
+                continue;
+            }
+        }
+        // ---- 1. stream the tile: all loads in flight before the first use
+        uint4 w[NW];
+        if (tile_fits) {
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const u32 c = it * 64u + lane;
+                if (c < chunks) w[it] = tb[c];
+            }
+        }
+        // ---- 2. pack + validate, stage packed words in LDS
+        u32 bad = 0;
+        if (tile_fits) {
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const u32 c = it * 64u + lane;
+                if (c < chunks) P[1u + c] = encode16(w[it], bad);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        if (!tile_fits || __any(chunk_has_invalid(bad))) {
+            // ---- rare: a non-ACGTacgt byte somewhere in this tile (or a ragged tile outside the frame) -> exact iterator semantics
+            sink.tile_slow_begin(read);
+            u32 roll_max = L;
+            if constexpr (RAGGED) roll_max = (u32)wave_max_u32(my_len);
+            roll_read_stepped(RAGGED ? bases + my_off : bases + lead + read * (u64)L, RAGGED ? my_len : L, roll_max, k,
+                              [&](u32 pos, u64 fw, u64 rc) { sink.tile_slow_emit(pos, fw, rc); }, [&](u32 wb) { sink.slow_block(wb); });
+            sink.tile_slow_end();
+            continue;
+        }
+
+        // ---- 3. this lane's read: forward words F, reverse-complement words G
+        u32 F[NW + 2], G[NW + 2];
+        {
+            u32 R[NW + 1];
+#pragma unroll
+            for (int j = 0; j <= NW; ++j) R[j] = P[qF + j];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) F[i] = SinkComplement<Sink>::value ? ~alignbit(R[i + 1], R[i], aF) : alignbit(R[i + 1], R[i], aF);
+            F[NW] = 0;
+            F[NW + 1] = 0;
+            u32 Rr[NW + 2];
+#pragma unroll
+            for (int j = 0; j <= NW + 1; ++j) Rr[j] = P[qR + j];
+#pragma unroll
+            for (int m = 0; m <= NW; ++m)
+                G[m] = SinkComplement<Sink>::value ? revgroups32(alignbit(Rr[NW - m + 1], Rr[NW - m], aR)) : revgroups32(~alignbit(Rr[NW - m + 1], Rr[NW - m], aR));
+            G[NW + 1] = 0;
+        }
+
+        // ---- 4. windows: o = 16*i + s;  fw from F[i..i+2] >> 2s;  rc from G[M..M+2] >> (30-2s), M = NW-V-i
+        sink.begin_read(read);
+#pragma unroll
+        for (int i = 0; i <= NW - V; ++i) {
+            const int M = NW - V - i;
+            if ((u32)i < imax) {
+                // Opaque copies of the six source words, made INSIDE the block: LLVM's speculative execution otherwise
+                // hoists the (cheap, side-effect-free) funnel shifts of every block above the chain of uniform branches
+                // and keeps them all live -- 228-256 VGPRs, 1-2 waves per SIMD instead of 4.
+                u32 f0 = F[i], f1 = F[i + 1], f2 = F[i + 2], g0 = G[M], g1 = G[M + 1], g2 = G[M + 2];
+                asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(g0), "+v"(g1), "+v"(g2));
+#if KMX_SCAN_RAGGED_2COPY
+                if (!RAGGED || 16u * i + 16u <= nwin_min) {   // every lane owns all 16 windows: straight-line code
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, false);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, true);
+                }
+#else
+                // (a second, unmasked copy of the block for tiles of equal-length reads doubles the code past the
+                //  instruction cache and costs more than the per-window mask it saves)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, RAGGED && !KMX_SCAN_DEV_NOGUARD, RAGGED ? -1 : s);
+#endif
+                sink.block_done(tile * 64u, 16u * i, 16u);
+            } else if ((u32)i == imax) {
+                for (u32 s = 0; s <= smax; ++s) window(16u * i + s, F[i], F[i + 1], F[i + 2], G[M], G[M + 1], G[M + 2], 2u * s, 30u - 2u * s);
+                sink.block_done(tile * 64u, 16u * i, smax + 1u);
+            }
+        }
+        sink.tile_fast_done(nwin);
+    }
+
+    // ---- final partial tile (n_reads % 64 reads): per-lane rolling
+    const u32 rem = (u32)(n_reads & 63u);
+    if (rem != 0u && wave_id == 0 && lane < rem) {
+        const u64 read = n_full * 64u + lane;
+        sink.begin_read(read);
+        if constexpr (RAGGED) {
+            const u64 o0 = offsets[read];
+            roll_read(bases + o0, (u32)(offsets[read + 1u] - o0), k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
+        } else {
+            roll_read(bases + lead + read * (u64)L, L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
+        }
+        sink.end_read();
+    }
+    sink.finish(params);
+}
+
+// ------------------------------------------------------------------ launchers
+
+// `pre(grid)` runs once the grid size is known and may finish filling `params` (the partitioned histogram sizes its
+// per-wave segments from it); it returns false to abandon the launch.
+struct NoPre {
+    bool operator()(u64) const { return true; }
+};
+template <int NW, int V, int DW, typename Sink, typename Params, typename Pre = NoPre, bool RAGGED = false>
+static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Params& params,
+                             unsigned long long* queue, int n_cu, hipStream_t stream, Pre pre = Pre(), const u64* offsets = nullptr) {
+    auto kern = scan_uniform_kernel<NW, V, DW, Sink, Params, RAGGED>;
+    u32 lead = 0;   // uniform reads from a base that is not 16-byte aligned: streamed from the aligned address below it
+    if constexpr (!RAGGED) {
+        lead = (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
+        bases -= lead;
+        if (lead != 0u && 4u * L + 1u > 64u * (u32)NW) return hipErrorInvalidValue;   // (scan_domain checks: the extra chunk must fit the frame)
+    }
+    const u32 chunks = RAGGED ? 64u * NW : 4u * L + (lead != 0u ? 1u : 0u);
+    const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
+    constexpr u32 BAL = SinkBlockAlign<Sink>::value;
+    const size_t lds_bytes = (size_t)((4u * (ldsw + Sink::kLdsDwordsPerWave) + BAL - 1u) / BAL * BAL) * 4u + (size_t)Sink::block_lds_dwords(params) * 4u;
+    // blocks per CU, cached per host thread and device (the ABI's model is one thread per context / GPU: a plain static
+    // would be written by all of them at once, and the function attribute below is a per-device setting)
+    static thread_local int bpc = 0, bpc_dev = -1;
+    static thread_local size_t bpc_lds = 0;
+    int dev_now = -1;
+    (void)hipGetDevice(&dev_now);
+    if (bpc == 0 || bpc_lds != lds_bytes || bpc_dev != dev_now) {
+        bpc_dev = dev_now;
+        if (lds_bytes > 64u * 1024u) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        int b = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, 256, lds_bytes);
+        if (e != hipSuccess) return e;
+        bpc = b > 0 ? b : 1;
+        bpc_lds = lds_bytes;
+    }
+    const u64 n_tiles = (n_reads + 63u) >> 6;
+    u64 grid = (u64)n_cu * (u64)bpc;
+    if (const char* ov = getenv("KMX_DEV_BPC")) grid = (u64)n_cu * (u64)atoi(ov);   // (dev) blocks per CU
+    const u64 need = (n_tiles + 3u) / 4u;
+    if (grid > need) grid = need;
+    if (grid == 0) grid = 1;
+    if (!pre(grid)) return hipErrorOutOfMemory;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, params, queue, offsets, lead);
+    return hipGetLastError();
+}
+
+static bool scan_domain(const uint8_t* bases, u64 n_reads, u32 L, u32 k) {
+    if (k < 2 || k > 31 || L < k || L > 256) return false;
+    if ((reinterpret_cast<uintptr_t>(bases) & 15u) && (L == 160 || L == 256)) return false;   // the extra chunk of an unaligned start must fit the frame
+    return n_reads * (u64)L < (1ull << 62);
+}
+// ragged reads: L is an optional upper bound of the lengths (0 = unknown); reads longer than the frame fall back per tile
+static bool scan_domain_ragged(const uint8_t* bases, u32 L, u32 k) {
+    return !(k < 2 || k > 31 || L > 256 || (reinterpret_cast<uintptr_t>(bases) & 15u));
+}
+
+// offsets != nullptr: ragged reads; L is then only an upper bound of the read lengths (0 = unknown) that selects the frame
+template <typename SinkT, typename Params, typename Pre = NoPre>
+static hipError_t dispatch(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Params p, unsigned long long* queue,
+                           int n_cu, hipStream_t stream, Pre pre = Pre(), const u64* offsets = nullptr) {
+    const bool big = L > 160 || (offsets && L == 0);
+    if constexpr (!SinkT::kRagged) {
+        if (offsets) return hipErrorInvalidValue;
+    } else if (offsets) {
+        if (k <= 16) {
+            if (big) return launch_one<16, 1, 1, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+            return launch_one<10, 1, 1, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+        }
+        if (k == 17) {   // the one k whose rc window sits at the V = 1 register index while the k-mer needs two dwords
+            if (big) return launch_one<16, 1, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+            return launch_one<10, 1, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+        }
+        if (big) return launch_one<16, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+        return launch_one<10, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+    }
+    if (k <= 16) {
+        if (big) return launch_one<16, 1, 1, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+        return launch_one<10, 1, 1, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+    }
+    if (k == 17) {
+        if (big) return launch_one<16, 1, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+        return launch_one<10, 1, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+    }
+    if (big) return launch_one<16, 2, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+    return launch_one<10, 2, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+}
+
+}  // namespace kmx

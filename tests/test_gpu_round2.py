@@ -421,6 +421,26 @@ def test_long_uniform_reads_take_the_segmented_bitsliced_path(ctx, orc, k, L, n)
 
 # ------------------------------------------------------------------ bench.py, N > 1 control flow on one GPU
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("hasher,hk", [(1, 31), (2, 0), (1, 27)])
+@pytest.mark.parametrize("hint", [0, 160, 120])
+def test_histogram_ragged_takes_the_partitioned_path(ctx, orc, hasher, hk, hint):
+    """>= 4096 ragged reads, 2^15..2^21 buckets: partition pass + per-partition tables, with the caller's length bound loose, absent
+    or too small (longer reads then overfill their segments and go to the global table), against the oracle"""
+    rng = np.random.default_rng(hint + hk)
+    k, b = 31, 20
+    lens = rng.integers(20, 161, size=64 * 90 + 17)
+    lens[::211] = 300          # past the frame: rolled per lane
+    lens[5::389] = 0
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]) + 16, 0.0005)[: int(offsets[-1])]
+    o = orc.histogram(host, len(lens), 0, k, hk if hasher == 1 else 0, b, offsets=offsets)
+    g = ctx.histogram(ctx.to_device(host), len(lens), hint, k, hasher, hk, b, offsets=ctx.to_device(offsets))
+    g = g.cpu().numpy().view(np.uint64)
+    assert int(g.sum()) == int(o.sum())
+    assert (g == o).all()
+
+
 @pytest.mark.parametrize("cfg", ["1", "3", "4"])
 def test_bench_two_ranks_share_the_gpu(cfg):
     """`python bench.py --gpus 2` (it starts its own ranks) with both ranks on cuda:0 and a gloo process group

@@ -25,4 +25,14 @@ for name, lens, hint in (("all 150 (hint 160)", np.full(n, 150), 160), ("all 150
         ts.append(a.elapsed_time(b))
     ms = sorted(ts)[2]
     print(f"{name:46s} {ms:8.3f} ms  {total/ms/1e6:7.0f} GB/s  {exp/ms/1e6:8.1f} G k-mers/s  n_valid {'ok' if out.n_valid == exp else 'WRONG'}")
+    if os.environ.get("HIST"):
+        b = int(os.environ["HIST"])
+        cnt = ctx.histogram(bases, n, hint, k, 1, k, b, offsets=d_off)
+        ts = []
+        for _ in range(3):
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); ctx.histogram(bases, n, hint, k, 1, k, b, offsets=d_off, counts=cnt); e.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(e))
+        print(f"    histogram 2^{b}: {sorted(ts)[1]:8.3f} ms   total {'ok' if int(cnt.sum().item()) == 4 * exp else 'WRONG'}")
+        del cnt
     del bases, d_off
