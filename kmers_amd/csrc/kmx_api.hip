@@ -105,23 +105,23 @@ namespace {
 
 void* big_scratch(void* user, size_t bytes);
 
-// The bit-sliced scan flags the tiles that hold an invalid byte (one byte per tile) for its second pass
-// (kmx_bitslice_kernel.h, "reads with an invalid byte").  The flags are the context's own grow-only array, zeroed when
-// it is allocated; the second pass clears every flag it consumes, so it is all-zero again when a call ends and nothing
-// has to be cleared per call.  Its address sits behind the 32 tile-queue heads (d_scratch[16 + 515]), rewritten only
+// The bit-sliced scan blanks the reads that hold an invalid byte out of their tile and leaves their 64-bit mask (8 bytes
+// per tile) for roll_flagged_kernel (kmx_bitslice_kernel.h, "reads with an invalid byte").  The masks are the context's
+// own grow-only array, zeroed when it is allocated; the rolling kernel clears every mask it consumes, so it is all-zero
+// again when a call ends and nothing has to be cleared per call.  Its address sits behind the 32 tile-queue heads (d_scratch[16 + 515]), rewritten only
 // when it changes.  No array: 0, and such tiles take the per-lane path as a whole, as they do for k without a second pass.
 int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k) {
     const uint64_t n_tiles = n_reads >> 6;
     uint8_t* buf = nullptr;
     if (n_tiles && ((k >= 13 && k <= 31) || (k >= 33 && k <= 64))) {   // the k with a bit-sliced kernel (and so a second pass)
-        if (n_tiles > ctx->flags_bytes) {
+        if (8u * n_tiles > ctx->flags_bytes) {   // one 64-bit read mask per tile
             if (ctx->d_flags) {
                 (void)hipStreamSynchronize(ctx->stream);
                 (void)hipFree(ctx->d_flags);
                 ctx->d_flags = nullptr;
                 ctx->flags_bytes = 0;
             }
-            const size_t want_bytes = (size_t)(n_tiles + n_tiles / 4u + 4096u);
+            const size_t want_bytes = 8u * (size_t)(n_tiles + n_tiles / 4u + 4096u);
             void* q = nullptr;
             // (cleared on the context's stream: a non-blocking stream is not ordered against the null stream hipMemset runs on)
             if (hipMalloc(&q, want_bytes) == hipSuccess && hipMemsetAsync(q, 0, want_bytes, ctx->stream) == hipSuccess) {
@@ -132,7 +132,7 @@ int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k) {
                 if (q) (void)hipFree(q);
             }
         }
-        buf = n_tiles <= ctx->flags_bytes ? ctx->d_flags : nullptr;
+        buf = 8u * n_tiles <= ctx->flags_bytes ? ctx->d_flags : nullptr;
         if (!buf) {   // one byte per 64 reads: if even that cannot be had, nothing else will work either
             std::snprintf(ctx->last_error, sizeof ctx->last_error, "kmx: no memory for %llu tile flags", (unsigned long long)n_tiles);
             return KMX_E_NOMEM;

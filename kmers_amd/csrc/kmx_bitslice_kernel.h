@@ -144,6 +144,11 @@ __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, 
 #ifndef KMX_BS_DIRTY
 #define KMX_BS_DIRTY 1
 #endif
+#ifndef KMX_BS_INLINE_DIRTY
+#define KMX_BS_INLINE_DIRTY 1   // 1: a tile with invalid bytes is scanned in the main pass with the offending reads blanked out, its 64-bit
+                                // read mask left for roll_flagged_kernel (which rolls just those reads); 0: (round 1 .. early round 2) the
+                                // main pass only flags the tile and the PASS = 1 instantiation of this kernel does it all over again
+#endif
 template <int K> constexpr bool bs_has_dirty_pass() { return KMX_BS_DIRTY != 0; }   // (one more kernel per frame and k)
 // Waves per SIMD of the ASCII kernel on the 10-word frame: 4 for every k now that half of the prefetch rows are requested
 // late (KMX_BS_LATE_ROWS).  Before that the counters D[] decided: up to k = 23 (k = 26 with <= 4 windows per lane) the
@@ -314,6 +319,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // queue[515] (behind the 32 tile-queue heads) = the flag array, 0 = none: such tiles then roll as a whole in PASS 0;
     // queue[512] = "some tile was flagged" (lets the second pass return at once on clean input).
     constexpr bool DIRTY_LIST = !PACKED && bs_has_dirty_pass<K>();
+    // INLINE (KMX_BS_INLINE_DIRTY): the main pass itself scans such a tile, with the offending reads blanked out exactly as the
+    // second pass used to (bases zeroed, windows masked out of m, nk counting the others), and leaves the tile's 64-bit mask
+    // of those reads in the array behind queue[515] (8 bytes per tile, all zero between calls); roll_flagged_kernel then
+    // rolls just those reads, 64 at a time.  0.5 % of reads with an N flag 27 % of the tiles: scanning those twice, the
+    // second time at 2 waves/SIMD, cost 38 % (1.89x at 2 % of reads); blanked in place they cost what every tile costs.
+    constexpr bool INLINE = PASS == 0 && DIRTY_LIST && KMX_BS_INLINE_DIRTY != 0;
+    constexpr bool BLANKS = PASS == 1 || INLINE;   // reads of the current tile may be blanked out (valid_reads)
     static_assert(PASS == 0 || DIRTY_LIST, "second pass: ASCII input");
     u64 valid_reads = ~0ull;                      // PASS 1: reads of the current tile that are not blanked (bit = lane = read)
     u32 n_blanked = 0;                            // PASS 1: reads blanked in this wave's tiles
@@ -691,7 +703,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             for (int g = 0; g < NW; ++g) F[g] = alignbit(R[g + 1], R[g], aF);
             if (KMX_BS_PRIO >= 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
         }
-        if constexpr (PASS == 1) {
+        if constexpr (BLANKS) {
             if (valid_reads != ~0ull) {
                 const bool blank = ((valid_reads >> lane) & 1ull) == 0ull;
 #pragma unroll
@@ -699,7 +711,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
         }
         if constexpr (RAGGED) {
-            const bool set_aside = PASS == 1 && ((valid_reads >> lane) & 1ull) == 0ull;   // second pass: a read with an invalid byte
+            const bool set_aside = BLANKS && ((valid_reads >> lane) & 1ull) == 0ull;   // a read with an invalid byte: rolled elsewhere
             const u32 len = (cur_m.len >= (u32)K && !set_aside) ? cur_m.len : 0u;   // a read shorter than k owns no window: it is blanked out entirely
             // bases past the end of the read belong to the next read.  KMX_BSR_VAL: they stay -- a window that holds one is masked
             // out of m by its validity plane, and the plane totals count a plane through the validity plane of its base (below)
@@ -1044,8 +1056,16 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     m[w] = ((u32)w < nwin) ? lt[w] : 0u;
                 }
                 if constexpr (PASS == 1) m[w] &= set ? (u32)(valid_reads >> 32) : (u32)valid_reads;   // blanked reads own no window
-                pc_acc(mcnt, m[w]);   // (a tile that is not scanned: lt == 0, nothing is added)
             }
+            if constexpr (INLINE) {
+                if (valid_reads != ~0ull) {   // (wave-uniform; a clean tile pays the branch)
+                    const u32 vm = set ? (u32)(valid_reads >> 32) : (u32)valid_reads;
+#pragma unroll
+                    for (int w = 0; w < WPL; ++w) m[w] &= vm;
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) pc_acc(mcnt, m[w]);   // (a tile that is not scanned: lt == 0, nothing is added)
             if constexpr (LATE > 0) {   // the rest of the next tile's rows: the registers of pass 1's plane window are free now
                 if constexpr (RAGGED) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -1192,9 +1212,53 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (as an instruction the waitcnt pass sees, not inline asm)
             flagged = true;
         };
+        // INLINE: which reads hold the invalid bytes?  The tile is still in w[]: its chunks' verdicts again, one ballot per row
+        // (the bitmap parks in the plane area, free until phase C), every lane looks up the chunks of its read, and the reads'
+        // mask goes to the array behind queue[515] for roll_flagged_kernel.  The tile is then scanned with those reads blanked.
+        auto blank_dirty_reads = [&](u32 n_chunks) -> bool {
+            u64* const masks = reinterpret_cast<u64*>(queue[515]);
+            if (masks == nullptr) {
+                if constexpr (!RAGGED) __builtin_trap();   // (the host side always provides the array)
+                return false;
+            }
+            u64* BM = reinterpret_cast<u64*>(PL);
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const u32 c = it * 64u + lane;
+                u32 rb = 0;
+                (void)encode16(w[it], rb);
+                const u64 row = __ballot(c < n_chunks && chunk_has_invalid(rb));
+                if (lane == 0) BM[it] = row;
+            }
+            if (lane == 0) { BM[NW] = 0; BM[NW + 1] = 0; }
+            lds_fence();
+            u32 rd_off = lane * L + lead, rd_len = L;    // the read's bytes, relative to the tile's aligned start
+            if constexpr (RAGGED) { rd_off = cur_m.rel; rd_len = cur_m.len; }
+            // a read is blanked if any chunk it touches is bad (a chunk shared by two reads blanks both: they are rolled exactly anyway)
+            const u32 c0 = rd_off >> 4, c1 = rd_len ? (rd_off + rd_len - 1u) >> 4 : c0;
+            const u32 q0 = c0 >> 6, b0 = c0 & 63u;
+            const u64 lo = BM[q0], hi = BM[q0 + 1u];
+            const u64 bits = b0 ? ((lo >> b0) | (hi << (64u - b0))) : lo;
+            const bool dirty = rd_len != 0u && (bits & ((1ull << (c1 - c0 + 1u)) - 1ull)) != 0ull;
+            const u64 dm = uniform_u64(__ballot(dirty));
+            if (lane == 0) {
+                u32 one = 1u;   // (made here: hoisted out of the tile loop these constants each hold a register for good)
+                asm volatile("" : "+v"(one));
+                masks[tile] = dm;
+                queue[512] = one;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see flag_tile
+            valid_reads = ~dm;
+            n_blanked += (u32)__builtin_popcountll(dm);
+            lds_fence();
+            return true;
+        };
+        if constexpr (INLINE) valid_reads = ~0ull;
         if constexpr (RAGGED) {
             bad_tile = !cur_m.fits || phase_A();
-            if constexpr (PASS == 0 && DIRTY_LIST) {
+            if constexpr (INLINE) {
+                if (bad_tile && cur_m.fits && blank_dirty_reads(cur_m.n_ch)) bad_tile = false;   // (tiles outside the frame roll as a whole)
+            } else if constexpr (PASS == 0 && DIRTY_LIST) {
                 if (bad_tile && cur_m.fits) flag_tile();   // (tiles outside the frame roll as a whole)
             }
             if constexpr (LATE > 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the uniform branch
@@ -1211,7 +1275,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             // until the late rows go out -- would cost an s_waitcnt vmcnt(0) with the next tile's loads already out.  Here, on
             // every path, the wait is free: the wave has just used all of them.
             if constexpr (LATE > 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-            if constexpr (PASS == 0 && DIRTY_LIST) {
+            if constexpr (INLINE) {
+                if (bad_tile && blank_dirty_reads(chunks)) bad_tile = false;
+            } else if constexpr (PASS == 0 && DIRTY_LIST) {
                 if (bad_tile) flag_tile();
             }
             prefetch(next_tile, tile, 0, NLD - LATE);
@@ -1376,6 +1442,119 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                   wave_xor(fb_all.x1) ^ bs_x1, wave_sum(fb_all.fw) + bs_fw);
 }
 
+// ------------------------------------------------------------------ the reads the main pass blanked out
+// KMX_BS_INLINE_DIRTY: masks[t] (behind queue[515]) = the reads of tile t that hold an invalid byte, left by the main pass,
+// which scanned the tile without them.  A lane takes the mask of one tile, the wave gathers the reads 64 at a time (one
+// ballot + one v_mbcnt per round: no list in memory, no atomics) and rolls them, one lane per read, with the reference's
+// iterator semantics (roll_read).  Every mask goes back to zero: the caller never clears the array.
+// Arguments as scan_bitsliced_kernel's (RAGGED with offsets == nullptr: segments of long uniform reads, lead = seg_T,
+// want_sumfw = seg_L).
+template <int K, bool RAGGED>
+__global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash,
+                                                           u32 want_sumfw, void* __restrict__ out, unsigned long long* __restrict__ queue,
+                                                           const u64* __restrict__ offsets, u32 lead) {
+    u64* const masks = reinterpret_cast<u64*>(queue[515]);
+    if (masks == nullptr || queue[512] == 0) return;   // queue[512]: "a tile was marked" (zeroed by the caller with the heads)
+    __shared__ u64 aside_all[4][64];
+    const u32 lane = threadIdx.x & 63u;
+    u64* const aside = aside_all[threadIdx.x >> 6];
+    const u64 n_full = n_reads >> 6;
+    const bool seg_mode = RAGGED && offsets == nullptr;
+    const u32 seg_T = lead, seg_L = want_sumfw;
+    const u32 seg_J = seg_mode ? (seg_L - (u32)K + seg_T) / seg_T : 1u;
+    u64 a_n = 0, a_s0 = 0, a_s1 = 0, a_x0 = 0, a_x1 = 0, a_fw = 0;
+    u32 n_aside = 0;
+    auto roll = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < n_aside) {
+            const u64 read = aside[lane];
+            const uint8_t* sp = bases + lead + read * (u64)L;
+            u32 len = L;
+            if constexpr (RAGGED) {
+                u64 o0, o1;
+                if (seg_mode) {
+                    const u64 i = read / seg_J;
+                    const u32 j = (u32)(read - i * seg_J);
+                    o0 = i * (u64)seg_L + (u64)j * seg_T;
+                    const u64 e = o0 + seg_T + (u32)(K - 1), re = (i + 1u) * (u64)seg_L;
+                    o1 = e < re ? e : re;
+                } else {
+                    o0 = offsets[read];
+                    o1 = offsets[read + 1u];
+                }
+                sp = bases + o0;
+                len = (u32)(o1 - o0);
+            }
+            if constexpr (K <= 32) {
+                roll_read(sp, len, (u32)K, [&](u32, u64 fw, u64 rc) {
+                    const u64 canon = fw < rc ? fw : rc;
+                    a_n += 1;
+                    a_s0 += canon;
+                    a_x0 ^= lex_hash(canon, (u32)K);
+                    a_fw += fw;
+                });
+            } else {
+                roll_read2(sp, len, (u32)K, [&](u32, U128 fw, U128 rc) {
+                    const U128 c = lt128(fw, rc) ? fw : rc;
+                    const U128 h = lex_hash128(c, (u32)K);
+                    a_n += 1;
+                    a_s0 += c.lo;
+                    a_s1 += c.hi;
+                    a_x0 ^= h.lo;
+                    a_x1 ^= h.hi;
+                });
+            }
+        }
+        n_aside = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const u64 n_groups = (n_full + 63u) >> 6;
+    for (u64 g = (u64)blockIdx.x * 4u + (threadIdx.x >> 6); g < n_groups; g += (u64)gridDim.x * 4u) {
+        const u64 t = g * 64u + lane;
+        u64 m = t < n_full ? masks[t] : 0ull;
+        if (m != 0ull) masks[t] = 0ull;
+        for (;;) {
+            const bool has = m != 0ull;
+            const u64 b = __ballot(has);
+            if (b == 0ull) break;
+            const u32 nd = (u32)__builtin_popcountll(b);
+            if (n_aside + nd > 64u) roll();
+            const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u));
+            if (has) {
+                aside[n_aside + rank] = t * 64u + (u32)__builtin_ctzll(m);
+                m &= m - 1ull;
+            }
+            n_aside += nd;
+        }
+    }
+    if (n_aside) roll();
+    const u64 n = wave_sum(a_n);
+    if (n == 0) return;   // (wave-uniform) nothing rolled: no atomics
+    const u64 s0 = wave_sum(a_s0), s1 = wave_sum(a_s1), x0 = wave_xor(a_x0), x1 = wave_xor(a_x1), f = wave_sum(a_fw);
+    if (lane == 0) {
+        if constexpr (K <= 32) {
+            kmx_summary* o = static_cast<kmx_summary*>(out);
+            atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
+            atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)s0);
+            if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)x0);
+            if (want_sumfw && !RAGGED) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
+        } else {
+            kmx_summary2* o = static_cast<kmx_summary2*>(out);
+            atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
+            atomicAdd((unsigned long long*)&o->sum_lo, (unsigned long long)s0);
+            atomicAdd((unsigned long long*)&o->sum_hi, (unsigned long long)s1);
+            if (want_hash) {
+                atomicXor((unsigned long long*)&o->xor_lo, (unsigned long long)x0);
+                atomicXor((unsigned long long*)&o->xor_hi, (unsigned long long)x1);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ launcher
 
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
@@ -1422,12 +1601,21 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets, lead);
     if constexpr (!PACKED && bs_has_dirty_pass<K>()) {
+#if KMX_BS_INLINE_DIRTY
+        // the reads the main pass blanked out (none on clean input: the waves return at once)
+        u64 grid1 = (u64)n_cu * 4u;
+        const u64 need1 = ((n_reads >> 6) + 255u) / 256u;   // a wave takes 64 masks at a time
+        if (grid1 > need1) grid1 = need1;
+        hipLaunchKernelGGL((roll_flagged_kernel<K, RAGGED>), dim3((unsigned)(grid1 ? grid1 : 1)), dim3(256), 0, stream, bases, n_reads, L, want_hash,
+                           want_sumfw, out, queue, offsets, lead);
+#else
         // second pass over the tiles the main pass flagged (none on clean input: a wave reads its share of the flags and returns)
         auto kern1 = scan_bitsliced_kernel<K, NW, WPL, false, RAGGED, 1>;
         u64 grid1 = (u64)n_cu * 2u;
         if (grid1 > need) grid1 = need;
         hipLaunchKernelGGL(kern1, dim3((unsigned)(grid1 ? grid1 : 1)), dim3(256), lds_bytes + 128u * 4u * 4u, stream, bases, n_reads, L, want_hash,
                            want_sumfw, out, queue, offsets, lead);
+#endif
     }
     return hipGetLastError();
 }
