@@ -214,19 +214,11 @@ __device__ __forceinline__ void roll_read(const uint8_t* __restrict__ s, u32 len
         }
     };
     u32 l = 0;
-    if (len >= 8u) {   // 8 bases per (unaligned) global_load_dwordx2, the next 8 requested before these are walked
+    for (; l + 8u <= len; l += 8u) {   // 8 bases per (unaligned) global_load_dwordx2
         u64 v;
-        __builtin_memcpy(&v, s, 8);
-        for (; l + 16u <= len; l += 8u) {
-            u64 vn;
-            __builtin_memcpy(&vn, s + l + 8u, 8);
-#pragma unroll
-            for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
-            v = vn;
-        }
+        __builtin_memcpy(&v, s + l, 8);
 #pragma unroll
         for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
-        l += 8u;
     }
     for (; l < len; ++l) step(s[l], l);
 }

@@ -22,6 +22,16 @@ for frac in (0.0, 0.001, 0.005, 0.02, 0.1):
         ts.append(a.elapsed_time(b))
     ms = sorted(ts)[2]
     print(f"{100*frac:5.1f} % of the reads hold an N: {ms:7.3f} ms  {n*L/ms/1e6:6.0f} GB/s   n_valid {out.n_valid}")
+    if os.environ.get("HIST"):   # the word-domain kernel (bucket histogram, 2^HIST buckets) on the same input
+        hb = int(os.environ["HIST"])
+        cnt = ctx.histogram(bases, n, L, k, 1, k, hb)
+        ts = []
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); ctx.histogram(bases, n, L, k, 1, k, hb, counts=cnt); b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        print(f"        histogram 2^{hb}: {sorted(ts)[1]:7.3f} ms   total {'ok' if int(cnt.sum().item()) == 4 * out.n_valid else 'WRONG'}")
+        del cnt
     del bases
 # the same through the ragged layout (an offsets array, frame 160)
 import numpy as np

@@ -1,3 +1,4 @@
-python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --sustain-steps 400 2>/dev/null | python tools/bench_line.py default
-python tools/bench_dirty.py 2>/dev/null
+for v in c38 default ragold c38 default ragold; do
+  if [ "$v" == "default" ]; then unset KMX_LIB_VARIANT; else export KMX_LIB_VARIANT=$v; fi
+  echo "== $v"; python tools/bench_ragged.py 100000000 31 2>/dev/null | sed -n 2p;  python tools/bench_ragged.py 100000000 21 2>/dev/null | sed -n 2p
+done
