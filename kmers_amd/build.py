@@ -66,16 +66,43 @@ def _headers_of(src: str) -> list[str]:
     return out
 
 
+def _split_usage(stderr: str) -> tuple[str, str]:
+    """hipcc's stderr -> (one line per kernel: name and resources, everything that is not a resource remark)"""
+    import re
+    kernels, cur, other = [], None, []
+    for ln in stderr.splitlines():
+        m = re.search(r"remark:\s+(.*?)\s+\[-Rpass-analysis=kernel-resource-usage\]", ln)
+        if not m:
+            # the source line and the caret clang prints under a remark, and the include stack above one in a header
+            if re.match(r"^\s*\d*\s*\|", ln) or ln.startswith("In file included from") or not ln.strip():
+                continue
+            other.append(ln)
+            continue
+        body = m.group(1)
+        if body.startswith("Function Name:"):
+            cur = [body.split(":", 1)[1].strip()]
+            kernels.append(cur)
+        elif cur is not None:
+            cur.append(body.strip())
+    return "\n".join(" | ".join(k) for k in kernels) + "\n", "\n".join(other)
+
+
 def _compile(src: str, obj_dir: str, force: bool, extra: list[str]) -> str:
     obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     if force or _stale(obj, [path] + _headers_of(src)):
-        cmd = [hipcc(), *CXXFLAGS, *extra, "-c", path, "-o", obj]
+        # -Rpass-analysis=kernel-resource-usage: registers / scratch / occupancy of every kernel, kept next to the object
+        # (<src>.usage.txt; tests/test_kernel_resources.py reads them: a hot kernel that starts using scratch, or stops
+        # inlining a lambda, shows there before it shows in a benchmark)
+        cmd = [hipcc(), *CXXFLAGS, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-        if r.stderr.strip():
-            sys.stderr.write(r.stderr)
+        usage, other = _split_usage(r.stderr)
+        with open(os.path.splitext(obj)[0] + ".usage.txt", "w") as f:
+            f.write(usage)
+        if other.strip():
+            sys.stderr.write(other)
     return obj
 
 

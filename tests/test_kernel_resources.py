@@ -1,0 +1,61 @@
+"""What hipcc reported for the hot kernels when libkmx was built (kmers_amd/build.py keeps -Rpass-analysis=kernel-resource-usage
+per translation unit): no scratch beyond a few spilled dwords, no dynamic stack (= a lambda that stopped being inlined: its
+closure then lives in scratch and the kernel loses ~20 %), and the occupancy each variant is laid out for."""
+import glob
+import os
+import re
+
+import pytest
+
+OBJ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmers_amd", "csrc", "_obj")
+
+
+def _kernels():
+    out = {}
+    for f in glob.glob(os.path.join(OBJ, "*.usage.txt")):
+        for ln in open(f):
+            parts = [p.strip() for p in ln.strip().split("|")]
+            if len(parts) < 2:
+                continue
+            d = {}
+            for p in parts[1:]:
+                k, _, v = p.rpartition(":")
+                d[k.strip()] = v.strip()
+            out[parts[0]] = d
+    return out
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    k = _kernels()
+    if not k:
+        pytest.skip("no *.usage.txt next to the objects (library not built by kmers_amd.build in this tree)")
+    return k
+
+
+def test_bitsliced_kernels_stay_out_of_scratch(kernels):
+    seen = 0
+    for name, d in kernels.items():
+        if "scan_bitsliced_kernel" not in name:
+            continue
+        seen += 1
+        assert d["Dynamic Stack"] == "False", name
+        assert int(d["ScratchSize [bytes/lane]"]) <= 64, (name, d["ScratchSize [bytes/lane]"])
+    assert seen >= 100   # every k of the three families, every frame
+
+
+def test_headline_kernel_occupancy(kernels):
+    """k = 31, 150 bp (10-word frame, 4 windows per lane): 4 waves per SIMD; the ragged variant 3; two-word k = 63 3"""
+    def occ(pattern):
+        hits = [d for n, d in kernels.items() if re.search(pattern, n)]
+        assert len(hits) == 1, (pattern, len(hits))
+        return int(hits[0]["Occupancy [waves/SIMD]"])
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0ELi0E") == 4
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb1ELi0E") == 3
+    assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb0ELi0E") == 3
+
+
+def test_scan_and_histogram_kernels_do_not_call(kernels):
+    for name, d in kernels.items():
+        if "scan_uniform_kernel" in name or "roll_flagged_kernel" in name or "hist_part_reduce_kernel" in name:
+            assert d["Dynamic Stack"] == "False", name
