@@ -422,6 +422,43 @@ def test_long_uniform_reads_take_the_segmented_bitsliced_path(ctx, orc, k, L, n)
 # ------------------------------------------------------------------ bench.py, N > 1 control flow on one GPU
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,L", [(31, 150), (21, 150), (13, 100), (47, 150), (64, 150), (31, 159)])
+@pytest.mark.parametrize("layout", ["uniform", "offsets"])
+def test_blanked_reads_in_every_position(ctx, orc, k, L, layout):
+    """the reads with an invalid byte are blanked out of their tile in the main pass and rolled by roll_flagged_kernel: a tile
+    with ALL its reads dirty, with exactly one, N at the first / last byte of a read (the chunk it shares with its neighbour
+    blanks both: they are rolled exactly), N in every read's k-th base, two calls in a row (the masks must be back to zero)"""
+    from kmers_amd import _lib
+    rng = np.random.default_rng(k * 1000 + L)
+    n = 64 * 14 + 5
+    host = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n * L).copy()
+    def put(read, pos):
+        host[read * L + pos] = ord("N")
+    for r in range(64):                 # tile 0: every read
+        put(r, int(rng.integers(0, L)))
+    put(64 + 17, 0)                     # tile 1: one read, first byte
+    put(128 + 63, L - 1)                # tile 2: last read of the tile, last byte (shares its chunk with tile 3's first read)
+    put(192, L - 1); put(193, 0)        # tile 3: neighbours across one chunk
+    for r in range(256, 320):           # tile 4: base k-1 of every read (no window of the first k survives)
+        put(r, k - 1)
+    put(5 * 64 + 3, 7); put(5 * 64 + 3, 90)   # tile 5: two in one read
+    put(n - 2, 11)                      # the final partial tile (rolled per lane anyway)
+    offsets = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L)) if layout == "offsets" else None
+    if layout == "offsets" and k > 32:
+        pytest.skip("two-word k-mers: uniform layout only")
+    d_host, d_off = ctx.to_device(host), (ctx.to_device(offsets) if offsets is not None else None)
+    for _ in range(2):
+        if k <= 32:
+            o = orc.canonical_reduce(host, n, L, k, hasher_k=k, offsets=offsets)
+            g = ctx.canonical_reduce(d_host, n, L if offsets is None else 160, k, _lib.HASH_LEX, k, 0, offsets=d_off)
+            assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+        else:
+            o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+            g = ctx.canonical_reduce2(d_host, n, L, k, with_hash=True)
+            assert tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hasher,hk", [(1, 31), (2, 0), (1, 27)])
 @pytest.mark.parametrize("hint", [0, 160, 120])
 def test_histogram_ragged_takes_the_partitioned_path(ctx, orc, hasher, hk, hint):

@@ -1,4 +1,1 @@
-for v in c38 default ragold c38 default ragold; do
-  if [ "$v" == "default" ]; then unset KMX_LIB_VARIANT; else export KMX_LIB_VARIANT=$v; fi
-  echo "== $v"; python tools/bench_ragged.py 100000000 31 2>/dev/null | sed -n 2p;  python tools/bench_ragged.py 100000000 21 2>/dev/null | sed -n 2p
-done
+python -m pytest tests -x -q -m gpu -k "blanked or hist" 2>&1 | tail -8
