@@ -240,10 +240,23 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
                     for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, true);
                 }
 #else
+                if constexpr (RAGGED && SinkBatch16<Sink>::value) {
+                    // a sink that takes the windows of a block in batches (the partitioned histogram: its LDS round trips, paid
+                    // once per batch instead of once per window, are what the ragged scan otherwise runs at): a second,
+                    // unmasked copy of the block for the blocks that every read of the tile owns in full
+                    if (16u * i + 16u <= nwin_min) {
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, false, s);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, true, -1);
+                    }
+                } else {
                 // (a second, unmasked copy of the block for tiles of equal-length reads doubles the code past the
                 //  instruction cache and costs more than the per-window mask it saves)
 #pragma unroll
                 for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, RAGGED && !KMX_SCAN_DEV_NOGUARD, RAGGED ? -1 : s);
+                }
 #endif
                 sink.block_done(tile * 64u, 16u * i, 16u);
             } else if ((u32)i == imax) {
