@@ -324,7 +324,6 @@ static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Pa
     }
     const u64 n_tiles = (n_reads + 63u) >> 6;
     u64 grid = (u64)n_cu * (u64)bpc;
-    if (const char* ov = getenv("KMX_DEV_BPC")) grid = (u64)n_cu * (u64)atoi(ov);   // (dev) blocks per CU
     const u64 need = (n_tiles + 3u) / 4u;
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
