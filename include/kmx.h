@@ -59,7 +59,9 @@ typedef struct kmx_ctx kmx_ctx;
  * offsets == NULL: uniform layout, read r = d_bases[r*read_len .. (r+1)*read_len).
  * offsets != NULL: ragged layout, read r = d_bases[offsets[r] .. offsets[r+1]) (n_reads+1 device u64); read_len may
  *   then carry an upper bound of the read lengths (0 = unknown): a bound <= 160 selects the smaller, faster frame of the
- *   tiled kernels.  It is only a hint -- tiles with a longer read take the exact per-read path. */
+ *   tiled kernels, and the tighter it is the fewer windows a lane carries (150 bp reads: 7 % faster at k = 31 with 150
+ *   than with 160 or 0).  It is only a hint -- tiles with a longer read take the exact per-read path, and the
+ *   histogram's work buffer, sized from it, overflows into exact (slow) global atomics. */
 typedef struct {
     const uint8_t *d_bases;
     uint64_t n_reads;
@@ -141,8 +143,8 @@ int kmx_canonical_windows2(kmx_ctx *ctx, const kmx_reads *reads, const uint64_t 
  * function: the top bits of a 32-bit multiplicative mix of the two halves; log2_buckets <= 30).
  * d_counts (2^log2_buckets device u64) is ACCUMULATED into; the caller zeroes it and, across
  * GPUs, all-reduces it (RCCL ncclSum/uint64).
- * Uniform reads with 2^15..2^21 buckets go through a grow-only work buffer owned by the context (at most 8 GiB or
- * half of the free device memory; KMX_HIST_SCRATCH_MB overrides): growing it synchronises the stream once. */
+ * With 2^15..2^21 buckets the reads (uniform or ragged) go through a grow-only work buffer owned by the context (at
+ * most 8 GiB or half of the free device memory; KMX_HIST_SCRATCH_MB overrides): growing it synchronises the stream once. */
 int kmx_histogram(kmx_ctx *ctx, const kmx_reads *reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
                   uint32_t log2_buckets, uint64_t *d_counts);
 

@@ -109,11 +109,11 @@ void* big_scratch(void* user, size_t bytes);
 // per tile) for roll_flagged_kernel (kmx_bitslice_kernel.h, "reads with an invalid byte").  The masks are the context's
 // own grow-only array, zeroed when it is allocated; the rolling kernel clears every mask it consumes, so it is all-zero
 // again when a call ends and nothing has to be cleared per call.  Its address sits behind the 32 tile-queue heads (d_scratch[16 + 515]), rewritten only
-// when it changes.  No array: 0, and such tiles take the per-lane path as a whole, as they do for k without a second pass.
+// when it changes.  No array: 0, and such tiles take the per-lane path as a whole, as they do for k without a bit-sliced kernel.
 int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k) {
     const uint64_t n_tiles = n_reads >> 6;
     uint8_t* buf = nullptr;
-    if (n_tiles && ((k >= 13 && k <= 31) || (k >= 33 && k <= 64))) {   // the k with a bit-sliced kernel (and so a second pass)
+    if (n_tiles && ((k >= 13 && k <= 31) || (k >= 33 && k <= 64))) {   // the k with a bit-sliced kernel
         if (8u * n_tiles > ctx->flags_bytes) {   // one 64-bit read mask per tile
             if (ctx->d_flags) {
                 (void)hipStreamSynchronize(ctx->stream);

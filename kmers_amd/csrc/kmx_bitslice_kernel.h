@@ -22,8 +22,8 @@
 //   D. the 64 lanes split the 2*(L-k+1) (set, window) items; each item = 2k plane loads
 //      (ds_read_b64), a k-step v_bitop3 ripple and 2k masked popcounts.
 // The final partial tile takes roll_read (exact iterator semantics, canonical_kmer_iterator.rs:42-70).  A tile with a
-// non-ACGTacgt byte is flagged and run by a second pass of this kernel (PASS = 1) with the offending reads blanked out
-// and rolled separately, 64 at a time -- see "reads with an invalid byte" in the kernel.
+// non-ACGTacgt byte is scanned with the offending reads blanked out; those are rolled separately, 64 at a time, by
+// roll_flagged_kernel -- see "reads with an invalid byte" in the kernel.
 #pragma once
 #include "kmx_device.h"
 
@@ -140,16 +140,10 @@ __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, 
 //     a read instead of stopping t bases before ITS end, and these per-base totals take the excess back out.
 // A tile whose span or longest read leaves the frame, or that would load past the end of the buffer, and tiles with
 // an invalid byte, take the per-lane rolling path as before.
-// PASS = 1: the second pass over the tiles that hold an invalid byte (see "reads with an invalid byte" below).
 #ifndef KMX_BS_DIRTY
 #define KMX_BS_DIRTY 1
 #endif
-#ifndef KMX_BS_INLINE_DIRTY
-#define KMX_BS_INLINE_DIRTY 1   // 1: a tile with invalid bytes is scanned in the main pass with the offending reads blanked out, its 64-bit
-                                // read mask left for roll_flagged_kernel (which rolls just those reads); 0: (round 1 .. early round 2) the
-                                // main pass only flags the tile and the PASS = 1 instantiation of this kernel does it all over again
-#endif
-template <int K> constexpr bool bs_has_dirty_pass() { return KMX_BS_DIRTY != 0; }   // (one more kernel per frame and k)
+template <int K> constexpr bool bs_has_dirty_pass() { return KMX_BS_DIRTY != 0; }   // (0, a dev switch: tiles with an invalid byte roll per lane as a whole)
 // Waves per SIMD of the ASCII kernel on the 10-word frame: 4 for every k now that half of the prefetch rows are requested
 // late (KMX_BS_LATE_ROWS).  Before that the counters D[] decided: up to k = 23 (k = 26 with <= 4 windows per lane) the
 // kernel fit 128 registers with at most 16 bytes of spills, k = 27 / 28 were neutral, k = 29 / 30 lost 3-6 % and k = 31
@@ -161,8 +155,8 @@ template <int K, int WPL> constexpr int bs_waves_ascii() {
     return (KMX_BS_LATE_ROWS >= 5 || K <= 23 || (K <= 26 && WPL <= 4)) ? 4 : KMX_BS_WAVES;
 #endif
 }
-template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, int PASS = 0>
-__global__ void __launch_bounds__(256, (PASS == 1 ? 2 : K > 32 ? KMX_BS_WAVES2 : RAGGED ? (NW > 10 ? 2 : KMX_BSR_WAVES) : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
+template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
+__global__ void __launch_bounds__(256, (K > 32 ? KMX_BS_WAVES2 : RAGGED ? (NW > 10 ? 2 : KMX_BSR_WAVES) : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead) {
@@ -198,7 +192,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
     const u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
     constexpr u32 TRC_DW = KMX_BS_TRC_LDS ? 256u : 0u;     // [32 lanes of a half-wave][8] transpose constants, shared by the block
-    u32* P = lds + TRC_DW + wib * (ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u) + (PASS == 1 ? 128u : 0u));
+    u32* P = lds + TRC_DW + wib * (ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u));
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
     const u64 n_full = n_reads >> 6;
@@ -307,36 +301,19 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         m.fits = nch <= (u64)chunks && nch <= 64u * NW && wave_max_u32(m.len) <= L && m.base + 16u * nch <= total_bytes;
     };
     u32 n_bs_tiles = 0;
-    // ---- reads with an invalid byte (ASCII input, uniform or ragged; k with a second-pass kernel).  A tile that holds one
-    // used to go to the per-lane path as a whole -- 64 reads rolled at 6.5x the cost of a bit-sliced tile, so 0.5 % of reads
-    // with an N (27 % of the tiles) made the scan 3.4x slower.  Now the main pass (PASS 0) only flags such a tile (one byte
-    // per tile, all zero between calls) and moves on; the second pass (PASS 1: this kernel again, with room for the extra
-    // state at 2 waves/SIMD) walks the flags, runs the flagged tiles bit-sliced with the offending reads blanked out --
-    // bases zeroed, windows masked out of m, nk counting the others only -- and collects those reads in a 64-entry buffer
-    // per wave that is rolled, one lane per read, whenever it is full: no list in memory, no atomics (one counter could
-    // take 25 M appends a second, less than the tiles a dirty input produces).  Doing all of this in the main pass cost it
-    // 6 % on clean input: the kernel sits at its register budget.
-    // queue[515] (behind the 32 tile-queue heads) = the flag array, 0 = none: such tiles then roll as a whole in PASS 0;
-    // queue[512] = "some tile was flagged" (lets the second pass return at once on clean input).
+    // ---- reads with an invalid byte (ASCII input, uniform or ragged).  A tile that holds one used to go to the per-lane path
+    // as a whole -- 64 reads rolled at 6.5x the cost of a bit-sliced tile, so 0.5 % of reads with an N (27 % of the tiles)
+    // made the scan 3.4x slower.  Rounds 1-2 had a second instantiation of this kernel scan the flagged tiles again with the
+    // offending reads blanked out (+38 % at 0.5 %).  Now this pass scans such a tile itself, with those reads blanked out
+    // -- bases zeroed, windows masked out of m, nk counting the others only -- and leaves the tile's 64-bit mask of those
+    // reads in the array behind queue[515] (8 bytes per tile, all zero between calls); roll_flagged_kernel then rolls just
+    // those reads, 64 at a time: blanked in place such a tile costs what every tile costs.
+    // queue[515] == 0: no array, such tiles roll as a whole here; queue[512] = "a tile was marked" (lets roll_flagged_kernel
+    // return at once on clean input).
     constexpr bool DIRTY_LIST = !PACKED && bs_has_dirty_pass<K>();
-    // INLINE (KMX_BS_INLINE_DIRTY): the main pass itself scans such a tile, with the offending reads blanked out exactly as the
-    // second pass used to (bases zeroed, windows masked out of m, nk counting the others), and leaves the tile's 64-bit mask
-    // of those reads in the array behind queue[515] (8 bytes per tile, all zero between calls); roll_flagged_kernel then
-    // rolls just those reads, 64 at a time.  0.5 % of reads with an N flag 27 % of the tiles: scanning those twice, the
-    // second time at 2 waves/SIMD, cost 38 % (1.89x at 2 % of reads); blanked in place they cost what every tile costs.
-    constexpr bool INLINE = PASS == 0 && DIRTY_LIST && KMX_BS_INLINE_DIRTY != 0;
-    constexpr bool BLANKS = PASS == 1 || INLINE;   // reads of the current tile may be blanked out (valid_reads)
-    static_assert(PASS == 0 || DIRTY_LIST, "second pass: ASCII input");
-    u64 valid_reads = ~0ull;                      // PASS 1: reads of the current tile that are not blanked (bit = lane = read)
-    u32 n_blanked = 0;                            // PASS 1: reads blanked in this wave's tiles
-    u32 n_set_aside = 0;                          // PASS 1: reads waiting in the wave's buffer
-    uint8_t* const tile_flags = PASS == 1 ? reinterpret_cast<uint8_t*>(queue[515]) : nullptr;
-    if constexpr (PASS == 1) {
-        if (tile_flags == nullptr || queue[512] == 0) return;   // queue[512]: "a tile was flagged" (zeroed by the caller with the heads)
-    }
-    u64 flag_group = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);   // PASS 1: 64 flags at a time, groups strided over the waves
-    u64 flag_bits = 0;                                             //         flagged tiles of the current group not yet handed out
-    u64 flag_base = 0;
+    constexpr bool INLINE = DIRTY_LIST;           // (kept as a name: the blanking code is fenced by it)
+    u64 valid_reads = ~0ull;                      // reads of the current tile that are not blanked (bit = lane = read)
+    u32 n_blanked = 0;                            // reads blanked in this wave's tiles
     // word-domain accumulators of the fallback path (tiles with invalid bytes, the final partial tile)
 #ifndef KMX_BS_FB_FLUSH
 #define KMX_BS_FB_FLUSH 1   // 1: the fallback path adds its sums to the output per tile (12 registers less across the main loop: +1.7 % at k=31)
@@ -362,7 +339,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
         }
     };
-    constexpr bool FB_FLUSH = KMX_BS_FB_FLUSH && K <= 32 && PASS == 0;   // (the second pass rolls reads in batches into fb_all)   // (two-word k-mers: the per-tile sums then live in scratch, 0.46 -> 0.37 of the roofline at k=63)
+    constexpr bool FB_FLUSH = KMX_BS_FB_FLUSH && K <= 32;   // (two-word k-mers: the per-tile sums then live in scratch, 0.46 -> 0.37 of the roofline at k=63)
     FbAcc fb_all;                                             // !FB_FLUSH: summed over the whole run of the wave
     auto fallback_read_acc = [&](u64 read, FbAcc& fb) {
         const uint8_t* s = bases + lead + read * (u64)L;
@@ -405,18 +382,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 fb.x1 ^= h.hi;
             });
         }
-    };
-    // PASS 1: the reads set aside by the bit-sliced tiles, 64 at a time, one lane per read
-    u64* const SET_ASIDE = reinterpret_cast<u64*>(P + ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u));
-    auto roll_set_aside = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < n_set_aside) fallback_read_acc(SET_ASIDE[lane], fb_all);
-        n_set_aside = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     // one tile (or the final partial one) on the per-lane path; `mine`: this lane has a read
     auto fallback_read = [&](u64 read, bool mine) {
@@ -462,7 +427,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             w[it] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    constexpr int LATE = (PACKED || PASS != 0) ? 0 : NW == 10 ? (RAGGED ? KMX_BSR_LATE : K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2) : (RAGGED || K > 32) ? 0 : KMX_BS_LATE16;   // rows of the prefetch requested late
+    constexpr int LATE = PACKED ? 0 : NW == 10 ? (RAGGED ? KMX_BSR_LATE : K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2) : (RAGGED || K > 32) ? 0 : KMX_BS_LATE16;   // rows of the prefetch requested late
     u64 tile = ~0ull, next_tile = ~0ull;
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
@@ -498,21 +463,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u32 qid = (blockIdx.x & 255u) >> 3;
     u32 heads_left = NQ;                                // heads this wave has not yet seen exhausted
     auto dequeue = [&]() -> u64 {
-        if constexpr (PASS == 1) {   // the next flagged tile of this wave's groups of 64 flags
-            const u64 n_groups = (n_full + 63u) >> 6;
-            while (flag_bits == 0) {
-                if (flag_group >= n_groups) return ~0ull;
-                flag_base = flag_group * 64u;
-                const u64 t = flag_base + lane;
-                const bool flagged = t < n_full && tile_flags[t] != 0;
-                if (flagged) tile_flags[t] = 0;     // the array goes back to all-zero: the caller never clears it
-                flag_bits = __ballot(flagged);
-                flag_group += (u64)gridDim.x * 4u;
-            }
-            const u32 bit = (u32)__builtin_ctzll(flag_bits);
-            flag_bits &= flag_bits - 1ull;
-            return flag_base + bit;
-        }
         while (heads_left != 0u) {
             unsigned long long v = 0;
             if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);   // heads are 128 bytes apart
@@ -529,7 +479,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u32 pend = 0;            // (the low word: a head hands out fewer than 2^32 tickets -- launch_bs checks the tile count)
     u32 pend_qid = 0;
     auto ticket_issue = [&]() {
-        if constexpr (PASS == 1) return;   // (no tickets: dequeue() walks the flags)
         pend_qid = qid;
         if (heads_left != 0u && lane == 0) {
             unsigned long long one = 1ull;   // (made here: hoisted, the constant holds a register pair across the tile loop)
@@ -538,7 +487,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
     };
     auto ticket_take = [&]() -> u64 {
-        if constexpr (PASS == 1) return dequeue();
         if (heads_left == 0u) return ~0ull;
         const u32 lo = __builtin_amdgcn_readfirstlane(pend);
         const u64 t = (u64)lo * NQ + pend_qid;
@@ -597,22 +545,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         const u32 lane = ln_;
         u32 bad = 0;
         if constexpr (RAGGED) {      // the tile spans cur_m.n_ch chunks from its aligned start (neighbouring tiles' bytes at both ends)
-            if constexpr (PASS == 1) {   // second pass: also the bitmap of bad chunks (see the uniform branch below)
-                u64* BM = reinterpret_cast<u64*>(PL);
-#pragma unroll
-                for (int it = 0; it < NW; ++it) {
-                    const u32 c = it * 64u + lane;
-                    u32 rb = 0;
-                    const u32 code = encode16(w[it], rb);
-                    if (c < cur_m.n_ch) P[1u + c] = code;
-                    const bool cb = c < cur_m.n_ch && chunk_has_invalid(rb);
-                    const u64 row = __ballot(cb);
-                    if (lane == 0) BM[it] = row;
-                    bad |= cb ? 1u : 0u;
-                }
-                if (lane == 0) { BM[NW] = 0; BM[NW + 1] = 0; }
-                return __any(bad != 0u);
-            }
             if (KMX_BSR_VAL && cur_m.n_ch >= 64u * (NW - 1)) {   // wave-uniform: only the last row is partial (64 reads of 150: 600 or 601 chunks)
 #pragma unroll
                 for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
@@ -635,24 +567,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             return false;
         } else {
-        if constexpr (PASS == 1) {
-            // second pass: also a bitmap of the bad 16-byte chunks, one ballot per row, parked in the plane area (free between
-            // phase D of the last tile and phase C of this one)
-            u64* BM = reinterpret_cast<u64*>(PL);
-#pragma unroll
-            for (int it = 0; it < NW; ++it) {
-                const u32 c = it * 64u + lane;
-                u32 rb = 0;
-                const u32 code = encode16(w[it], rb);
-                if (c < chunks) P[1u + c] = code;
-                const bool cb = c < chunks && chunk_has_invalid(rb);
-                const u64 row = __ballot(cb);
-                if (lane == 0) BM[it] = row;
-                bad |= cb ? 1u : 0u;
-            }
-            if (lane == 0) { BM[NW] = 0; BM[NW + 1] = 0; }
-            return __any(bad != 0u);
-        }
         if (KMX_BS_PRIO && !(KMX_BS_ABLATE & 24) && chunks >= 64u * (NW - 1)) {
             // wave-uniform: only the last row of chunks is partial (L = 150: 600 = 9*64 + 24)
 #pragma unroll
@@ -703,7 +617,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             for (int g = 0; g < NW; ++g) F[g] = alignbit(R[g + 1], R[g], aF);
             if (KMX_BS_PRIO >= 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
         }
-        if constexpr (BLANKS) {
+        if constexpr (INLINE) {
             if (valid_reads != ~0ull) {
                 const bool blank = ((valid_reads >> lane) & 1ull) == 0ull;
 #pragma unroll
@@ -711,7 +625,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
         }
         if constexpr (RAGGED) {
-            const bool set_aside = BLANKS && ((valid_reads >> lane) & 1ull) == 0ull;   // a read with an invalid byte: rolled elsewhere
+            const bool set_aside = INLINE && ((valid_reads >> lane) & 1ull) == 0ull;   // a read with an invalid byte: rolled elsewhere
             const u32 len = (cur_m.len >= (u32)K && !set_aside) ? cur_m.len : 0u;   // a read shorter than k owns no window: it is blanked out entirely
             // bases past the end of the read belong to the next read.  KMX_BSR_VAL: they stay -- a window that holds one is masked
             // out of m by its validity plane, and the plane totals count a plane through the validity plane of its base (below)
@@ -949,7 +863,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         // ---- D. a lane handles the WPL windows o..o+WPL-1 of one set (o = WPL*group): they share the planes of
         //      bases o..o+K+WPL-2, streamed twice from LDS as u64 (2 planes per base):
         //      pass 1 = four interleaved fw<rc ripples, pass 2 = masked popcounts.
-        // `run` (wave-uniform) = false: a tile that is not scanned here (flagged for the second pass); with LATE > 0 the call
+        // `run` (wave-uniform) = false: a tile that is not scanned here (it rolled per lane); with LATE > 0 the call
         // is still made, for the ONE static site of the late prefetch rows between the passes (a second site in another
         // branch gets its own registers and is hoisted above the branch).
         // The launchers pick WPL so that the 2 * NG (set, group) items of a tile fit the 64 lanes: ONE round, always
@@ -1055,7 +969,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 } else {
                     m[w] = ((u32)w < nwin) ? lt[w] : 0u;
                 }
-                if constexpr (PASS == 1) m[w] &= set ? (u32)(valid_reads >> 32) : (u32)valid_reads;   // blanked reads own no window
             }
             if constexpr (INLINE) {
                 if (valid_reads != ~0ull) {   // (wave-uniform; a clean tile pays the branch)
@@ -1193,25 +1106,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         KMX_T(0)
 #endif
         bool bad_tile;
-        bool flagged = false;
-        // main pass: a tile with an invalid byte is flagged for the second pass.  Here, before the loads of the next tile go
-        // out, and with the stores waited for: a store still in flight at the loop head makes hipcc replace the counted
-        // waits of phase A (vmcnt(9), vmcnt(8), ...) by vmcnt(0) throughout, 1.8 % on clean input.
-        auto flag_tile = [&]() {
-            uint8_t* const flags = reinterpret_cast<uint8_t*>(queue[515]);
-            if (flags == nullptr) {
-                if constexpr (!RAGGED) __builtin_trap();   // (the host side always provides the flags)
-                return;
-            }
-            if (lane == 0) {
-                u32 one = 1u;   // (made here: hoisted out of the tile loop these constants each hold a register for good)
-                asm volatile("" : "+v"(one));
-                flags[tile] = (uint8_t)one;
-                queue[512] = one;
-            }
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (as an instruction the waitcnt pass sees, not inline asm)
-            flagged = true;
-        };
         // INLINE: which reads hold the invalid bytes?  The tile is still in w[]: its chunks' verdicts again, one ballot per row
         // (the bitmap parks in the plane area, free until phase C), every lane looks up the chunks of its read, and the reads'
         // mask goes to the array behind queue[515] for roll_flagged_kernel.  The tile is then scanned with those reads blanked.
@@ -1258,8 +1152,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             bad_tile = !cur_m.fits || phase_A();
             if constexpr (INLINE) {
                 if (bad_tile && cur_m.fits && blank_dirty_reads(cur_m.n_ch)) bad_tile = false;   // (tiles outside the frame roll as a whole)
-            } else if constexpr (PASS == 0 && DIRTY_LIST) {
-                if (bad_tile && cur_m.fits) flag_tile();   // (tiles outside the frame roll as a whole)
             }
             if constexpr (LATE > 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the uniform branch
             __builtin_amdgcn_sched_barrier(0);
@@ -1277,44 +1169,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             if constexpr (LATE > 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             if constexpr (INLINE) {
                 if (bad_tile && blank_dirty_reads(chunks)) bad_tile = false;
-            } else if constexpr (PASS == 0 && DIRTY_LIST) {
-                if (bad_tile) flag_tile();
             }
             prefetch(next_tile, tile, 0, NLD - LATE);
         }
         lds_fence();
         KMX_T(1)
-        if constexpr (PASS == 1) {
-            valid_reads = ~0ull;
-            bool have_bitmap = bad_tile;
-            if constexpr (RAGGED) have_bitmap = bad_tile && cur_m.fits;   // (a tile outside the frame was never packed: it rolls as a whole)
-            if (have_bitmap) {
-                // which reads?  a read is set aside if any chunk it touches is bad (a chunk shared by two reads sets both aside:
-                // they are rolled exactly anyway)
-                const u64* BM = reinterpret_cast<const u64*>(PL);
-                u32 rd_off = lane * L + lead, rd_len = L;    // the read's bytes, relative to the tile's aligned start
-                if constexpr (RAGGED) { rd_off = cur_m.rel; rd_len = cur_m.len; }
-                const u32 c0 = rd_off >> 4, c1 = rd_len ? (rd_off + rd_len - 1u) >> 4 : c0;
-                const u32 q0 = c0 >> 6, b0 = c0 & 63u;
-                const u64 lo = BM[q0], hi = BM[q0 + 1u];
-                const u64 bits = b0 ? ((lo >> b0) | (hi << (64u - b0))) : lo;
-                const bool dirty = rd_len != 0u && (bits & ((1ull << (c1 - c0 + 1u)) - 1ull)) != 0ull;
-                const u64 dm = __ballot(dirty);
-                const u32 nd = (u32)__builtin_popcountll(dm);
-                const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(dm >> 32), __builtin_amdgcn_mbcnt_lo((u32)dm, 0u));
-                if (n_set_aside + nd > 64u) roll_set_aside();
-                if (dirty) SET_ASIDE[n_set_aside + rank] = tile * 64u + lane;
-                n_set_aside += nd;
-                bad_tile = false;
-                valid_reads = ~dm;
-                n_blanked += nd;
-                lds_fence();
-            }
-        }
-        if (bad_tile) {
-            if constexpr (!(PASS == 0 && DIRTY_LIST && !RAGGED)) {   // (the uniform main pass never rolls a full tile itself)
-                if (!flagged) fallback_read(tile * 64u + lane, true);
-            }
+        if (bad_tile) {   // not blanked in place: packed input has no such tiles; a ragged tile outside the frame; KMX_BS_DIRTY = 0
+            if constexpr (!(DIRTY_LIST && !RAGGED)) fallback_read(tile * 64u + lane, true);   // (uniform ASCII reads never get here)
         }
         {
             const bool run = !bad_tile && !(KMX_BS_ABLATE & 32);
@@ -1346,11 +1207,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 
     // ---- final partial tile: per-lane rolling
     const u32 rem = (u32)(n_reads & 63u);
-    if (PASS == 0 && rem != 0u && wave_id == 0) fallback_read(n_full * 64u + lane, lane < rem);
-    if constexpr (PASS == 1) {
-        if (n_bs_tiles == 0) return;          // nothing flagged in this wave's share: no sums, no atomics
-        if (n_set_aside) roll_set_aside();
-    }
+    if (rem != 0u && wave_id == 0) fallback_read(n_full * 64u + lane, lane < rem);
 
     // ---- combine the bit-sliced counters into word-domain results (once per wave; wave-uniform branch)
     // Number of set bits of canonical bit (t,b) over all k-mers of the wave:
@@ -1601,21 +1458,12 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets, lead);
     if constexpr (!PACKED && bs_has_dirty_pass<K>()) {
-#if KMX_BS_INLINE_DIRTY
         // the reads the main pass blanked out (none on clean input: the waves return at once)
         u64 grid1 = (u64)n_cu * 4u;
         const u64 need1 = ((n_reads >> 6) + 255u) / 256u;   // a wave takes 64 masks at a time
         if (grid1 > need1) grid1 = need1;
         hipLaunchKernelGGL((roll_flagged_kernel<K, RAGGED>), dim3((unsigned)(grid1 ? grid1 : 1)), dim3(256), 0, stream, bases, n_reads, L, want_hash,
                            want_sumfw, out, queue, offsets, lead);
-#else
-        // second pass over the tiles the main pass flagged (none on clean input: a wave reads its share of the flags and returns)
-        auto kern1 = scan_bitsliced_kernel<K, NW, WPL, false, RAGGED, 1>;
-        u64 grid1 = (u64)n_cu * 2u;
-        if (grid1 > need) grid1 = need;
-        hipLaunchKernelGGL(kern1, dim3((unsigned)(grid1 ? grid1 : 1)), dim3(256), lds_bytes + 128u * 4u * 4u, stream, bases, n_reads, L, want_hash,
-                           want_sumfw, out, queue, offsets, lead);
-#endif
     }
     return hipGetLastError();
 }

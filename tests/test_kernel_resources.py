@@ -50,9 +50,9 @@ def test_headline_kernel_occupancy(kernels):
         hits = [d for n, d in kernels.items() if re.search(pattern, n)]
         assert len(hits) == 1, (pattern, len(hits))
         return int(hits[0]["Occupancy [waves/SIMD]"])
-    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0ELi0E") == 4
-    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb1ELi0E") == 3
-    assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb0ELi0E") == 3
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0EEEv") == 4
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb1EEEv") == 3
+    assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb0EEEv") == 3
 
 
 def test_scan_and_histogram_kernels_do_not_call(kernels):

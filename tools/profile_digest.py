@@ -56,10 +56,10 @@ for a, b in (("trace/t_kernel_stats.csv", "kernel_stats.csv"), ("trace_k21/t_ker
 out = [f"# Round {tag[1:]} -- rocprofv3 --kernel-trace --stats of `python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --sustain-steps 0` (MI355X, 1 GPU)",
        "", "Collected by `tools/profile_round.sh` on the committed build, condensed by `tools/profile_digest.py`.",
        f"Raw rocprofv3 stats tables: `{tag}_kernel_stats*.csv` (their averages mix the full-size launches with the small parity-check launch).", ""]
-for trace_dir, needle, label, bench in (("trace", "scan_bitsliced_kernel<31, 10, 4, false, false, 0>", "k=31 (the metric, BASELINE configs[1])", "bench_under_trace"),
-                                        ("trace_k21", "scan_bitsliced_kernel<21, 10, 5, false, false, 0>", "k=21 (configs[2])", "bench_k21_under_trace"),
-                                        ("trace_k63", "scan_bitsliced_kernel<63, 10, 3, false, false, 0>", "k=63 (configs[2], [u64;2])", "bench_k63_under_trace"),
-                                        ("trace_hash", "scan_bitsliced_kernel<31, 10, 4, false, false, 0>", "k=31 + LexHasher fold, 1.25e8 reads (configs[3])", "bench_hash_under_trace")):
+for trace_dir, needle, label, bench in (("trace", "scan_bitsliced_kernel<31, 10, 4, false, false", "k=31 (the metric, BASELINE configs[1])", "bench_under_trace"),
+                                        ("trace_k21", "scan_bitsliced_kernel<21, 10, 5, false, false", "k=21 (configs[2])", "bench_k21_under_trace"),
+                                        ("trace_k63", "scan_bitsliced_kernel<63, 10, 3, false, false", "k=63 (configs[2], [u64;2])", "bench_k63_under_trace"),
+                                        ("trace_hash", "scan_bitsliced_kernel<31, 10, 4, false, false", "k=31 + LexHasher fold, 1.25e8 reads (configs[3])", "bench_hash_under_trace")):
     st = full_launch_stats(trace_dir, needle)
     b = line(os.path.join(src, bench + ".json")) if os.path.exists(os.path.join(src, bench + ".json")) else None
     if st and b:
