@@ -58,6 +58,9 @@
 #ifndef KMX_BS_SWZ
 #define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
 #endif
+#ifndef KMX_BS_LATE7
+#define KMX_BS_LATE7 3    // late prefetch rows (of 7) of the 7-word frame (uniform ASCII reads of up to 112 bases)
+#endif
 #ifndef KMX_BS_LATE16
 #define KMX_BS_LATE16 8   // late prefetch rows (of 16) of the 16-word frame (uniform ASCII reads of 161..256 bases): 160 registers, no spills (168 with 10 spilled before)
 #endif
@@ -427,7 +430,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             w[it] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    constexpr int LATE = PACKED ? 0 : NW == 10 ? (RAGGED ? KMX_BSR_LATE : K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2) : (RAGGED || K > 32) ? 0 : KMX_BS_LATE16;   // rows of the prefetch requested late
+    constexpr int LATE = PACKED ? 0 : NW == 10 ? (RAGGED ? KMX_BSR_LATE : K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2)
+                         : NW < 10 ? ((RAGGED || K > 32) ? 0 : KMX_BS_LATE7) : (RAGGED || K > 32) ? 0 : KMX_BS_LATE16;   // rows of the prefetch requested late
     u64 tile = ~0ull, next_tile = ~0ull;
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
@@ -1475,6 +1479,15 @@ template <int K, bool PACKED>
 static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
                                 unsigned long long* queue, int n_cu, hipStream_t stream) {
     const u32 W = L - (u32)K + 1u;
+    if constexpr (!PACKED) {
+        // up to 112 bp (the 100 / 101 / 75 / 76 / 50 / 36 bp of older runs): the 7-word frame -- 7 instead of 10 transposes per
+        // half-wave, 28 instead of 40 prefetch registers, two thirds of the plane area (a read's extra chunk from an unaligned base must fit too)
+        const u32 mis = (reinterpret_cast<uintptr_t>(bases) & 15u) ? 1u : 0u;
+        if (4u * L + mis <= 64u * 7u) {
+            if (W <= 96u) return launch_bs<K, 7, 3, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+            return launch_bs<K, 7, 4, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        }
+    }
     if (L > 160) {   // 161..256 bp: the 16-word frame, as few windows per lane as keep the 2*ceil(W/WPL) items inside 64 lanes
         if constexpr (!PACKED) {
             if (W <= 160u) return launch_bs<K, 16, 5, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
