@@ -510,7 +510,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // (v_perm_b32 validation look-ups; v_dot4_u32_u8 packs + v_lshl_or_b32 merges) run as two raised-priority runs
     // (one asm statement each, so that nothing else is scheduled into them), the full-rate ones (v_and, v_xor,
     // v_bitop3, v_lshrrev) around them at base priority.
-    const u32 k55 = vgpr_const<0x55555555u>();
+    const u32 k55 = 0x55555555u;   // (a literal: an SGPR or literal source does not keep a full-rate instruction from pairing -- profiles/r02_valu_coissue_ubench9.txt)
     auto encode_prio = [&](const uint4& wv, u32& bad) -> u32 {
         constexpr u32 TBL_LO = 0x00430041u, TBL_HI = 0x00470054u, W4 = 0x40100401u;   // as in encode16
         u32 t0 = wv.x & 0x06060606u, t1 = wv.y & 0x06060606u, t2 = wv.z & 0x06060606u, t3 = wv.w & 0x06060606u;
@@ -623,13 +623,24 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
         if constexpr (INLINE) {
             if (valid_reads != ~0ull) {
-                const bool blank = ((valid_reads >> lane) & 1ull) == 0ull;
+                // (from an opaque copy of the lane id, made here: hipcc otherwise keeps 1 << lane and its complement, two
+                // 64-bit values, in registers across the tile loop for this rare branch)
+                u32 ln_o = lane;
+                asm volatile("" : "+v"(ln_o));
+                const bool blank = ((valid_reads >> ln_o) & 1ull) == 0ull;
 #pragma unroll
                 for (int g = 0; g < NW; ++g) F[g] = blank ? 0u : F[g];
             }
         }
         if constexpr (RAGGED) {
-            const bool set_aside = INLINE && ((valid_reads >> lane) & 1ull) == 0ull;   // a read with an invalid byte: rolled elsewhere
+            bool set_aside = false;   // a read with an invalid byte: rolled elsewhere
+            if constexpr (INLINE) {
+                if (valid_reads != ~0ull) {
+                    u32 ln_o = lane;   // (opaque copy: see above)
+                    asm volatile("" : "+v"(ln_o));
+                    set_aside = ((valid_reads >> ln_o) & 1ull) == 0ull;
+                }
+            }
             const u32 len = (cur_m.len >= (u32)K && !set_aside) ? cur_m.len : 0u;   // a read shorter than k owns no window: it is blanked out entirely
             // bases past the end of the read belong to the next read.  KMX_BSR_VAL: they stay -- a window that holds one is masked
             // out of m by its validity plane, and the plane totals count a plane through the validity plane of its base (below)
