@@ -57,6 +57,49 @@ def test_full_size_counts_linearity_and_prefix(ctx, orc, big, k):
     assert (gg.n_valid, gg.sum_canon, gg.xor_hash, gg.sum_fw) == (gf.n_valid, gf.sum_canon, gf.xor_hash, gf.sum_fw)
 
 
+@pytest.mark.parametrize("k", [31, 21])
+def test_full_size_half_a_percent_of_dirty_reads(ctx, orc, big, k):
+    """5e5 reads with an N (27 % of the tiles hold one): the reads are blanked out of their tiles in the main pass and rolled by
+    roll_flagged_kernel.  Window accounting, shard linearity with the dirt in, the ragged kernel on the same bytes, an
+    oracle-checked prefix, and the array of masks back to all-zero (a second call gives the same)."""
+    import torch
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(k)
+    nd = N_FULL // 200
+    reads = rng.choice(N_FULL, size=nd, replace=False)
+    offs = rng.integers(0, L, size=nd)
+    idx = torch.from_numpy((reads.astype(np.int64) * L + offs)).to(big.device)
+    saved = big[idx].clone()
+    big[idx] = ord("N")
+    try:
+        whole = ctx.canonical_reduce(big, N_FULL, L, k, _lib.HASH_LEX, k, 0)
+        p = offs.astype(np.int64)
+        killed = int((np.minimum(p, L - k) - np.maximum(0, p - k + 1) + 1).sum())
+        assert whole.n_valid == N_FULL * (L - k + 1) - killed
+        again = ctx.canonical_reduce(big, N_FULL, L, k, _lib.HASH_LEX, k, 0)
+        assert (again.n_valid, again.sum_canon, again.xor_hash) == (whole.n_valid, whole.sum_canon, whole.xor_hash)
+        cuts = [0, N_FULL // 4 + 3, N_FULL // 2 + 64 * 5 + 1, N_FULL]
+        n = s = x = 0
+        for a, b in zip(cuts, cuts[1:]):
+            part = ctx.canonical_reduce(big[a * L:b * L], b - a, L, k, _lib.HASH_LEX, k, 0)
+            n += part.n_valid
+            s = (s + part.sum_canon) & M64
+            x ^= part.xor_hash
+        assert (n, s, x) == (whole.n_valid, whole.sum_canon, whole.xor_hash)
+        n_mid = min(N_FULL, 20_000_000)   # the ragged kernel (its own blanking path) on the same bytes
+        off = ctx.to_device(np.arange(n_mid + 1, dtype=np.uint64) * np.uint64(L))
+        gr = ctx.canonical_reduce(big[: n_mid * L], n_mid, L, k, _lib.HASH_LEX, k, 0, offsets=off)
+        gu = ctx.canonical_reduce(big[: n_mid * L], n_mid, L, k, _lib.HASH_LEX, k, 0)
+        assert (gr.n_valid, gr.sum_canon, gr.xor_hash) == (gu.n_valid, gu.sum_canon, gu.xor_hash)
+        n_chk = min(N_FULL, 1_000_000)
+        o = orc.canonical_reduce(big[: n_chk * L].cpu().numpy(), n_chk, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(big[: n_chk * L], n_chk, L, k, _lib.HASH_LEX, k, 0)
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+    finally:
+        big[idx] = saved
+
+
 def test_full_size_invalid_byte_accounting(ctx, big):
     """an 'N' at read offset p kills exactly min(p, L-k) - max(0, p-k+1) + 1 windows of that read"""
     import torch
@@ -136,6 +179,21 @@ def test_full_size_three_paths_agree(ctx, big, k):
     p = ctx.seqvec_canonical_reduce(words, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
     assert (p.n_valid, p.sum_canon, p.xor_hash, p.sum_fw) == (a.n_valid, a.sum_canon, a.xor_hash, a.sum_fw)
     assert ctx.seqvec_to_bytes(words, 4096).cpu().numpy().tobytes() == view[:4096].cpu().numpy().tobytes()
+
+
+def test_full_size_ragged_histogram_matches_uniform(ctx, big):
+    """2^20 buckets: the partitioned histogram through the offsets layout (batched and per-window slot paths) counts what the
+    uniform layout counts, bucket by bucket"""
+    import torch
+
+    n = min(N_FULL, 30_000_000)
+    k, b = 31, 20
+    off = ctx.to_device(np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    hu = ctx.histogram(big[: n * L], n, L, k, 1, k, b)
+    hr = ctx.histogram(big[: n * L], n, L, k, 1, k, b, offsets=off)
+    hr0 = ctx.histogram(big[: n * L], n, 0, k, 1, k, b, offsets=off)
+    assert int(hu.sum().item()) == n * (L - k + 1)
+    assert torch.equal(hu, hr) and torch.equal(hu, hr0)
 
 
 @pytest.mark.parametrize("b", [12, 20])

@@ -1,1 +1,1 @@
-bash tools/variants.sh default prev
+python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | tail -4
