@@ -1,1 +1,1 @@
-python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | tail -4
+python -m pytest tests/test_gpu_round2.py -x -q -m gpu -k "aligned" 2>&1 | tail -3
