@@ -1495,6 +1495,7 @@ static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
         // half-wave, 28 instead of 40 prefetch registers, two thirds of the plane area (a read's extra chunk from an unaligned base must fit too)
         const u32 mis = (reinterpret_cast<uintptr_t>(bases) & 15u) ? 1u : 0u;
         if (4u * L + mis <= 64u * 7u) {
+            if (W <= 64u) return launch_bs<K, 7, 2, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
             if (W <= 96u) return launch_bs<K, 7, 3, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
             return launch_bs<K, 7, 4, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
         }

@@ -1,6 +1,4 @@
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print({k:d[k] for k in ('metric','value','unit','n_gpus','steps','ms_per_step','dtype','parity_vs_oracle')})
-print(d['roofline']); print(d['cpu_baseline']); print(d.get('sustained'))"
+python -m pytest tests -x -q -m gpu -k "uniform_lengths or aligned or dirty or blanked" 2>&1 | tail -2
+for spec in "75 200000000" "50 300000000" "64 230000000"; do set -- $spec
+  python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len $1 --reads-per-gpu $2 2>/dev/null | python3 tools/bench_line.py "L=$1"; done
+python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len 50 --reads-per-gpu 300000000 -k 21 2>/dev/null | python3 tools/bench_line.py "L=50 k=21"
