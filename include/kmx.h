@@ -288,6 +288,12 @@ int kmx_seqvec_minimizers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_read
 #define KMX_FASTX_FASTA 2
 int kmx_fastx_parse(kmx_ctx *ctx, const uint8_t *d_text, uint64_t n_bytes, uint32_t format, uint8_t *d_bases,
                     uint64_t *d_offsets, uint64_t max_reads, uint64_t *h_n_reads, uint64_t *h_n_bases);
+/* The longest and the shortest read of a ragged batch (d_offsets: n_reads+1 device u64, as kmx_fastx_parse writes them):
+ * what kmx_reads.read_len wants as its bound for ragged input (the tiled kernels size their frame and the windows per
+ * lane from it; a tight bound is up to 7 % faster than none), and whether the batch is uniform after all (min == max:
+ * hand it over with d_offsets = NULL, or pack it with kmx_seqvec_push_chars).  Lengths of 2^32 or more come back as
+ * UINT32_MAX.  BUILD-DEFINED helper; synchronises the context's stream (the two values come back to the host). */
+int kmx_reads_length_range(kmx_ctx *ctx, const uint64_t *d_offsets, uint64_t n_reads, uint32_t *h_min_len, uint32_t *h_max_len);
 
 /* ---------------------------------------------------------------- multi-GPU exchange ----
  * The reference has no distributed code; reads shard embarrassingly (k-mers never span reads,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "kmx_histogram_allreduce": (_int, [_vp, _vp, _u64]),
     "kmx_summary_allreduce": (_int, [_vp, _vp]),
     "kmx_calib_stream_read": (_int, [_vp, _vp, _u64, _vp]),
+    "kmx_reads_length_range": (_int, [_vp, _vp, _u64, _vp, _vp]),
 }
 
 FASTX_AUTO, FASTX_FASTQ, FASTX_FASTA = 0, 1, 2

@@ -334,6 +334,14 @@ class Context:
         return bases[:nb.value], offsets
 
     @_on_ctx_stream
+    def reads_length_range(self, offsets: torch.Tensor) -> tuple[int, int]:
+        """kmx_reads_length_range: (shortest, longest) read of a ragged batch (offsets: int64[n_reads+1] on the device)"""
+        n = int(offsets.numel()) - 1
+        mn, mx = C.c_uint32(0), C.c_uint32(0)
+        self._ck(self.lib.kmx_reads_length_range(self._h, _ptr(offsets) if n > 0 else None, max(n, 0), C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
+
+    @_on_ctx_stream
     def encoding_decode(self, words: torch.Tensor, enc_byte: int, words_per_kmer: int) -> torch.Tensor:
         n = words.numel() // words_per_kmer
         out = self.empty(n * 32 * words_per_kmer, torch.uint8)

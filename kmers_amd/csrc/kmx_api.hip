@@ -86,6 +86,7 @@ hipError_t launch_encode_kmers_bytes(const uint8_t* seqs, u64 n, u32 seq_len, u3
 hipError_t launch_encoding_rev_comp_bytes(const uint8_t* in, u64 n, u32 K, u32 comp_lut, u32 nb, uint8_t* out, int n_cu, hipStream_t st);
 hipError_t launch_encoding_decode_bytes(const uint8_t* in, u64 total_bytes, u32 nuc_lut, uint8_t* seqs, int n_cu, hipStream_t st);
 hipError_t launch_calib_stream_read(const uint8_t* buf, u64 nbytes, unsigned long long* out, int n_cu, hipStream_t st);
+hipError_t launch_length_range(const u64* offsets, u64 n_reads, u32* out, int n_cu, hipStream_t st);
 hipError_t launch_fix_hash_fold(kmx_summary* out, u32 k, u32 hasher, u32 hk, hipStream_t st);
 }  // namespace kmx
 
@@ -849,6 +850,24 @@ int kmx_fastx_parse(kmx_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, uint3
     }
     KMX_HIP(ctx, kmx::launch_fastx_emit(d_text, n_bytes, fasta, scratch, d_totals, d_bases, d_offsets, ctx->stream));
     KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_reads_length_range(kmx_ctx* ctx, const uint64_t* d_offsets, uint64_t n_reads, uint32_t* h_min_len, uint32_t* h_max_len) {
+    if (!ctx || (n_reads && !d_offsets)) return KMX_E_ARG;
+    if (h_min_len) *h_min_len = 0;
+    if (h_max_len) *h_max_len = 0;
+    if (n_reads == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    uint32_t* d_out = reinterpret_cast<uint32_t*>(ctx->d_scratch + 4);   // (d_scratch[4]: free between calls)
+    const uint32_t init[2] = {0xFFFFFFFFu, 0u};
+    uint32_t got[2] = {0, 0};
+    KMX_HIP(ctx, hipMemcpyAsync(d_out, init, 8, hipMemcpyHostToDevice, ctx->stream));
+    KMX_HIP(ctx, kmx::launch_length_range(d_offsets, n_reads, d_out, ctx->n_cu, ctx->stream));
+    KMX_HIP(ctx, hipMemcpyAsync(got, d_out, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_min_len) *h_min_len = got[0];
+    if (h_max_len) *h_max_len = got[1];
     return KMX_OK;
 }
 

@@ -444,4 +444,28 @@ hipError_t launch_calib_stream_read(const uint8_t* buf, u64 nbytes, unsigned lon
     return hipGetLastError();
 }
 
+// min / max of offsets[r+1] - offsets[r] (clamped to 32 bits) into out[0] / out[1] (preset to ~0 / 0 by the caller)
+__global__ void __launch_bounds__(256) length_range_kernel(const u64* __restrict__ offsets, u64 n_reads, u32* __restrict__ out) {
+    u32 mn = 0xFFFFFFFFu, mx = 0u;
+    for (u64 r = (u64)blockIdx.x * 256u + threadIdx.x; r < n_reads; r += (u64)gridDim.x * 256u) {
+        const u64 d = offsets[r + 1u] - offsets[r];
+        const u32 len = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)d;
+        mn = len < mn ? len : mn;
+        mx = len > mx ? len : mx;
+    }
+    mx = wave_max_u32(mx);
+    mn = ~wave_max_u32(~mn);
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicMin(&out[0], mn);
+        atomicMax(&out[1], mx);
+    }
+}
+
+hipError_t launch_length_range(const u64* offsets, u64 n_reads, u32* out, int n_cu, hipStream_t st) {
+    u64 grid = (n_reads + 255u) / 256u;
+    if (grid > (u64)n_cu * 8u) grid = (u64)n_cu * 8u;
+    hipLaunchKernelGGL(length_range_kernel, dim3((unsigned)(grid ? grid : 1)), dim3(256), 0, st, offsets, n_reads, out);
+    return hipGetLastError();
+}
+
 }  // namespace kmx

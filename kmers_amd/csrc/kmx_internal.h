@@ -13,7 +13,7 @@ struct kmx_ctx {
     hipStream_t stream;
     bool owns_stream;
     int n_cu;
-    unsigned long long* d_scratch;  // 8 KiB: [0] first_bad, [2..3] fastx totals, [16..] tile-queue heads
+    unsigned long long* d_scratch;  // 8 KiB: [0] first_bad, [2..3] fastx totals, [4] length range, [16..] tile-queue heads
     void* d_big;                    // grow-only work buffer of the partitioned histogram (bucket-id streams)
     size_t big_bytes;
     unsigned long long dirty_desc;  // address of the dirty-tile flags as last written behind the queue heads

@@ -422,6 +422,21 @@ def test_long_uniform_reads_take_the_segmented_bitsliced_path(ctx, orc, k, L, n)
 # ------------------------------------------------------------------ bench.py, N > 1 control flow on one GPU
 
 @pytest.mark.gpu
+def test_reads_length_range(ctx):
+    """kmx_reads_length_range: the bound kmx_reads.read_len wants for ragged input"""
+    rng = np.random.default_rng(3)
+    lens = rng.integers(37, 152, size=100_003)
+    lens[77] = 7
+    lens[99_999] = 301
+    off = ctx.to_device(np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64))
+    assert ctx.reads_length_range(off) == (7, 301)
+    assert ctx.reads_length_range(ctx.to_device(np.arange(1001, dtype=np.uint64) * np.uint64(150))) == (150, 150)
+    assert ctx.reads_length_range(ctx.to_device(np.zeros(1, dtype=np.uint64))) == (0, 0)
+    big = np.array([0, 5, 5 + (1 << 33)], dtype=np.uint64)        # a length past 32 bits saturates
+    assert ctx.reads_length_range(ctx.to_device(big)) == (5, 0xFFFFFFFF)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,L", [(31, 150), (21, 150), (13, 100), (47, 150), (64, 150), (31, 159)])
 @pytest.mark.parametrize("layout", ["uniform", "offsets"])
 def test_blanked_reads_in_every_position(ctx, orc, k, L, layout):
