@@ -212,7 +212,7 @@ def measure_traffic(argv, log=sys.stderr):
                     if row["Counter_Name"] != ctr:
                         continue
                     name = row["Kernel_Name"]
-                    key = "calib" if "calib_stream_read_kernel" in name else ("scan" if ("scan_" in name or "reduce" in name or "hist" in name) else None)
+                    key = "calib" if "calib_stream_read_kernel" in name else ("scan" if ("scan_" in name or "reduce" in name or "hist" in name or "roll_flagged" in name) else None)
                     if key:
                         per.setdefault(key, {}).setdefault(name, []).append(float(row["Counter_Value"]))
             res[ctr] = per
@@ -225,7 +225,7 @@ def measure_traffic(argv, log=sys.stderr):
 
 def traffic_from_counters(res, algo_read_bytes, n_step_launch_sets):
     """counter csv digest -> bytes per step.  Counter values are KiB.  All kernels of a step are summed
-    (main pass + second pass of the bit-sliced scan; the passes of the partitioned histogram)."""
+    (the bit-sliced scan + the kernel that rolls the reads it blanked out; the passes of the partitioned histogram)."""
     fetch, write = res["FETCH_SIZE"], res["WRITE_SIZE"]
     if "calib" not in fetch or "scan" not in fetch:
         return None
@@ -565,7 +565,7 @@ def worker(args, traffic_raw=None, traffic_err=None):
         if hist_mode:
             kernel_name = "kmx::scan_uniform_kernel<SinkHist*> (partition pass + per-partition tables)"
         elif bs_kernel:
-            kernel_name = "kmx::scan_bitsliced_kernel<%d,%d,*>" % (k, 10 if L <= 160 else 16)
+            kernel_name = "kmx::scan_bitsliced_kernel<%d,%d,*>" % (k, 7 if (L <= 112 and k <= 32) else 10 if L <= 160 else 16)
         else:
             kernel_name = "kmx::scan_uniform_kernel" if k <= 31 else "kmx::reduce2_generic_kernel"
         cfg_names = {"1": "BASELINE configs[1]", "2": "BASELINE configs[2]", "3": "BASELINE configs[3]", "4": "BASELINE configs[4]"}
