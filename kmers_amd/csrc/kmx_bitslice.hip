@@ -100,8 +100,12 @@ hipError_t launch_scan_bitsliced_long(const uint8_t* bases, u64 n_reads, u32 L, 
                                       unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
     if (L <= 256 || k < 13 || k > 31 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
-    const u32 T = 161u - k, Lf = 160u;
-    const u64 J = ((u64)L - k + T) / T;             // segments per read
+    // as few segments as fit the 160-base frame, all of (nearly) the same size: windows per segment T = ceil(W / J) -- a
+    // 300-base read is three segments of 90 windows (3 windows per lane), not 130 + 130 + 10 (4 per lane, the third tile idle)
+    const u32 Tmax = 161u - k, W = L - k + 1u;
+    const u32 J0 = (W + Tmax - 1u) / Tmax;
+    const u32 T = (W + J0 - 1u) / J0, Lf = T + k - 1u;
+    const u64 J = ((u64)W + T - 1u) / T;            // segments per read (as the kernel derives it from T)
     if (n_reads > (1ull << 40) / J || n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
     const u64 n_seg = n_reads * J;
 #define KMX_BSL_CASE(K) \

@@ -1,4 +1,3 @@
-for v in default p2t1024 p2t256 default p2t1024; do
-  if [ "$v" == "default" ]; then unset KMX_LIB_VARIANT; else export KMX_LIB_VARIANT=$v; fi
-  python bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --sustain-steps 0 2>/dev/null | python tools/bench_line.py "[$v]"
-done
+python -m pytest tests -x -q -m gpu -k "long or segment" 2>&1 | tail -2
+for spec in "300 50000000" "400 37000000" "257 58000000" "1000 15000000" "10000 1500000"; do set -- $spec
+  python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len $1 --reads-per-gpu $2 2>/dev/null | python3 tools/bench_line.py "L=$1"; done
