@@ -59,7 +59,7 @@
 #define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
 #endif
 #ifndef KMX_BS_LATE7
-#define KMX_BS_LATE7 3    // late prefetch rows (of 7) of the 7-word frame (uniform ASCII reads of up to 112 bases)
+#define KMX_BS_LATE7 3    // late prefetch rows (of 7) of the 7-word frame (ASCII reads of up to 112 bases, uniform or ragged)
 #endif
 #ifndef KMX_BS_LATE16
 #define KMX_BS_LATE16 8   // late prefetch rows (of 16) of the 16-word frame (uniform ASCII reads of 161..256 bases): 160 registers, no spills (168 with 10 spilled before)
@@ -431,7 +431,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
     };
     constexpr int LATE = PACKED ? 0 : NW == 10 ? (RAGGED ? KMX_BSR_LATE : K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2)
-                         : NW < 10 ? ((RAGGED || K > 32) ? 0 : KMX_BS_LATE7) : (RAGGED || K > 32) ? 0 : KMX_BS_LATE16;   // rows of the prefetch requested late
+                         : NW < 10 ? (K > 32 ? 0 : KMX_BS_LATE7) : (RAGGED || K > 32) ? 0 : KMX_BS_LATE16;   // rows of the prefetch requested late
     u64 tile = ~0ull, next_tile = ~0ull;
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
@@ -1545,6 +1545,10 @@ static hipError_t launch_bs_ragged_any(const uint8_t* bases, const u64* offsets,
         if (W <= 192u) return launch_bs<K, 16, 6, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
         if (W <= 224u) return launch_bs<K, 16, 7, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
         return launch_bs<K, 16, 8, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+    }
+    if (Lf <= 111u && Lf >= (u32)K) {   // short reads (a tile of 64 spans at most 448 chunks): the 7-word frame
+        if (W <= 96u) return launch_bs<K, 7, 3, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+        return launch_bs<K, 7, 4, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
     }
     if (W <= 96u) return launch_bs<K, 10, 3, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
     if (W <= 128u) return launch_bs<K, 10, 4, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);

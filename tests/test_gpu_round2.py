@@ -422,6 +422,27 @@ def test_long_uniform_reads_take_the_segmented_bitsliced_path(ctx, orc, k, L, n)
 # ------------------------------------------------------------------ bench.py, N > 1 control flow on one GPU
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", [13, 21, 31])
+@pytest.mark.parametrize("hint", [100, 111, 64, 40])
+def test_short_ragged_reads_on_the_7_word_frame(ctx, orc, k, hint):
+    """ragged reads with a length bound of at most 111: the 7-word frame of the bit-sliced kernel; reads longer than the bound
+    (the hint is only a hint), shorter than k, empty, dirty"""
+    from kmers_amd import _lib
+    rng = np.random.default_rng(k * 100 + hint)
+    n = 64 * 40 + 13
+    lens = rng.integers(0, min(hint, 100) + 1, size=n)
+    lens[::131] = hint + 9          # past the bound: the tile must still come out right
+    lens[7::257] = 0
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]) + 16, 0.002)[: int(offsets[-1])]
+    d_host, d_off = ctx.to_device(host), ctx.to_device(offsets)
+    o = orc.canonical_reduce(host, n, 0, k, hasher_k=k, offsets=offsets)
+    for _ in range(2):
+        g = ctx.canonical_reduce(d_host, n, hint, k, _lib.HASH_LEX, k, 0, offsets=d_off)
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+
+
+@pytest.mark.gpu
 def test_reads_length_range(ctx):
     """kmx_reads_length_range: the bound kmx_reads.read_len wants for ragged input"""
     rng = np.random.default_rng(3)

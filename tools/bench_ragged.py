@@ -11,7 +11,9 @@ rng = np.random.default_rng(1)
 for name, lens, hint in (("all 150 (hint 160)", np.full(n, 150), 160), ("all 150 (hint 150)", np.full(n, 150), 150), ("all 150 (no hint)", np.full(n, 150), 0),
                          ("150 with 2% trimmed to 36..149 (hint 150)", np.where(rng.random(n) < 0.02, rng.integers(36, 150, n), 150), 150),
                          ("uniform 100..160 (hint 160)", rng.integers(100, 161, n), 160),
-                         ("150 with 2% trimmed to 36..149 (hint 160)", np.where(rng.random(n) < 0.02, rng.integers(36, 150, n), 150), 160)):
+                         ("150 with 2% trimmed to 36..149 (hint 160)", np.where(rng.random(n) < 0.02, rng.integers(36, 150, n), 150), 160),
+                         ("all 100 (hint 100)", np.full(n, 100), 100), ("uniform 50..100 (hint 100)", rng.integers(50, 101, n), 100),
+                         ("uniform 50..100 (hint 160)", rng.integers(50, 101, n), 160)):
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     total = int(offsets[-1])
     bases = ctx.gen_reads(total)
