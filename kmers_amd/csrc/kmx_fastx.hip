@@ -261,10 +261,13 @@ fastx_summarise_kernel(const uint8_t* __restrict__ text, u64 n, u32* __restrict_
     __syncthreads();
     u32 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u32 state = 0;     // FASTQ: newlines so far in the chunk; FASTA: type of the current line (T_NONE: as entered)
+    // (the next row's 64 bytes are requested before this row is analysed: one HBM round trip per row hidden)
+    Lane64 d_next = c0 < n ? load_lane(text, n, c0 + threadIdx.x * FX_LANE) : Lane64{};
     for (u32 row = 0; row < FX_ROWS; ++row) {
         const u64 p = c0 + (u64)row * FX_ROW + threadIdx.x * FX_LANE;
         if (c0 + (u64)row * FX_ROW >= n) break;
-        const Lane64 d = load_lane(text, n, p);
+        const Lane64 d = d_next;
+        if (row + 1u < FX_ROWS && c0 + (u64)(row + 1u) * FX_ROW < n) d_next = load_lane(text, n, p + FX_ROW);
         if constexpr (!FASTA) {
             const FqLane a = fq_analyse(d);
             const u32 nl = pc64(a.nl);
@@ -394,10 +397,13 @@ fastx_emit_kernel(const uint8_t* __restrict__ text, u64 n, const u64* __restrict
     u32 state = (u32)pf[0];
     u64 out_pos = pf[1], rec = pf[2];
     if (chunk == 0 && threadIdx.x == 0 && FASTA) offsets[0] = 0;     // record 0 (see fastx_scan_kernel)
+    // (the next row's 64 bytes are requested before this row is analysed: one HBM round trip per row hidden)
+    Lane64 d_next = c0 < n ? load_lane(text, n, c0 + threadIdx.x * FX_LANE) : Lane64{};
     for (u32 row = 0; row < FX_ROWS; ++row) {
         const u64 p = c0 + (u64)row * FX_ROW + threadIdx.x * FX_LANE;
         if (c0 + (u64)row * FX_ROW >= n) break;
-        const Lane64 d = load_lane(text, n, p);
+        const Lane64 d = d_next;
+        if (row + 1u < FX_ROWS && c0 + (u64)(row + 1u) * FX_ROW < n) d_next = load_lane(text, n, p + FX_ROW);
         u64 ks, rs;       // bytes to emit; newlines after which a read begins
         u32 tot;
         if constexpr (!FASTA) {
