@@ -1,1 +1,1 @@
-python -m pytest tests -x -q -m gpu -k "fastx" 2>&1 | tail -2; python tools/bench_fastx.py 2>/dev/null
+KMX_FUZZ_N=3000 python -m pytest tests/test_gpu_fuzz.py -q -m gpu 2>&1 | tail -15
