@@ -286,6 +286,11 @@ int kmx_seqvec_minimizers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_read
 #define KMX_FASTX_AUTO 0
 #define KMX_FASTX_FASTQ 1
 #define KMX_FASTX_FASTA 2
+/* OR-ed into `format` on the second call of the usual pair (counts first, then the emit into buffers of exactly that
+ * size): "d_text / n_bytes are the image the previous kmx_fastx_parse call on this context counted, unchanged, and no
+ * kmx_histogram call came in between" -- the emit then reuses the chunk summaries of the counting call instead of
+ * reading the text a third time (the pair: 1.06 -> 1.4 TB/s of text).  Ignored when the context has nothing to reuse. */
+#define KMX_FASTX_SAME_TEXT 0x100u
 int kmx_fastx_parse(kmx_ctx *ctx, const uint8_t *d_text, uint64_t n_bytes, uint32_t format, uint8_t *d_bases,
                     uint64_t *d_offsets, uint64_t max_reads, uint64_t *h_n_reads, uint64_t *h_n_bases);
 /* The longest and the shortest read of a ragged batch (d_offsets: n_reads+1 device u64, as kmx_fastx_parse writes them):

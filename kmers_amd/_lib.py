@@ -104,6 +104,7 @@ SIGNATURES = {
 }
 
 FASTX_AUTO, FASTX_FASTQ, FASTX_FASTA = 0, 1, 2
+FASTX_SAME_TEXT = 0x100   # or-ed into the format of the emit call that follows the counting call on the same image
 
 _LIB = None
 

@@ -329,8 +329,9 @@ class Context:
         self._ck(self.lib.kmx_fastx_parse(self._h, _ptr(text) if n else None, n, fmt, None, None, 0, C.byref(nr), C.byref(nb)))
         bases = self.empty(max(nb.value, 1), torch.uint8)
         offsets = self.empty(nr.value + 1, torch.int64)
-        self._ck(self.lib.kmx_fastx_parse(self._h, _ptr(text) if n else None, n, fmt, _ptr(bases), _ptr(offsets), nr.value,
-                                          C.byref(nr), C.byref(nb)))
+        # (KMX_FASTX_SAME_TEXT: the emit reuses the chunk summaries of the counting call just made on the same image)
+        self._ck(self.lib.kmx_fastx_parse(self._h, _ptr(text) if n else None, n, fmt | _lib.FASTX_SAME_TEXT, _ptr(bases), _ptr(offsets),
+                                          nr.value, C.byref(nr), C.byref(nb)))
         return bases[:nb.value], offsets
 
     @_on_ctx_stream

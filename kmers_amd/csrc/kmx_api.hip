@@ -153,6 +153,7 @@ int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k) {
 void* big_scratch(void* user, size_t bytes) {
     kmx_ctx* ctx = static_cast<kmx_ctx*>(user);
     if (bytes <= ctx->big_bytes) return ctx->d_big;
+    ctx->fx_valid = false;   // (the buffer moves: the fastx chunk prefixes in it are gone)
     if (ctx->d_big) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(ctx->d_big);
@@ -461,6 +462,7 @@ int kmx_histogram(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t has
     if (hasher == KMX_HASH_LEX && (hasher_k < 1 || hasher_k > 32)) return KMX_E_K_RANGE;
     if (reads->n_reads == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
+    ctx->fx_valid = false;   // (the partitioned histogram writes its id streams over the work buffer)
     {
         bool handled = false;
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
@@ -812,6 +814,8 @@ int kmx_seqvec_minimizers(kmx_ctx* ctx, const uint64_t* d_words, uint64_t n_read
 
 int kmx_fastx_parse(kmx_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, uint32_t format, uint8_t* d_bases,
                     uint64_t* d_offsets, uint64_t max_reads, uint64_t* h_n_reads, uint64_t* h_n_bases) {
+    const bool same_text = (format & KMX_FASTX_SAME_TEXT) != 0u;
+    format &= ~KMX_FASTX_SAME_TEXT;
     if (!ctx || format > KMX_FASTX_FASTA || (n_bytes && !d_text) || (!d_bases != !d_offsets)) return KMX_E_ARG;
     if (reinterpret_cast<uintptr_t>(d_text) & 15u) return KMX_E_ARG;
     if (h_n_reads) *h_n_reads = 0;
@@ -836,10 +840,24 @@ int kmx_fastx_parse(kmx_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, uint3
     void* scratch = big_scratch(ctx, kmx::fastx_scratch_bytes(n_bytes));
     if (!scratch) return KMX_E_NOMEM;
     unsigned long long* d_totals = ctx->d_scratch + 2;
-    KMX_HIP(ctx, kmx::launch_fastx_count(d_text, n_bytes, fasta, scratch, d_totals, ctx->stream));
     unsigned long long totals[2] = {0, 0};
-    KMX_HIP(ctx, hipMemcpyAsync(totals, d_totals, 16, hipMemcpyDeviceToHost, ctx->stream));
-    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (same_text && ctx->fx_valid && ctx->fx_text == d_text && ctx->fx_bytes == n_bytes && ctx->fx_fasta == (fasta ? 1u : 0u) &&
+        scratch == ctx->d_big) {
+        // the chunk prefixes of the counting call are still in the work buffer, its totals in d_scratch[2..3]
+        totals[0] = ctx->fx_totals[0];
+        totals[1] = ctx->fx_totals[1];
+    } else {
+        ctx->fx_valid = false;
+        KMX_HIP(ctx, kmx::launch_fastx_count(d_text, n_bytes, fasta, scratch, d_totals, ctx->stream));
+        KMX_HIP(ctx, hipMemcpyAsync(totals, d_totals, 16, hipMemcpyDeviceToHost, ctx->stream));
+        KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->fx_text = d_text;
+        ctx->fx_bytes = n_bytes;
+        ctx->fx_fasta = fasta ? 1u : 0u;
+        ctx->fx_totals[0] = totals[0];
+        ctx->fx_totals[1] = totals[1];
+        ctx->fx_valid = true;
+    }
     if (h_n_reads) *h_n_reads = totals[0];
     if (h_n_bases) *h_n_bases = totals[1];
     if (!d_bases) return KMX_OK;

@@ -19,6 +19,13 @@ struct kmx_ctx {
     unsigned long long dirty_desc;  // address of the dirty-tile flags as last written behind the queue heads
     uint8_t* d_flags;               // one byte per tile, all zero between calls
     size_t flags_bytes;
+    // kmx_fastx_parse: what the last counting pass was run on -- a second call on the same image with KMX_FASTX_SAME_TEXT
+    // reuses its chunk prefixes (they live in d_big) instead of summarising the text again
+    const uint8_t* fx_text;
+    uint64_t fx_bytes;
+    uint32_t fx_fasta;
+    bool fx_valid;
+    unsigned long long fx_totals[2];
     char last_error[256];
 };
 

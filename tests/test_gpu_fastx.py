@@ -87,3 +87,46 @@ def test_file_image_to_summary(ctx, orc, k):
     g = ctx.canonical_reduce(bases, n, 160, k, _lib.HASH_LEX, k, 0, offsets=offsets)
     o = orc.canonical_reduce(eb, n, 0, k, hasher_k=k, offsets=eo)
     assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+
+
+def test_same_text_flag_only_reuses_what_it_may(ctx, orc):
+    """KMX_FASTX_SAME_TEXT on the emit call reuses the counting call's chunk summaries; another image, another size, a
+    histogram call in between (it overwrites the work buffer) or no counting call at all must fall back to a full parse"""
+    import ctypes as C
+
+    import torch
+
+    from kmers_amd import _lib
+    from kmers_amd.api import _ptr, u64_numpy
+
+    rng = np.random.default_rng(77)
+    ta, tb = fastq_text(rng, 3000, 20, 200), fastq_text(rng, 2500, 30, 180)
+    da, db = ctx.to_device(ta), ctx.to_device(tb)
+
+    def count(d):
+        nr, nb = C.c_uint64(0), C.c_uint64(0)
+        ctx._ck(ctx.lib.kmx_fastx_parse(ctx._h, _ptr(d), d.numel(), 0, None, None, 0, C.byref(nr), C.byref(nb)))
+        return nr.value, nb.value
+
+    def emit(d, n_bytes, nr, nb, flag):
+        bases, offsets = ctx.empty(max(nb, 1), torch.uint8), ctx.empty(nr + 1, torch.int64)
+        r, b = C.c_uint64(0), C.c_uint64(0)
+        ctx._ck(ctx.lib.kmx_fastx_parse(ctx._h, _ptr(d), n_bytes, flag, _ptr(bases), _ptr(offsets), nr, C.byref(r), C.byref(b)))
+        return bases[:b.value].cpu().numpy(), u64_numpy(offsets)[: r.value + 1]
+
+    ea, eb = orc.fastx_parse(ta, 0), orc.fastx_parse(tb, 0)
+    nra, nba = count(da)
+    got = emit(db, db.numel(), len(eb[1]) - 1, len(eb[0]), _lib.FASTX_SAME_TEXT)           # another image
+    assert np.array_equal(got[0], eb[0]) and np.array_equal(got[1], eb[1])
+    nra, nba = count(da)
+    ctx.histogram(ctx.gen_reads(150 * 8192), 8192, 150, 31, 1, 31, 20)                     # the work buffer is overwritten
+    got = emit(da, da.numel(), nra, nba, _lib.FASTX_SAME_TEXT)
+    assert np.array_equal(got[0], ea[0]) and np.array_equal(got[1], ea[1])
+    nra, nba = count(da)
+    cut = int(ea[1][1500]) * 0 + (len(ta) // 2)                                            # another size: a prefix of the image
+    ec = orc.fastx_parse(ta[:cut], 0)
+    got = emit(da, cut, len(ec[1]) - 1, len(ec[0]), _lib.FASTX_SAME_TEXT)
+    assert np.array_equal(got[0], ec[0]) and np.array_equal(got[1], ec[1])
+    nra, nba = count(da)
+    got = emit(da, da.numel(), nra, nba, _lib.FASTX_SAME_TEXT)                             # the reuse itself
+    assert np.array_equal(got[0], ea[0]) and np.array_equal(got[1], ea[1])

@@ -1,1 +1,1 @@
-KMX_FUZZ_N=3000 python -m pytest tests/test_gpu_fuzz.py -q -m gpu 2>&1 | tail -15
+python tools/bench_fastq_pipeline.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fastq_pipeline.txt
