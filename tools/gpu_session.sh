@@ -1,1 +1,3 @@
-python tools/bench_fastq_pipeline.py 2>&1 | grep -v amdgpu.ids > gpurun_out/fastq_pipeline.txt
+python -m pytest tests -q -m gpu 2>&1 | tail -2
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | python tools/bench_line.py driver
