@@ -301,7 +301,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         m.len = len64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)len64;
         m.rel = (u32)(o0 - m.base);
         m.n_ch = (u32)(nch > 0xFFFFFFFFull ? 0xFFFFFFFFull : nch);
-        m.fits = nch <= (u64)chunks && nch <= 64u * NW && wave_max_u32(m.len) <= L && m.base + 16u * nch <= total_bytes;
+        m.fits = nch <= (u64)chunks && nch <= 64u * NW && !__any(m.len > L) && m.base + 16u * nch <= total_bytes;   // (one compare + a scalar test: a wave-wide max costs ten instructions)
     };
     u32 n_bs_tiles = 0;
     // ---- reads with an invalid byte (ASCII input, uniform or ragged).  A tile that holds one used to go to the per-lane path
