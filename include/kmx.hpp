@@ -355,9 +355,25 @@ class FastxReads {
         ctx.check(kmx_fastx_parse(ctx.get(), d.data(), text.size(), format, nullptr, nullptr, 0, &nr, &nb), "fastx_parse (count)");
         bases_.reset(new DeviceBuffer<uint8_t>(ctx, nb ? nb : 1));
         offsets_.reset(new DeviceBuffer<uint64_t>(ctx, nr + 1));
-        ctx.check(kmx_fastx_parse(ctx.get(), d.data(), text.size(), format, bases_->data(), offsets_->data(), nr, &nr, &nb), "fastx_parse");
+        // (the emit reuses the chunk summaries of the counting call just made on the same image)
+        ctx.check(kmx_fastx_parse(ctx.get(), d.data(), text.size(), format | KMX_FASTX_SAME_TEXT, bases_->data(), offsets_->data(), nr, &nr, &nb),
+                  "fastx_parse");
         n_reads_ = nr;
         n_bases_ = nb;
+        uint32_t mn = 0, mx = 0;
+        ctx.check(kmx_reads_length_range(ctx.get(), offsets_->data(), n_reads_, &mn, &mx), "reads_length_range");
+        min_len_ = mn;
+        max_len_ = mx;
+    }
+    // shortest / longest read; uniform(): every read has the same length (hand such a batch over with d_offsets = NULL)
+    uint32_t min_len() const { return min_len_; }
+    uint32_t max_len() const { return max_len_; }
+    bool uniform() const { return n_reads_ != 0 && min_len_ == max_len_; }
+    // the batch the way the scan kernels like it best: uniform layout if it is uniform, else ragged with the tight length bound
+    kmx_reads best_reads() const {
+        kmx_reads r = reads(max_len_);
+        if (uniform()) r.d_offsets = nullptr;
+        return r;
     }
     size_t len() const { return n_reads_; }
     size_t n_bases() const { return n_bases_; }
@@ -382,6 +398,7 @@ class FastxReads {
     std::unique_ptr<DeviceBuffer<uint8_t>> bases_;
     std::unique_ptr<DeviceBuffer<uint64_t>> offsets_;
     size_t n_reads_ = 0, n_bases_ = 0;
+    uint32_t min_len_ = 0, max_len_ = 0;
 };
 
 // src/naive_impl/seq_vector.rs: the 2-bit packed sequence container, resident on the device.

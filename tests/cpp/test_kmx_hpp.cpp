@@ -242,6 +242,11 @@ int main() {
                 sum += it.get().km.get_canonical_word();
             }
         CHECK(s.n_valid == n && s.sum_canon == sum && n == 6 + 2);
+        CHECK(fq.min_len() == 7 && fq.max_len() == 8 && !fq.uniform() && fq.best_reads().d_offsets != nullptr && fq.best_reads().read_len == 8);
+        FastxReads fu(std::string("@a\nACGTTGCA\n+\nIIIIIIII\n@b\nGGTACGTA\n+\nIIIIIIII\n"));
+        CHECK(fu.uniform() && fu.max_len() == 8 && fu.best_reads().d_offsets == nullptr);
+        kmx_summary su = canonical_reduce(Context::instance(), fu.best_reads(), 3), sr = canonical_reduce(Context::instance(), fu.reads(), 3);
+        CHECK(su.n_valid == 12 && su.n_valid == sr.n_valid && su.sum_canon == sr.sum_canon);
         FastxReads fa(std::string(">s1 d\nACG\nTTA\n\n>s2\n>s3\r\nNN\r\nA"));
         CHECK(fa.len() == 3 && fa.read(0) == "ACGTTA" && fa.read(1).empty() && fa.read(2) == "NNA");
         CHECK(panics([] { FastxReads bad(std::string("ACGT\n")); }));
