@@ -170,12 +170,15 @@ void* big_scratch(void* user, size_t bytes) {
     return q;
 }
 
-// at most 8 GiB (KMX_HIST_SCRATCH_MB overrides) and at most half of the free device memory
+// an eighth of the device memory, at least 8 GiB (KMX_HIST_SCRATCH_MB overrides), and at most half of what is free: fewer,
+// larger chunks of reads per call (configs[4], 1.25e8 reads: 6 chunks at 8 GiB 19.3 ms, 2 at 36 GiB 18.6 ms)
 size_t hist_scratch_budget() {
-    size_t budget = (size_t)8 << 30;
-    if (const char* e = std::getenv("KMX_HIST_SCRATCH_MB")) budget = (size_t)std::strtoull(e, nullptr, 10) << 20;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && budget > free_b / 2) budget = free_b / 2;
+    const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    size_t budget = (size_t)8 << 30;
+    if (have && total_b / 8u > budget) budget = total_b / 8u;
+    if (const char* e = std::getenv("KMX_HIST_SCRATCH_MB")) budget = (size_t)std::strtoull(e, nullptr, 10) << 20;
+    if (have && budget > free_b / 2) budget = free_b / 2;
     return budget;
 }
 
