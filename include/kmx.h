@@ -143,7 +143,7 @@ int kmx_canonical_windows2(kmx_ctx *ctx, const kmx_reads *reads, const uint64_t 
  * function: the top bits of a 32-bit multiplicative mix of the two halves; log2_buckets <= 30).
  * d_counts (2^log2_buckets device u64) is ACCUMULATED into; the caller zeroes it and, across
  * GPUs, all-reduces it (RCCL ncclSum/uint64).
- * With 2^15..2^21 buckets the reads (uniform or ragged) go through a grow-only work buffer owned by the context (sized to
+ * With 2^15..2^22 buckets the reads (uniform or ragged) go through a grow-only work buffer owned by the context (sized to
  * the call: 3 bytes per window, at most an eighth of the device memory -- 8 GiB if that is more -- and at most half of
  * what is free; KMX_HIST_SCRATCH_MB overrides): growing it synchronises the stream once. */
 int kmx_histogram(kmx_ctx *ctx, const kmx_reads *reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,

@@ -83,7 +83,7 @@ struct SinkHistLds {
     }
 };
 
-// Histogram, 2^15..2^21 buckets, pass 1 of 2: scatter the bucket ids into 64 partitions (the top 6 bits of the bucket).
+// Histogram, 2^15..2^22 buckets, pass 1 of 2: scatter the bucket ids into 64 partitions (the top 6 bits of the bucket).
 // Every wave owns a private segment of every partition's stream, so no global cursor and no global atomic is
 // involved.  The low b-6 bits of an id are staged in a ROW-entry ring per partition in the wave's LDS slice: ONE
 // ds_add_rtn_u32 on a packed {entries appended : 16 | entries written out : 16} word returns the slot and tells
@@ -312,12 +312,15 @@ struct SinkHistPartT {
 };
 
 // pass 2: block (partition q, group g) adds the segments of the waves w == g (mod gridDim.y) into an LDS table
-template <int THREADS>
+// SUB_BITS = 1 (2^22 buckets: a partition's 2^16-entry table does not fit the LDS): blockIdx.z picks the half of the partition's
+// buckets this block counts; both halves read the whole id stream of the partition.
+template <int THREADS, int SUB_BITS = 0>
 __global__ void __launch_bounds__(THREADS)
 hist_part_reduce_kernel(const uint16_t* __restrict__ stream, const u32* __restrict__ seg_len, u32 cap, u32 n_waves,
                         u32 log2_buckets, u64* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) u32 tab[];
-    const u32 lowbits = log2_buckets - 6u, nb = 1u << lowbits, idm = nb - 1u;
+    const u32 lowbits = log2_buckets - 6u, idm = (1u << lowbits) - 1u;
+    const u32 tb = lowbits - (u32)SUB_BITS, nb = 1u << tb, sub = SUB_BITS ? blockIdx.z : 0u;
     const u32 q = blockIdx.x;
     for (u32 j = threadIdx.x; j < nb; j += THREADS) tab[j] = 0;
     __syncthreads();
@@ -326,15 +329,14 @@ hist_part_reduce_kernel(const uint16_t* __restrict__ stream, const u32* __restri
     const u32 wv = threadIdx.x >> 6, ln = threadIdx.x & 63u, nwv = THREADS / 64u;
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     // (an id carries the low bits of its partition above bit lowbits: the scan writes the bucket's low 16 bits as they are)
+    auto count1 = [&](u32 id) {
+        id &= idm;
+        if constexpr (SUB_BITS == 0) atomicAdd(&tab[id], 1u);
+        else if ((id >> tb) == sub) atomicAdd(&tab[id & (nb - 1u)], 1u);
+    };
     auto count8 = [&](const u32x4 v) {
-        atomicAdd(&tab[v.x & idm], 1u);
-        atomicAdd(&tab[(v.x >> 16) & idm], 1u);
-        atomicAdd(&tab[v.y & idm], 1u);
-        atomicAdd(&tab[(v.y >> 16) & idm], 1u);
-        atomicAdd(&tab[v.z & idm], 1u);
-        atomicAdd(&tab[(v.z >> 16) & idm], 1u);
-        atomicAdd(&tab[v.w & idm], 1u);
-        atomicAdd(&tab[(v.w >> 16) & idm], 1u);
+        count1(v.x); count1(v.x >> 16); count1(v.y); count1(v.y >> 16);
+        count1(v.z); count1(v.z >> 16); count1(v.w); count1(v.w >> 16);
     };
     const u32 w0 = blockIdx.y * nwv + wv, wstep = gridDim.y * nwv;
     u32 len_next = w0 < n_waves ? seg_len[(u64)w0 * 64u + q] : 0u;
@@ -358,12 +360,12 @@ hist_part_reduce_kernel(const uint16_t* __restrict__ stream, const u32* __restri
             count8(v3);
         }
         for (; i < n16; i += 64u) count8(__builtin_nontemporal_load(sp8 + i));
-        for (u32 j = (len & ~7u) + ln; j < len; j += 64u) atomicAdd(&tab[sp[j] & idm], 1u);
+        for (u32 j = (len & ~7u) + ln; j < len; j += 64u) count1(sp[j]);
     }
     __syncthreads();
     for (u32 j = threadIdx.x; j < nb; j += THREADS) {
         const u32 c = tab[j];
-        if (c) atomicAdd((unsigned long long*)&counts[((u64)q << lowbits) | j], (unsigned long long)c);
+        if (c) atomicAdd((unsigned long long*)&counts[((u64)q << lowbits) | ((u64)sub << tb) | j], (unsigned long long)c);
     }
 }
 
@@ -392,7 +394,7 @@ static hipError_t dispatch_part(const uint8_t* bases, u64 n_reads, u32 L, u32 k,
     return dispatch_part_mode<SinkHistPartT<2>, Pre, false>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, nullptr);
 }
 
-// Histogram over uniform or ragged reads.  2^b <= 2^14: block-private LDS tables (SinkHistLds).  2^15..2^21: two passes through
+// Histogram over uniform or ragged reads.  2^b <= 2^14: block-private LDS tables (SinkHistLds).  2^15..2^22: two passes through
 // 64 partitions (SinkHistPart + hist_part_reduce_kernel) in chunks of reads sized to `scratch_budget` bytes of
 // caller-provided scratch (`get_scratch(user, bytes)` returns a device buffer of at least `bytes`, or nullptr).
 // Larger tables, or no scratch: device-scope u64 atomics (SinkHist).
@@ -403,7 +405,7 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
     if (!*handled) return hipSuccess;
     const HistParams p{counts, hasher, hk, log2_buckets};
     if (log2_buckets <= 14u) return dispatch<SinkHistLds>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
-    if (log2_buckets <= 21u && get_scratch != nullptr && n_reads >= 4096u) {
+    if (log2_buckets <= 22u && get_scratch != nullptr && n_reads >= 4096u) {
         // windows per read the segments are sized for.  Ragged reads: from the caller's bound of the lengths (the frame's 256 if
         // there is none); a read that is longer after all only fills its wave's segments sooner, and what finds a segment full
         // goes to the global table (exact, slow).
@@ -446,14 +448,15 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
                     return dispatch<SinkHist>(cb, n_reads - first, L, k, p, queue, n_cu, stream, NoPre(), co);
                 }
                 if (e != hipSuccess) return e;
-                const u32 nb_bytes = 4u << (log2_buckets - 6u);
-                auto red = hist_part_reduce_kernel<512>;
+                const bool halves = log2_buckets == 22u;   // 2^16 buckets per partition: two blocks of 2^15 each
+                const u32 nb_bytes = 4u << (log2_buckets - 6u - (halves ? 1u : 0u));
+                auto red = halves ? hist_part_reduce_kernel<512, 1> : hist_part_reduce_kernel<512, 0>;
                 if (nb_bytes > 64u * 1024u) {
                     e = hipFuncSetAttribute(reinterpret_cast<const void*>(red), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_bytes);
                     if (e != hipSuccess) return e;
                 }
                 const u32 groups = n_waves < 16u ? n_waves : 16u;
-                hipLaunchKernelGGL(red, dim3(64, groups), dim3(512), nb_bytes, stream, pp.stream, pp.seg_len, pp.cap, n_waves,
+                hipLaunchKernelGGL(red, dim3(64, groups, halves ? 2 : 1), dim3(512), nb_bytes, stream, pp.stream, pp.seg_len, pp.cap, n_waves,
                                    log2_buckets, counts);
                 e = hipGetLastError();
                 if (e != hipSuccess) return e;

@@ -196,7 +196,7 @@ def test_full_size_ragged_histogram_matches_uniform(ctx, big):
     assert torch.equal(hu, hr) and torch.equal(hu, hr0)
 
 
-@pytest.mark.parametrize("b", [12, 20])
+@pytest.mark.parametrize("b", [12, 20, 22])
 def test_full_size_histogram_totals_and_linearity(ctx, big, b):
     """the LDS-table and the partitioned histogram count every k-mer exactly once: totals, and two halves add up to the whole"""
     import torch

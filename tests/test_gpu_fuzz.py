@@ -87,7 +87,7 @@ def test_reduce2_and_histogram_random_configuration(ctx, orc, seed):
         assert tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_), (k, L, n)
     else:
         k = int(rng.choice([9, 15, 21, 31]))
-        b = int(rng.choice([10, 14, 15, 18, 20, 21, 23]))
+        b = int(rng.choice([10, 14, 15, 18, 20, 21, 22, 23]))
         hasher, hk = [(1, k), (2, 0), (1, max(1, k - 2))][int(rng.integers(0, 3))]
         if rng.integers(0, 2):
             L = max(k, int(rng.choice([50, 100, 150, 200])))

@@ -498,9 +498,9 @@ def test_histogram_fast_kernel_many_tiles(ctx, orc, b):
     assert (g21.cpu().numpy().view(np.uint64) == o21).all()
 
 
-@pytest.mark.parametrize("b", [10, 14, 15, 18, 21, 22])
+@pytest.mark.parametrize("b", [10, 14, 15, 18, 21, 22, 23])
 def test_histogram_three_regimes(ctx, orc, b, monkeypatch):
-    """2^b <= 2^14: block-private LDS tables; 2^15..2^21: 64-way partition + LDS tables (here in several chunks of reads,
+    """2^b <= 2^14: block-private LDS tables; 2^15..2^22: 64-way partition + LDS tables (2^22: two half tables per partition; here in several chunks of reads,
     forced by a 4 MiB work buffer); above: device atomics.  All three must equal the oracle, dirty tiles included."""
     monkeypatch.setenv("KMX_HIST_SCRATCH_MB", "4")
     rng = np.random.default_rng(100 + b)
