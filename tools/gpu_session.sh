@@ -1,2 +1,3 @@
-python -m pytest tests -x -q -m gpu -k "hist or fuzz" 2>&1 | tail -2
-python3 tools/bench_hist.py 100000000 20,21,22,23 2>/dev/null
+python -m pytest tests -q -m gpu 2>&1 | tail -2
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | python tools/bench_line.py driver
