@@ -1,3 +1,1 @@
-python -m pytest tests -q -m gpu 2>&1 | tail -2
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | python tools/bench_line.py driver
+bash tools/variants.sh --config 2 -k 21 -- default k21w5

@@ -34,10 +34,11 @@ for spec in "100 150000000" "250 60000000" "300 50000000" "1000 15000000" "10000
   python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len $1 --reads-per-gpu $2 2>/dev/null | python3 tools/bench_line.py "L=$1"; done > $out/len_sweep.txt
 python3 tools/bench_ragged.py 100000000 31 > $out/ragged_bench.txt 2>/dev/null
 python3 tools/bench_ragged.py 100000000 21 >> $out/ragged_bench.txt 2>/dev/null
-python3 tools/bench_dirty.py > $out/dirty_bench.txt 2>/dev/null
+HIST=20 python3 tools/bench_dirty.py > $out/dirty_bench.txt 2>/dev/null
 python3 tools/bench_windows.py > $out/windows_bench.txt 2>/dev/null
-python3 tools/bench_hist.py 100000000 12,16,20,22 > $out/hist_bench.txt 2>/dev/null
+python3 tools/bench_hist.py 100000000 12,16,20,22,23 > $out/hist_bench.txt 2>/dev/null
 python3 tools/bench_minimizers.py > $out/minimizers_bench.txt 2>/dev/null
 python3 tools/bench_fastx.py > $out/fastx_bench.txt 2>/dev/null
+python3 tools/bench_fastq_pipeline.py 2>/dev/null | grep -v amdgpu.ids > $out/fastq_pipeline.txt
 python3 tools/step_times.py > $out/step_times.txt 2>/dev/null
 ls $out
