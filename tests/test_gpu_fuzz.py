@@ -99,5 +99,33 @@ def test_reduce2_and_histogram_random_configuration(ctx, orc, seed):
             offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
             host = _bytes(rng, int(offsets[-1]) + 16, p_bad, False)[: int(offsets[-1])]
             o = orc.histogram(host, n, 0, k, hk if hasher == 1 else 0, b, offsets=offsets)
-            g = ctx.histogram(ctx.to_device(host), n, int(rng.choice([0, 160])), k, hasher, hk, b, offsets=ctx.to_device(offsets))
+            d_host = ctx.to_device(host) if len(host) else ctx.to_device(np.zeros(16, np.uint8))
+            g = ctx.histogram(d_host, n, int(rng.choice([0, 160])), k, hasher, hk, b, offsets=ctx.to_device(offsets))
         assert (g.cpu().numpy().view(np.uint64) == o).all(), (k, b, hasher, hk, n)
+
+
+@pytest.mark.parametrize("seed", range(max(40, N_FUZZ // 3)))
+def test_windows_random_configuration(ctx, orc, seed):
+    """kmx_canonical_windows (materialise: staged / line-aligned write-back, uniform or ragged) against the oracle"""
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.choice([1, 2, 7, 13, 16, 17, 21, 27, 31]))
+    n = int(rng.choice([1, 64, 65, 64 * 9 + 5]))
+    p_bad = float(rng.choice([0.0, 0.0, 0.003, 0.05]))
+    want = [("canon",), ("fw",), ("rc", "flags"), ("fw", "rc", "canon", "flags")][int(rng.integers(0, 4))]
+    if rng.integers(0, 2):
+        L = max(k, int(rng.choice([k, 40, 100, 128, 150, 158, 160, 200, 256, 300])))
+        host = _bytes(rng, n * L, p_bad, bool(rng.integers(0, 2)))
+        o = orc.canonical_windows(host, n, L, k)
+        g = ctx.canonical_windows(ctx.to_device(host), n, L, k, want=want)
+    else:
+        lens = rng.integers(0, int(rng.choice([60, 160, 260])) + 1, size=n)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        host = _bytes(rng, int(offsets[-1]) + 16, p_bad, False)[: int(offsets[-1])]
+        o = orc.canonical_windows(host, n, 0, k, offsets=offsets)
+        d_host = ctx.to_device(host) if len(host) else ctx.to_device(np.zeros(16, np.uint8))   # (a NULL base pointer is an argument error even for empty reads)
+        g = ctx.canonical_windows(d_host, n, int(rng.choice([0, 160])), k, offsets=ctx.to_device(offsets), host_offsets=offsets, want=want)
+    ref = dict(zip(("fw", "rc", "canon", "flags"), o))
+    for name in want:
+        got = g[name].cpu().numpy()
+        got = got.view(np.uint64) if name != "flags" else got
+        assert np.array_equal(got, ref[name]), (name, k, n, p_bad)
