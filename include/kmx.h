@@ -61,7 +61,8 @@ typedef struct kmx_ctx kmx_ctx;
  *   then carry an upper bound of the read lengths (0 = unknown): a bound <= 160 selects the smaller, faster frame of the
  *   tiled kernels, and the tighter it is the fewer windows a lane carries (150 bp reads: 7 % faster at k = 31 with 150
  *   than with 160 or 0).  It is only a hint -- tiles with a longer read take the exact per-read path, and the
- *   histogram's work buffer, sized from it, overflows into exact (slow) global atomics. */
+ *   histogram's work buffer, sized from it, overflows into exact (slow) global atomics.
+ * d_bases must be a device pointer whenever n_reads > 0, also when every read is empty (KMX_E_ARG otherwise). */
 typedef struct {
     const uint8_t *d_bases;
     uint64_t n_reads;
