@@ -129,3 +129,30 @@ def test_windows_random_configuration(ctx, orc, seed):
         got = g[name].cpu().numpy()
         got = got.view(np.uint64) if name != "flags" else got
         assert np.array_equal(got, ref[name]), (name, k, n, p_bad)
+
+
+@pytest.mark.parametrize("seed", range(max(40, N_FUZZ // 3)))
+def test_seqvec_random_configuration(ctx, orc, seed):
+    """2-bit packed reads: kmx_seqvec_canonical_reduce (the packed bit-sliced kernel and its fallbacks) against the oracle's
+    scan of the same bases as ASCII; kmx_seqvec_minimizers against the oracle's deque"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(12000 + seed)
+    k = int(rng.choice([1, 3, 12, 13, 16, 17, 21, 24, 29, 31]))
+    L = max(k, int(rng.choice([k, 31, 32, 50, 64, 100, 128, 150, 151, 160, 161, 200, 256, 300])))
+    n = int(rng.choice([1, 16, 64, 64 * 6 + 3]))
+    host = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * L)]
+    words = ctx.seqvec_from_bytes(ctx.to_device(host))
+    hasher, hk = [(_lib.HASH_NONE, 0), (_lib.HASH_LEX, k), (_lib.HASH_LEX, int(rng.integers(1, 33)))][int(rng.integers(0, 3))]
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=hk if hasher == _lib.HASH_LEX else 0)
+    g = ctx.seqvec_canonical_reduce(words, n, L, k, hasher, hk, 0)
+    assert (g.n_valid, g.sum_canon) == (o.n_valid, o.sum_canon), (k, L, n)
+    if hasher == _lib.HASH_LEX:
+        assert g.xor_hash == o.xor_hash, (k, L, n, hk)
+    if seed % 3 == 0 and L <= 200 and n <= 64:
+        w = int(rng.integers(1, k + 1))
+        mhk = int(rng.choice([0, w, min(32, w + 3)]))
+        sv = orc.SeqVector(host.tobytes())
+        ow, op = orc.seqvec_minimizers(sv, n, L, k, w, mhk)
+        gw, gp = ctx.seqvec_minimizers(words, n, L, k, w, _lib.HASH_LEX if mhk else _lib.HASH_IDENTITY, mhk)
+        assert np.array_equal(gw.cpu().numpy().view(np.uint64), ow) and np.array_equal(gp.cpu().numpy().view(np.uint32), op), (k, w, mhk, L, n)

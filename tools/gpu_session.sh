@@ -1,1 +1,1 @@
-KMX_FUZZ_N=9000 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -k "windows or histogram" 2>&1 | tail -4
+KMX_FUZZ_N=3000 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -k "seqvec" 2>&1 | tail -6
