@@ -334,6 +334,17 @@ class Context:
                                           nr.value, C.byref(nr), C.byref(nb)))
         return bases[:nb.value], offsets
 
+    def fastx_reads(self, text: torch.Tensor, fmt: int = 0):
+        """file image -> (bases, n_reads, read_len, offsets) the way the scan calls like it best: the uniform layout
+        (offsets None, read_len = the length) when every read has the same length, else the ragged layout with the
+        longest read as the length bound ("Real FASTQ / FASTA, end to end")"""
+        bases, offsets = self.fastx_parse(text, fmt)
+        n = int(offsets.numel()) - 1
+        mn, mx = self.reads_length_range(offsets)
+        if n > 0 and mn == mx:
+            return bases, n, mx, None
+        return bases, n, mx, offsets
+
     @_on_ctx_stream
     def reads_length_range(self, offsets: torch.Tensor) -> tuple[int, int]:
         """kmx_reads_length_range: (shortest, longest) read of a ragged batch (offsets: int64[n_reads+1] on the device)"""

@@ -130,3 +130,20 @@ def test_same_text_flag_only_reuses_what_it_may(ctx, orc):
     nra, nba = count(da)
     got = emit(da, da.numel(), nra, nba, _lib.FASTX_SAME_TEXT)                             # the reuse itself
     assert np.array_equal(got[0], ea[0]) and np.array_equal(got[1], ea[1])
+
+
+def test_fastx_reads_picks_the_layout(ctx, orc):
+    """Context.fastx_reads: uniform layout when every read has the same length, else ragged with the tight bound; the
+    summaries equal the oracle's over the parsed reads either way"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(5)
+    for fixed in (150, None):
+        text = fastq_text(rng, 700, fixed=fixed) if fixed else fastq_text(rng, 700, 40, 150)
+        eb, eo = orc.fastx_parse(text, 0)
+        bases, n, L, offsets = ctx.fastx_reads(ctx.to_device(text))
+        assert n == len(eo) - 1 and L == int(np.diff(eo.astype(np.int64)).max())
+        assert (offsets is None) == (fixed is not None)
+        o = orc.canonical_reduce(eb, n, 0, 21, hasher_k=21, offsets=eo)
+        g = ctx.canonical_reduce(bases, n, L, 21, _lib.HASH_LEX, 21, 0, offsets=offsets)
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)

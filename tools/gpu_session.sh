@@ -1,1 +1,1 @@
-KMX_FUZZ_N=3000 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -k "seqvec" 2>&1 | tail -6
+python -m pytest tests/test_gpu_fastx.py -x -q -m gpu -k "picks" 2>&1 | tail -3
