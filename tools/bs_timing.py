@@ -37,7 +37,7 @@ print("waves", len(d), "start ms: min %.3f p50 %.3f p90 %.3f max %.3f | end ms: 
 print("late starters (>0.1 ms):", int((st > 0.1).sum()))
 print("per-wave lifetime ms (first 64 waves): min %.3f max %.3f" % (d[:,7].min()/1e5, d[:,7].max()/1e5))
 tiles = d[:, 5]
-names = ["A0 wait loads", "A encode+lds", "B realign", "C transpose", "D main loop"]
+names = ["A0 wait loads", "A encode+lds", "ticket take/issue", "B+C realign+transpose", "D main loop"]
 print("tiles per wave", tiles.mean())
 tot = 0
 for i, nme in enumerate(names):

@@ -3,6 +3,7 @@
 # usage: tools/pmc_pass.sh OUTDIR "CTR_A CTR_B ..." ["CTR_C ..."] ...     (KMX_PMC_BENCH_ARGS: extra bench.py arguments)
 cd /tmp && export TMPDIR=/tmp
 out=$1; shift
+mkdir -p $GRAFT_REPO_ROOT/$out
 i=0
 for grp in "$@"; do
   i=$((i+1))
