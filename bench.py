@@ -138,6 +138,50 @@ def cpu_baseline(host_sample, n_reads, L, k, seconds_target=24.0):
     }
 
 
+def cpu_baseline2(host_sample, n_reads, L, k, with_hash, seconds_target=12.0):
+    """[u64;2] k-mers (k = 33..64, BASELINE configs[2]): the oracle's kmo_canonical_reduce2 -- the same iterator walk as
+    canonical_kmer_iterator.rs:42-70 on 128-bit words (build-defined, as the GPU path: the reference has no two-word
+    naive_impl) -- at all usable threads and at one."""
+    from oracle import oracle
+
+    oracle.lib()
+    cores = usable_cores()
+    per = L - k + 1
+
+    def timed(nthreads, reads_each, reps):
+        outs = [0] * nthreads
+
+        def work(i):
+            lo = (i * reads_each) % max(n_reads - reads_each + 1, 1)
+            for _ in range(reps):
+                outs[i] += oracle.canonical_reduce2(host_sample[lo * L:(lo + reads_each) * L], reads_each, L, k, with_hash=with_hash).n_valid
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+        return sum(outs) / dt, dt
+
+    def leg(nthreads, seconds):
+        rate, _ = timed(nthreads, min(n_reads, 20_000), 1)
+        want = max(20_000, rate / nthreads * seconds / per)
+        reads = int(min(n_reads // nthreads if n_reads >= nthreads * 20_000 else n_reads, want))
+        reps = max(1, int(round(want / reads)))
+        rate, dt = timed(nthreads, reads, reps)
+        return rate, dt, reads, reps
+
+    r_mt, dt_mt, reads_mt, reps_mt = leg(cores, seconds_target * 0.6)
+    r_1t, dt_1t, reads_1t, reps_1t = leg(1, seconds_target * 0.4)
+    return {
+        "value": r_mt, "unit": "canonical k-mers/s", "cores": cores, "kind": "port", "value_1thread": r_1t,
+        "sample": f"{cores} threads x {reads_mt} reads x {reps_mt} passes x {L} bp (same synthetic stream as the GPU run), k={k} ([u64;2]), "
+                  f"{dt_mt:.1f}s; 1 thread x {reads_1t} reads x {reps_1t} passes {dt_1t:.1f}s; oracle kmo_canonical_reduce2, gcc -O3",
+    }
+
+
 # ------------------------------------------------------------------------------------------------ launch of N ranks
 
 def passthrough_args(argv):
@@ -162,7 +206,13 @@ def spawn_ranks(args, argv) -> int:
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     alive = set(range(args.gpus))
+    deadline = time.monotonic() + float(os.environ.get("KMX_BENCH_SPAWN_TIMEOUT_S", "3600"))   # a hung rank must not hang the caller
     while alive:
+        if time.monotonic() > deadline:
+            sys.stderr.write("bench.py: ranks still running at the wall-clock limit; stopping them\n")
+            for o in alive:
+                procs[o].kill()      # exactly the processes started above
+            return 5
         for r in list(alive):
             c = procs[r].poll()
             if c is None:
@@ -200,7 +250,22 @@ def measure_traffic(argv, log=sys.stderr):
             env = dict(os.environ, TMPDIR="/tmp")
             cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--",
                    sys.executable, os.path.abspath(__file__), *argv, "--pmc-child"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            # own session: on a timeout the profiler AND the python child under it are stopped (a surviving child would keep
+            # its 15 GB of HBM and its launches next to the timed region of this run)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                _, err_txt = pr.communicate(timeout=600)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, 9)    # the group this call created, nothing else
+                except OSError:
+                    pass
+                pr.wait()
+                return None, f"rocprofv3 --pmc {ctr}: timed out, pass stopped"
+
+            class _R:
+                returncode, stderr = pr.returncode, err_txt
+            r = _R
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {ctr} exited with {r.returncode}: {r.stderr[-300:]}"
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -256,6 +321,7 @@ def parse_args(argv=None):
     ap.add_argument("-k", type=int, default=None)
     ap.add_argument("--hash", action="store_true", help="also fold the LexHasher(k) word hash (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=24.0, help="CPU work the cpu_baseline leg is sized for (rank 0, after the timed region)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--sustain-steps", type=int, default=1000,
                     help="after the timed region: this many more back-to-back steps, timed as one interval (the package reaches its "
@@ -481,10 +547,21 @@ def worker(args, traffic_raw=None, traffic_err=None):
     avg_scan_ms = sum(scan_ms) / len(scan_ms)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    per_rank_s = [elapsed]
     if dist is not None:
+        # every rank's own wall time of the K steps and its kernel average: the line's value uses the MAX, the spread says
+        # how evenly the shards ran (scaling efficiency falls out of one run)
+        mine = torch.tensor([elapsed, avg_kernel_ms], dtype=torch.float64, device=coll_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_s = [float(x[0].item()) for x in allr]
+        per_rank_kernel_ms = [float(x[1].item()) for x in allr]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    else:
+        per_rank_kernel_ms = [avg_kernel_ms]
     elapsed_max = float(t.item())
 
+    summary_combine_ms = None
     if hist_mode:
         total_count = int(counts.sum().item())            # after the all-reduce: k-mers of ALL ranks
         total_kmers_per_step = total_count
@@ -493,8 +570,10 @@ def worker(args, traffic_raw=None, traffic_err=None):
     else:
         summ = out.cpu().numpy().view(np.uint64)
         n_valid_local, sum_canon = int(summ[0]), int(summ[1])
+        t_comb = time.perf_counter()
         tot = kd.combine_summaries({"n_valid": n_valid_local, "sum_canon": sum_canon, "xor_hash": int(summ[2]) if not two_word else 0, "sum_fw": 0},
                                    device=coll_dev)   # wrapping add / xor of the per-shard summaries
+        summary_combine_ms = (time.perf_counter() - t_comb) * 1e3   # the only exchange of configs[1..3]: 32 bytes per rank, once per job
         total_kmers_per_step = tot["n_valid"]
 
     # ---- outside the timed region: sustained run, same-run read ceiling, optional histogram, parity, CPU baseline
@@ -580,6 +659,9 @@ def worker(args, traffic_raw=None, traffic_err=None):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
+            "per_rank": {"ms_per_step_min": min(per_rank_s) / args.steps * 1e3, "ms_per_step_max": max(per_rank_s) / args.steps * 1e3,
+                         "kernel_ms_min": min(per_rank_kernel_ms), "kernel_ms_max": max(per_rank_kernel_ms),
+                         "summary_combine_ms": summary_combine_ms},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -613,9 +695,12 @@ def worker(args, traffic_raw=None, traffic_err=None):
                                 "total_count": total_count, "expect": world * n * max(L - k + 1, 0), "collective": collective}
         elif hist_info is not None:
             res["histogram"] = hist_info
-        if world == 1 and not args.no_cpu_baseline and not two_word:
+        if not args.no_cpu_baseline:
+            # rank 0 only, after the timed region, at every N (the other ranks wait at the verdict broadcast below)
             n_s = min(n, 4_000_000)
-            res["cpu_baseline"] = cpu_baseline(bases[: n_s * L].cpu().numpy(), n_s, L, k)
+            sample = bases[: n_s * L].cpu().numpy()
+            res["cpu_baseline"] = (cpu_baseline2(sample, n_s, L, k, args.hash, args.cpu_baseline_seconds / 2.0) if two_word
+                                   else cpu_baseline(sample, n_s, L, k, args.cpu_baseline_seconds))
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     # every rank learns the verdict and leaves together (a lone sys.exit on rank 0 would strand the others in a collective)
     if dist is not None:

@@ -136,7 +136,7 @@ def build(force: bool = False, extra: list[str] | None = None, variant: str | No
         f.write(flags_now)
     if force or _stale(lib, objs):
         cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs,
-               "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lrccl", f"-Wl,-soname,{os.path.basename(lib)}"]
+               "-Wl,-rpath,/opt/rocm/lib", "-ldl", f"-Wl,-soname,{os.path.basename(lib)}"]   # (RCCL: dlopen at the first kmx_comm_* call)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

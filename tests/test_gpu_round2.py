@@ -529,7 +529,7 @@ def test_bench_two_ranks_share_the_gpu(cfg):
     env["KMX_BENCH_TEST_SHARED_GPU"] = "1"
     n = 2_000_000
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", cfg, "--reads-per-gpu", str(n),
-                        "--steps", "3", "--warmup", "1", "--sustain-steps", "5", "--no-traffic", "--no-cpu-baseline"],
+                        "--steps", "3", "--warmup", "1", "--sustain-steps", "5", "--no-traffic", "--cpu-baseline-seconds", "2"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -537,11 +537,19 @@ def test_bench_two_ranks_share_the_gpu(cfg):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["parity_vs_oracle"] == "ok"
     assert "TEST_MODE" in d["config"]
+    # an N > 1 line is complete: the CPU baseline of the same run (rank 0, host cores stated), the spread over the ranks
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and "sample" in cb
+    pr = d["per_rank"]
+    assert 0 < pr["ms_per_step_min"] <= pr["ms_per_step_max"] <= d["ms_per_step"] * 1.0001
+    assert 0 < pr["kernel_ms_min"] <= pr["kernel_ms_max"]
     per_rank = n * (150 - 31 + 1)
     if cfg == "4":
         h = d["histogram"]
         assert h["total_count"] == h["expect"] == 2 * per_rank
         assert "torch.distributed" in h["collective"]
+        assert h["allreduce_ms"] > 0 and h["scan_ms"] > 0
     else:
         # value = k-mers of BOTH ranks per step / time
         assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * per_rank) < 1e-6 * 2 * per_rank
+        assert pr["summary_combine_ms"] is not None and pr["summary_combine_ms"] >= 0

@@ -1,0 +1,194 @@
+"""Round-3 GPU parity tests (all through the C ABI, bit-exact against the CPU oracle):
+  * the producer/consumer form of the k = 31 scan (kmx_bitslice_pc.h, opt-in through KMX_BS_PC) on the same inputs as the
+    one-role kernel: clean, dirty, unaligned base, partial tiles, every read length of its frame;
+  * the error path of kmx_comm_create: two ranks on ONE device -- RCCL refuses the duplicate GPU, both processes must come
+    back with KMX_E_HIP and a text in kmx_last_error, without hanging;
+  * libkmx.so loads without librccl on the link line (RCCL is resolved at the first kmx_comm_* call)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from kmers_amd.api import Context
+
+    c = Context()
+    yield c
+    c.close()
+
+
+@pytest.fixture(params=["1", "2"])
+def pc_mode(request):
+    """KMX_BS_PC is read by the launcher at every call (kmx_bitslice.hip): set for the test, restored after"""
+    old = os.environ.get("KMX_BS_PC")
+    os.environ["KMX_BS_PC"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("KMX_BS_PC", None)
+    else:
+        os.environ["KMX_BS_PC"] = old
+
+
+def _dirty(rng, n, p_bad):
+    alpha = np.frombuffer(b"ACGTacgt", np.uint8)
+    a = alpha[rng.integers(0, 8, n)].copy()
+    bad = rng.random(n) < p_bad
+    a[bad] = rng.integers(0, 256, int(bad.sum()), dtype=np.uint8)
+    return a
+
+
+def _same(g, o, want_hash, want_sumfw):
+    assert g.n_valid == o.n_valid
+    assert g.sum_canon == o.sum_canon
+    assert g.xor_hash == (o.xor_hash if want_hash else 0)
+    assert g.sum_fw == (o.sum_fw if want_sumfw else 0)
+
+
+@pytest.mark.parametrize("n_reads", [1, 63, 64, 65, 64 * 7 + 5, 20_000, 200_003])
+def test_pc_clean_reads(ctx, orc, pc_mode, n_reads):
+    from kmers_amd import _lib
+
+    L, k = 150, 31
+    bases = ctx.gen_reads(n_reads * L, first_byte=L * 777)
+    o = orc.canonical_reduce(bases.cpu().numpy(), n_reads, L, k, hasher_k=k)
+    _same(ctx.canonical_reduce(bases, n_reads, L, k), o, False, False)
+    _same(ctx.canonical_reduce(bases, n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW), o, True, True)
+    assert o.n_valid == n_reads * (L - k + 1)
+
+
+@pytest.mark.parametrize("L", [127, 128, 131, 140, 149, 151, 157, 158])
+def test_pc_every_length_of_the_frame(ctx, orc, pc_mode, L):
+    """k = 31 with 97..128 windows per read is what the producer/consumer kernel is instantiated for (4 windows per lane)"""
+    from kmers_amd import _lib
+
+    k, n_reads = 31, 64 * 11 + 9
+    bases = ctx.gen_reads(n_reads * L, first_byte=4242)
+    o = orc.canonical_reduce(bases.cpu().numpy(), n_reads, L, k, hasher_k=k)
+    _same(ctx.canonical_reduce(bases, n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW), o, True, True)
+
+
+@pytest.mark.parametrize("p_bad", [0.0002, 0.002, 0.02])
+def test_pc_dirty_reads(ctx, orc, pc_mode, p_bad):
+    """reads with an invalid byte: the producers blank them, the consumers mask them out of m, roll_flagged_kernel rolls them"""
+    from kmers_amd import _lib
+
+    L, k, n_reads = 150, 31, 64 * 300 + 17
+    rng = np.random.default_rng(31 + int(p_bad * 1e5))
+    host = _dirty(rng, n_reads * L, p_bad)
+    o = orc.canonical_reduce(host, n_reads, L, k, hasher_k=k)
+    g = ctx.canonical_reduce(ctx.to_device(host), n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _same(g, o, True, True)
+    assert o.n_valid < n_reads * (L - k + 1)
+    # and again: the masks the main pass leaves behind are cleared by the roll kernel, nothing carries over between calls
+    g = ctx.canonical_reduce(ctx.to_device(host), n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _same(g, o, True, True)
+
+
+@pytest.mark.parametrize("lead", [1, 5, 8, 15])
+def test_pc_unaligned_base(ctx, orc, pc_mode, lead):
+    from kmers_amd import _lib
+
+    L, k, n_reads = 150, 31, 64 * 40 + 3
+    rng = np.random.default_rng(lead)
+    host = _dirty(rng, lead + n_reads * L, 0.0005)
+    dev = ctx.to_device(host)
+    o = orc.canonical_reduce(host[lead:], n_reads, L, k, hasher_k=k)
+    g = ctx.canonical_reduce(dev[lead:], n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _same(g, o, True, True)
+
+
+def test_pc_matches_the_one_role_kernel_at_size(ctx, pc_mode):
+    """2e6 reads (31 250 tiles: every producer of every block runs many tiles, the hand-off rings wrap): same summary"""
+    from kmers_amd import _lib
+
+    L, k, n_reads = 150, 31, 2_000_000
+    bases = ctx.gen_reads(n_reads * L)
+    g = ctx.canonical_reduce(bases, n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    os.environ.pop("KMX_BS_PC")
+    r = ctx.canonical_reduce(bases, n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    os.environ["KMX_BS_PC"] = pc_mode
+    assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (r.n_valid, r.sum_canon, r.xor_hash, r.sum_fw)
+    assert g.n_valid == n_reads * (L - k + 1)
+
+
+# ------------------------------------------------------------------ kmx_comm_create: the error path
+
+_CHILD = r"""
+import sys, ctypes as C
+sys.path.insert(0, sys.argv[1])
+from kmers_amd import _lib
+from kmers_amd.api import Context
+rank, id_path = int(sys.argv[2]), sys.argv[3]
+ctx = Context(0)
+raw = open(id_path, "rb").read()
+buf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(raw)
+h = C.c_void_p()
+st = ctx.lib.kmx_comm_create(ctx._h, buf, 2, rank, C.byref(h))
+txt = ctx.lib.kmx_last_error(ctx._h)
+print("STATUS", st, "HANDLE", h.value, "TEXT", (txt or b"").decode(), flush=True)
+# the context is still usable after the failed create (its stream was not leaked or left in error)
+import torch
+b = ctx.gen_reads(150 * 64)
+s = ctx.canonical_reduce(b, 64, 150, 31)
+print("AFTER", s.n_valid, flush=True)
+ctx.close()
+"""
+
+
+def test_comm_create_refuses_two_ranks_on_one_gpu(tmp_path):
+    import ctypes as C
+
+    from kmers_amd import _lib
+
+    lib = _lib.load()
+    buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    assert lib.kmx_comm_get_unique_id(buf) == 0
+    idp = tmp_path / "id.bin"
+    idp.write_bytes(bytes(buf))
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(idp)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()     # exactly the two children started above
+            pytest.fail("kmx_comm_create hung with two ranks on one device")
+        outs.append((p.returncode, out, err))
+    for rc, out, err in outs:
+        assert rc == 0, (out[-1500:], err[-1500:])
+        # (RCCL writes its own warnings to stdout as well, not always newline-terminated: search, do not split)
+        import re
+
+        m = re.search(r"STATUS (\d+) HANDLE (\S+) TEXT ([^\n]*)", out)
+        assert m, out[-1500:]
+        assert int(m.group(1)) == _lib.E_HIP                                                # KMX_E_HIP
+        assert m.group(2) in ("None", "0")                                                  # no handle came back
+        assert "RCCL" in m.group(3) and len(m.group(3)) > 10                                # kmx_last_error names the failure
+        assert "AFTER 7680" in out                                                          # 64 reads x 120 windows: the context still works
+
+
+def test_libkmx_does_not_link_rccl():
+    """single-GPU hosts load libkmx.so without librccl: RCCL is dlopen'ed by the first kmx_comm_* call"""
+    so = os.path.join(ROOT, "kmers_amd", "libkmx.so")
+    r = subprocess.run(["readelf", "-d", so], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("readelf not available")
+    needed = [ln for ln in r.stdout.splitlines() if "NEEDED" in ln]
+    assert needed and not any("rccl" in ln for ln in needed), needed
