@@ -87,6 +87,7 @@ hipError_t launch_encoding_rev_comp_bytes(const uint8_t* in, u64 n, u32 K, u32 c
 hipError_t launch_encoding_decode_bytes(const uint8_t* in, u64 total_bytes, u32 nuc_lut, uint8_t* seqs, int n_cu, hipStream_t st);
 hipError_t launch_calib_stream_read(const uint8_t* buf, u64 nbytes, unsigned long long* out, int n_cu, hipStream_t st);
 hipError_t launch_length_range(const u64* offsets, u64 n_reads, u32* out, int n_cu, hipStream_t st);
+hipError_t launch_offsets_uniform_gate(const u64* offsets, u64 n_reads, u32 L, u32* gate, int n_cu, hipStream_t st);
 hipError_t launch_fix_hash_fold(kmx_summary* out, u32 k, u32 hasher, u32 hk, hipStream_t st);
 }  // namespace kmx
 
@@ -373,7 +374,36 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
     const bool fix_fold = want_fold && !(hasher == KMX_HASH_LEX && hasher_k == k);
     {
         bool handled = false;
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 8, ctx->stream));  // 32 tile-queue heads, 128 B apart, + the "a tile was flagged" word
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 16, ctx->stream));  // 32 tile-queue heads, 128 B apart, + the "a tile was flagged" word + the uniform/ragged gate
+        // Reads behind an offsets array with a length bound L that the uniform bit-sliced kernels take: most FASTQ is
+        // untrimmed -- every read exactly L bases -- and the uniform kernel is ~1.4x the ragged one.  Decided on the device:
+        // a small kernel checks offsets[i] == i*L, both scans are launched behind its verdict, the one it names runs.
+        const uint32_t Lh = reads->read_len;
+        if (reads->d_offsets && !want_sumfw && k >= 13 && k <= 31 && Lh >= k && Lh <= 256 &&
+            !((reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) && (Lh == 160 || Lh == 256))) {
+            uint32_t* gate = reinterpret_cast<uint32_t*>(ctx->d_scratch + 16 + 513);
+            KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 1, 1, ctx->stream));
+            KMX_HIP(ctx, kmx::launch_offsets_uniform_gate(reads->d_offsets, reads->n_reads, Lh, gate, ctx->n_cu, ctx->stream));
+            if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
+            bool h_u = false, h_r = false;
+            KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, Lh, k, want_fold, false, d_out, ctx->d_scratch + 16,
+                                                    ctx->n_cu, ctx->stream, &h_u));
+            if (h_u) {
+                // (the uniform scan took tickets from the queue heads only if it ran; if it did not they are still zero)
+                KMX_HIP(ctx, kmx::launch_scan_bitsliced_ragged(reads->d_bases, reads->d_offsets, reads->n_reads, Lh, k, want_fold, d_out,
+                                                               ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &h_r));
+                if (h_r) {
+                    KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));   // never left armed
+                    if (fix_fold) KMX_HIP(ctx, kmx::launch_fix_hash_fold(d_out, k, hasher, hasher_k, ctx->stream));
+                    return KMX_OK;
+                }
+                // (cannot happen -- the ragged launcher takes every (k, L) the uniform one takes -- but if it did, the gate
+                // must not stay armed for what follows: finish on the ragged word-domain path with the gate cleared)
+                KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 2, 1, ctx->stream));
+            } else {
+                KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));
+            }
+        }
         if (!reads->d_offsets) {
             if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
             KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, want_fold, want_sumfw,

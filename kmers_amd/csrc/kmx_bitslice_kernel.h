@@ -204,6 +204,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     constexpr int NVT = KMX_BSR_VAL ? 0 : NV;                    // validity words that go through the transposes
     constexpr int NXT = NW + NE + NVT;                           // 32x32 transposes per half-wave and tile
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    // Gate (queue[513], zero unless kmx_canonical_reduce is deciding on the device whether reads behind an offsets array are
+    // in fact uniform -- offsets_uniform_gate_kernel): 1 = only the uniform kernels run, 2 = only the ragged ones.
+    if constexpr (!PACKED && K <= 32) {
+        const u32 gate = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513]);
+        if (gate == (RAGGED ? 1u : 2u)) return;
+    }
     // Plane storage of one 32-read set: base beta (2 planes = one u64) lives at u64 index
     // (beta & 3) * S2 + (beta >> 2).  In phase D lane g reads bases 4g+i: consecutive lanes then touch
     // consecutive u64s (conflict-free ds_read_b64) instead of a 32-byte stride (4-way bank conflicts,
@@ -459,6 +465,18 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         const u32 lo = m.fits ? (m.n_ch - 1u) * 16u : 0u;
         u32 l16 = lane16;                       // (opaque copy: see issue_loads)
         asm volatile("" : "+v"(l16));
+        if constexpr (KMX_BS_BUFLOAD) {         // per-tile descriptor over the tile's chunks: lanes past its end read zeros (see issue_loads)
+            uint8_t* const tbu = reinterpret_cast<uint8_t*>(uniform_u64(reinterpret_cast<u64>(tb)));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tbu, 0, (int)__builtin_amdgcn_readfirstlane(lo + 16u), 0x00020000);
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                if (it < row0 || it >= row1) continue;
+                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, l16 + (u32)it * 1024u, 0, KMX_BS_LOAD_AUX);
+                w[it] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             if (it < row0 || it >= row1) continue;

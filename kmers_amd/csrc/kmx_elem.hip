@@ -461,6 +461,30 @@ __global__ void __launch_bounds__(256) length_range_kernel(const u64* __restrict
     }
 }
 
+// Are the reads behind `offsets` all exactly L bases, starting at byte 0?  *gate stays 1 ("run the uniform kernels") if so and
+// becomes 2 ("run the ragged kernels") at the first read that is not -- kmx_canonical_reduce launches both scans behind it,
+// each returns at once when the gate names the other (kmx_bitslice_kernel.h), and the host never waits for the answer.
+__global__ void __launch_bounds__(256) offsets_uniform_gate_kernel(const u64* __restrict__ offsets, u64 n_reads, u32 L, u32* __restrict__ gate) {
+    bool bad = false;
+    // two offsets per 16-byte load (hipMalloc'ed arrays are 256-byte aligned; an odd tail is looked at by itself)
+    const bool al16 = (reinterpret_cast<uintptr_t>(offsets) & 15u) == 0u;
+    const u64 n_off = n_reads + 1u, pairs = al16 ? n_off >> 1 : 0u;
+    for (u64 j = (u64)blockIdx.x * 256u + threadIdx.x; j < pairs; j += (u64)gridDim.x * 256u) {
+        const ulonglong2 v = reinterpret_cast<const ulonglong2*>(offsets)[j];
+        bad |= v.x != (2u * j) * (u64)L || v.y != (2u * j + 1u) * (u64)L;
+    }
+    for (u64 i = 2u * pairs + (u64)blockIdx.x * 256u + threadIdx.x; i < n_off; i += (u64)gridDim.x * 256u) bad |= offsets[i] != i * (u64)L;
+    if (__any(bad) && (threadIdx.x & 63u) == 0u) *gate = 2u;   // (a plain store of one constant: every writer agrees)
+}
+
+hipError_t launch_offsets_uniform_gate(const u64* offsets, u64 n_reads, u32 L, u32* gate, int n_cu, hipStream_t st) {
+    u64 grid = (u64)n_cu * 8u;
+    const u64 need = (n_reads / 2u + 256u) / 256u;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(offsets_uniform_gate_kernel, dim3((unsigned)(grid ? grid : 1)), dim3(256), 0, st, offsets, n_reads, L, gate);
+    return hipGetLastError();
+}
+
 hipError_t launch_length_range(const u64* offsets, u64 n_reads, u32* out, int n_cu, hipStream_t st) {
     u64 grid = (n_reads + 255u) / 256u;
     if (grid > (u64)n_cu * 8u) grid = (u64)n_cu * 8u;

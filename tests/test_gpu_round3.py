@@ -192,3 +192,36 @@ def test_libkmx_does_not_link_rccl():
         pytest.skip("readelf not available")
     needed = [ln for ln in r.stdout.splitlines() if "NEEDED" in ln]
     assert needed and not any("rccl" in ln for ln in needed), needed
+
+
+# ------------------------------------------------------------------ offsets array whose reads are in fact uniform
+
+@pytest.mark.parametrize("k", [13, 21, 31])
+@pytest.mark.parametrize("case", ["uniform", "one_trimmed", "shifted_start", "loose_bound", "dirty_uniform"])
+def test_reduce_picks_the_uniform_kernel_on_the_device(ctx, orc, k, case):
+    """kmx_canonical_reduce with an offsets array and a length bound: a device-side check of offsets[i] == i*L gates the
+    uniform and the ragged scan (both are launched, one runs).  Whatever it picks, the summary is the oracle's."""
+    from kmers_amd import _lib
+
+    L, n_reads = 150, 64 * 50 + 11
+    rng = np.random.default_rng(k * 7 + len(case))
+    lens = np.full(n_reads, L, np.int64)
+    start = 0
+    hint = L
+    if case == "one_trimmed":
+        lens[n_reads // 2] = L - 7
+    elif case == "shifted_start":
+        start = 16
+    elif case == "loose_bound":
+        hint = 160
+    offsets = (start + np.concatenate([[0], np.cumsum(lens)])).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]), 0.001 if case == "dirty_uniform" else 0.0)
+    o = orc.canonical_reduce(host, n_reads, 0, k, hasher_k=k, offsets=offsets)
+    g = ctx.canonical_reduce(ctx.to_device(host), n_reads, hint, k, _lib.HASH_LEX, k, 0, offsets=ctx.to_device(offsets))
+    _same(g, o, True, False)
+    # and a second call right after (the gate word does not stay armed, the queue heads start from zero again)
+    g = ctx.canonical_reduce(ctx.to_device(host), n_reads, hint, k, _lib.HASH_NONE, 0, 0, offsets=ctx.to_device(offsets))
+    _same(g, o, False, False)
+    if case in ("uniform", "dirty_uniform"):
+        u = ctx.canonical_reduce(ctx.to_device(host), n_reads, L, k, _lib.HASH_LEX, k, 0)
+        assert (u.n_valid, u.sum_canon, u.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
