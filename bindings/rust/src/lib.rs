@@ -4,8 +4,10 @@
 //! per call = a one-element batch: the correctness path, bit-identical to the CPU implementation) next to a batch
 //! form (the throughput path).  Reference lines (`kmers` @ COMBINE-lab) are cited per item.
 //!
-//! * [`HipEncoder`]             — `impl Encoding<u64, B>` (src/encoding/mod.rs:14-23) for every `Naive` map (+ Xor10 = `Naive::ACTG`)
-//! * [`HipCanonicalKmerBatch`]  — `CanonicalKmerIterator` over many reads (src/naive_impl/canonical_kmer_iterator.rs:42-116)
+//! * [`HipEncoder`]             — `impl Encoding<P, B>` for every `utils::Data` word type P = u8 .. u128 (src/encoding/mod.rs:14-23,
+//!                                src/encoding/naive.rs:112-115, src/utils.rs:4-24) and every `Naive` map (+ Xor10 = `Naive::ACTG`)
+//! * [`HipCanonicalKmerBatch`]  — `CanonicalKmerIterator` over many reads (src/naive_impl/canonical_kmer_iterator.rs:42-116);
+//!                                [`HipCanonicalKmerIter`] walks one read of it with the crate's own `inc` / `get` / `exhausted`
 //! * [`canonical_sum`]          — the consumer shape of benches/simple_benchmark.rs:14-22 on device-resident reads
 //! * [`HipSeqVector`]           — `SeqVector` (src/naive_impl/seq_vector.rs) with the words on the device
 //! * [`HipComm`]                — the RCCL exchange of the optional bucket histogram (no counterpart: the crate is single-process)
@@ -13,6 +15,7 @@ pub mod ffi;
 
 use ffi::*;
 use kmers::encoding::{Encoding, Naive};
+use kmers::utils::Data;
 use std::os::raw::c_void;
 use std::ptr;
 
@@ -124,58 +127,68 @@ impl<'c> HipEncoder<'c> {
         Self { ctx, enc }
     }
 
-    /// `seqs`: n sequences of `seq_len` bytes, contiguous -> n * B words.  Panics where the crate panics
-    /// (`bit_field` index out of bounds when `seq_len > 32 * B`, naive.rs:120).
-    pub fn encode_batch<const B: usize>(&self, seqs: &[u8], seq_len: usize) -> Result<Vec<u64>, KmxError> {
-        let n = if seq_len == 0 { 0 } else { seqs.len() / seq_len };
-        let d_s = self.ctx.upload(seqs)?;
-        let d_w = self.ctx.alloc(8 * B * n.max(1))?;
-        let st = unsafe { kmx_encode_kmers(self.ctx.0, d_s.as_ptr(), n as u64, seq_len as u32, self.enc as u8, B as u32, d_w.as_mut_ptr()) };
-        assert_ne!(st, KMX_E_TOO_LONG, "index out of bounds: the sequence is longer than the k-mer storage");
-        self.ctx.ck(st)?;
-        d_w.download::<u64>(B * n)
+    /// the little-endian byte image of a `[P; B]` slice (what the `_p` calls of the C ABI take: bit_field puts flat bit i into
+    /// word i / BITS, bit i % BITS, so that image is the same flat bit string for every P -- include/kmx.h)
+    fn bytes_of<P: Data>(words: &[P]) -> &[u8] {
+        unsafe { std::slice::from_raw_parts(words.as_ptr() as *const u8, std::mem::size_of_val(words)) }
     }
 
-    /// `Encoding::decode` per k-mer: ALL 32 * B letters each (naive.rs:126-136)
-    pub fn decode_batch<const B: usize>(&self, words: &[u64]) -> Result<Vec<u8>, KmxError> {
+    /// `seqs`: n sequences of `seq_len` bytes, contiguous -> n * B words of P.  Panics where the crate panics
+    /// (`bit_field` index out of bounds when `2 * seq_len > P::BITS * B`, naive.rs:120).
+    pub fn encode_batch<P: Data + Default, const B: usize>(&self, seqs: &[u8], seq_len: usize) -> Result<Vec<P>, KmxError> {
+        let n = if seq_len == 0 { 0 } else { seqs.len() / seq_len };
+        let wb = std::mem::size_of::<P>();
+        let d_s = self.ctx.upload(seqs)?;
+        let d_w = self.ctx.alloc(wb * B * n.max(1))?;
+        let st = unsafe { kmx_encode_kmers_p(self.ctx.0, d_s.as_ptr(), n as u64, seq_len as u32, self.enc as u8, 8 * wb as u32, B as u32, d_w.as_mut_ptr()) };
+        assert_ne!(st, KMX_E_TOO_LONG, "index out of bounds: the sequence is longer than the k-mer storage");
+        self.ctx.ck(st)?;
+        d_w.download::<P>(B * n)
+    }
+
+    /// `Encoding::decode` per k-mer: ALL `P::BITS * B / 2` letters each (naive.rs:126-136)
+    pub fn decode_batch<P: Data, const B: usize>(&self, words: &[P]) -> Result<Vec<u8>, KmxError> {
         let n = words.len() / B;
-        let bytes = unsafe { std::slice::from_raw_parts(words.as_ptr() as *const u8, 8 * words.len()) };
-        let d_w = self.ctx.upload(bytes)?;
-        let d_s = self.ctx.alloc(32 * B * n.max(1))?;
-        self.ctx.ck(unsafe { kmx_encoding_decode(self.ctx.0, d_w.as_ptr(), n as u64, self.enc as u8, B as u32, d_s.as_mut_ptr()) })?;
-        d_s.download::<u8>(32 * B * n)
+        let wb = std::mem::size_of::<P>();
+        let letters = 4 * wb * B;
+        let d_w = self.ctx.upload(Self::bytes_of(words))?;
+        let d_s = self.ctx.alloc(letters * n.max(1))?;
+        self.ctx.ck(unsafe { kmx_encoding_decode_p(self.ctx.0, d_w.as_ptr(), n as u64, self.enc as u8, 8 * wb as u32, B as u32, d_s.as_mut_ptr()) })?;
+        d_s.download::<u8>(letters * n)
     }
 
     /// `Encoding::rev_comp::<K>` per k-mer (naive.rs:138-154): base i = complement(base K-1-i) for i < K, bits >= 2K unchanged
-    pub fn rev_comp_batch<const B: usize>(&self, words: &[u64], big_k: usize) -> Result<Vec<u64>, KmxError> {
+    pub fn rev_comp_batch<P: Data + Default, const B: usize>(&self, words: &[P], big_k: usize) -> Result<Vec<P>, KmxError> {
         let n = words.len() / B;
-        let bytes = unsafe { std::slice::from_raw_parts(words.as_ptr() as *const u8, 8 * words.len()) };
-        let d_in = self.ctx.upload(bytes)?;
-        let d_out = self.ctx.alloc(8 * words.len().max(1))?;
-        let st = unsafe { kmx_encoding_rev_comp(self.ctx.0, d_in.as_ptr(), n as u64, big_k as u32, self.enc as u8, B as u32, d_out.as_mut_ptr()) };
+        let wb = std::mem::size_of::<P>();
+        let d_in = self.ctx.upload(Self::bytes_of(words))?;
+        let d_out = self.ctx.alloc((wb * words.len()).max(1))?;
+        let st = unsafe { kmx_encoding_rev_comp_p(self.ctx.0, d_in.as_ptr(), n as u64, big_k as u32, self.enc as u8, 8 * wb as u32, B as u32, d_out.as_mut_ptr()) };
         assert_ne!(st, KMX_E_K_RANGE, "attempt to subtract with overflow"); // K == 1 in the crate (naive.rs:140,150)
         self.ctx.ck(st)?;
-        d_out.download::<u64>(words.len())
+        d_out.download::<P>(words.len())
     }
 }
 
-impl<'c, const B: usize> Encoding<u64, B> for HipEncoder<'c> {
-    fn encode(&self, seq: &[u8]) -> [u64; B] {
-        let v = self.encode_batch::<B>(seq, seq.len().max(1)).expect("Encoding::encode");
-        let mut out = [0u64; B];
+/// `impl<P, const B: usize> Encoding<P, B> for Naive where P: utils::Data` (src/encoding/naive.rs:112-115), on the device:
+/// P = u8, u16, u32, u64, u128 (src/utils.rs:24).
+impl<'c, P: Data + Default, const B: usize> Encoding<P, B> for HipEncoder<'c> {
+    fn encode(&self, seq: &[u8]) -> [P; B] {
+        let v = self.encode_batch::<P, B>(seq, seq.len().max(1)).expect("Encoding::encode");
+        let mut out = [P::default(); B];
         if !seq.is_empty() {
             out.copy_from_slice(&v[..B]);
         }
         out
     }
 
-    fn decode(&self, array: [u64; B]) -> Vec<u8> {
-        self.decode_batch::<B>(&array).expect("Encoding::decode")
+    fn decode(&self, array: [P; B]) -> Vec<u8> {
+        self.decode_batch::<P, B>(&array).expect("Encoding::decode")
     }
 
-    fn rev_comp<const K: usize>(&self, array: [u64; B]) -> [u64; B] {
-        let v = self.rev_comp_batch::<B>(&array, K).expect("Encoding::rev_comp");
-        let mut out = [0u64; B];
+    fn rev_comp<const K: usize>(&self, array: [P; B]) -> [P; B] {
+        let v = self.rev_comp_batch::<P, B>(&array, K).expect("Encoding::rev_comp");
+        let mut out = [P::default(); B];
         out.copy_from_slice(&v[..B]);
         out
     }
@@ -213,11 +226,87 @@ impl HipCanonicalKmerBatch {
     }
 }
 
+/// What `CanonicalKmerIterator::get()` shows (canonical_kmer_iterator.rs:13-16,113-116): the k-mer pair and its offset on the read.
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub struct HipCanonicalKmerPos {
+    pub fw: u64,
+    pub rc: u64,
+    pub pos: i32,
+}
+
+impl HipCanonicalKmerPos {
+    /// `CanonicalKmer::get_canonical_word()` (canonical_kmer.rs:113-119)
+    pub fn canonical_word(&self) -> u64 {
+        if self.fw < self.rc { self.fw } else { self.rc }
+    }
+}
+
+/// One read of a [`HipCanonicalKmerBatch`] behind the crate's iterator protocol
+/// (canonical_kmer_iterator.rs:89-116): `from_u8_slice` positions on the first valid k-mer, `inc()` moves to the next and
+/// returns whether there is one, `exhausted()` tells when there is none, `get()` shows the current pair -- so a loop written
+/// as `while !it.exhausted() { use(it.get()); it.inc(); }` against the crate runs unchanged over a scanned batch.
+pub struct HipCanonicalKmerIter<'b> {
+    batch: &'b HipCanonicalKmerBatch,
+    base: usize,      // first window slot of the read
+    slot: usize,      // current window (valid only while !invalid)
+    invalid: bool,
+}
+
+impl<'b> HipCanonicalKmerIter<'b> {
+    fn seek(&mut self, from: usize) {
+        let w = self.batch.windows_per_read;
+        let mut i = from;
+        while i < w && self.batch.flags[self.base + i] & KMX_WIN_VALID == 0 {
+            i += 1;
+        }
+        self.invalid = i >= w;
+        self.slot = i;
+    }
+    /// `exhausted()` (canonical_kmer_iterator.rs:89-92)
+    pub fn exhausted(&self) -> bool {
+        self.invalid
+    }
+    /// `inc()` (canonical_kmer_iterator.rs:94-102)
+    pub fn inc(&mut self) -> bool {
+        if !self.invalid {
+            let next = self.slot + 1;
+            self.seek(next);
+        }
+        !self.invalid
+    }
+    /// `inc_by(count)` (canonical_kmer_iterator.rs:104-112)
+    pub fn inc_by(&mut self, mut count: usize) -> bool {
+        let mut v = !self.invalid;
+        while count > 0 && v {
+            v = self.inc();
+            count -= 1;
+        }
+        v
+    }
+    /// `get()` (canonical_kmer_iterator.rs:113-116); like the crate's, meaningful while `!exhausted()`
+    pub fn get(&self) -> HipCanonicalKmerPos {
+        let i = self.base + self.slot.min(self.batch.windows_per_read.saturating_sub(1));
+        HipCanonicalKmerPos { fw: self.batch.fw[i], rc: self.batch.rc[i], pos: self.slot as i32 }
+    }
+}
+
+impl HipCanonicalKmerBatch {
+    /// the iterator of read `read` (`CanonicalKmerIterator::from_u8_slice(read_bytes, k)`, canonical_kmer_iterator.rs:72-83)
+    pub fn read_iter(&self, read: usize) -> HipCanonicalKmerIter<'_> {
+        let mut it = HipCanonicalKmerIter { batch: self, base: read * self.windows_per_read, slot: 0, invalid: self.windows_per_read == 0 };
+        if !it.invalid {
+            it.seek(0);
+        }
+        it
+    }
+}
+
 /// The consumer shape of benches/simple_benchmark.rs:14-22 (`.sum()` over the words of all windows) on device-resident
 /// reads: count, wrapping sum of canonical words, xor of `hash_one(LexHasherState::new(k), ..)`, wrapping sum of fw words.
-pub fn canonical_sum(ctx: &HipContext, d_reads: *const u8, n_reads: u64, read_len: u32, k: u8) -> Result<kmx_summary, KmxError> {
+pub fn canonical_sum(ctx: &HipContext, d_reads: &DeviceBuf<'_>, n_reads: u64, read_len: u32, k: u8) -> Result<kmx_summary, KmxError> {
+    assert!(n_reads as u128 * read_len as u128 <= d_reads.len() as u128, "reads past the end of the device buffer");
     let d_out = ctx.alloc(std::mem::size_of::<kmx_summary>())?;
-    let r = kmx_reads { d_bases: d_reads, n_reads, read_len, d_offsets: ptr::null() };
+    let r = kmx_reads { d_bases: d_reads.as_ptr(), n_reads, read_len, d_offsets: ptr::null() };
     ctx.ck(unsafe { kmx_canonical_reduce(ctx.0, &r, k as u32, KMX_HASH_LEX, k as u32, KMX_REDUCE_SUM_FW, d_out.as_mut_ptr()) })?;
     Ok(d_out.download::<kmx_summary>(1)?[0])
 }
@@ -303,12 +392,19 @@ impl<'c> HipComm<'c> {
         Ok(Self { ctx, comm })
     }
     /// in place: counts[i] = sum over ranks (ncclAllReduce, ncclUint64 / ncclSum, on the context's stream)
-    pub fn histogram_allreduce(&self, d_counts: *mut u64, n_counts: u64) -> Result<(), KmxError> {
-        self.ctx.ck(unsafe { kmx_histogram_allreduce(self.comm, d_counts, n_counts) })
+    pub fn histogram_allreduce(&self, d_counts: &DeviceBuf<'_>, n_counts: u64) -> Result<(), KmxError> {
+        assert!(8 * n_counts as u128 <= d_counts.len() as u128, "counters past the end of the device buffer");
+        self.ctx.ck(unsafe { kmx_histogram_allreduce(self.comm, d_counts.as_mut_ptr(), n_counts) })
     }
-    /// in place: wrapping sums / xor of the per-shard summaries
-    pub fn summary_allreduce(&self, d_summary: *mut kmx_summary) -> Result<(), KmxError> {
-        self.ctx.ck(unsafe { kmx_summary_allreduce(self.comm, d_summary) })
+    /// in place: wrapping sums / xor of the per-shard summaries (`d_summary`: one device-resident `kmx_summary`)
+    pub fn summary_allreduce(&self, d_summary: &DeviceBuf<'_>) -> Result<(), KmxError> {
+        assert!(std::mem::size_of::<kmx_summary>() <= d_summary.len());
+        self.ctx.ck(unsafe { kmx_summary_allreduce(self.comm, d_summary.as_mut_ptr()) })
+    }
+    /// # Safety
+    /// `d_counts` must be a device pointer to `n_counts` u64 owned by the caller for the duration of the call.
+    pub unsafe fn histogram_allreduce_raw(&self, d_counts: *mut u64, n_counts: u64) -> Result<(), KmxError> {
+        self.ctx.ck(kmx_histogram_allreduce(self.comm, d_counts, n_counts))
     }
 }
 

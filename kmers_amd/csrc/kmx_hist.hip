@@ -95,7 +95,7 @@ struct SinkHistLds {
 struct HistPartParams {
     u64* counts;
     u32 hasher, hk, log2_buckets;
-    uint16_t* stream;   // [n_waves][64][cap]
+    void* stream;       // [n_waves][64][cap] ids of E bytes each (E = uint16_t: the low 16 bits of the bucket; u32: the bucket)
     u32* seg_len;       // [n_waves][64]
     u32 cap;            // entries per (wave, partition) segment, multiple of 64
 };
@@ -103,30 +103,34 @@ struct HistPartParams {
 //   0 LexHasher with hasher_k == k: hash = the 2k-bit complement of the LARGER of fw / rc (kmx_device.h lex_hash: the
 //     reversed groups of the canonical word are the complement of the other strand) -- no hash arithmetic at all;
 //   1 identity: hash = the smaller of the two;   2 LexHasher with another hasher_k.
-template <int MODE>
+// E (round 3): the stream's entry type.  uint16_t: up to 16 low bits per id (2^15..2^22 buckets).  u32: the whole bucket --
+// the first level of the TWO-level partition of 2^23..2^28 buckets (hist_repartition_kernel splits every partition's u32 stream
+// once more, by the next six bits, into uint16_t streams).  A ring is 128 bytes either way: 64 or 32 entries.
+template <int MODE, typename E = uint16_t>
 struct SinkHistPartT {
-#ifndef KMX_HIST_ROW
-#define KMX_HIST_ROW 64
-#endif
-    static constexpr u32 NP = 64, ROW = KMX_HIST_ROW;   // partitions; ring entries per partition (u16); rows of ROW/2 ids leave together
-    static constexpr u32 HALF = ROW / 2u, PER_LANE = HALF / 16u;   // ids per lane of the quarter-wave that writes a row (2 or 4)
+    static_assert(sizeof(E) == 2 || sizeof(E) == 4, "stream entries: uint16_t or u32");
+    static constexpr u32 NP = 64, ROW = 128u / (u32)sizeof(E);   // partitions; ring entries per partition; rows of ROW/2 ids (64 bytes) leave together
+    static constexpr u32 HALF = ROW / 2u;
+    static constexpr u32 ESH = sizeof(E) == 2 ? 1u : 2u;         // log2 of the entry size
+    static constexpr u32 EPL = 16u / (u32)sizeof(E);             // entries per 16-byte piece of a row
     // LDS: per wave the {appended|written} words, the segment cursors and the rank -> ring bytes; the rings of the four waves
     // together at the end of the block's LDS, each wave's 8 KB at a multiple of 8 KB: the ring address of an id is then
     // (mix >> 26 | base >> 13 << 6) << 7 -- one v_alignbit_b32 with the wave's base in the high word -- plus the slot bytes
     static constexpr u32 kLdsDwordsPerWave = 2u * NP + NP / 4u;
     static constexpr u32 kBlockLdsAlign = 2048u;   // dwords (8 KB)
     static constexpr bool kRagged = true;   // (ragged reads come window by window through fast(): no batches)
-    static u32 block_lds_dwords(const HistPartParams&) { return 4u * NP * ROW / 2u; }
+    static constexpr u32 kRingDwords = 4u * NP * 32u;   // 4 waves x 64 rings x 128 bytes
+    static u32 block_lds_dwords(const HistPartParams&) { return kRingDwords; }
     HistPartParams p;
-    uint16_t* ring;    // [NP][ROW]
+    E* ring;           // [NP][ROW]
     u32* word;         // [NP] appended (mod 2^16) << 16 | written out (mod 2^16)
     u32* cur;          // [NP] ids already in this wave's segment of the partition
-    uint16_t* seg;     // this wave's [NP][cap] segments
+    E* seg;            // this wave's [NP][cap] segments
     u64 maskk;
     u32 k, lane, lowbits;
     u32 shift_b, ring_hi, word_rel;   // 32 - log2_buckets; LDS byte address of ring[] >> 13; LDS byte address of word[] minus 4 * (ring_hi << 6)
     __device__ SinkHistPartT(const HistPartParams& p_, u32 k_, u32, u32* lds, u32 lane_, u32* block_lds, u32 tid)
-        : p(p_), ring(reinterpret_cast<uint16_t*>(block_lds + (tid >> 6) * (NP * ROW / 2u))), word(lds), cur(lds + NP),
+        : p(p_), ring(reinterpret_cast<E*>(block_lds + (tid >> 6) * (NP * 32u))), word(lds), cur(lds + NP),
           maskk(mask2k(k_)), k(k_), lane(lane_), lowbits(p_.log2_buckets - 6u) {
         shift_b = 32u - p.log2_buckets;
         typedef u32 __attribute__((address_space(3))) * lds_u32p;
@@ -135,7 +139,7 @@ struct SinkHistPartT {
         ring_hi = (u32)__builtin_amdgcn_readfirstlane(ring_lds >> 13);
         word_rel = (u32)(uintptr_t)(lds_u32p)word - ((ring_hi << 6) << 2);
         const u64 wave = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);
-        seg = p.stream + wave * NP * (u64)p.cap;
+        seg = static_cast<E*>(p.stream) + wave * NP * (u64)p.cap;
         word[lane] = 0;
         cur[lane] = 0;
         wave_sync();
@@ -165,7 +169,7 @@ struct SinkHistPartT {
     __device__ __forceinline__ void place(u32 bucket, u32 w) {
         const u32 q = bucket >> lowbits;
         const u32 slot = w >> 16;
-        if (((slot - w) & 0xFFFFu) < ROW) ring[q * ROW + (slot & (ROW - 1u))] = (uint16_t)(bucket & ((1u << lowbits) - 1u));
+        if (((slot - w) & 0xFFFFu) < ROW) ring[q * ROW + (slot & (ROW - 1u))] = (E)(bucket & ((1u << lowbits) - 1u));
         else {   // ring full: take the slot back (every slot handed out past the ring is, so the count ends exact) and divert
             atomicSub(&word[q], 0x10000u);
             atomicAdd((unsigned long long*)&p.counts[bucket], 1ull);
@@ -191,12 +195,14 @@ struct SinkHistPartT {
     // 2 * (appended mod ROW) is the 7-bit field at bit 15, and ONE test per batch (an OR over the staged counts) tells
     // whether any of its ids found its ring full -- then, and only then, the batch takes the id-by-id path with the
     // diversion to the global table.
-    __device__ __forceinline__ void fast_slot(int s, u64 fw, u64 rc) {
-        static_assert(ROW == 64, "ring addressing below: 64 entries of 2 bytes");
-        pend[s % NB] = mix_of_window<kComplement>(fw, rc);
+    __device__ __forceinline__ void fast_slot(int s, u64 fw, u64 rc) { push_mix(s, mix_of_window<kComplement>(fw, rc)); }
+    // (also the entry of hist_repartition_kernel: an id whose mix is already known)
+    __device__ __forceinline__ void push_mix(int s, u32 mix) {
+        static_assert(ROW * sizeof(E) == 128, "ring addressing below: 128 bytes per ring");
+        pend[s % NB] = mix;
         if (s % NB == NB - 1) {
             typedef u32 __attribute__((address_space(3))) * lds_u32p;
-            typedef uint16_t __attribute__((address_space(3))) * lds_u16p;
+            typedef E __attribute__((address_space(3))) * lds_u16p;
             u32 w[NB];
             u32 qb[NB];   // ring base >> 7: partition | the wave's 8 KB index << 6
 #pragma unroll
@@ -214,9 +220,17 @@ struct SinkHistPartT {
             } else {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const u32 a = (qb[j] << 7) + __builtin_amdgcn_ubfe(w[j], 15, 7);
-                    *(lds_u16p)(uintptr_t)a = (uint16_t)(pend[j] >> shift_b);   // (bits lowbits..15 belong to the partition: pass 2 masks them off)
+                    // byte offset of the slot in its ring, sizeof(E) * (appended mod ROW): the 7-bit field at bit 16 - ESH (the bits
+                    // it takes from the written-out half of the word are zero: written out is 0 or HALF)
+                    const u32 a = (qb[j] << 7) + __builtin_amdgcn_ubfe(w[j], 16u - ESH, 7);
+                    *(lds_u16p)(uintptr_t)a = (E)(pend[j] >> shift_b);   // (the bits above lowbits belong to the partition: the next pass masks them off)
                 }
+            }
+            // u32 entries: a ring holds 32, and a block of 16 windows adds 16 +- 4 to one that may hold 15 already -- every
+            // other block a ring overflowed and its ids took the global-atomic path (pass 1 ran 2.3x slower than with 16-bit
+            // entries).  Draining after every batch of 8 keeps the staged count under 32.
+            if constexpr (sizeof(E) == 4) {
+                if (s < 15) flush_rows();
             }
         }
     }
@@ -229,7 +243,7 @@ struct SinkHistPartT {
     // scalar ctz loop, a quarter-wave busy and a wave_sync -- cost more than the 16 windows they followed
     // (pass 1 at 2^20 buckets: 22 -> see DESIGN 4.3).
     __device__ __forceinline__ void flush_rows() {
-        static_assert(ROW == 64, "row flush: 32 ids = 64 bytes = 4 lanes x 16 bytes");
+        static_assert(HALF * sizeof(E) == 64, "row flush: half a ring = 64 bytes = 4 lanes x 16 bytes");
         wave_sync();
         const bool due = staged(word[lane]) >= HALF;
         const u64 m = __ballot(due);
@@ -247,16 +261,16 @@ struct SinkHistPartT {
                 const u32 w = word[q];
                 const u32 pos = cur[q];
                 const u32 half = w & HALF;   // written-out count is a multiple of HALF: the row starts at ring entry 0 or HALF
-                const uint4 v = *reinterpret_cast<const uint4*>(ring + q * ROW + half + 8u * l4);
+                const uint4 v = *reinterpret_cast<const uint4*>(ring + q * ROW + half + EPL * l4);
                 if (pos + HALF <= p.cap) {
-                    *reinterpret_cast<uint4*>(seg + (u64)q * p.cap + pos + 8u * l4) = v;
+                    *reinterpret_cast<uint4*>(seg + (u64)q * p.cap + pos + EPL * l4) = v;
                 } else {   // segment full: the ids go to the global table
                     const u32 hi = q << lowbits, idm = (1u << lowbits) - 1u;
                     const u32 vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (u32 i = 0; i < 4; ++i) {
                         atomicAdd((unsigned long long*)&p.counts[hi | (vv[i] & idm)], 1ull);
-                        atomicAdd((unsigned long long*)&p.counts[hi | ((vv[i] >> 16) & idm)], 1ull);
+                        if constexpr (sizeof(E) == 2) atomicAdd((unsigned long long*)&p.counts[hi | ((vv[i] >> 16) & idm)], 1ull);
                     }
                 }
                 if (l4 == 0) {
@@ -298,8 +312,8 @@ struct SinkHistPartT {
             const u32 w = word[q];
             const u32 n = staged(w), pos = cur[q];
             if (lane < n) {
-                const uint16_t e = ring[q * ROW + ((w + lane) & (ROW - 1u))];
-                if (pos + n <= p.cap) seg[(u64)q * p.cap + pos + lane] = e;
+                const u32 e = ring[q * ROW + ((w + lane) & (ROW - 1u))];
+                if (pos + n <= p.cap) seg[(u64)q * p.cap + pos + lane] = (E)e;
                 else atomicAdd((unsigned long long*)&p.counts[(q << lowbits) | (e & ((1u << lowbits) - 1u))], 1ull);
             }
             wave_sync();
@@ -317,10 +331,17 @@ struct SinkHistPartT {
 template <int THREADS, int SUB_BITS = 0>
 __global__ void __launch_bounds__(THREADS)
 hist_part_reduce_kernel(const uint16_t* __restrict__ stream, const u32* __restrict__ seg_len, u32 cap, u32 n_waves,
-                        u32 log2_buckets, u64* __restrict__ counts) {
+                        u32 log2_buckets, u64* __restrict__ counts, u64 top_stream_stride, u32 top_len_stride) {
+    // blockIdx.z = (top partition T << SUB_BITS) | sub.  One level (2^15..2^22 buckets): T = 0.  Two levels (2^23..2^28): T = the
+    // first-level partition whose 64 second-level streams this launch counts; log2_buckets is then the bucket bits BELOW
+    // the first level (b - 6), the streams and lengths of T start T strides in, its counters at counts + (T << log2_buckets).
     extern __shared__ __attribute__((aligned(16))) u32 tab[];
     const u32 lowbits = log2_buckets - 6u, idm = (1u << lowbits) - 1u;
-    const u32 tb = lowbits - (u32)SUB_BITS, nb = 1u << tb, sub = SUB_BITS ? blockIdx.z : 0u;
+    const u32 tb = lowbits - (u32)SUB_BITS, nb = 1u << tb, sub = SUB_BITS ? (blockIdx.z & ((1u << SUB_BITS) - 1u)) : 0u;
+    const u32 top = blockIdx.z >> SUB_BITS;
+    stream += (u64)top * top_stream_stride;
+    seg_len += (u64)top * top_len_stride;
+    counts += (u64)top << log2_buckets;
     const u32 q = blockIdx.x;
     for (u32 j = threadIdx.x; j < nb; j += THREADS) tab[j] = 0;
     __syncthreads();
@@ -369,6 +390,62 @@ hist_part_reduce_kernel(const uint16_t* __restrict__ stream, const u32* __restri
     }
 }
 
+// 2^23..2^28 buckets, the pass between: the u32 stream of first-level partition T (blockIdx.y; the ids of all waves of pass
+// 1) is split by the NEXT six bits of the bucket into 64 uint16_t streams -- through the same rings and rows as pass 1 (the
+// sink is reused as it is: an id is pushed as the 32-bit mix whose top bits are the bucket below the first level).
+// Every wave owns a segment of each of T's 64 second-level streams: stream2[T][wave][64][cap2], seg_len2[T][wave][64].
+__global__ void __launch_bounds__(256)
+hist_repartition_kernel(const u32* __restrict__ stream1, const u32* __restrict__ seg_len1, u32 cap1, u32 n_waves1, u32 log2_buckets,
+                        u64* __restrict__ counts, uint16_t* __restrict__ stream2, u32* __restrict__ seg_len2, u32 cap2) {
+    typedef SinkHistPartT<1, uint16_t> Sink;
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const u32 T = blockIdx.y, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u32 n_waves2 = gridDim.x * 4u;
+    const u32 low1 = log2_buckets - 6u;                       // bucket bits below the first level (17..22)
+    HistPartParams p2{counts + ((u64)T << low1), KMX_HASH_IDENTITY, 0u, low1,
+                      stream2 + (u64)T * n_waves2 * 64u * (u64)cap2, seg_len2 + (u64)T * n_waves2 * 64u, cap2};
+    // LDS: the four waves' rings first (32 KB, 8 KB-aligned as the sink wants them), then each wave's words
+    u32* const rings = lds;
+    u32* const mine = lds + Sink::kRingDwords + wv * Sink::kLdsDwordsPerWave;
+    Sink sink(p2, 0u, 0u, mine, lane, rings, threadIdx.x);
+    const u32 up = 32u - low1;                                // id -> mix: the bucket below the first level in the top bits
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const u32 w0 = blockIdx.x * 4u + wv;
+    for (u32 w = w0; w < n_waves1; w += n_waves2) {
+        const u32 len = seg_len1[(u64)w * 64u + T];
+        const u32* __restrict__ sp = stream1 + ((u64)w * 64u + T) * (u64)cap1;
+        const u32x4* __restrict__ sp4 = reinterpret_cast<const u32x4*>(sp);
+        const u32 n16 = len / 4u;                             // 16-byte pieces
+        u32 i = 0;
+        // 16 ids per lane and round (four loads in flight), then the rings holding a half row write it out -- the rhythm of
+        // pass 1 (16 windows per read, then flush_rows)
+        for (; i + 256u <= n16; i += 256u) {
+            const u32x4 v0 = __builtin_nontemporal_load(sp4 + i + lane);
+            const u32x4 v1 = __builtin_nontemporal_load(sp4 + i + 64u + lane);
+            const u32x4 v2 = __builtin_nontemporal_load(sp4 + i + 128u + lane);
+            const u32x4 v3 = __builtin_nontemporal_load(sp4 + i + 192u + lane);
+            sink.push_mix(0, v0.x << up); sink.push_mix(1, v0.y << up); sink.push_mix(2, v0.z << up); sink.push_mix(3, v0.w << up);
+            sink.push_mix(4, v1.x << up); sink.push_mix(5, v1.y << up); sink.push_mix(6, v1.z << up); sink.push_mix(7, v1.w << up);
+            sink.push_mix(8, v2.x << up); sink.push_mix(9, v2.y << up); sink.push_mix(10, v2.z << up); sink.push_mix(11, v2.w << up);
+            sink.push_mix(12, v3.x << up); sink.push_mix(13, v3.y << up); sink.push_mix(14, v3.z << up); sink.push_mix(15, v3.w << up);
+            sink.flush_rows();
+        }
+        // the tail of the segment: id by id, a quarter of a round at a time
+        for (u32 j = 4u * i; j < len; j += 256u) {
+#pragma unroll
+            for (u32 t = 0; t < 4u; ++t) {
+                const u32 e = j + 64u * t + lane;
+                if (e < len) {
+                    const u32 bucket = (sp[e] << up) >> (32u - low1);
+                    sink.place(bucket, sink.take_slot(bucket));
+                }
+            }
+            sink.flush_rows();
+        }
+    }
+    sink.finish(p2);
+}
+
 template <typename SinkHistPart, typename Pre, bool RAGGED>
 static hipError_t dispatch_part_mode(const uint8_t* bases, u64 n_reads, u32 L, u32 k, HistPartParams& p, unsigned long long* queue,
                                      int n_cu, hipStream_t stream, Pre pre, const u64* offsets) {
@@ -380,10 +457,20 @@ static hipError_t dispatch_part_mode(const uint8_t* bases, u64 n_reads, u32 L, u
 #undef KMX_PART
 }
 
-template <typename Pre>
+template <typename Pre, typename E = uint16_t>
 static hipError_t dispatch_part(const uint8_t* bases, u64 n_reads, u32 L, u32 k, HistPartParams& p, unsigned long long* queue,
                                 int n_cu, hipStream_t stream, Pre pre, const u64* offsets) {
     const int mode = p.hasher != KMX_HASH_LEX ? 1 : p.hk == k ? 0 : 2;
+    if constexpr (sizeof(E) == 4) {   // first level of the two-level partition (2^23..2^28 buckets)
+        if (offsets) {
+            if (mode == 0) return dispatch_part_mode<SinkHistPartT<0, u32>, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+            if (mode == 1) return dispatch_part_mode<SinkHistPartT<1, u32>, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+            return dispatch_part_mode<SinkHistPartT<2, u32>, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+        }
+        if (mode == 0) return dispatch_part_mode<SinkHistPartT<0, u32>, Pre, false>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, nullptr);
+        if (mode == 1) return dispatch_part_mode<SinkHistPartT<1, u32>, Pre, false>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, nullptr);
+        return dispatch_part_mode<SinkHistPartT<2, u32>, Pre, false>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, nullptr);
+    }
     if (offsets) {
         if (mode == 0) return dispatch_part_mode<SinkHistPartT<0>, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
         if (mode == 1) return dispatch_part_mode<SinkHistPartT<1>, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
@@ -397,6 +484,7 @@ static hipError_t dispatch_part(const uint8_t* bases, u64 n_reads, u32 L, u32 k,
 // Histogram over uniform or ragged reads.  2^b <= 2^14: block-private LDS tables (SinkHistLds).  2^15..2^22: two passes through
 // 64 partitions (SinkHistPart + hist_part_reduce_kernel) in chunks of reads sized to `scratch_budget` bytes of
 // caller-provided scratch (`get_scratch(user, bytes)` returns a device buffer of at least `bytes`, or nullptr).
+// 2^23..2^28: the same with a second level of 64 partitions in between (hist_repartition_kernel).
 // Larger tables, or no scratch: device-scope u64 atomics (SinkHist).
 hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 hasher, u32 hk, u32 log2_buckets,
                                u64* counts, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
@@ -405,6 +493,78 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
     if (!*handled) return hipSuccess;
     const HistParams p{counts, hasher, hk, log2_buckets};
     if (log2_buckets <= 14u) return dispatch<SinkHistLds>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
+    if (log2_buckets >= 23u && log2_buckets <= 28u && get_scratch != nullptr && n_reads >= 4096u) {
+        // Two levels of 64 partitions each (round 3; these sizes took device atomics before: 0.5 s per 1e8 reads).  Pass 1 as
+        // below but with the whole bucket per id (u32 entries); hist_repartition_kernel splits each partition's stream by the
+        // next six bits into uint16_t streams; hist_part_reduce_kernel counts the 64 x 64 streams in LDS tables of 2^(b-12)
+        // entries (2^16 at b = 28: two halves).  Scratch per window: 1.5 x (4 + 2) bytes.
+        const u32 Lb = offsets ? (L ? L : 256u) : L;
+        const u64 W = Lb >= k ? Lb - k + 1u : 1u;
+        u64 chunk = scratch_budget / (10u * W);
+        if (chunk > n_reads) chunk = n_reads;
+        chunk &= ~63ull;
+        if (chunk >= 4096u) {
+            const u32 low1 = log2_buckets - 6u;
+            for (u64 first = 0; first < n_reads; first += chunk) {
+                const u64 n = n_reads - first < chunk ? n_reads - first : chunk;
+                HistPartParams pp{counts, hasher, hk, log2_buckets, nullptr, nullptr, 0};
+                u32 n_waves = 0, n_waves2 = 0, cap2 = 0;
+                uint16_t* stream2 = nullptr;
+                u32* seg_len2 = nullptr;
+                const u32 gx2 = (u32)((n_cu * 4 + 63) / 64 > 0 ? (n_cu * 4 + 63) / 64 : 1);   // blocks per first-level partition in the pass between
+                auto pre = [&](u64 grid) -> bool {
+                    n_waves = (u32)(grid * 4u);
+                    const u64 per_seg = (n * W * 3u / 2u) / ((u64)n_waves * 64u) + 256u;
+                    pp.cap = (u32)((per_seg + 63u) & ~63ull);
+                    if (pp.cap > (1u << 24)) return false;
+                    n_waves2 = gx2 * 4u;
+                    const u64 per_seg2 = (n * W * 3u / 2u) / (64ull * n_waves2 * 64u) + 256u;
+                    cap2 = (u32)((per_seg2 + 63u) & ~63ull);
+                    const size_t s1 = (size_t)n_waves * 64u * pp.cap * 4u, l1 = (size_t)n_waves * 64u * 4u;
+                    const size_t s2 = (size_t)64u * n_waves2 * 64u * cap2 * 2u, l2 = (size_t)64u * n_waves2 * 64u * 4u;
+                    char* buf = static_cast<char*>(get_scratch(user, s1 + l1 + s2 + l2));
+                    if (!buf) return false;
+                    pp.stream = buf;
+                    pp.seg_len = reinterpret_cast<u32*>(buf + s1);
+                    stream2 = reinterpret_cast<uint16_t*>(buf + s1 + l1);
+                    seg_len2 = reinterpret_cast<u32*>(buf + s1 + l1 + s2);
+                    return true;
+                };
+                if (first != 0) {
+                    hipError_t e = hipMemsetAsync(queue, 0, 32 * 128, stream);
+                    if (e != hipSuccess) return e;
+                }
+                const uint8_t* cb = offsets ? bases : bases + first * (u64)L;
+                const u64* co = offsets ? offsets + first : nullptr;
+                hipError_t e = dispatch_part<decltype(pre), u32>(cb, n, L, k, pp, queue, n_cu, stream, pre, co);
+                if (e == hipErrorOutOfMemory) {   // no scratch: the atomic sink handles the rest
+                    (void)hipGetLastError();
+                    return dispatch<SinkHist>(cb, n_reads - first, L, k, p, queue, n_cu, stream, NoPre(), co);
+                }
+                if (e != hipSuccess) return e;
+                typedef SinkHistPartT<1, uint16_t> Sink2;
+                const HistPartParams dummy{};
+                const size_t lds2 = ((size_t)Sink2::block_lds_dwords(dummy) + 4u * Sink2::kLdsDwordsPerWave) * 4u;
+                hipLaunchKernelGGL(hist_repartition_kernel, dim3(gx2, 64), dim3(256), lds2, stream, static_cast<const u32*>(pp.stream), pp.seg_len,
+                                   pp.cap, n_waves, log2_buckets, counts, stream2, seg_len2, cap2);
+                e = hipGetLastError();
+                if (e != hipSuccess) return e;
+                const bool halves = low1 == 22u;   // 2^16 buckets per second-level partition: two blocks of 2^15 each
+                const u32 nb_bytes = 4u << (low1 - 6u - (halves ? 1u : 0u));
+                auto red = halves ? hist_part_reduce_kernel<512, 1> : hist_part_reduce_kernel<512, 0>;
+                if (nb_bytes > 64u * 1024u) {
+                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(red), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_bytes);
+                    if (e != hipSuccess) return e;
+                }
+                const u32 groups = n_waves2 < 4u ? n_waves2 : 4u;
+                hipLaunchKernelGGL(red, dim3(64, groups, 64u * (halves ? 2u : 1u)), dim3(512), nb_bytes, stream, stream2, seg_len2, cap2, n_waves2,
+                                   low1, counts, (u64)n_waves2 * 64u * (u64)cap2, n_waves2 * 64u);
+                e = hipGetLastError();
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        }
+    }
     if (log2_buckets <= 22u && get_scratch != nullptr && n_reads >= 4096u) {
         // windows per read the segments are sized for.  Ragged reads: from the caller's bound of the lengths (the frame's 256 if
         // there is none); a read that is longer after all only fills its wave's segments sooner, and what finds a segment full
@@ -429,7 +589,7 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
                     const size_t len_bytes = (size_t)n_waves * 64u * 4u;
                     char* buf = static_cast<char*>(get_scratch(user, stream_bytes + len_bytes));
                     if (!buf) return false;
-                    pp.stream = reinterpret_cast<uint16_t*>(buf);
+                    pp.stream = buf;
                     pp.seg_len = reinterpret_cast<u32*>(buf + stream_bytes);
                     return true;
                 };
@@ -456,8 +616,8 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
                     if (e != hipSuccess) return e;
                 }
                 const u32 groups = n_waves < 16u ? n_waves : 16u;
-                hipLaunchKernelGGL(red, dim3(64, groups, halves ? 2 : 1), dim3(512), nb_bytes, stream, pp.stream, pp.seg_len, pp.cap, n_waves,
-                                   log2_buckets, counts);
+                hipLaunchKernelGGL(red, dim3(64, groups, halves ? 2 : 1), dim3(512), nb_bytes, stream, static_cast<const uint16_t*>(pp.stream), pp.seg_len,
+                                   pp.cap, n_waves, log2_buckets, counts, (u64)0, 0u);
                 e = hipGetLastError();
                 if (e != hipSuccess) return e;
             }

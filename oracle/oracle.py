@@ -79,7 +79,14 @@ class Summary2(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    """Compile oracle/libkmx_oracle.so (portable flags) if missing; return its path."""
+    """Compile oracle/libkmx_oracle.so (portable flags) if missing; return its path.
+    KMX_ORACLE_SANITIZE=1 (tests/test_sanitizers.py: a python started with libasan preloaded): the ASan + UBSan build."""
+    if os.environ.get("KMX_ORACLE_SANITIZE") == "1":
+        so = os.path.join(_HERE, "libkmx_oracle_asan.so")
+        src = os.path.join(_HERE, "kmx_oracle.c")
+        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "libkmx_oracle_asan.so"], stdout=subprocess.DEVNULL)
+        return so
     so = os.path.join(_HERE, "libkmx_oracle.so")
     src = os.path.join(_HERE, "kmx_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

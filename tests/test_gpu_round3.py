@@ -225,3 +225,46 @@ def test_reduce_picks_the_uniform_kernel_on_the_device(ctx, orc, k, case):
     if case in ("uniform", "dirty_uniform"):
         u = ctx.canonical_reduce(ctx.to_device(host), n_reads, L, k, _lib.HASH_LEX, k, 0)
         assert (u.n_valid, u.sum_canon, u.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+
+
+# ------------------------------------------------------------------ histogram, 2^23..2^28 buckets: two partition levels
+
+@pytest.mark.parametrize("b", [23, 24, 26])
+@pytest.mark.parametrize("hasher,hk", [(1, 31), (2, 0), (1, 17)])
+def test_histogram_two_levels(ctx, orc, b, hasher, hk):
+    """2^23..2^28 buckets took device atomics before (0.5 s per 1e8 reads); now pass 1 writes whole buckets (u32), a second
+    pass splits each partition by the next six bits, the third counts in LDS.  Bit-exact against the oracle's table."""
+    if b == 26 and hasher != 1:
+        pytest.skip("one hasher at the 512 MB table")
+    L, k, n_reads = 150, 31, 64 * 700 + 29
+    rng = np.random.default_rng(b * 11 + hasher)
+    host = _dirty(rng, n_reads * L, 0.0004)
+    o = orc.histogram(host, n_reads, L, k, hk if hasher == 1 else 0, b)
+    g = ctx.histogram(ctx.to_device(host), n_reads, L, k, hasher, hk, b).cpu().numpy().view(np.uint64)
+    assert int(g.sum()) == int(o.sum())
+    assert (g == o).all()
+
+
+def test_histogram_two_levels_at_2_28_folds_to_2_23(ctx, orc):
+    """the 2 GB table of 2^28 buckets against the oracle's 2^23 table: both are top bits of the same 32-bit mix"""
+    L, k, n_reads = 150, 31, 64 * 900 + 3
+    bases = ctx.gen_reads(n_reads * L, first_byte=12345)
+    o = orc.histogram(bases.cpu().numpy(), n_reads, L, k, k, 23)
+    g = ctx.histogram(bases, n_reads, L, k, 1, k, 28)
+    folded = g.view(-1, 32).sum(dim=1).cpu().numpy().view(np.uint64)
+    assert int(folded.sum()) == n_reads * (L - k + 1)
+    assert (folded == o).all()
+
+
+def test_histogram_two_levels_ragged(ctx, orc):
+    L_hint, k, b = 160, 21, 24
+    rng = np.random.default_rng(5)
+    lens = rng.integers(20, 161, size=64 * 400 + 7)
+    lens[::97] = 0
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]) + 16, 0.0005)[: int(offsets[-1])]
+    o = orc.histogram(host, len(lens), 0, k, k, b, offsets=offsets)
+    g = ctx.histogram(ctx.to_device(host), len(lens), L_hint, k, 1, k, b, offsets=ctx.to_device(offsets))
+    g = g.cpu().numpy().view(np.uint64)
+    assert int(g.sum()) == int(o.sum())
+    assert (g == o).all()

@@ -2,7 +2,7 @@
 textual: every `extern "C"` declaration of src/ffi.rs is compared, parameter by parameter, with the prototype of the same
 name in include/kmx.h (an independent parser, not the generator's), the committed ffi.rs is what the generator emits
 today, and the safe layer (src/lib.rs) only calls declared functions with the declared number of arguments and has no
-unimplemented!() / todo!() left -- in particular `impl Encoding<u64, B> for HipEncoder` has all three trait methods
+unimplemented!() / todo!() left -- in particular `impl Encoding<P, B> for HipEncoder` (every utils::Data word type) has all three trait methods
 (/root/reference/src/encoding/mod.rs:14-23)."""
 import os
 import re
@@ -119,12 +119,49 @@ def test_safe_layer_is_complete_and_calls_only_what_exists():
             i += 1
         n_args = 0 if empty else commas + 1
         assert n_args == len(r[m.group(1)][1]), (m.group(1), n_args, len(r[m.group(1)][1]))
-    # the trait of /root/reference/src/encoding/mod.rs:14-23, all three methods
-    impl = lib[lib.index("impl<'c, const B: usize> Encoding<u64, B> for HipEncoder<'c>"):]
+    # the trait of /root/reference/src/encoding/mod.rs:14-23, all three methods, generic over the word type like
+    # `impl<P, const B: usize> Encoding<P, B> for Naive where P: utils::Data` (/root/reference/src/encoding/naive.rs:112-115)
+    impl = lib[lib.index("impl<'c, P: Data + Default, const B: usize> Encoding<P, B> for HipEncoder<'c>"):]
     impl = impl[:impl.index("\n}\n") + 3]
-    for sig in ("fn encode(&self, seq: &[u8]) -> [u64; B]", "fn decode(&self, array: [u64; B]) -> Vec<u8>",
-                "fn rev_comp<const K: usize>(&self, array: [u64; B]) -> [u64; B]"):
+    for sig in ("fn encode(&self, seq: &[u8]) -> [P; B]", "fn decode(&self, array: [P; B]) -> Vec<u8>",
+                "fn rev_comp<const K: usize>(&self, array: [P; B]) -> [P; B]"):
         assert sig in impl, sig
+    # ... through the word-size-generic calls of the C ABI
+    for call in ("kmx_encode_kmers_p", "kmx_encoding_decode_p", "kmx_encoding_rev_comp_p"):
+        assert call in lib, call
+    # the iterator protocol of /root/reference/src/naive_impl/canonical_kmer_iterator.rs:89-116 over a scanned batch
+    it = lib[lib.index("impl<'b> HipCanonicalKmerIter<'b>"):]
+    for sig in ("pub fn exhausted(&self) -> bool", "pub fn inc(&mut self) -> bool", "pub fn inc_by(&mut self, mut count: usize) -> bool",
+                "pub fn get(&self) -> HipCanonicalKmerPos"):
+        assert sig in it, sig
+    assert "pub fn read_iter(&self, read: usize) -> HipCanonicalKmerIter" in lib
+
+
+def test_safe_functions_do_not_take_raw_device_pointers():
+    """a safe `pub fn` taking a raw device pointer is unsound -- they take a DeviceBuf, or are `unsafe fn`"""
+    lib = open(os.path.join(RS, "src", "lib.rs")).read()
+    for m in re.finditer(r"pub (unsafe )?fn (\w+)\s*(<[^>]*>)?\(([^)]*)\)", lib):
+        is_unsafe, name, args = bool(m.group(1)), m.group(2), m.group(4)
+        if name in ("raw", "as_ptr", "as_mut_ptr"):
+            continue
+        if "*const" in args or "*mut" in args:
+            assert is_unsafe, f"pub fn {name} takes a raw pointer but is not unsafe"
+
+
+def test_every_header_constant_is_in_ffi_rs():
+    """the generator used to drop hex / U-suffixed literals (KMX_FASTX_SAME_TEXT 0x100u)"""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "kmx.h")).read(), flags=re.S)
+    ffi = open(os.path.join(RS, "src", "ffi.rs")).read()
+    names = re.findall(r"^#define\s+(KMX_[A-Z0-9_]+)\s+\S", hdr, flags=re.M)
+    assert len(names) >= 20
+    for nm in names:
+        if nm in ("KMX_H",):
+            continue
+        m = re.search(r"^#define\s+%s\s+(0[xX][0-9A-Fa-f]+|[0-9]+)[uU]?\s*$" % nm, hdr, flags=re.M)
+        assert m, f"{nm}: not an integer literal the generator understands"
+        r = re.search(r"pub const %s: \w+ = (\d+);" % nm, ffi)
+        assert r, f"{nm} missing from ffi.rs"
+        assert int(r.group(1)) == int(m.group(1), 0), nm
 
 
 def test_crate_files_exist():
