@@ -63,6 +63,8 @@ hipError_t launch_windows_generic(const kmx_reads* r, const u64* win_off, u32 k,
 hipError_t launch_histogram_generic(const kmx_reads* r, u32 k, u32 hasher, u32 hk, u32 log2_buckets, u64* counts,
                                     int n_cu, hipStream_t st);
 hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_summary2* out, int n_cu, hipStream_t st);
+hipError_t launch_windows2_tiled(const kmx_reads* r, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu, hipStream_t st,
+                                 bool* handled);
 hipError_t launch_windows2_generic(const kmx_reads* r, const u64* win_off, u32 k, u64* fw, u64* rc, u64* canon,
                                    uint8_t* flags, int n_cu, hipStream_t st);
 // kmx_elem.hip
@@ -483,6 +485,9 @@ int kmx_canonical_windows2(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t*
     if (reads->d_offsets && !d_win_offsets) return KMX_E_ARG;
     if (reads->n_reads == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
+    bool handled = false;   // uniform reads of up to 256 bases: the tiled kernel (kmx_generic.hip)
+    KMX_HIP(ctx, kmx::launch_windows2_tiled(reads, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled));
+    if (handled) return KMX_OK;
     KMX_HIP(ctx, kmx::launch_windows2_generic(reads, d_win_offsets, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream));
     return KMX_OK;
 }

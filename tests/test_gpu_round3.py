@@ -268,3 +268,69 @@ def test_histogram_two_levels_ragged(ctx, orc):
     g = g.cpu().numpy().view(np.uint64)
     assert int(g.sum()) == int(o.sum())
     assert (g == o).all()
+
+
+# ------------------------------------------------------------------ [u64;2] materialise: the tiled kernel
+
+def _cmp_windows2(ctx, orc, host, dev, n, L, k):
+    fw, rc, canon, flags = orc.canonical_windows2(host, n, L, k)
+    outs = ctx.canonical_windows2(dev, n, L, k)
+    assert (outs["flags"].cpu().numpy() == flags).all()
+    assert (outs["fw"].cpu().numpy().view(np.uint64).reshape(-1, 2) == fw).all()
+    assert (outs["rc"].cpu().numpy().view(np.uint64).reshape(-1, 2) == rc).all()
+    assert (outs["canon"].cpu().numpy().view(np.uint64).reshape(-1, 2) == canon).all()
+
+
+@pytest.mark.parametrize("k", [33, 34, 40, 47, 48, 49, 56, 63, 64])
+@pytest.mark.parametrize("L", [64, 65, 100, 150, 159, 160, 161, 200, 256])
+def test_windows2_tiled_every_frame(ctx, orc, k, L):
+    """kmx_canonical_windows2 on uniform reads: the tiled kernel (kmx_generic.hip: rolling 128-bit windows out of the packed
+    tile) against the oracle's per-read rolling -- clean reads, 64 * n + tail reads, both frames"""
+    n = 64 * 6 + 13
+    bases = ctx.gen_reads(n * L, first_byte=k * 1000 + L)
+    _cmp_windows2(ctx, orc, bases.cpu().numpy(), bases, n, L, k)
+
+
+@pytest.mark.parametrize("k", [33, 47, 63, 64])
+@pytest.mark.parametrize("p_bad", [0.0003, 0.01])
+def test_windows2_tiled_dirty(ctx, orc, k, p_bad):
+    """tiles with an invalid byte take the exact per-read body; slots of skipped windows are zero with flags 0"""
+    n, L = 64 * 20 + 5, 150
+    rng = np.random.default_rng(k + int(p_bad * 1e4))
+    host = _dirty(rng, n * L, p_bad)
+    _cmp_windows2(ctx, orc, host, ctx.to_device(host), n, L, k)
+
+
+@pytest.mark.parametrize("lead", [1, 7, 8, 15])
+def test_windows2_tiled_unaligned_base(ctx, orc, lead):
+    n, L, k = 64 * 5 + 1, 150, 63
+    rng = np.random.default_rng(lead)
+    host = _dirty(rng, lead + n * L, 0.0002)
+    dev = ctx.to_device(host)
+    _cmp_windows2(ctx, orc, host[lead:], dev[lead:], n, L, k)
+
+
+def test_windows2_single_output_arrays(ctx, orc):
+    """any of the four outputs may be NULL"""
+    import ctypes as C
+
+    import torch
+
+    from kmers_amd.api import _ptr
+
+    n, L, k = 64 * 9, 150, 47
+    bases = ctx.gen_reads(n * L, first_byte=5)
+    fw, rc, canon, flags = orc.canonical_windows2(bases.cpu().numpy(), n, L, k)
+    tot = n * (L - k + 1)
+    r = ctx._reads(bases, n, L, None)
+    for which, ref in (("canon", canon), ("fw", fw), ("rc", rc)):
+        buf = ctx.empty(2 * tot, torch.int64)
+        args = {"fw": None, "rc": None, "canon": None}
+        args[which] = _ptr(buf)
+        ctx._ck(ctx.lib.kmx_canonical_windows2(ctx._h, C.byref(r), None, k, args["fw"], args["rc"], args["canon"], None))
+        torch.cuda.synchronize()
+        assert (buf.cpu().numpy().view(np.uint64).reshape(-1, 2) == ref).all(), which
+    fl = ctx.empty(tot, torch.uint8)
+    ctx._ck(ctx.lib.kmx_canonical_windows2(ctx._h, C.byref(r), None, k, None, None, None, _ptr(fl)))
+    torch.cuda.synchronize()
+    assert (fl.cpu().numpy() == flags).all()
