@@ -120,6 +120,12 @@
 #ifndef KMX_BS_LOAD_AUX
 #define KMX_BS_LOAD_AUX 2
 #endif
+#ifndef KMX_BS_LATE13
+#define KMX_BS_LATE13 7   // late prefetch rows (of 13) of the 13-word frame (uniform ASCII reads of 161..208 bases)
+#endif
+#ifndef KMX_BS_WAVES13
+#define KMX_BS_WAVES13 4  // waves per SIMD of the 13-word frame
+#endif
 #ifndef KMX_BS_ABLATE
 #define KMX_BS_ABLATE 0   // dev: bitmask of phases to skip (timing experiments only; results become wrong)
 #endif
@@ -189,7 +195,7 @@ template <int K, int WPL> constexpr int bs_waves_ascii() {
 #endif
 }
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
-__global__ void __launch_bounds__(256, (K > 32 ? KMX_BS_WAVES2 : RAGGED ? (NW > 10 ? 2 : KMX_BSR_WAVES) : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
+__global__ void __launch_bounds__(256, (K > 32 ? KMX_BS_WAVES2 : RAGGED ? (NW > 10 ? 2 : KMX_BSR_WAVES) : NW == 13 ? KMX_BS_WAVES13 : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead) {
@@ -488,7 +494,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
     };
     constexpr int LATE = PACKED ? 0 : NW == 10 ? (RAGGED ? KMX_BSR_LATE : K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2)
-                         : NW < 10 ? (K > 32 ? 0 : KMX_BS_LATE7) : (RAGGED || K > 32) ? 0 : KMX_BS_LATE16;   // rows of the prefetch requested late
+                         : NW < 10 ? (K > 32 ? 0 : KMX_BS_LATE7) : (RAGGED || K > 32) ? 0 : NW == 13 ? KMX_BS_LATE13 : KMX_BS_LATE16;   // rows of the prefetch requested late
     u64 tile = ~0ull, next_tile = ~0ull;
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
@@ -1584,6 +1590,14 @@ static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
     }
     if (L > 160) {   // 161..256 bp: the 16-word frame, as few windows per lane as keep the 2*ceil(W/WPL) items inside 64 lanes
         if constexpr (!PACKED) {
+            // 161..208 bp (round 3): the 13-word frame -- 13 instead of 16 transposes per half-wave, 52 instead of 64 prefetch
+            // registers (4 waves/SIMD), four fifths of the plane area
+            const u32 mis13 = (reinterpret_cast<uintptr_t>(bases) & 15u) ? 1u : 0u;
+            if (4u * L + mis13 <= 64u * 13u) {
+                if (W <= 160u) return launch_bs<K, 13, 5, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+                if (W <= 192u) return launch_bs<K, 13, 6, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+                return launch_bs<K, 13, 7, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+            }
             if (W <= 160u) return launch_bs<K, 16, 5, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
             if (W <= 192u) return launch_bs<K, 16, 6, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
             if (W <= 224u) return launch_bs<K, 16, 7, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);

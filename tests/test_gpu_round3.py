@@ -334,3 +334,22 @@ def test_windows2_single_output_arrays(ctx, orc):
     ctx._ck(ctx.lib.kmx_canonical_windows2(ctx._h, C.byref(r), None, k, None, None, None, _ptr(fl)))
     torch.cuda.synchronize()
     assert (fl.cpu().numpy() == flags).all()
+
+
+# ------------------------------------------------------------------ the 13-word frame (reads of 161..208 bases)
+
+@pytest.mark.parametrize("L", [161, 163, 170, 176, 185, 192, 200, 207, 208, 209])
+@pytest.mark.parametrize("k", [13, 16, 21, 27, 31])
+def test_reduce_thirteen_word_frame(ctx, orc, L, k):
+    """uniform reads of 161..208 bases take the 13-word frame of the bit-sliced kernel (5, 6 or 7 windows per lane); 209 is the
+    first length of the 16-word frame again.  Clean and dirty reads, an unaligned base, against the oracle."""
+    from kmers_amd import _lib
+
+    n_reads = 64 * 9 + 21
+    rng = np.random.default_rng(L * 31 + k)
+    for p_bad, lead in ((0.0, 0), (0.0004, 0), (0.0, 9)):
+        host = _dirty(rng, lead + n_reads * L, p_bad)
+        dev = ctx.to_device(host)
+        o = orc.canonical_reduce(host[lead:], n_reads, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(dev[lead:], n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        _same(g, o, True, True)
