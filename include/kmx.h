@@ -71,10 +71,12 @@ typedef struct {
 } kmx_reads;
 /* Limits: a single read is shorter than 2^31 bases (the iterator's positions are i32 in the reference as well,
  * canonical_kmer_iterator.rs:15); offsets and totals are 64-bit.  A ragged read of 2^31 bases or more -- e.g. a whole
- * chromosome out of kmx_fastx_parse's FASTA mode -- is not diagnosed: cut such records into overlapping pieces first
- * (k - 1 bases of overlap, or hand the bytes over as uniform reads: reads longer than 256 bases are scanned in
- * 160-base segments).  Uniform reads may start at any byte address; ragged reads need a 16-byte-aligned d_bases for the
- * tiled kernels (any address is served, by the per-read kernel). */
+ * chromosome out of kmx_fastx_parse's FASTA mode -- is DIAGNOSED, not scanned: the scan kernels skip it (it contributes no
+ * window) and raise a sticky flag on the context, the next kmx_ctx_synchronize returns KMX_E_ARG with the text in
+ * kmx_last_error and clears the flag; kmx_reads_length_range returns KMX_E_ARG for such a batch right away.  Cut such
+ * records into overlapping pieces first (k - 1 bases of overlap, or hand the bytes over as uniform reads: reads longer
+ * than 256 bases are scanned in 160-base segments).  Uniform reads may start at any byte address; ragged reads need a
+ * 16-byte-aligned d_bases for the tiled kernels (any address is served, by the per-read kernel). */
 
 /* Result of a streaming reduce pass (device-resident, 32 bytes).
  * == what a consumer loop over CanonicalKmerIterator accumulates
@@ -99,7 +101,7 @@ typedef struct {
 int kmx_ctx_create(int device, kmx_ctx **out);                 /* owns a new non-blocking stream */
 int kmx_ctx_create_on_stream(int device, void *hip_stream, kmx_ctx **out); /* borrows the caller's hipStream_t (NULL = default stream) */
 void kmx_ctx_destroy(kmx_ctx *ctx);
-int kmx_ctx_synchronize(kmx_ctx *ctx);
+int kmx_ctx_synchronize(kmx_ctx *ctx);                         /* also reports what the asynchronous scans could not: KMX_E_ARG after a read of >= 2^31 bases was skipped */
 int kmx_ctx_device(const kmx_ctx *ctx);
 const char *kmx_strerror(int status);
 const char *kmx_last_error(const kmx_ctx *ctx); /* text of the last HIP failure on this ctx */

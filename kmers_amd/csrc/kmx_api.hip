@@ -57,16 +57,16 @@ hipError_t launch_reduce_packed_generic(const u64* words, u64 n_reads, u32 L, u3
                                         kmx_summary* out, int n_cu, hipStream_t st);
 // kmx_generic.hip
 hipError_t launch_reduce_generic(const kmx_reads* r, u32 k, u32 hasher, u32 hk, u32 want_sumfw, kmx_summary* out,
-                                 int n_cu, hipStream_t st);
+                                 int n_cu, hipStream_t st, unsigned long long* too_long);
 hipError_t launch_windows_generic(const kmx_reads* r, const u64* win_off, u32 k, u64* fw, u64* rc, u64* canon,
-                                  uint8_t* flags, int n_cu, hipStream_t st);
+                                  uint8_t* flags, int n_cu, hipStream_t st, unsigned long long* too_long);
 hipError_t launch_histogram_generic(const kmx_reads* r, u32 k, u32 hasher, u32 hk, u32 log2_buckets, u64* counts,
-                                    int n_cu, hipStream_t st);
-hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_summary2* out, int n_cu, hipStream_t st);
+                                    int n_cu, hipStream_t st, unsigned long long* too_long);
+hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_summary2* out, int n_cu, hipStream_t st, unsigned long long* too_long);
 hipError_t launch_windows2_tiled(const kmx_reads* r, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu, hipStream_t st,
                                  bool* handled);
 hipError_t launch_windows2_generic(const kmx_reads* r, const u64* win_off, u32 k, u64* fw, u64* rc, u64* canon,
-                                   uint8_t* flags, int n_cu, hipStream_t st);
+                                   uint8_t* flags, int n_cu, hipStream_t st, unsigned long long* too_long);
 // kmx_elem.hip
 hipError_t launch_gen_reads(u64 seed, u64 first_byte, uint8_t* out, u64 nbytes, int n_cu, hipStream_t st);
 hipError_t launch_kmers_from_bytes(const uint8_t* seqs, u64 n, u32 k, u64* words, unsigned long long* first_bad, int n_cu,
@@ -306,6 +306,16 @@ int kmx_ctx_synchronize(kmx_ctx* ctx) {
     if (!ctx) return KMX_E_ARG;
     DeviceGuard g(ctx->device);
     KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // the sticky flag of the scans: a ragged read of 2^31 bases or more was skipped (kmx.h "Limits")
+    unsigned long long too_long = 0;
+    KMX_HIP(ctx, hipMemcpy(&too_long, ctx->d_scratch + 8, 8, hipMemcpyDeviceToHost));
+    if (too_long) {
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 8, 0, 8, ctx->stream));
+        KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::snprintf(ctx->last_error, sizeof ctx->last_error,
+                      "a read of 2^31 bases or more was skipped by a scan since the last kmx_ctx_synchronize (cut such records into overlapping pieces)");
+        return KMX_E_ARG;
+    }
     return KMX_OK;
 }
 
@@ -431,7 +441,7 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
             return KMX_OK;
         }
     }
-    KMX_HIP(ctx, kmx::launch_reduce_generic(reads, k, hasher, hasher_k, want_sumfw ? 1u : 0u, d_out, ctx->n_cu, ctx->stream));
+    KMX_HIP(ctx, kmx::launch_reduce_generic(reads, k, hasher, hasher_k, want_sumfw ? 1u : 0u, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8));
     return KMX_OK;
 }
 
@@ -456,7 +466,7 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
                                                 d_fw, d_rc, d_canon, d_flags, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
     }
-    KMX_HIP(ctx, kmx::launch_windows_generic(reads, d_win_offsets, k, d_fw, d_rc, d_canon, d_flags, ctx->n_cu, ctx->stream));
+    KMX_HIP(ctx, kmx::launch_windows_generic(reads, d_win_offsets, k, d_fw, d_rc, d_canon, d_flags, ctx->n_cu, ctx->stream, ctx->d_scratch + 8));
     return KMX_OK;
 }
 
@@ -474,7 +484,7 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
                                                  ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
     }
-    KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream));
+    KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8));
     return KMX_OK;
 }
 
@@ -488,7 +498,7 @@ int kmx_canonical_windows2(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t*
     bool handled = false;   // uniform reads of up to 256 bases: the tiled kernel (kmx_generic.hip)
     KMX_HIP(ctx, kmx::launch_windows2_tiled(reads, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled));
     if (handled) return KMX_OK;
-    KMX_HIP(ctx, kmx::launch_windows2_generic(reads, d_win_offsets, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream));
+    KMX_HIP(ctx, kmx::launch_windows2_generic(reads, d_win_offsets, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, ctx->d_scratch + 8));
     return KMX_OK;
 }
 
@@ -509,7 +519,7 @@ int kmx_histogram(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t has
                                               &big_scratch, ctx, hist_scratch_budget(), reads->d_offsets));
         if (handled) return KMX_OK;
     }
-    KMX_HIP(ctx, kmx::launch_histogram_generic(reads, k, hasher, hasher_k, log2_buckets, d_counts, ctx->n_cu, ctx->stream));
+    KMX_HIP(ctx, kmx::launch_histogram_generic(reads, k, hasher, hasher_k, log2_buckets, d_counts, ctx->n_cu, ctx->stream, ctx->d_scratch + 8));
     return KMX_OK;
 }
 
@@ -924,6 +934,10 @@ int kmx_reads_length_range(kmx_ctx* ctx, const uint64_t* d_offsets, uint64_t n_r
     KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h_min_len) *h_min_len = got[0];
     if (h_max_len) *h_max_len = got[1];
+    if (got[1] >= 0x80000000u) {   // (lengths are clamped to 32 bits by the kernel: anything from 2^31 up lands here)
+        std::snprintf(ctx->last_error, sizeof ctx->last_error, "kmx_reads_length_range: a read of 2^31 bases or more (the scans skip such reads)");
+        return KMX_E_ARG;
+    }
     return KMX_OK;
 }
 

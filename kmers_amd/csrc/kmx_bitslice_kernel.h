@@ -401,6 +401,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             u64 o0, o1;
             if (seg_mode) seg_bounds(read, o0, o1);
             else { o0 = offsets[read]; o1 = offsets[read + 1u]; }
+            if (read_too_long(o1 - o0, queue + KMX_TOOLONG_FROM_QUEUE)) return;   // (not scanned; kmx_ctx_synchronize reports it)
             roll_read(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
                 const u64 canon = fw < rc ? fw : rc;
                 fb.n += 1;

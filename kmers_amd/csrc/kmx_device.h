@@ -171,6 +171,16 @@ __device__ __forceinline__ u64 wave_xor(u64 v) {
     return v;
 }
 
+// A read of 2^31 bases or more (the iterator's positions are i32, canonical_kmer_iterator.rs:15; kmx.h "Limits") is not
+// scanned: the kernels skip it and raise the context's sticky flag, which kmx_ctx_synchronize reports as KMX_E_ARG.
+// `queue` = the tile-queue block of the context (d_scratch + 16); the flag lives 8 words below it (kmx_internal.h).
+constexpr int KMX_TOOLONG_FROM_QUEUE = -8;
+__device__ __forceinline__ bool read_too_long(u64 len, unsigned long long* flag) {
+    if (len < (1ull << 31)) return false;
+    if (flag) *flag = 1ull;   // (a plain store of one constant: every writer agrees)
+    return true;
+}
+
 // accumulators of one reduce pass, per lane
 struct Acc {
     u64 n_valid = 0, sum_canon = 0, xor_hash = 0, sum_fw = 0;

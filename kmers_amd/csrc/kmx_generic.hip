@@ -12,11 +12,12 @@ struct ReadsView {
     u64 n_reads;
     u32 read_len;
     const u64* offsets;
+    unsigned long long* too_long;   // the context's sticky "a read of 2^31 bases or more was skipped" flag
     __device__ __forceinline__ void span(u64 r, const uint8_t*& s, u32& len) const {
         if (offsets) {
             const u64 a = offsets[r], b = offsets[r + 1];
             s = bases + a;
-            len = (u32)(b - a);
+            len = read_too_long(b - a, too_long) ? 0u : (u32)(b - a);
         } else {
             s = bases + r * (u64)read_len;
             len = read_len;
@@ -436,40 +437,39 @@ static inline unsigned grid_for(u64 n, int n_cu) {
 }
 
 hipError_t launch_reduce_generic(const kmx_reads* r, u32 k, u32 hasher, u32 hk, u32 want_sumfw, kmx_summary* out,
-                                 int n_cu, hipStream_t st) {
-    ReadsView rv{r->d_bases, r->n_reads, r->read_len, r->d_offsets};
+                                 int n_cu, hipStream_t st, unsigned long long* too_long) {
+    ReadsView rv{r->d_bases, r->n_reads, r->read_len, r->d_offsets, too_long};
     hipLaunchKernelGGL(reduce_generic_kernel, dim3(grid_for(r->n_reads, n_cu)), dim3(256), 0, st, rv, k, hasher, hk,
                        want_sumfw, out);
     return hipGetLastError();
 }
 
 hipError_t launch_windows_generic(const kmx_reads* r, const u64* win_off, u32 k, u64* fw, u64* rc, u64* canon,
-                                  uint8_t* flags, int n_cu, hipStream_t st) {
-    ReadsView rv{r->d_bases, r->n_reads, r->read_len, r->d_offsets};
+                                  uint8_t* flags, int n_cu, hipStream_t st, unsigned long long* too_long) {
+    ReadsView rv{r->d_bases, r->n_reads, r->read_len, r->d_offsets, too_long};
     hipLaunchKernelGGL(windows_generic_kernel, dim3(grid_for(r->n_reads, n_cu)), dim3(256), 0, st, rv, win_off, k, fw,
                        rc, canon, flags);
     return hipGetLastError();
 }
 
 hipError_t launch_histogram_generic(const kmx_reads* r, u32 k, u32 hasher, u32 hk, u32 log2_buckets, u64* counts,
-                                    int n_cu, hipStream_t st) {
-    ReadsView rv{r->d_bases, r->n_reads, r->read_len, r->d_offsets};
+                                    int n_cu, hipStream_t st, unsigned long long* too_long) {
+    ReadsView rv{r->d_bases, r->n_reads, r->read_len, r->d_offsets, too_long};
     hipLaunchKernelGGL(histogram_generic_kernel, dim3(grid_for(r->n_reads, n_cu)), dim3(256), 0, st, rv, k, hasher, hk,
                        log2_buckets, counts);
     return hipGetLastError();
 }
 
-hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_summary2* out, int n_cu,
-                                  hipStream_t st) {
-    ReadsView rv{r->d_bases, r->n_reads, r->read_len, r->d_offsets};
+hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_summary2* out, int n_cu, hipStream_t st, unsigned long long* too_long) {
+    ReadsView rv{r->d_bases, r->n_reads, r->read_len, r->d_offsets, too_long};
     hipLaunchKernelGGL(reduce2_generic_kernel, dim3(grid_for(r->n_reads, n_cu)), dim3(256), 0, st, rv, k, with_hash,
                        out);
     return hipGetLastError();
 }
 
 hipError_t launch_windows2_generic(const kmx_reads* r, const u64* win_off, u32 k, u64* fw, u64* rc, u64* canon,
-                                   uint8_t* flags, int n_cu, hipStream_t st) {
-    ReadsView rv{r->d_bases, r->n_reads, r->read_len, r->d_offsets};
+                                   uint8_t* flags, int n_cu, hipStream_t st, unsigned long long* too_long) {
+    ReadsView rv{r->d_bases, r->n_reads, r->read_len, r->d_offsets, too_long};
     hipLaunchKernelGGL(windows2_generic_kernel, dim3(grid_for(r->n_reads, n_cu)), dim3(256), 0, st, rv, win_off, k, fw,
                        rc, canon, flags);
     return hipGetLastError();

@@ -138,6 +138,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         if constexpr (RAGGED) {
             my_off = nx_off;
             my_len = (u32)(nx_end - nx_off);
+            if (read_too_long(nx_end - nx_off, queue + KMX_TOOLONG_FROM_QUEUE)) my_len = 0u;   // (not scanned; kmx_ctx_synchronize reports it)
             // (the builtins return int: through u32 first, or offsets >= 2^31 get sign-extended into the high word)
             const u32 t0l = __builtin_amdgcn_readfirstlane((u32)nx_off), t0h = __builtin_amdgcn_readfirstlane((u32)(nx_off >> 32));
             const u32 t1l = __builtin_amdgcn_readlane((u32)nx_end, 63), t1h = __builtin_amdgcn_readlane((u32)(nx_end >> 32), 63);
@@ -273,8 +274,9 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         const u64 read = n_full * 64u + lane;
         sink.begin_read(read);
         if constexpr (RAGGED) {
-            const u64 o0 = offsets[read];
-            roll_read(bases + o0, (u32)(offsets[read + 1u] - o0), k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
+            const u64 o0 = offsets[read], len64 = offsets[read + 1u] - o0;
+            if (!read_too_long(len64, queue + KMX_TOOLONG_FROM_QUEUE))
+                roll_read(bases + o0, (u32)len64, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
         } else {
             roll_read(bases + lead + read * (u64)L, L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
         }

@@ -453,8 +453,15 @@ def test_reads_length_range(ctx):
     assert ctx.reads_length_range(off) == (7, 301)
     assert ctx.reads_length_range(ctx.to_device(np.arange(1001, dtype=np.uint64) * np.uint64(150))) == (150, 150)
     assert ctx.reads_length_range(ctx.to_device(np.zeros(1, dtype=np.uint64))) == (0, 0)
-    big = np.array([0, 5, 5 + (1 << 33)], dtype=np.uint64)        # a length past 32 bits saturates
-    assert ctx.reads_length_range(ctx.to_device(big)) == (5, 0xFFFFFFFF)
+    # (round 3) a read of 2^31 bases or more is refused: KMX_E_ARG (the scans skip such reads; kmx.h "Limits")
+    from kmers_amd._lib import E_ARG, KmxError
+
+    big = np.array([0, 5, 5 + (1 << 33)], dtype=np.uint64)
+    with pytest.raises(KmxError) as ei:
+        ctx.reads_length_range(ctx.to_device(big))
+    assert ei.value.status == E_ARG
+    ok = np.array([0, 5, 5 + (1 << 31) - 1], dtype=np.uint64)     # the longest read the scans take
+    assert ctx.reads_length_range(ctx.to_device(ok)) == (5, (1 << 31) - 1)
 
 
 @pytest.mark.gpu

@@ -353,3 +353,52 @@ def test_reduce_thirteen_word_frame(ctx, orc, L, k):
         o = orc.canonical_reduce(host[lead:], n_reads, L, k, hasher_k=k)
         g = ctx.canonical_reduce(dev[lead:], n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
         _same(g, o, True, True)
+
+
+# ------------------------------------------------------------------ a ragged read of 2^31 bases is diagnosed
+
+def test_read_of_2_31_bases_is_skipped_and_reported(ctx, orc):
+    """kmx.h "Limits": positions are i32 like the reference's (canonical_kmer_iterator.rs:15).  A ragged read of >= 2^31
+    bases used to be scanned with wrapped positions, silently; now the scans skip it, the summary is that of the other
+    reads, kmx_ctx_synchronize returns KMX_E_ARG once (sticky flag), and kmx_reads_length_range refuses the batch."""
+    import torch
+
+    from kmers_amd import _lib
+    from kmers_amd._lib import KmxError
+
+    k, small = 31, 64 * 3 + 5
+    huge = (1 << 31) + 160
+    rng = np.random.default_rng(3)
+    lens = np.full(small + 1, 150, np.int64)
+    lens[70] = huge                                   # one read past the limit, in the middle of a tile
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    dev = torch.full((int(offsets[-1]) + 64,), ord("A"), dtype=torch.uint8, device=ctx.device)
+    ok_reads = _dirty(rng, small * 150, 0.0)
+    # place the ordinary reads where the offsets say they are
+    pos = 0
+    chunks = []
+    for r in range(small + 1):
+        if r == 70:
+            continue
+        o0 = int(offsets[r])
+        dev[o0:o0 + 150] = torch.from_numpy(ok_reads[pos:pos + 150].copy()).to(ctx.device)
+        pos += 150
+    d_off = ctx.to_device(offsets)
+    ctx.synchronize()                                  # clean slate
+    for hint in (150, 0):
+        g = ctx.canonical_reduce(dev, small + 1, hint, k, _lib.HASH_LEX, k, 0, offsets=d_off)
+        o = orc.canonical_reduce(ok_reads, small, 150, k, hasher_k=k)
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+        with pytest.raises(KmxError) as ei:
+            ctx.synchronize()
+        assert ei.value.status == _lib.E_ARG
+        ctx.synchronize()                              # the flag was cleared by the report
+    with pytest.raises(KmxError) as ei:
+        ctx.reads_length_range(d_off)
+    assert ei.value.status == _lib.E_ARG
+    # the histogram and the per-read kernels take the same exit
+    h = ctx.histogram(dev, small + 1, 150, k, 1, k, 12, offsets=d_off)
+    assert int(h.sum().item()) == small * 120
+    with pytest.raises(KmxError):
+        ctx.synchronize()
+    del dev
