@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/r3r
-python -m pytest tests/test_gpu_round3.py -x -q -m gpu -k "2_31 or thirteen" 2>&1 | tail -15 > gpurun_out/r3r/pytest_a.txt
-python -m pytest tests -x -q -m gpu 2>&1 | tail -5 > gpurun_out/r3r/pytest_all.txt
+mkdir -p gpurun_out/r3u
+for b in 1 2 4 8; do echo "== blocks per CU $b"; KMX_ROLL_BPC=$b python3 tools/bench_dirty.py 2>&1 | grep -v amdgpu | head -5; done > gpurun_out/r3u/dirty_bpc.txt
