@@ -123,6 +123,9 @@
 #ifndef KMX_BS_LATE13
 #define KMX_BS_LATE13 7   // late prefetch rows (of 13) of the 13-word frame (uniform ASCII reads of 161..208 bases)
 #endif
+#ifndef KMX_BS_WAVES5
+#define KMX_BS_WAVES5 5   // waves per SIMD of the 5-word frame (uniform ASCII reads of up to 80 bases): 92..96 registers, at most 52 bytes spilled; 75 bp k=31: 0.609 -> 0.627
+#endif
 #ifndef KMX_BS_WAVES13
 #define KMX_BS_WAVES13 4  // waves per SIMD of the 13-word frame
 #endif
@@ -195,7 +198,7 @@ template <int K, int WPL> constexpr int bs_waves_ascii() {
 #endif
 }
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
-__global__ void __launch_bounds__(256, (K > 32 ? KMX_BS_WAVES2 : RAGGED ? (NW > 10 ? 2 : KMX_BSR_WAVES) : NW == 13 ? KMX_BS_WAVES13 : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
+__global__ void __launch_bounds__(256, (K > 32 ? KMX_BS_WAVES2 : RAGGED ? (NW > 10 ? 2 : KMX_BSR_WAVES) : (NW == 5 && !PACKED) ? KMX_BS_WAVES5 : NW == 13 ? KMX_BS_WAVES13 : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead) {
@@ -1583,6 +1586,11 @@ static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
         // up to 112 bp (the 100 / 101 / 75 / 76 / 50 / 36 bp of older runs): the 7-word frame -- 7 instead of 10 transposes per
         // half-wave, 28 instead of 40 prefetch registers, two thirds of the plane area (a read's extra chunk from an unaligned base must fit too)
         const u32 mis = (reinterpret_cast<uintptr_t>(bases) & 15u) ? 1u : 0u;
+        // up to 80 bp (round 3; the 75 / 76 / 50 / 36 bp of older runs): the 5-word frame -- 5 transposes, 20 prefetch registers
+        if (4u * L + mis <= 64u * 5u) {
+            if (W <= 64u) return launch_bs<K, 5, 2, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+            return launch_bs<K, 5, 3, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        }
         if (4u * L + mis <= 64u * 7u) {
             if (W <= 64u) return launch_bs<K, 7, 2, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
             if (W <= 96u) return launch_bs<K, 7, 3, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);

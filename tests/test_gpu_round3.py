@@ -402,3 +402,24 @@ def test_read_of_2_31_bases_is_skipped_and_reported(ctx, orc):
     with pytest.raises(KmxError):
         ctx.synchronize()
     del dev
+
+
+# ------------------------------------------------------------------ the 5-word frame (reads of up to 80 bases)
+
+@pytest.mark.parametrize("L", [31, 36, 50, 64, 65, 75, 76, 79, 80, 81])
+@pytest.mark.parametrize("k", [13, 17, 21, 31])
+def test_reduce_five_word_frame(ctx, orc, L, k):
+    """uniform reads of up to 80 bases take the 5-word frame (2 or 3 windows per lane, 5 waves/SIMD); 81 is the first length
+    of the 7-word frame.  Clean and dirty reads, an unaligned base, against the oracle."""
+    from kmers_amd import _lib
+
+    if L < k:
+        pytest.skip("read shorter than k")
+    n_reads = 64 * 11 + 3
+    rng = np.random.default_rng(L * 131 + k)
+    for p_bad, lead in ((0.0, 0), (0.001, 0), (0.0, 5)):
+        host = _dirty(rng, lead + n_reads * L, p_bad)
+        dev = ctx.to_device(host)
+        o = orc.canonical_reduce(host[lead:], n_reads, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(dev[lead:], n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        _same(g, o, True, True)
