@@ -1596,6 +1596,11 @@ static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
             if (W <= 96u) return launch_bs<K, 7, 3, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
             return launch_bs<K, 7, 4, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
         }
+        // 113..128 bp (round 3; the 125 / 126 bp of HiSeq runs): the 8-word frame instead of the 10-word one
+        if (4u * L + mis <= 64u * 8u) {
+            if (W <= 96u) return launch_bs<K, 8, 3, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+            return launch_bs<K, 8, 4, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
+        }
     }
     if (L > 160) {   // 161..256 bp: the 16-word frame, as few windows per lane as keep the 2*ceil(W/WPL) items inside 64 lanes
         if constexpr (!PACKED) {

@@ -423,3 +423,22 @@ def test_reduce_five_word_frame(ctx, orc, L, k):
         o = orc.canonical_reduce(host[lead:], n_reads, L, k, hasher_k=k)
         g = ctx.canonical_reduce(dev[lead:], n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
         _same(g, o, True, True)
+
+
+# ------------------------------------------------------------------ the 8-word frame (reads of 113..128 bases)
+
+@pytest.mark.parametrize("L", [112, 113, 120, 125, 126, 127, 128, 129])
+@pytest.mark.parametrize("k", [13, 19, 25, 31])
+def test_reduce_eight_word_frame(ctx, orc, L, k):
+    """uniform reads of 113..128 bases take the 8-word frame (3 or 4 windows per lane); 112 is the last length of the 7-word
+    frame and 129 the first of the 10-word one.  Clean and dirty reads, an unaligned base, against the oracle."""
+    from kmers_amd import _lib
+
+    n_reads = 64 * 10 + 33
+    rng = np.random.default_rng(L * 17 + k)
+    for p_bad, lead in ((0.0, 0), (0.0006, 0), (0.0, 13)):
+        host = _dirty(rng, lead + n_reads * L, p_bad)
+        dev = ctx.to_device(host)
+        o = orc.canonical_reduce(host[lead:], n_reads, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(dev[lead:], n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        _same(g, o, True, True)

@@ -56,9 +56,14 @@ for name, lens in (("150 bp, untrimmed", np.full(65536, 150)),
         ms_scan, s = timed(lambda: ctx.canonical_reduce(bases, n_reads, mx, k, _lib.HASH_LEX, k, 0, offsets=offsets))
         ms_hist, h = timed(lambda: ctx.histogram(bases, n_reads, mx, k, 1, k, 20, offsets=offsets))
         path = "ragged kernels, bound %d" % mx
+    # (round 3) straight from the parser's offsets: kmx_canonical_reduce checks on the device whether the reads are uniform
+    ms_gate, sg = timed(lambda: ctx.canonical_reduce(bases, n_reads, mx, k, _lib.HASH_LEX, k, 0, offsets=offsets))
+    assert (sg.n_valid, sg.sum_canon, sg.xor_hash) == (s.n_valid, s.sum_canon, s.xor_hash)
     nb = bases.numel()
     print(f"{name}: {text.numel()/1e9:.2f} GB of FASTQ, {n_reads} reads, {nb/1e9:.2f} GB of bases, lengths {mn}..{mx} ({path})")
     print(f"    parse {ms_parse:7.2f} ms ({text.numel()/ms_parse/1e6:5.0f} GB/s of text)   length range {ms_range:5.2f} ms   "
           f"reduce k={k} {ms_scan:6.2f} ms ({nb/ms_scan/1e6:5.0f} GB/s of bases, {s.n_valid/ms_scan/1e6:6.0f} G k-mers/s)   "
-          f"histogram 2^20 {ms_hist:6.2f} ms")
+          f"histogram 2^20 {ms_hist:6.2f} ms\n"
+          f"    reduce called with the offsets array as it is (uniform / ragged decided on the device): {ms_gate:6.2f} ms;  "
+          f"parse + that = {ms_parse + ms_gate:6.2f} ms")
     del text, bases, offsets, h

@@ -40,7 +40,7 @@ def full_launch_stats(trace_dir, needle):
 
 for name in ("bench_default", "bench_under_trace", "bench_sustained3000", "bench_k21", "bench_k63", "bench_hash", "bench_hist20",
              "bench_hist20_rccl1", "bench_packed", "bench_k21_under_trace", "bench_k63_under_trace", "bench_hash_under_trace",
-             "bench_hist20_under_trace"):
+             "bench_hist20_under_trace", "bench_2ranks_shared_gpu", "bench_2ranks_shared_gpu_hist20"):
     d = line(os.path.join(src, name + ".json")) if os.path.exists(os.path.join(src, name + ".json")) else None
     if d is not None:
         with open(os.path.join(dst, f"{tag}_{name}.json"), "w") as f:
@@ -50,7 +50,7 @@ for a, b in (("trace/t_kernel_stats.csv", "kernel_stats.csv"), ("trace_k21/t_ker
              ("trace_hist20/t_kernel_stats.csv", "kernel_stats_hist20.csv"), ("pmc_summary.txt", "pmc_summary.txt"),
              ("k_sweep.txt", "k_sweep.txt"), ("len_sweep.txt", "len_sweep.txt"), ("ragged_bench.txt", "ragged_bench.txt"),
              ("dirty_bench.txt", "dirty_bench.txt"), ("windows_bench.txt", "windows_bench.txt"), ("hist_bench.txt", "hist_bench.txt"),
-             ("minimizers_bench.txt", "minimizers_bench.txt"), ("fastx_bench.txt", "fastx_bench.txt"), ("fastq_pipeline.txt", "fastq_pipeline.txt"), ("step_times.txt", "step_times.txt")):
+             ("minimizers_bench.txt", "minimizers_bench.txt"), ("windows2_bench.txt", "windows2_bench.txt"), ("pc_bench.txt", "pc_bench.txt"), ("fastx_bench.txt", "fastx_bench.txt"), ("fastq_pipeline.txt", "fastq_pipeline.txt"), ("step_times.txt", "step_times.txt")):
     copy(a, b)
 
 out = [f"# Round {tag[1:]} -- rocprofv3 --kernel-trace --stats of `python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --sustain-steps 0` (MI355X, 1 GPU)",

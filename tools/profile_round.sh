@@ -28,15 +28,23 @@ python3 bench.py --config 2 -k 63 --no-traffic > $out/bench_k63.json 2> /dev/nul
 python3 bench.py --config 3 --no-traffic > $out/bench_hash.json 2> /dev/null
 python3 bench.py --config 4 --no-traffic --no-cpu-baseline --steps 5 --warmup 2 --sustain-steps 20 > $out/bench_hist20.json 2> /dev/null
 python3 bench.py --config 4 --dist-single --no-cpu-baseline --steps 5 --warmup 2 --sustain-steps 0 > $out/bench_hist20_rccl1.json 2> /dev/null
+# the N > 1 control flow on this one-GPU box (both ranks on cuda:0, gloo; stated in the line): what an 8-GPU line will carry
+KMX_BENCH_TEST_SHARED_GPU=1 python3 bench.py --gpus 2 --reads-per-gpu 20000000 --steps 5 --warmup 2 --sustain-steps 0 --no-traffic --cpu-baseline-seconds 8 > $out/bench_2ranks_shared_gpu.json 2> /dev/null
+KMX_BENCH_TEST_SHARED_GPU=1 python3 bench.py --gpus 2 --config 4 --reads-per-gpu 20000000 --steps 3 --warmup 1 --sustain-steps 0 --no-traffic --cpu-baseline-seconds 8 > $out/bench_2ranks_shared_gpu_hist20.json 2> /dev/null
 python3 bench.py --packed --no-cpu-baseline --no-traffic > $out/bench_packed.json 2> /dev/null
-for k in 13 17 25 27 29 33 41 47 51 55; do python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 200 -k $k 2>/dev/null | python3 tools/bench_line.py "k=$k"; done > $out/k_sweep.txt
-for spec in "100 150000000" "250 60000000" "300 50000000" "1000 15000000" "10000 1500000"; do set -- $spec
+for k in 13 17 21 25 27 29 31 33 41 47 51 55 63; do python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 200 -k $k 2>/dev/null | python3 tools/bench_line.py "k=$k"; done > $out/k_sweep.txt
+for spec in "50 300000000" "75 200000000" "100 150000000" "125 120000000" "150 100000000" "161 93000000" "170 88000000" "200 75000000" "208 72000000" "250 60000000" "256 58000000" "300 50000000" "1000 15000000" "10000 1500000"; do set -- $spec
   python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len $1 --reads-per-gpu $2 2>/dev/null | python3 tools/bench_line.py "L=$1"; done > $out/len_sweep.txt
+# the producer/consumer form of the k=31 scan (opt-in) next to the one-role kernel, same box
+for c in 0 1 2; do if [ $c == 0 ]; then unset KMX_BS_PC; else export KMX_BS_PC=$c; fi
+  python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-traffic --sustain-steps 400 2>/dev/null | python3 tools/bench_line.py "[KMX_BS_PC=$c]"; done > $out/pc_bench.txt
+unset KMX_BS_PC
+python3 tools/bench_windows2.py > $out/windows2_bench.txt 2>/dev/null
 python3 tools/bench_ragged.py 100000000 31 > $out/ragged_bench.txt 2>/dev/null
 python3 tools/bench_ragged.py 100000000 21 >> $out/ragged_bench.txt 2>/dev/null
 HIST=20 python3 tools/bench_dirty.py > $out/dirty_bench.txt 2>/dev/null
 python3 tools/bench_windows.py > $out/windows_bench.txt 2>/dev/null
-python3 tools/bench_hist.py 100000000 12,16,20,22,23 > $out/hist_bench.txt 2>/dev/null
+python3 tools/bench_hist.py 100000000 12,16,20,22,23,24,26,28 > $out/hist_bench.txt 2>/dev/null
 python3 tools/bench_minimizers.py > $out/minimizers_bench.txt 2>/dev/null
 python3 tools/bench_fastx.py > $out/fastx_bench.txt 2>/dev/null
 python3 tools/bench_fastq_pipeline.py 2>/dev/null | grep -v amdgpu.ids > $out/fastq_pipeline.txt
