@@ -428,13 +428,20 @@ class Comm:
         self.ctx = ctx
         lib = ctx.lib
         buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
-        if rank == 0:
-            _lib.check(lib, None, lib.kmx_comm_get_unique_id(buf))
+        # rank 0's status travels WITH the id (one extra byte): if kmx_comm_get_unique_id fails there -- no RCCL on the loader
+        # path, say -- every rank learns it from the same broadcast and raises, instead of rank 0 raising alone while the
+        # others wait in ncclCommInitRank for a peer that never comes.
+        st0 = lib.kmx_comm_get_unique_id(buf) if rank == 0 else 0
         if n_ranks > 1:
             if exchange_id is None:
                 exchange_id = self._torch_broadcast
-            raw = exchange_id(bytes(buf) if rank == 0 else None)
+            raw = exchange_id((bytes(buf) + bytes([st0 & 0xFF])) if rank == 0 else None)
+            if len(raw) > _lib.COMM_ID_BYTES:
+                st0 = raw[_lib.COMM_ID_BYTES]
+                raw = raw[:_lib.COMM_ID_BYTES]
             buf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(raw)
+        if st0 != 0:
+            raise KmxError(int(st0), "kmx_comm_get_unique_id failed on rank 0 (is librccl.so.1 on the loader path?)")
         h = C.c_void_p()
         ctx._ck(lib.kmx_comm_create(ctx._h, buf, n_ranks, rank, C.byref(h)))
         self._h = h
@@ -443,7 +450,7 @@ class Comm:
     def _torch_broadcast(self, raw):
         import torch.distributed as dist
 
-        t = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+        t = torch.zeros(_lib.COMM_ID_BYTES + 1, dtype=torch.uint8)   # the id + rank 0's status byte
         if raw is not None:
             t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
         if dist.get_backend() == "nccl":

@@ -175,13 +175,17 @@ void* big_scratch(void* user, size_t bytes) {
 
 // an eighth of the device memory, at least 8 GiB (KMX_HIST_SCRATCH_MB overrides), and at most half of what is free: fewer,
 // larger chunks of reads per call (configs[4], 1.25e8 reads: 6 chunks at 8 GiB 19.3 ms, 2 at 36 GiB 18.6 ms)
-size_t hist_scratch_budget() {
+// (`held`: the work buffer the context already owns -- it is not part of "free" any more, but it IS available: without adding
+// it back a second call under memory pressure got a smaller budget than the buffer it holds, cut the reads into more chunks
+// than the first call had, and timing depended on call order)
+size_t hist_scratch_budget(size_t held) {
     size_t free_b = 0, total_b = 0;
     const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
     size_t budget = (size_t)8 << 30;
     if (have && total_b / 8u > budget) budget = total_b / 8u;
     if (const char* e = std::getenv("KMX_HIST_SCRATCH_MB")) budget = (size_t)std::strtoull(e, nullptr, 10) << 20;
-    if (have && budget > free_b / 2) budget = free_b / 2;
+    if (have && budget > (free_b + held) / 2) budget = (free_b + held) / 2;
+    if (budget < held) budget = held;
     return budget;
 }
 
@@ -516,7 +520,7 @@ int kmx_histogram(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t has
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
         KMX_HIP(ctx, kmx::launch_hist_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, hasher, hasher_k,
                                               log2_buckets, d_counts, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled,
-                                              &big_scratch, ctx, hist_scratch_budget(), reads->d_offsets));
+                                              &big_scratch, ctx, hist_scratch_budget(ctx->big_bytes), reads->d_offsets));
         if (handled) return KMX_OK;
     }
     KMX_HIP(ctx, kmx::launch_histogram_generic(reads, k, hasher, hasher_k, log2_buckets, d_counts, ctx->n_cu, ctx->stream, ctx->d_scratch + 8));

@@ -101,3 +101,39 @@ def test_combine_wraps_mod_2_64_single_process():
     # without a process group the local summary is returned unchanged
     loc = {"n_valid": 5, "sum_canon": kd.M64, "xor_hash": 1 << 63, "sum_fw": 7}
     assert kd.combine_summaries(loc) == loc
+
+
+# ---- kmers_amd.api.Comm: rank 0's id travels with its status byte (a failure on rank 0 must reach every rank)
+
+def _comm_id_worker(rank, world, port, status0, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+
+    from kmers_amd import _lib
+    from kmers_amd.api import Comm
+
+    ident = bytes(range(128))
+    raw = Comm._torch_broadcast(SimpleNamespace(ctx=None), (ident + bytes([status0])) if rank == 0 else None)
+    out_q.put((rank, len(raw), raw[:_lib.COMM_ID_BYTES] == ident, raw[_lib.COMM_ID_BYTES]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("status0", [0, 3])
+def test_comm_id_broadcast_carries_rank0_status(status0):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_id_worker, args=(r, world, port, status0, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert [g[0] for g in got] == [0, 1]
+    for _, n, same_id, st in got:
+        assert n == 129 and same_id and st == status0
