@@ -20,13 +20,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libkmx.so")
-SOURCES = ["kmx_bitslice.hip", "kmx_bitslice_k21.hip", "kmx_bitslice_k13_17.hip", "kmx_bitslice_k18_23.hip", "kmx_bitslice_k24_27.hip",
-           "kmx_bitslice_k28_30.hip", "kmx_bitslice_k33_39.hip", "kmx_bitslice_k41_47.hip", "kmx_bitslice_k49_55.hip",
+# (the slowest translation units first: the pool starts them in this order, and the build is as long as its longest tail)
+SOURCES = ["kmx_hist.hip", "kmx_hist32.hip", "kmx_bitslice.hip", "kmx_scan.hip", "kmx_bitslice_k21.hip", "kmx_bitslice_k13_17.hip", "kmx_bitslice_k18_23.hip",
+           "kmx_bitslice_k24_27.hip", "kmx_bitslice_k28_30.hip", "kmx_bitslice_k33_39.hip", "kmx_bitslice_k41_47.hip", "kmx_bitslice_k49_55.hip",
            "kmx_bitslice_k57_61.hip", "kmx_bitslice_k34_40.hip", "kmx_bitslice_k42_48.hip", "kmx_bitslice_k50_56.hip", "kmx_bitslice_k58_64.hip",
            "kmx_bitslice_ragged_k13_16.hip", "kmx_bitslice_ragged_k17_20.hip", "kmx_bitslice_ragged_k21_24.hip", "kmx_bitslice_ragged_k25_28.hip",
-           "kmx_bitslice_ragged_k29_31.hip", "kmx_scan.hip", "kmx_hist.hip", "kmx_generic.hip", "kmx_elem.hip", "kmx_seqvec.hip", "kmx_fastx.hip",
-           "kmx_comm.hip", "kmx_api.hip"]
-HEADERS = [os.path.join(CSRC, "kmx_device.h"), os.path.join(CSRC, "kmx_bitslice_kernel.h"), os.path.join(CSRC, "kmx_internal.h"), os.path.join(CSRC, "kmx_scan_kernel.h"),
+           "kmx_bitslice_ragged_k29_31.hip", "kmx_generic.hip", "kmx_elem.hip", "kmx_seqvec.hip", "kmx_fastx.hip", "kmx_comm.hip", "kmx_api.hip"]
+HEADERS = [os.path.join(CSRC, "kmx_device.h"), os.path.join(CSRC, "kmx_hist_part.h"), os.path.join(CSRC, "kmx_bitslice_pc.h"), os.path.join(CSRC, "kmx_bitslice_kernel.h"), os.path.join(CSRC, "kmx_internal.h"), os.path.join(CSRC, "kmx_scan_kernel.h"),
            os.path.join(HERE, "..", "include", "kmx.h")]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
@@ -57,9 +57,11 @@ def _headers_of(src: str) -> list[str]:
     out = []
     for h in HEADERS:
         base = os.path.basename(h)
-        if base == "kmx_bitslice_kernel.h" and not src.startswith("kmx_bitslice"):
+        if base in ("kmx_bitslice_kernel.h", "kmx_bitslice_pc.h") and not src.startswith("kmx_bitslice"):
             continue
-        if base == "kmx_scan_kernel.h" and src not in ("kmx_scan.hip", "kmx_hist.hip"):
+        if base in ("kmx_scan_kernel.h", "kmx_hist_part.h") and src not in ("kmx_scan.hip", "kmx_hist.hip", "kmx_hist32.hip"):
+            continue
+        if base == "kmx_hist_part.h" and src == "kmx_scan.hip":
             continue
         if os.path.exists(h):
             out.append(h)
