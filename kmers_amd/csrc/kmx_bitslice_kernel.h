@@ -129,6 +129,15 @@
 #ifndef KMX_BS_WAVES13
 #define KMX_BS_WAVES13 4  // waves per SIMD of the 13-word frame
 #endif
+#ifndef KMX_BS_XORC
+// 1: (round 3) phase A leaves the packed words in the internal ACTG codes ((byte >> 1) & 3); the conversion to naive_impl's
+// ACGT codes (bit 0 ^= bit 1) happens on the PLANES after the transposes, where the two bits of a base sit in neighbouring
+// lanes: the even lanes fetch the odd lane's plane through the LDS crossbar (ds_swizzle, no VALU) and one v_bitop3 per word
+// applies it -- 10 VALU instructions a tile instead of a shift and a v_bitop3 per 16-byte row of phase A (20).  Bit-exact, and
+// 0.7 % SLOWER at k = 31 / 150 bp (profiles/r03_swizzle_variants.txt): the ten crossbar trips cost more than the ten full-rate
+// VALU instructions they replace; so does KMX_BS_SWZ = 2 (-20 VALU, +20 ds_swizzle: -0.9 %).  Off.
+#define KMX_BS_XORC 0
+#endif
 #ifndef KMX_BS_ABLATE
 #define KMX_BS_ABLATE 0   // dev: bitmask of phases to skip (timing experiments only; results become wrong)
 #endif
@@ -207,6 +216,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // it), exactly like a ragged tile streamed from its aligned start; 0 for every other input.
     static_assert(!RAGGED || (!PACKED && K <= 32 && KMX_BS_PRIO >= 2), "ragged input: ASCII, single-word k-mers");
     static_assert(WPL <= 8, "the zero words behind the validity planes cover a lane's windows");
+    static_assert(!KMX_BS_XORC || KMX_BS_PRIO >= 2, "the plane-domain code conversion lives in the stage-major transposes");
     constexpr int NE = RAGGED ? (K - 1 + 15) / 16 : 0;            // dwords holding the last K-1 bases of a read
     constexpr int NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;  // validity words per read (one bit per window of the frame)
     constexpr u32 VS = RAGGED ? 32u * NV + 8u : 0u;             // validity planes of one set + 8 always-zero words (a lane's windows past the frame, idle lanes)
@@ -623,7 +633,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                      "s_setprio 0"
                      : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3)
                      : "s"(W4));
+        if constexpr (KMX_BS_XORC && !PACKED) return t0;               // (converted on the planes, end of phase C)
         return __builtin_amdgcn_bitop3_b32(t0 >> 1, t0, k55, 0x6c);   // internal (ACTG) -> naive_impl (ACGT) codes
+    };
+    auto enc16_p = [&](const uint4& wv, u32& bad) -> u32 {   // encode16 for the packed buffer (KMX_BS_XORC: back to ACTG codes -- c ^ (c >> 1) on 2-bit codes is an involution)
+        const u32 v = encode16(wv, bad);
+        if constexpr (KMX_BS_XORC && !PACKED) return __builtin_amdgcn_bitop3_b32(v >> 1, v, k55, 0x6c);
+        return v;
     };
     auto phase_A = [&]() -> bool {   // pack + validate the tile sitting in w[] into the packed LDS buffer
         const u32 ln_ = relane();
@@ -661,14 +677,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 
         } else if (chunks >= 64u * (NW - 1)) {
 #pragma unroll
-            for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode16(w[it], bad);
+            for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = enc16_p(w[it], bad);
             const u32 c = (NW - 1) * 64u + lane;
-            if (c < chunks) P[1u + c] = encode16(w[NW - 1], bad);
+            if (c < chunks) P[1u + c] = enc16_p(w[NW - 1], bad);
         } else {
 #pragma unroll
             for (int it = 0; it < NW; ++it) {
                 const u32 c = it * 64u + lane;
-                if (c < chunks) P[1u + c] = encode16(w[it], bad);
+                if (c < chunks) P[1u + c] = enc16_p(w[it], bad);
             }
         }
         return __any(chunk_has_invalid(bad));
@@ -849,6 +865,18 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 KMX_HRUN_END
 #pragma unroll
                 for (int g = 0; g < NXT; ++g) F[g] = bitsel(F[g], Y[g], st == 3 ? c_keep3 : c_keep4);
+            }
+            if constexpr (KMX_BS_XORC && !PACKED) {
+                // ACTG -> ACGT on the planes: lane 2j holds bit 0 and lane 2j + 1 bit 1 of base j.  Every lane fetches the odd
+                // lane of its pair (quad_perm [1,1,3,3] of ds_swizzle); the even lanes xor it in, the odd lanes keep their plane
+                // (evn = all ones on even lanes, from the rotate amount of the last stage: 31 on even, 1 on odd lanes)
+                u32 sh_o = c_sh4;
+                asm volatile("" : "+v"(sh_o));
+                const u32 evn = (u32)__builtin_amdgcn_sbfe((int)sh_o, 1u, 1u);
+#pragma unroll
+                for (int g = 0; g < NW + NE; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], 0x80F5);
+#pragma unroll
+                for (int g = 0; g < NW + NE; ++g) F[g] = __builtin_amdgcn_bitop3_b32(F[g], Y[g], evn, 0x78);   // F ^ (Y & evn)
             }
             {
                 // plane q = 32g + p  <->  base beta = 16g + p/2, bit p & 1.  One lane-dependent base and a compile-time offset per
