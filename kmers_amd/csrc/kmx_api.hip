@@ -880,21 +880,27 @@ int kmx_fastx_parse(kmx_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, uint3
         }
         return KMX_OK;
     }
-    uint8_t first = 0;
-    KMX_HIP(ctx, hipMemcpyAsync(&first, d_text, 1, hipMemcpyDeviceToHost, ctx->stream));
-    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (format == KMX_FASTX_AUTO) format = first == '@' ? KMX_FASTX_FASTQ : first == '>' ? KMX_FASTX_FASTA : 3u;
-    if (format == 3u || first != (format == KMX_FASTX_FASTQ ? '@' : '>')) {
-        std::snprintf(ctx->last_error, sizeof ctx->last_error, "kmx_fastx_parse: the text starts with byte 0x%02x, not with '@' (FASTQ) or '>' (FASTA)", first);
-        return KMX_E_ARG;
+    // (the emit call of a counts-then-emit pair: the counting call looked at the first byte and settled the format)
+    const bool reuse = same_text && ctx->fx_valid && ctx->fx_text == d_text && ctx->fx_bytes == n_bytes &&
+                       (format == KMX_FASTX_AUTO || ctx->fx_fasta == (format == KMX_FASTX_FASTA ? 1u : 0u));
+    if (reuse) {
+        format = ctx->fx_fasta ? KMX_FASTX_FASTA : KMX_FASTX_FASTQ;
+    } else {
+        uint8_t first = 0;
+        KMX_HIP(ctx, hipMemcpyAsync(&first, d_text, 1, hipMemcpyDeviceToHost, ctx->stream));
+        KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (format == KMX_FASTX_AUTO) format = first == '@' ? KMX_FASTX_FASTQ : first == '>' ? KMX_FASTX_FASTA : 3u;
+        if (format == 3u || first != (format == KMX_FASTX_FASTQ ? '@' : '>')) {
+            std::snprintf(ctx->last_error, sizeof ctx->last_error, "kmx_fastx_parse: the text starts with byte 0x%02x, not with '@' (FASTQ) or '>' (FASTA)", first);
+            return KMX_E_ARG;
+        }
     }
     const bool fasta = format == KMX_FASTX_FASTA;
     void* scratch = big_scratch(ctx, kmx::fastx_scratch_bytes(n_bytes));
     if (!scratch) return KMX_E_NOMEM;
     unsigned long long* d_totals = ctx->d_scratch + 2;
     unsigned long long totals[2] = {0, 0};
-    if (same_text && ctx->fx_valid && ctx->fx_text == d_text && ctx->fx_bytes == n_bytes && ctx->fx_fasta == (fasta ? 1u : 0u) &&
-        scratch == ctx->d_big) {
+    if (reuse && scratch == ctx->d_big) {
         // the chunk prefixes of the counting call are still in the work buffer, its totals in d_scratch[2..3]
         totals[0] = ctx->fx_totals[0];
         totals[1] = ctx->fx_totals[1];
