@@ -286,7 +286,7 @@ __device__ __forceinline__ void emit_bytes(const Lane64& d, u64 ks, uint8_t* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const u32 k = (u32)(ks >> (16 * q)) & 0xFFFFu;
-        if (k == 0xFFFFu) {          // the common case: one unaligned 16-byte store (plain: the L2 merges the four pieces of a line; with the nt hint pass 3 takes 6.3 instead of 1.9 ms)
+        if (k == 0xFFFFu) {          // the common case: one unaligned 16-byte store (plain: the L2 merges the four pieces of a line; with the nt hint pass 3 takes 6-7 instead of 1.9 ms: profiles/r03_fastx_variants.txt)
             P16 v{d.w[4 * q], d.w[4 * q + 1], d.w[4 * q + 2], d.w[4 * q + 3]};
             *reinterpret_cast<P16*>(dst + pc64(ks & ((1ull << (16 * q)) - 1ull))) = v;
         } else if (k) {
