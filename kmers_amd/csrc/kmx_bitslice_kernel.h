@@ -387,6 +387,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #endif
     struct FbAcc { u64 n = 0, s0 = 0, s1 = 0, x0 = 0, x1 = 0, fw = 0; };
     auto emit_sums = [&](u64 n, u64 r0, u64 r1, u64 h0, u64 h1, u64 f) {   // wave-uniform values, one set of atomics
+        if ((KMX_BS_ABLATE & 256) && wave_id != 0) return;   // (dev: timing of the end-of-kernel atomics)
         if (lane == 0) {
             if constexpr (K <= 32) {
                 kmx_summary* o = static_cast<kmx_summary*>(out);
@@ -1460,8 +1461,13 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < n_aside) {
-            const u64 read = aside[lane];
+        // Few reads set aside (the usual case: an N in 0.1 % of the reads leaves ~5 per wave): 8, 4 or 2 lanes share a read, each
+        // rolling its own run of windows from a fresh start -- a window depends on its own k bases only, so the runs add up to
+        // exactly the read's windows, and the walk, whose length is what this kernel costs, is 45-90 bases instead of 150.
+        const u32 sh = n_aside <= 8u ? 3u : n_aside <= 16u ? 2u : n_aside <= 32u ? 1u : 0u;   // (wave-uniform)
+        const u32 slot = lane >> sh, part = lane & ((1u << sh) - 1u);
+        if (slot < n_aside && !(KMX_BS_ABLATE & 512)) {
+            const u64 read = aside[slot];
             const uint8_t* sp = bases + lead + read * (u64)L;
             u32 len = L;
             if constexpr (RAGGED) {
@@ -1478,6 +1484,13 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
                 }
                 sp = bases + o0;
                 len = (u32)(o1 - o0);
+            }
+            {
+                const u32 wr = len >= (u32)K ? len - (u32)K + 1u : 0u;            // windows of the read
+                const u32 per = (wr + (1u << sh) - 1u) >> sh;                      // ... of a part
+                const u32 w0 = part * per < wr ? part * per : wr, w1 = w0 + per < wr ? w0 + per : wr;
+                sp += w0;
+                len = w1 > w0 ? (w1 - w0) + (u32)(K - 1) : 0u;
             }
             if constexpr (K <= 32) {
                 roll_read(sp, len, (u32)K, [&](u32, u64 fw, u64 rc) {
@@ -1524,10 +1537,24 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
         }
     }
     if (n_aside) roll();
-    const u64 n = wave_sum(a_n);
-    if (n == 0) return;   // (wave-uniform) nothing rolled: no atomics
-    const u64 s0 = wave_sum(a_s0), s1 = wave_sum(a_s1), x0 = wave_xor(a_x0), x1 = wave_xor(a_x1), f = wave_sum(a_fw);
-    if (lane == 0) {
+    // One set of atomics per BLOCK: the waves of this kernel all finish within microseconds of each other, and 4 x 4096 atomics on
+    // the one cache line of the summary were most of its ~110 us (whether 0.1 % or 0.5 % of the reads had been set aside).
+    __shared__ u64 part[4][6];
+    {
+        const u64 wn = wave_sum(a_n), ws0 = wave_sum(a_s0), ws1 = wave_sum(a_s1), wx0 = wave_xor(a_x0), wx1 = wave_xor(a_x1), wf = wave_sum(a_fw);
+        if (lane == 0) {
+            u64* pw = part[threadIdx.x >> 6];
+            pw[0] = wn; pw[1] = ws0; pw[2] = ws1; pw[3] = wx0; pw[4] = wx1; pw[5] = wf;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const u64 n = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+    if (n == 0 || (KMX_BS_ABLATE & 1024)) return;   // nothing rolled: no atomics
+    const u64 s0 = part[0][1] + part[1][1] + part[2][1] + part[3][1], s1 = part[0][2] + part[1][2] + part[2][2] + part[3][2];
+    const u64 x0 = part[0][3] ^ part[1][3] ^ part[2][3] ^ part[3][3], x1 = part[0][4] ^ part[1][4] ^ part[2][4] ^ part[3][4];
+    const u64 f = part[0][5] + part[1][5] + part[2][5] + part[3][5];
+    {
         if constexpr (K <= 32) {
             kmx_summary* o = static_cast<kmx_summary*>(out);
             atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
