@@ -442,3 +442,37 @@ def test_reduce_eight_word_frame(ctx, orc, L, k):
         o = orc.canonical_reduce(host[lead:], n_reads, L, k, hasher_k=k)
         g = ctx.canonical_reduce(dev[lead:], n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
         _same(g, o, True, True)
+
+
+# ------------------------------------------------------------------ the rolling kernel of the blanked reads
+@pytest.mark.parametrize("n_dirty", [1, 3, 8, 9, 16, 17, 32, 33, 64, 65, 200])
+@pytest.mark.parametrize("k,ragged", [(31, False), (21, False), (31, True), (63, False)])
+def test_rolled_reads_shared_by_lanes(ctx, orc, n_dirty, k, ragged):
+    """roll_flagged_kernel lets 8 / 4 / 2 lanes share a read when a wave has gathered at most 8 / 16 / 32 of them (every part
+    rolls its own run of windows from a fresh start) and ends with one set of atomics per block: each regime, single- and
+    two-word k, uniform and ragged reads, invalid bytes at the ends, in the middle and twice in a read -- against the oracle"""
+    from kmers_amd import _lib
+
+    L, n_reads = 150, 64 * 40          # 40 tiles: their masks are one group, gathered by one wave
+    rng = np.random.default_rng(1000 * k + n_dirty + (7 if ragged else 0))
+    host = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n_reads * L)].copy()
+    for i, r in enumerate(rng.choice(n_reads, n_dirty, replace=False)):
+        for p in ((0,), (L - 1,), (L // 2,), (k - 1, L - k), (int(rng.integers(0, L)),))[i % 5]:
+            host[r * L + p] = ord("N")
+    dev = ctx.to_device(host)
+    if ragged:
+        lens = np.full(n_reads, L, np.int64)
+        lens[:: 97] -= 1 + (np.arange(len(lens[:: 97])) % 60)     # some reads shorter: the reads stay where they are, gaps between them are not allowed
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        hostr = np.concatenate([host[r * L : r * L + lens[r]] for r in range(n_reads)])
+        o = orc.canonical_reduce(hostr, n_reads, L, k, hasher_k=k, offsets=offs)
+        g = ctx.canonical_reduce(ctx.to_device(hostr), n_reads, L, k, _lib.HASH_LEX, k, 0, offsets=ctx.to_device(offs))
+        _same(g, o, True, False)
+    elif k <= 32:
+        o = orc.canonical_reduce(host, n_reads, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(dev, n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        _same(g, o, True, True)
+    else:
+        o = orc.canonical_reduce2(host, n_reads, L, k, with_hash=True)
+        g = ctx.canonical_reduce2(dev, n_reads, L, k, with_hash=True)
+        assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
