@@ -1643,6 +1643,8 @@ static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
         const u32 mis = (reinterpret_cast<uintptr_t>(bases) & 15u) ? 1u : 0u;
         // up to 80 bp (round 3; the 75 / 76 / 50 / 36 bp of older runs): the 5-word frame -- 5 transposes, 20 prefetch registers
         if (4u * L + mis <= 64u * 5u) {
+            // (up to 32 windows -- 50 bp at k = 31, 36 bp at any k: one window per lane; two would leave half of phase D's lanes idle and double its passes)
+            if (W <= 32u) return launch_bs<K, 5, 1, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
             if (W <= 64u) return launch_bs<K, 5, 2, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
             return launch_bs<K, 5, 3, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
         }
