@@ -168,6 +168,7 @@ void* big_scratch(void* user, size_t bytes) {
         (void)hipGetLastError();
         return nullptr;
     }
+    if (std::getenv("KMX_DEBUG_ALLOC")) std::fprintf(stderr, "kmx: work buffer (re)allocated, %zu bytes\n", bytes);   // (tests count these)
     ctx->d_big = q;
     ctx->big_bytes = bytes;
     return q;
@@ -183,7 +184,7 @@ size_t hist_scratch_budget(size_t held) {
     const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
     size_t budget = (size_t)8 << 30;
     if (have && total_b / 8u > budget) budget = total_b / 8u;
-    if (const char* e = std::getenv("KMX_HIST_SCRATCH_MB")) budget = (size_t)std::strtoull(e, nullptr, 10) << 20;
+    if (const char* e = std::getenv("KMX_HIST_SCRATCH_MB")) return (size_t)std::strtoull(e, nullptr, 10) << 20;   // (tests: forces chunks)
     if (have && budget > (free_b + held) / 2) budget = (free_b + held) / 2;
     if (budget < held) budget = held;
     return budget;

@@ -297,8 +297,13 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
         // goes to the global table (exact, slow).
         const u32 Lb = offsets ? (L ? L : 256u) : L;
         const u64 W = Lb >= k ? Lb - k + 1u : 1u;
-        // scratch per read: 1.5x slack on 2 bytes per window, plus the fixed per-segment pad; chunk the reads to fit
-        u64 chunk = scratch_budget / (3u * W);
+        // scratch per read: 1.5x slack on 2 bytes per window, plus the fixed per-segment pad (at most 319 entries for each of the 64
+        // segments of at most 8 blocks per CU of four waves, and their lengths); chunk the reads so that a request never EXCEEDS
+        // the budget -- a request above it made the context's buffer larger than the budget, the next call was handed that size as
+        // its budget (kmx_api.hip), asked for a little more again, and every call re-allocated a 36 GB buffer (1.1 s; round 3)
+        const u64 fixed_max = (u64)n_cu * 8u * 4u * 64u * (319u * 2u + 4u);
+        const u64 fixed = fixed_max < scratch_budget / 4u ? fixed_max : scratch_budget / 4u;
+        u64 chunk = (scratch_budget - fixed) / (3u * W);
         if (chunk > n_reads) chunk = n_reads;
         chunk &= ~63ull;
         if (chunk >= 4096u) {

@@ -48,5 +48,5 @@ python3 tools/bench_hist.py 100000000 12,16,20,22,23,24,26,28 > $out/hist_bench.
 python3 tools/bench_minimizers.py > $out/minimizers_bench.txt 2>/dev/null
 python3 tools/bench_fastx.py > $out/fastx_bench.txt 2>/dev/null
 python3 tools/bench_fastq_pipeline.py 2>/dev/null | grep -v amdgpu.ids > $out/fastq_pipeline.txt
-python3 tools/step_times.py > $out/step_times.txt 2>/dev/null
+python3 tools/step_times.py > $out/step_times_cold.txt 2>/dev/null
 ls $out
