@@ -27,12 +27,16 @@ namespace kmx {
 namespace {
 
 #ifndef KMX_FX_ABLATE
-#define KMX_FX_ABLATE 0   // dev: 1 = pass 3 without its byte stores, 2 = without the offsets, 4 = without the output scan (timing only)
+#define KMX_FX_ABLATE 0   // dev: 1 = pass 3 without its byte stores (timing only)
+#endif
+#ifndef KMX_FX_STAGE
+#define KMX_FX_STAGE 1   // pass 3 writes its bytes through an LDS image of the row's output (0: straight from the lanes)
 #endif
 constexpr u32 FX_THREADS = 256;
 constexpr u32 FX_LANE = 64;                  // consecutive bytes a lane owns per step (four dwordx4 loads)
 constexpr u32 FX_ROW = FX_THREADS * FX_LANE; // bytes a block handles per step (16 KiB)
 constexpr u32 FX_ROWS = 8;                   // steps per chunk
+constexpr u32 FX_OB = FX_THREADS * 64u + 32u;   // staged output of a row: its bytes behind up to 15 of alignment
 constexpr u64 FX_CHUNK = (u64)FX_ROW * FX_ROWS;   // 128 KiB
 constexpr u32 FX_SUM_WORDS = 12;             // u32 per chunk summary
 constexpr u32 FX_PFX_WORDS = 4;              // u64 per chunk prefix: entry state, first output byte, first record, -
@@ -539,7 +543,7 @@ fastx_scan_chunks_kernel(const u32* __restrict__ summ, u64 n_chunks, const u32* 
 // pass 3
 template <bool FASTA, bool CR>
 __device__ __forceinline__ void fastx_emit_rows(const uint8_t* __restrict__ text, u64 n, u64 c0, u32 state, u64 out_pos, u64 rec,
-                                                uint8_t* __restrict__ bases, u64* __restrict__ offsets, u32* tmp32, u32* wave_last) {
+                                                uint8_t* __restrict__ bases, u64* __restrict__ offsets, u32* tmp32, u32* wave_last, uint8_t* stage) {
     // (the next row's 64 bytes are requested before this row is analysed: one HBM round trip per row hidden)
     Lane64 d_next = c0 < n ? load_lane(text, n, c0 + threadIdx.x * FX_LANE) : Lane64{};
     u32 unused = 0;
@@ -575,15 +579,35 @@ __device__ __forceinline__ void fastx_emit_rows(const uint8_t* __restrict__ text
         // output positions: bytes and records packed into one scan (a row emits <= 16384 of either)
         const u32 kept = pc64(ks), recs = pc64(rs);
         u32 tkr;
-        u32 ikr = kept | (recs << 16);
-        if (!(KMX_FX_ABLATE & 4)) ikr = block_scan_add_dpp(kept | (recs << 16), tmp32, tkr); else tkr = ikr;
+        const u32 ikr = block_scan_add_dpp(kept | (recs << 16), tmp32, tkr);
         const u64 o = out_pos + ((ikr & 0xFFFFu) - kept);
         u64 r = rec + ((ikr >> 16) - recs);
+#if KMX_FX_STAGE
+        {
+            // The row's bytes go out through LDS: the lanes deposit their pieces where they will lie (same offset modulo 16 as in
+            // memory), then the block writes whole 16-byte pieces, consecutive lanes consecutive addresses -- full lines instead of
+            // four 16-byte stores per lane at a 64-byte stride.  Two buffers: the next row deposits while this one is still read.
+            uint8_t* const ob = stage + (row & 1u) * FX_OB;
+            const u32 row_kept = tkr & 0xFFFFu;
+            const u32 al = (u32)((reinterpret_cast<uintptr_t>(bases) + out_pos) & 15u);       // where the row's first byte sits in its 16-byte piece
+            if (ks && !(KMX_FX_ABLATE & 1)) emit_bytes(d, ks, ob + al + (u32)(o - out_pos));
+            __syncthreads();
+            uint8_t* const g0 = bases + out_pos - al;                                          // 16-byte aligned
+            const u32 end = al + row_kept;
+            for (u32 lo = 16u * threadIdx.x; lo < end && !(KMX_FX_ABLATE & 1); lo += 16u * FX_THREADS) {
+                if (lo >= al && lo + 16u <= end) {
+                    *reinterpret_cast<uint4*>(g0 + lo) = *reinterpret_cast<const uint4*>(ob + lo);
+                } else {                       // the first and the last piece of a row: shared with the rows around it, byte by byte
+                    const u32 b0 = lo > al ? lo : al, b1 = lo + 16u < end ? lo + 16u : end;
+                    for (u32 b = b0; b < b1; ++b) g0[b] = ob[b];
+                }
+            }
+        }
+#else
+        if (ks && !(KMX_FX_ABLATE & 1)) emit_bytes(d, ks, bases + o);
+#endif
         out_pos += tkr & 0xFFFFu;
         rec += tkr >> 16;
-        if (ks && !(KMX_FX_ABLATE & 1)) emit_bytes(d, ks, bases + o);
-        if (KMX_FX_ABLATE & 1) { if (ks == 0x123456789ull) bases[o] = 1; }
-        if (KMX_FX_ABLATE & 2) rs = rs == 0x123456789ull ? 1ull : 0ull;
         while (rs) {      // the read that begins after newline q starts at the output position of the bytes kept so far
             const u32 q = (u32)__builtin_ctzll(rs);
             rs &= rs - 1ull;
@@ -597,15 +621,16 @@ fastx_emit_kernel(const uint8_t* __restrict__ text, u64 n, const u64* __restrict
                   uint8_t* __restrict__ bases, u64* __restrict__ offsets) {
     __shared__ u32 tmp32[FX_THREADS / 64];
     __shared__ u32 wave_last[FX_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[KMX_FX_STAGE ? 2 * FX_OB : 16];
     const u64 chunk = blockIdx.x;
     const u64 c0 = chunk * FX_CHUNK;
     const u64* pf = prefix + chunk * FX_PFX_WORDS;
     if (chunk == 0 && threadIdx.x == 0 && FASTA) offsets[0] = 0;     // record 0 (see fastx_scan_kernel)
     // (a chunk the counting pass found free of '\r' suspects skips that test)
     if (summ[chunk * FX_SUM_WORDS + 9] != 0u)
-        fastx_emit_rows<FASTA, true>(text, n, c0, (u32)pf[0], pf[1], pf[2], bases, offsets, tmp32, wave_last);
+        fastx_emit_rows<FASTA, true>(text, n, c0, (u32)pf[0], pf[1], pf[2], bases, offsets, tmp32, wave_last, stage);
     else
-        fastx_emit_rows<FASTA, false>(text, n, c0, (u32)pf[0], pf[1], pf[2], bases, offsets, tmp32, wave_last);
+        fastx_emit_rows<FASTA, false>(text, n, c0, (u32)pf[0], pf[1], pf[2], bases, offsets, tmp32, wave_last, stage);
 }
 
 __global__ void fastx_last_offset_kernel(const unsigned long long* __restrict__ totals, u64* __restrict__ offsets) {
