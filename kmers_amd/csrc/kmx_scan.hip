@@ -94,6 +94,12 @@ struct SinkWindowsT {
 #ifndef KMX_WIN_WAVES
 #define KMX_WIN_WAVES 3
 #endif
+#ifndef KMX_WIN_UNROLL_A
+#define KMX_WIN_UNROLL_A 1   // unroll factor of the line-aligned write-back loop (4: 253-256 registers and up to 276 bytes of spills in the window loop; rolled: 182, none -- canon-only materialise at k = 31 5.4 -> 4.9 ms per 2e7 reads)
+#endif
+#ifndef KMX_WIN_UNROLL_S
+#define KMX_WIN_UNROLL_S 1   // ... of the staged (several arrays / flags) write-back loop (fw + rc + canon + flags: 18.3-19.0 -> 17.1 ms per 2e7 reads)
+#endif
     // store latency is all this sink waits for: occupancy over registers (the line-aligned variant spills at 168 registers
     // and its 17 KB ring per wave caps a CU at two blocks anyway)
     static constexpr int kWaves = ALIGNED ? 2 : KMX_WIN_WAVES;
@@ -175,7 +181,7 @@ struct SinkWindowsT {
         if (out1) {
             const bool last = o0 + cnt == W;      // the last pass also writes what is left of each read (< 32 windows)
             for (u32 sub = 0; sub < (last ? 2u : 1u); ++sub) {
-#pragma unroll 4
+#pragma unroll KMX_WIN_UNROLL_A
                 for (u32 it = 0; it < 16u; ++it) {
                     const u32 idx = it * 64u + lane, r = idx >> 4, s = idx & 15u;
                     const u64 read = read0 + r;
@@ -191,7 +197,7 @@ struct SinkWindowsT {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             return;
         }
-#pragma unroll 4
+#pragma unroll KMX_WIN_UNROLL_S
         for (u32 it = 0; it < 16u; ++it) {
             const u32 idx = it * 64u + lane, r = idx >> 4, sw = idx & 15u;
             if (sw < cnt && (!p.win_offsets || o0 + sw < NWL[r])) {

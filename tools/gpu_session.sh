@@ -1,2 +1,4 @@
-mkdir -p gpurun_out/r3aux
-tools/variants.sh default aux0 aux1 aux3 aux16 aux17 aux18 aux19 > gpurun_out/r3aux/variants.txt 2>&1
+mkdir -p gpurun_out/r3wu
+timeout 1500 python -m pytest tests/ -x -q -m gpu -k "windows or materialise or fuzz" 2>&1 | tail -3 > gpurun_out/r3wu/pytest.txt
+timeout 600 python tools/bench_windows.py 2>&1 | grep -v amdgpu > gpurun_out/r3wu/windows_bench.txt
+timeout 600 python tools/bench_windows2.py 2>&1 | grep -v amdgpu > gpurun_out/r3wu/windows2_bench.txt
