@@ -94,6 +94,9 @@ struct SinkWindowsT {
 #ifndef KMX_WIN_WAVES
 #define KMX_WIN_WAVES 3
 #endif
+#ifndef KMX_WIN_NT
+#define KMX_WIN_NT 1   // 1: the stores of the line-aligned write-back, and of the staged one when W is a multiple of 8 (whole or half lines), carry the nt hint: canon-only k = 31 4.9 -> 4.3 ms per 2e7 reads (smaller pieces must NOT: the L2 merges those)
+#endif
 #ifndef KMX_WIN_UNROLL_A
 #define KMX_WIN_UNROLL_A 1   // unroll factor of the line-aligned write-back loop (4: 253-256 registers and up to 276 bytes of spills in the window loop; rolled: 182, none -- canon-only materialise at k = 31 5.4 -> 4.9 ms per 2e7 reads)
 #endif
@@ -189,7 +192,13 @@ struct SinkWindowsT {
                     const u32 lo = o0 > a ? o0 - a : 0u;
                     const u32 hi = last ? W : o0 + 16u - a;
                     const u32 o = lo + 16u * sub + s;
+#if KMX_WIN_NT
+                    // (every store of this loop, the half lines at the ends of a read too: nt only on the whole lines measured like no nt at all,
+                    // 4.93 against 4.14-4.30 ms -- the half lines, 64 contiguous bytes from 8 lanes, are what stays open in the L2 otherwise)
+                    if (o < hi) __builtin_nontemporal_store(Tfw[r * RPITCH + (o & 31u)], &out1[read * W + o]);
+#else
                     if (o < hi) out1[read * W + o] = Tfw[r * RPITCH + (o & 31u)];
+#endif
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -197,6 +206,18 @@ struct SinkWindowsT {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             return;
         }
+        if (KMX_WIN_NT && !p.win_offsets && (W & 7u) == 0u && cnt == 16u) {   // uniform reads, W a multiple of 8: every 16-window run is a whole line or two half lines (W = 120: 17.5 -> 15.7 ms for all four arrays; at W = 130, 16-byte aligned runs, nt costs 40 %)
+#pragma unroll KMX_WIN_UNROLL_S
+            for (u32 it = 0; it < 16u; ++it) {
+                const u32 idx = it * 64u + lane, r = idx >> 4, sw = idx & 15u;
+                const u64 slot = (read0 + r) * W + o0 + sw;
+                const u32 at = r * PITCH + sw;
+                if (p.fw) __builtin_nontemporal_store(Tfw[at], &p.fw[slot]);
+                if (p.rc) __builtin_nontemporal_store(Trc[at], &p.rc[slot]);
+                if (p.canon) __builtin_nontemporal_store(Tcn[at], &p.canon[slot]);
+                if (p.flags) p.flags[slot] = TF[r * 16u + sw];
+            }
+        } else {
 #pragma unroll KMX_WIN_UNROLL_S
         for (u32 it = 0; it < 16u; ++it) {
             const u32 idx = it * 64u + lane, r = idx >> 4, sw = idx & 15u;
@@ -208,6 +229,7 @@ struct SinkWindowsT {
                 if (p.canon) p.canon[slot] = Tcn[at];
                 if (p.flags) p.flags[slot] = TF[r * 16u + sw];
             }
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
