@@ -29,6 +29,9 @@ namespace {
 #ifndef KMX_FX_ABLATE
 #define KMX_FX_ABLATE 0   // dev: 1 = pass 3 without its byte stores (timing only)
 #endif
+#ifndef KMX_FX_STAGE_NT
+#define KMX_FX_STAGE_NT 1   // 1: the aligned 16-byte stores of the staged write-back carry the nt hint (whole lines from consecutive lanes: FASTA +3 %, FASTQ unchanged)
+#endif
 #ifndef KMX_FX_STAGE
 #define KMX_FX_STAGE 1   // pass 3 writes its bytes through an LDS image of the row's output (0: straight from the lanes)
 #endif
@@ -596,7 +599,11 @@ __device__ __forceinline__ void fastx_emit_rows(const uint8_t* __restrict__ text
             const u32 end = al + row_kept;
             for (u32 lo = 16u * threadIdx.x; lo < end && !(KMX_FX_ABLATE & 1); lo += 16u * FX_THREADS) {
                 if (lo >= al && lo + 16u <= end) {
+#if KMX_FX_STAGE_NT
+                    { typedef u32 v4u __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(*reinterpret_cast<const v4u*>(ob + lo), reinterpret_cast<v4u*>(g0 + lo)); }
+#else
                     *reinterpret_cast<uint4*>(g0 + lo) = *reinterpret_cast<const uint4*>(ob + lo);
+#endif
                 } else {                       // the first and the last piece of a row: shared with the rows around it, byte by byte
                     const u32 b0 = lo > al ? lo : al, b1 = lo + 16u < end ? lo + 16u : end;
                     for (u32 b = b0; b < b1; ++b) g0[b] = ob[b];

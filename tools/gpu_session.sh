@@ -1,3 +1,4 @@
-mkdir -p gpurun_out/r3wu
-timeout 1500 python -m pytest tests/ -x -q -m gpu -k "windows or materialise or fuzz" 2>&1 | tail -3 > gpurun_out/r3wu/pytest8.txt
-timeout 600 python tools/bench_windows.py 2>&1 | grep -v amdgpu > gpurun_out/r3wu/windows_bench8.txt
+mkdir -p gpurun_out/r3nt
+timeout 600 python tools/bench_windows2.py 2>&1 | grep -v amdgpu > gpurun_out/r3nt/windows2_bench.txt
+timeout 300 python tools/bench_fastx.py 2>&1 | grep -v amdgpu > gpurun_out/r3nt/fastx_bench.txt
+timeout 3000 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -3 > gpurun_out/r3nt/pytest.txt
