@@ -87,7 +87,7 @@ __device__ __forceinline__ Lane64 load_lane(const uint8_t* __restrict__ text, u6
     if (p + FX_LANE <= n) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint4 v = *reinterpret_cast<const uint4*>(text + p + 16u * q);
+            const uint4 v = *reinterpret_cast<const uint4*>(text + p + 16u * q);   // (plain: a lane's four loads share their lines with its neighbours'; with the nt hint the parse is 25 % slower)
             r.w[4 * q] = v.x; r.w[4 * q + 1] = v.y; r.w[4 * q + 2] = v.z; r.w[4 * q + 3] = v.w;
         }
         r.val = ~0ull;

@@ -1,3 +1,6 @@
-mkdir -p gpurun_out/r3el
-timeout 600 python tools/bench_elem.py > gpurun_out/r3el/elem2.txt 2>&1
-timeout 1500 python -m pytest tests/ -x -q -m gpu -k "word or revcomp or canonical_words or hash_words or kats or cpp" 2>&1 | tail -3 > gpurun_out/r3el/pytest.txt
+mkdir -p gpurun_out/r3nt
+for v in "" fxl "" fxl; do
+  echo "== variant '$v'"
+  KMX_LIB_VARIANT=$v timeout 600 python tools/bench_fastq_pipeline.py 2>&1 | grep "parse" | cut -c1-60
+  KMX_LIB_VARIANT=$v timeout 600 python tools/bench_fastx.py 2>&1 | grep -v amdgpu | cut -c1-150
+done > gpurun_out/r3nt/fxl.txt 2>&1
