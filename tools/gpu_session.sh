@@ -1,6 +1,3 @@
-mkdir -p gpurun_out/r3nt
-for v in "" snt "" snt; do
-  echo "== variant '$v'"
-  KMX_LIB_VARIANT=$v timeout 600 python tools/bench_hist.py 100000000 12,20 2>&1 | grep -v amdgpu | cut -c1-100
-  KMX_LIB_VARIANT=$v timeout 600 python tools/bench_windows.py 2>&1 | grep -v amdgpu | head -2 | cut -c1-100
-done > gpurun_out/r3nt/snt.txt 2>&1
+mkdir -p gpurun_out/r3fz
+KMX_FUZZ_N=6000 timeout 3000 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -3 > gpurun_out/r3fz/fuzz.txt
+timeout 3000 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -3 > gpurun_out/r3fz/pytest.txt
