@@ -147,3 +147,28 @@ def test_fastx_reads_picks_the_layout(ctx, orc):
         o = orc.canonical_reduce(eb, n, 0, 21, hasher_k=21, offsets=eo)
         g = ctx.canonical_reduce(bases, n, L, 21, _lib.HASH_LEX, 21, 0, offsets=offsets)
         assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+
+
+@pytest.mark.parametrize("shift", [1, 3, 8, 13])
+def test_output_buffer_at_any_alignment(ctx, orc, shift):
+    """pass 3 stages a row's bytes in LDS at their offset modulo 16 in MEMORY and writes whole aligned 16-byte pieces: the caller's
+    d_bases need not be aligned, and nothing may be written before or behind the n_bases bytes"""
+    import ctypes as C
+
+    import torch
+
+    from kmers_amd.api import _ptr, u64_numpy
+
+    rng = np.random.default_rng(90 + shift)
+    for text, fmt in ((fastq_text(rng, 3000, 0, 180), 1), (fasta_text(rng, 300, 0, 3000, width=61), 2)):
+        eb, eo = orc.fastx_parse(text, fmt)
+        d = ctx.to_device(text)
+        buf = torch.full((len(eb) + 64,), 0xEE, dtype=torch.uint8, device=d.device)
+        bases = buf[shift : shift + len(eb)]
+        offsets = torch.empty(len(eo), dtype=torch.int64, device=d.device)
+        nr, nb = C.c_uint64(0), C.c_uint64(0)
+        ctx._ck(ctx.lib.kmx_fastx_parse(ctx._h, _ptr(d), d.numel(), fmt, _ptr(bases), _ptr(offsets), len(eo) - 1, C.byref(nr), C.byref(nb)))
+        assert nr.value == len(eo) - 1 and nb.value == len(eb)
+        assert np.array_equal(u64_numpy(offsets), eo)
+        assert np.array_equal(bases.cpu().numpy(), eb)
+        assert bool((buf[:shift] == 0xEE).all()) and bool((buf[shift + len(eb) :] == 0xEE).all())
