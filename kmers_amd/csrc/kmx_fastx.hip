@@ -13,13 +13,15 @@
 //   1. fastx_summarise_kernel: per chunk, what it does to the state and how many bytes / records it emits for each
 //      state it may be entered in (FASTQ: 4 phases; FASTA: a chunk whose first line start is known emits a fixed amount
 //      plus what its leading partial line adds if that line is sequence);
-//   2. fastx_scan_kernel (one block): runs the state through the chunk summaries, exclusive sums of the emitted bytes
-//      and records per chunk, totals;
+//   2. fastx_scan_blocks_kernel + fastx_scan_chunks_kernel: the same summary per block of 1024 chunks, then every block composes
+//      the aggregates before it and runs the state through its chunk summaries: entry state, exclusive sums of the emitted
+//      bytes and records per chunk, totals;
 //   3. fastx_emit_kernel: every chunk again, now knowing its entry state and output positions: compacts the bases
-//      and writes the offsets.
+//      (through an LDS image of each row's output, written back in whole aligned 16-byte pieces) and writes the offsets.
 // Traffic: the text is read twice, the bases written once (HBM-bound byte work: no LDS staging of the text, a lane
 // owns 64 consecutive bytes per step and turns them into 64-bit masks -- newlines, line classes, bytes to keep -- a dword
-// at a time; only the 16-byte pieces with a line end inside are then copied byte by byte).
+// at a time; only the 16-byte pieces with a line end inside are then copied byte by byte).  One pass over the text with
+// chained tile descriptors was built and measured (profiles/r03_fastx_one_pass.txt): 6x slower on this machine.
 #include "kmx_device.h"
 
 namespace kmx {
