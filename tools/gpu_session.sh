@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r3fz
-timeout 900 python -m pytest tests/test_gpu_fastx.py -x -q -m gpu 2>&1 | tail -3 > gpurun_out/r3fz/fastx.txt
+bash tools/profile_round.sh gpurun_out/r03c > gpurun_out/r03c.log 2>&1
+python3 tools/bench_elem.py 2>/dev/null | grep -v amdgpu > gpurun_out/r03c/elem_bench.txt
