@@ -1,2 +1,2 @@
-# scratch: the command list of the current gpurun call (tools/README.md); the round's profile set is tools/profile_round.sh
-bash tools/profile_round.sh gpurun_out/r03
+mkdir -p gpurun_out/r3fz
+timeout 900 python tools/stress_contexts.py > gpurun_out/r3fz/stress.txt 2>&1; echo "rc=$?" >> gpurun_out/r3fz/stress.txt
