@@ -31,7 +31,8 @@ hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 L_hint, u32 k, bool want_hash,
-                                        kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+                                        kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
+                                        bool want_sumfw = false);
 hipError_t launch_scan_bitsliced_long(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary* out,
                                       unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
@@ -432,10 +433,10 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
             KMX_HIP(ctx, kmx::launch_scan_bitsliced_long(reads->d_bases, reads->n_reads, reads->read_len, k, want_fold, d_out,
                                                          ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         }
-        if (!handled && reads->d_offsets && !want_sumfw) {   // ragged reads on the bit-sliced kernel (read_len = optional length bound)
+        if (!handled && reads->d_offsets) {   // ragged reads on the bit-sliced kernel (read_len = optional length bound)
             if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
             KMX_HIP(ctx, kmx::launch_scan_bitsliced_ragged(reads->d_bases, reads->d_offsets, reads->n_reads, reads->read_len, k,
-                                                           want_fold, d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+                                                           want_fold, d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled, want_sumfw));
         }
         // word-domain kernel: uniform reads of any (k, L) in its domain, and ragged reads (read_len = optional length bound)
         if (!handled)

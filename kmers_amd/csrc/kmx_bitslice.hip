@@ -76,9 +76,11 @@ hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 
 KMX_BS2_DEFINE_K(63)
 
 // Ragged reads (offsets array): `L_hint` = upper bound of the read lengths if the caller knows one (0 = unknown -> the
-// 160-base frame; tiles holding a longer read roll per lane).  No sum_fw in this mode (its closed form needs one length).
+// 160-base frame; tiles holding a longer read roll per lane).  `want_sumfw` rides in the argument that carries seg_L for the
+// segments of long uniform reads (offsets == nullptr there).
 hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 L_hint, u32 k, bool want_hash,
-                                        kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
+                                        kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
+                                        bool want_sumfw) {
     *handled = false;
     if (!offsets || (reinterpret_cast<uintptr_t>(bases) & 15u) || L_hint > 256) return hipSuccess;
     if (const char* e = getenv("KMX_BS_RAGGED")) {   // dev knob: 0 = leave ragged reads to the word-domain kernel
@@ -90,7 +92,7 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
 #define KMX_BSR_CASE(K) \
     case K:             \
         *handled = true; \
-        return launch_bs_ragged_k##K(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, 0, 0);
+        return launch_bs_ragged_k##K(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, 0, want_sumfw ? 1u : 0u);
     switch (k) {
         KMX_BSR_FOR_EACH_K(KMX_BSR_CASE)
         default:

@@ -326,6 +326,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const bool seg_mode = RAGGED && offsets == nullptr;
     const u32 seg_T = lead, seg_L = want_sumfw;
     const u32 seg_J = seg_mode ? (seg_L - (u32)K + seg_T) / seg_T : 1u;      // ceil((seg_L - K + 1) / seg_T)
+    // (reads behind an offsets array: the argument is what its name says; uniform reads: as given)
+    const bool sumfw_on = RAGGED ? (!seg_mode && want_sumfw != 0u) : (want_sumfw != 0u);
     auto seg_bounds = [&](u64 g, u64& o0, u64& o1) {
         const u64 i = g / seg_J;
         const u32 j = (u32)(g - i * seg_J);
@@ -394,7 +396,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
                 atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)r0);
                 if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)h0);
-                if (want_sumfw && !RAGGED) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);   // (ragged: no sum_fw; the argument carries seg_L)
+                if (sumfw_on) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);   // (segments of long reads: no sum_fw; the argument carries seg_L)
             } else {
                 kmx_summary2* o = static_cast<kmx_summary2*>(out);
                 atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
@@ -1425,6 +1427,22 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         bs_s1 = wave_sum(s1);
         bs_x0 = wave_xor(x0);
         bs_x1 = wave_xor(x1);
+        if constexpr (K <= 32 && RAGGED) {
+            // Sum of the forward words of reads of unequal length (round 3).  Base i of a read of len bases sits at exponent e = i - o of
+            // the windows o = max(0, i-K+1) .. min(i, len-K): its weight is S(min(i, K-1)) - S(i - (len-K+1)), S(n) = (4^(n+1) - 1) / 3,
+            // S(<0) = 0.  The first term needs the plane totals only (a plane counts a base for the reads that have it); the second is
+            // non-zero for the last K-1 bases of a read, whose totals by position from the end are QE[].
+            if (sumfw_on) {
+                u64 f = 0;
+                for (u32 pid = lane; pid < 2u * L; pid += 64u) {
+                    const u32 i = pid >> 1, e = i < (u32)(K - 1) ? i : (u32)(K - 1);
+                    f += (u64)PL[pid] * ((((1ull << (2u * e + 2u)) - 1ull) / 3ull) << (pid & 1u));
+                }
+                for (u32 pid = lane; pid < 2u * (u32)(K - 1); pid += 64u)
+                    f -= (u64)QE[pid] * ((((1ull << (2u * (pid >> 1) + 2u)) - 1ull) / 3ull) << (pid & 1u));
+                bs_fw = wave_sum(f);
+            }
+        }
     }
 
     // ---- one set of atomics per wave
@@ -1560,7 +1578,7 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
             atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
             atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)s0);
             if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)x0);
-            if (want_sumfw && !RAGGED) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
+            if (RAGGED ? (!seg_mode && want_sumfw != 0u) : (want_sumfw != 0u)) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
         } else {
             kmx_summary2* o = static_cast<kmx_summary2*>(out);
             atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);

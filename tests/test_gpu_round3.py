@@ -476,3 +476,34 @@ def test_rolled_reads_shared_by_lanes(ctx, orc, n_dirty, k, ragged):
         o = orc.canonical_reduce2(host, n_reads, L, k, with_hash=True)
         g = ctx.canonical_reduce2(dev, n_reads, L, k, with_hash=True)
         assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+
+# ------------------------------------------------------------------ sum_fw of ragged reads on the bit-sliced kernel
+@pytest.mark.parametrize("k", [13, 16, 21, 27, 31])
+@pytest.mark.parametrize("case", ["150_trimmed", "mix_100_160", "short_20_100", "long_161_250", "tiny_and_empty", "dirty"])
+def test_ragged_sum_fw(ctx, orc, k, case):
+    """KMX_REDUCE_SUM_FW for reads behind an offsets array: the closed form of the bit-sliced kernel (plane totals weighted by
+    position from the start, minus the totals of every read's last k-1 bases weighted by position from the end) against the
+    oracle's per-read rolling -- every frame, reads shorter than k and than 2k-1, empty reads, reads with an N"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(k * 11 + len(case))
+    n_reads = 64 * 30 + 17
+    if case == "150_trimmed":
+        lens, hint = np.where(rng.random(n_reads) < 0.1, rng.integers(36, 150, n_reads), 150), 150
+    elif case == "mix_100_160":
+        lens, hint = rng.integers(100, 161, n_reads), 160
+    elif case == "short_20_100":
+        lens, hint = rng.integers(20, 101, n_reads), 100
+    elif case == "long_161_250":
+        lens, hint = rng.integers(161, 251, n_reads), 250
+    elif case == "tiny_and_empty":
+        lens, hint = rng.integers(0, 2 * k + 3, n_reads), 0
+    else:
+        lens, hint = rng.integers(60, 151, n_reads), 150
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]) + 16, 0.002 if case == "dirty" else 0.0)[: int(offsets[-1])]
+    o = orc.canonical_reduce(host, n_reads, 0, k, hasher_k=k, offsets=offsets)
+    g = ctx.canonical_reduce(ctx.to_device(host) if len(host) else ctx.empty(0, __import__("torch").uint8), n_reads, hint, k, _lib.HASH_LEX, k,
+                             _lib.REDUCE_SUM_FW, offsets=ctx.to_device(offsets))
+    _same(g, o, True, True)

@@ -2,6 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, ctypes as C
+from _timing import warm
 from kmers_amd.api import Context, _ptr
 from kmers_amd import _lib
 
@@ -12,7 +13,7 @@ words = torch.randint(0, 2**62, (n,), dtype=torch.int64, device=ctx.device)
 out = torch.empty_like(words)
 isc = ctx.empty(n, torch.uint8)
 def t(f, reps=5):
-    f(); ts = []
+    warm(f); ts = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(ctx.stream); f(); b.record(ctx.stream); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))

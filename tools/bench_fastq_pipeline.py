@@ -6,6 +6,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
+from _timing import warm
 from kmers_amd.api import Context
 from kmers_amd import _lib
 
@@ -16,7 +17,7 @@ rng = np.random.default_rng(7)
 
 
 def timed(f, n=3):
-    f()
+    warm(f)
     ts = []
     for _ in range(n):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -2,6 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from _timing import warm
 from kmers_amd.api import Context
 from kmers_amd import _lib
 
@@ -16,6 +17,7 @@ for b in bs:
     ctx.histogram(bases, n, L, k, _lib.HASH_LEX, k, b, counts=counts)
     torch.cuda.synchronize()
     ok = int(counts.sum().item()) == tot
+    warm(lambda: ctx.histogram(bases, n, L, k, _lib.HASH_LEX, k, b, counts=counts), at_least=6)
     ts = []
     for _ in range(3):
         counts.zero_()

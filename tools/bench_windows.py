@@ -2,6 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, ctypes as C
+from _timing import warm
 from kmers_amd.api import Context, _ptr
 
 ctx = Context(0)
@@ -9,7 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 bases = ctx.gen_reads(n * L)
 def t(f, reps=5):
-    f(); ts = []
+    warm(f); ts = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); f(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
