@@ -1,2 +1,2 @@
-# scratch: the command list of the current gpurun call (tools/README.md); the round's profile set is tools/profile_round.sh
-bash tools/profile_round.sh gpurun_out/r03
+mkdir -p gpurun_out/r3a1
+tools/variants.sh default a1 > gpurun_out/r3a1/variants.txt 2>&1
