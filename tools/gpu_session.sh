@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r3a1
-tools/variants.sh default a1 > gpurun_out/r3a1/variants.txt 2>&1
+mkdir -p gpurun_out/r3uc
+timeout 600 python tools/_uc_tmp.py > gpurun_out/r3uc/uc.txt 2>&1
