@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r3uc
-timeout 600 python tools/_uc_tmp.py > gpurun_out/r3uc/uc.txt 2>&1
+# scratch: the command list of the current gpurun call (tools/README.md); the round's profile set is tools/profile_round.sh
+bash tools/profile_round.sh gpurun_out/r03
