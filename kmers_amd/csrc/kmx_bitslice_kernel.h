@@ -141,6 +141,19 @@
 #ifndef KMX_BS_ABLATE
 #define KMX_BS_ABLATE 0   // dev: bitmask of phases to skip (timing experiments only; results become wrong)
 #endif
+#ifndef KMX_BS_MFMA
+// 1: (round 4) pass 2 of phase D -- C[t][b] = sum over windows o and reads r of m[o][r] * plane[o+t][b][r], a 0/1 correlation --
+// runs on the matrix pipe: G[o][beta] = sum_r m[o][r] * plane[beta][r] as v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands
+// (K = the tile's 64 reads), all window blocks accumulating into the same NAB x 16 fp32 registers; the diagonals beta - o = t
+// are summed once per wave.  See "pass 2 on the matrix pipe" in phase D.
+#define KMX_BS_MFMA 1
+#endif
+#ifndef KMX_BS_MFMA_WAVES
+#define KMX_BS_MFMA_WAVES 3   // waves per SIMD of the KMX_BS_MFMA build (NAB x 16 accumulators instead of K + 1 counters)
+#endif
+#ifndef KMX_BS_MFMA_FLUSH
+#define KMX_BS_MFMA_FLUSH 256    // tiles between two folds of the fp32 accumulators into the 64-bit sums (a power of two; far below the 2^24 / (8 blocks x 64 reads) the sums stay exact for: the full-size runs -- ~500 tiles per wave -- exercise the fold, at ~1.5 instructions per tile)
+#endif
 
 namespace kmx {
 
@@ -176,6 +189,54 @@ __device__ __forceinline__ u32 bitsel(u32 x, u32 y, u32 keep) { return __builtin
 // d += popcount(x) as ONE v_bcnt_u32_b32 (hipcc otherwise splits it into v_bcnt(x,0) + v_add3_u32)
 __device__ __forceinline__ void pc_acc(u32& d, u32 x) { asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x)); }
 
+// ---- FP4 (E2M1) operands of v_mfma_scale_f32_32x32x64_f8f6f4 out of bit planes, without spreading bits (tools/mfma/fp4_probe.hip).
+// A nibble with ONE bit set is 0.5 (bit 0), 1.0 (bit 1) or 2.0 (bit 2); bit 3 is the sign.  A lane's operand is 4 dwords = 32
+// nibbles = its row's (column's) 32 values along K, and K-slot (dword d, nibble n) may stand for any read as long as both
+// operands agree.  So dword d of the B operand (a plane word P, bit rho = read rho) is just P masked to one bit per nibble --
+// reads 4n+2 at weight 2, 4n+1 at 1, 4n at 0.5, and 4n+3 (one shift: bit 3 would be the sign) at 2 -- and the A operand (a
+// mask word M) carries the same reads in the same slots at the reciprocal weights (rotations of M): every product is exactly
+// 0 or 1, the fp32 sums are exact integers below 2^24.
+typedef int bs_v8i __attribute__((ext_vector_type(8)));
+typedef float bs_v16f __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ bs_v8i fp4_operand_b(u32 x) {
+    bs_v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+    r[0] = (int)(x & 0x44444444u);
+    r[1] = (int)(x & 0x22222222u);
+    r[2] = (int)(x & 0x11111111u);
+    r[3] = (int)((x >> 1) & 0x44444444u);
+    return r;
+}
+__device__ __forceinline__ bs_v8i fp4_operand_a(u32 m) {
+    bs_v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+    r[0] = (int)(alignbit(m, m, 2) & 0x11111111u);
+    r[1] = (int)(m & 0x22222222u);
+    r[2] = (int)(alignbit(m, m, 30) & 0x44444444u);
+    r[3] = (int)(alignbit(m, m, 3) & 0x11111111u);
+    return r;
+}
+
+// The weighted form: nibble = the 2-bit code of a base (bit 0 from plane p0, bit 1 from p1) = 0, 0.5, 1 or 1.5; against mask
+// nibbles of 2.0 the products are the codes 0..3 themselves, so ONE product sums C[t][0] + 2 C[t][1] -- all the wrapping sum
+// of canonical words needs (the xor-fold of the hashes needs the two parities apart).  K-slot (dword c, nibble n) = read 4n + c.
+__device__ __forceinline__ bs_v8i fp4_operand_codes(u32 p0, u32 p1) {
+    const u32 ev = __builtin_amdgcn_bitop3_b32(p0, p1 << 1, 0x55555555u, 0xE4);    // bits (2m, 2m+1) = code of read 2m
+    const u32 od = __builtin_amdgcn_bitop3_b32(p0 >> 1, p1, 0x55555555u, 0xE4);    //                = code of read 2m + 1
+    bs_v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+    r[0] = (int)(ev & 0x33333333u);
+    r[1] = (int)(od & 0x33333333u);
+    r[2] = (int)((ev >> 2) & 0x33333333u);
+    r[3] = (int)((od >> 2) & 0x33333333u);
+    return r;
+}
+__device__ __forceinline__ bs_v8i fp4_operand_mask2(u32 m) {
+    bs_v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+    r[0] = (int)(alignbit(m, m, 30) & 0x44444444u);
+    r[1] = (int)(alignbit(m, m, 31) & 0x44444444u);
+    r[2] = (int)(m & 0x44444444u);
+    r[3] = (int)(alignbit(m, m, 1) & 0x44444444u);
+    return r;
+}
+
 // PACKED: `bases` is a SeqVector (kmx_seqvec.hip), read r = its bases [r*L, (r+1)*L): a tile is 16*L bytes of ready-made
 // 2-bit codes that go from HBM straight into the packed LDS buffer -- no phase A, nothing to validate.
 // RAGGED: reads of different lengths, read r = bases[offsets[r], offsets[r+1]); L is then the frame: the longest read a
@@ -206,8 +267,13 @@ template <int K, int WPL> constexpr int bs_waves_ascii() {
     return (KMX_BS_LATE_ROWS >= 5 || K <= 23 || (K <= 26 && WPL <= 4)) ? 4 : KMX_BS_WAVES;
 #endif
 }
+// waves per SIMD a variant is compiled for (64 prefetch registers at NW = 16; 2 x counters at K > 32)
+template <int K, int NW, int WPL, bool PACKED, bool RAGGED> constexpr int bs_waves() {
+    const int w = K > 32 ? KMX_BS_WAVES2 : RAGGED ? (NW > 10 ? 2 : KMX_BSR_WAVES) : (NW == 5 && !PACKED) ? KMX_BS_WAVES5 : NW == 13 ? KMX_BS_WAVES13 : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>();
+    return (KMX_BS_MFMA && w > KMX_BS_MFMA_WAVES) ? KMX_BS_MFMA_WAVES : w;
+}
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
-__global__ void __launch_bounds__(256, (K > 32 ? KMX_BS_WAVES2 : RAGGED ? (NW > 10 ? 2 : KMX_BSR_WAVES) : (NW == 5 && !PACKED) ? KMX_BS_WAVES5 : NW == 13 ? KMX_BS_WAVES13 : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>()))   // 64 prefetch registers at NW=16; 2x counters at K>32
+__global__ void __launch_bounds__(256, (bs_waves<K, NW, WPL, PACKED, RAGGED>()))
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead) {
@@ -252,9 +318,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     const u32 chunks = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);   // 16-byte chunks a tile may span (+1 for an unaligned start)
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
-    const u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
+    u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
+    if (KMX_BS_MFMA && ldsw < 64u * WPL) ldsw = 64u * WPL;   // (it holds the m words of pass 2 afterwards)
+    constexpr u32 CSA_DW = KMX_BS_MFMA ? 4u * ((K + 1) / 2) : 0u;   // KMX_BS_MFMA: 2 * NT 64-bit sums of the counter classes
     constexpr u32 TRC_DW = KMX_BS_TRC_LDS ? 256u : 0u;     // [32 lanes of a half-wave][8] transpose constants, shared by the block
-    u32* P = lds + TRC_DW + wib * (ldsw + 4u * PLANES + BS_SET_SLACK + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u));
+    u32* P = lds + TRC_DW + wib * (ldsw + 4u * PLANES + BS_SET_SLACK + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW);
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
     const u64 n_full = n_reads >> 6;
@@ -370,6 +438,40 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         m.fits = nch <= (u64)chunks && nch <= 64u * NW && !__any(m.len > L) && m.base + 16u * nch <= total_bytes;   // (one compare + a scalar test: a wave-wide max costs ten instructions)
     };
     u32 n_bs_tiles = 0;
+#if KMX_BS_MFMA
+    // pass 2 on the matrix pipe: window block i (windows 32i .. 32i+31) meets the planes of bases 32i .. 32i+K+30, i.e. the NAB
+    // blocks of 16 bases (32 planes) from 2i on; acc[q] collects block pair (i, 2i + q) of EVERY i and every tile.
+    constexpr bool WSUM = KMX_BS_MFMA == 2;     // the weighted form: columns = bases, one accumulator block per 32 of them (no hash fold)
+    constexpr int NAB = WSUM ? (K + 30) / 32 + 1 : (K + 30) / 16 + 1;
+    bs_v16f acc[NAB];
+#pragma unroll
+    for (int q = 0; q < NAB; ++q)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
+    u64* const CSA = reinterpret_cast<u64*>(P + ldsw + 4u * PLANES + BS_SET_SLACK + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u));
+    for (u32 i = lane; i < 2u * NT; i += 64u) CSA[i] = 0ull;
+    // acc[q][j] of lane (half, p) is G[o][beta] for o = (j & 3) + 8 (j >> 2) + 4 half (mod 32), plane 32 q + p relative to the
+    // window block: base o_blk + 16 q + p / 2, bit p & 1.  The diagonal t = beta - o in [0, K) is base t of the window; t and
+    // K-1-t share a counter class as D[] does.
+    auto fold_acc = [&]() {
+        u32 ln_ = lane;
+        asm volatile("" : "+v"(ln_));   // (opaque: hipcc otherwise hoists the 16 NAB addresses and conditions of this rare path out of the tile loop -- and spills them)
+        const int pb = (WSUM ? (int)(ln_ & 31u) : (int)((ln_ & 31u) >> 1)) - 4 * (int)(ln_ >> 5);
+        u64* const cs_b = CSA + (WSUM ? 0u : (ln_ & 1u));
+#pragma unroll
+        for (int q = 0; q < NAB; ++q) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int t = (WSUM ? 32 : 16) * q + pb - ((j & 3) + 8 * (j >> 2));
+                if (t >= 0 && t <= K - 1) {
+                    const int tc = t < K - 1 - t ? t : K - 1 - t;
+                    atomicAdd(reinterpret_cast<unsigned long long*>(cs_b + 2 * tc), (unsigned long long)(u32)acc[q][j]);
+                }
+                acc[q][j] = 0.f;
+            }
+        }
+    };
+#endif
     // ---- reads with an invalid byte (ASCII input, uniform or ragged).  A tile that holds one used to go to the per-lane path
     // as a whole -- 64 reads rolled at 6.5x the cost of a bit-sliced tile, so 0.5 % of reads with an N (27 % of the tiles)
     // made the scan 3.4x slower.  Rounds 1-2 had a second instantiation of this kernel scan the flagged tiles again with the
@@ -468,6 +570,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #ifdef KMX_BS_TIMING
     const u64 k_c0 = __builtin_readcyclecounter(), k_w0 = wall_clock64();
     u64 tph[6] = {0, 0, 0, 0, 0, 0};
+    u64 t_last = 0;
 #define KMX_T(i) { const u64 t_now = __builtin_readcyclecounter(); tph[i] += t_now - t_last; t_last = t_now; }
 #else
 #define KMX_T(i)
@@ -1003,6 +1106,15 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll 1
         for (u32 r = 0; LATE > 0 ? r < 1u : r < n_rounds; ++r) {
             if (KMX_BS_ABLATE & 64) break;
+#if KMX_BS_MFMA
+            // a half-wave per set, lane p of it the windows WPL p .. WPL p + WPL - 1 (the launchers pick WPL = ceil(W / 32)): the
+            // lanes past the last group compute on whatever lies behind the planes and count nothing (nwin = 0), but they write
+            // the zero words that complete the set's 32 WPL mask words -- the A operands of the matrix products.
+            const u32 set = lane >> 5;
+            const bool active = (lane & 31u) < NG;
+            const u32 o = (u32)WPL * (lane & 31u);
+            const u32 nwin = active ? (W - o < (u32)WPL ? W - o : (u32)WPL) : 0u;   // valid windows in this group
+#else
             const u32 gidx = r * 64u + lane;
             const bool active = gidx < 2u * NG;
             // (KMX_BS_BANKFIX: the idle lanes continue set 1's sequence -- their reads land on banks no active lane of their
@@ -1010,6 +1122,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             const u32 set = (gidx >= NG && (active || KMX_BS_BANKFIX)) ? 1u : 0u;
             const u32 o = (active || KMX_BS_BANKFIX) ? (u32)WPL * (gidx - set * NG) : 0u;
             const u32 nwin = active ? (W - o < (u32)WPL ? W - o : (u32)WPL) : 0u;   // valid windows in this group
+#endif
             // base o+i  ->  u64 index (i % WPL) * S2 + o / WPL + i / WPL in the rotated layout (o is a multiple of WPL), else o + i
 #if KMX_BS_LDS64
             // (an address-space-3 pointer: a volatile access through a generic pointer stays a flat load)
@@ -1124,7 +1237,76 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 }
             }
             if (!run) break;
+            KMX_T(5)
             asm volatile("" ::: "memory");   // pass 2 re-reads the planes instead of keeping 2K+6 registers live
+#if KMX_BS_MFMA
+            {
+                // ---- pass 2 on the matrix pipe.  C[t][b] = sum_o sum_r m[o][r] & plane[o+t][b][r] is the sum along the diagonal
+                // beta - o = t of G[o][beta] = sum_r m[o][r] * plane[beta][r], a 0/1 matrix product over the tile's 64 reads:
+                // v_mfma_scale_f32_32x32x64_f8f6f4, FP4 operands (fp4_operand_a / _b), unit scales.  Rows = the 32 windows of a
+                // block, columns = the 32 planes of 16 bases, K = reads: lanes 0..31 carry set 0, lanes 32..63 set 1 -- which is
+                // how phase C left the planes (lane (half, p) holds plane 32 g + p of set `half`) and how the mask words come back
+                // from LDS below.  Per tile: WPL + NW ds_read_b32, 7 WPL + 5 NW VALU instructions for the operands and at most
+                // NAB WPL matrix instructions, instead of 2 (v_and + v_bcnt) per (window, plane) pair (504 VALU instructions at
+                // k = 31, L = 150).
+                u32* const MW = P;          // the packed reads are dead since phase B
+                u32* const mwr = MW + set * (32u * WPL) + (u32)WPL * (lane & 31u);
+                if constexpr (WPL == 4) {
+                    *reinterpret_cast<uint4*>(mwr) = make_uint4(m[0], m[1], m[2], m[3]);
+                } else if constexpr (WPL == 2) {
+                    *reinterpret_cast<uint2*>(mwr) = make_uint2(m[0], m[1]);
+                } else if constexpr (WPL == 8) {
+                    reinterpret_cast<uint4*>(mwr)[0] = make_uint4(m[0], m[1], m[2], m[3]);
+                    reinterpret_cast<uint4*>(mwr)[1] = make_uint4(m[4], m[5], m[6], m[7]);
+                } else {
+#pragma unroll
+                    for (int w = 0; w < WPL; ++w) mwr[w] = m[w];
+                }
+                lds_fence();
+                const u32 pp = lane & 31u;
+                u32 ab[WPL];
+#pragma unroll
+                for (int i = 0; i < WPL; ++i) ab[i] = MW[set * (32u * WPL) + 32u * i + pp];
+                // the lane's own planes, where phase C put them
+                const u32 b0 = pp >> 1;
+                const u32 slot0 = ROT ? (b0 % (u32)RW) * S2 + (b0 / (u32)RW) : b0;
+                const u32* const prd = PL + (set * SP + 2u * slot0 + (pp & 1u));
+                const int unit = 0x7F7F7F7F;    // E8M0 scale 2^0 in every byte
+                bs_v8i A[WPL];
+                if constexpr (WSUM) {
+                    // columns = the 32 bases of a block (both planes of a base in one operand), window block i meets the base blocks i .. i + NAB - 1
+                    const u32 slot64 = ROT ? (pp % (u32)RW) * S2 + (pp / (u32)RW) : pp;
+                    const u64* const prd64 = reinterpret_cast<const u64*>(PL + set * SP) + slot64;
+#pragma unroll
+                    for (int j = 0; 32 * j < 16 * NW; ++j) {
+                        const u64 pv = prd64[ROT ? (32 / RW) * j : 32 * j];
+                        const bs_v8i B = fp4_operand_codes((u32)pv, (u32)(pv >> 32));
+#pragma unroll
+                        for (int i = 0; i < WPL; ++i) {
+                            const int q = j - i;
+                            if (q < 0 || q >= NAB) continue;
+                            if (q == 0) A[i] = fp4_operand_mask2(ab[i]);
+                            acc[q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[i], B, acc[q], 4, 4, 0, unit, 0, unit);
+                        }
+                    }
+                } else
+#pragma unroll
+                for (int g = 0; g < NW; ++g) {
+                    const bs_v8i B = fp4_operand_b(prd[ROT ? (32 / RW) * g : 32 * g]);
+#pragma unroll
+                    for (int i = 0; i < WPL; ++i) {
+                        const int q = g - 2 * i;
+                        if (q < 0 || q >= NAB) continue;
+                        if (q == 0) A[i] = fp4_operand_a(ab[i]);     // first use of window block i
+#ifdef KMX_BS_MFMA_PROBE2   // (dev, timing only: two accumulator blocks -- the register need of a 32-accumulator form; results are wrong)
+                        acc[q & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[i], B, acc[q & 1], 4, 4, 0, unit, 0, unit);
+#else
+                        acc[q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[i], B, acc[q], 4, 4, 0, unit, 0, unit);
+#endif
+                    }
+                }
+            }
+#else
             constexpr int NPL = (KMX_BS_ABLATE & 1) ? 1 : K + WPL - 1;
             if (!KMX_BS_EXECMASK || active) {
 #if KMX_BS_PRIO
@@ -1216,10 +1398,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             }
             }
+#endif
         }
 #undef KMX_PLANE
 #undef KMX_PLANE_AT
         if (run) n_bs_tiles += 1;
+#if KMX_BS_MFMA
+        if (run && (n_bs_tiles & (u32)(KMX_BS_MFMA_FLUSH - 1)) == 0u) fold_acc();   // (wave-uniform, rare: keeps every fp32 accumulator an exact integer)
+#endif
     };
 
     // Pipeline order 1: [A of tile t] [issue loads of tile t+1] [B,C,D of tile t]
@@ -1238,7 +1424,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     }
     while (tile < n_full) {
 #ifdef KMX_BS_TIMING
-        u64 t_last = __builtin_readcyclecounter();
+        t_last = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         KMX_T(0)
 #endif
@@ -1333,8 +1519,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     }
 #ifdef KMX_BS_TIMING
     if (lane == 0 && wave_id < 4096) {
-        u64* dbg = reinterpret_cast<u64*>(out) + 8 + wave_id * 8;
+        u64* dbg = reinterpret_cast<u64*>(out) + 8 + wave_id * 10;
         for (int i = 0; i < 5; ++i) dbg[i] = tph[i];
+        dbg[8] = tph[5];
         dbg[5] = n_bs_tiles;
         dbg[6] = __builtin_readcyclecounter() - k_c0;   // shader cycles of this wave's whole run
         dbg[7] = wall_clock64() - k_w0;                 // same interval in 100 MHz ticks
@@ -1376,6 +1563,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         u32 mcnt_c;
         asm volatile("v_mov_b32 %0, %1" : "=&v"(mcnt_c) : "v"(mcnt));
         const u64 mc = wave_sum((u64)mcnt_c);
+#if KMX_BS_MFMA
+        fold_acc();
+        const u64* const CS = CSA;
+#else
         u64* CS = reinterpret_cast<u64*>(PL + PLANES);      // set-1 plane area is free now
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1387,6 +1578,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             const u64 v = wave_sum((u64)dq);
             if (lane == 0) CS[q] = v;
         }
+#endif
 #pragma unroll
         for (int g = 0; g < NW; ++g)
             if (half == 0) PL[32u * g + p] = tot[g];        // PL[2*base + bit] = popcount total of that plane
@@ -1608,10 +1800,12 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
         if (lead != 0u && 4u * L + 1u > 64u * (u32)NW) return hipErrorInvalidValue;   // (callers check: the extra chunk must fit the frame)
     }
     const u32 chunks = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);
-    const u32 ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
+    u32 ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
+    if (KMX_BS_MFMA && ldsw < 64u * (u32)WPL) ldsw = 64u * (u32)WPL;
     constexpr u32 NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;
     constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
-    size_t lds_bytes = (size_t)(ldsw + 4u * (u32)bs_plane_dwords(NW) + BS_SET_SLACK + (RAGGED ? 2u * (32u * NV + 8u) : 0u) + (RAGGED ? 64u * (NE + 2) : 0u)) * 4u * 4u;
+    constexpr u32 CSA_DW = KMX_BS_MFMA ? 4u * ((K + 1) / 2) : 0u;
+    size_t lds_bytes = (size_t)(ldsw + 4u * (u32)bs_plane_dwords(NW) + BS_SET_SLACK + (RAGGED ? 2u * (32u * NV + 8u) : 0u) + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW) * 4u * 4u;
     if (KMX_BS_TRC_LDS) lds_bytes += 1024u;
     if (const char* e = getenv("KMX_BS_EXTRA_LDS")) lds_bytes += (size_t)atol(e);   // dev knob: caps blocks per CU
     // blocks per CU, cached per host thread and device (one thread per context / GPU is the ABI's model: a plain static
@@ -1630,6 +1824,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
         if (getenv("KMX_BS_PRINT_BPC")) fprintf(stderr, "kmx: bit-sliced K=%d NW=%d WPL=%d: %d blocks per CU, %zu B of LDS each\n", K, NW, WPL, bpc, lds_bytes);
     }
     if (L < (u32)K || 2u * ((L - (u32)K + 1u + (u32)WPL - 1u) / (u32)WPL) > 64u) return hipErrorInvalidValue;   // phase D runs ONE round of 64 items
+    if (KMX_BS_MFMA && L - (u32)K + 1u > 32u * (u32)WPL) return hipErrorInvalidValue;   // a half-wave per set: the 32 lanes hold all of a read's windows
     if ((n_reads >> 6) >= (1ull << 36)) return hipErrorInvalidValue;   // tickets are kept as 32-bit values (32 heads x 2^32 tiles; 2^42 reads is far past any HBM)
     const u64 n_tiles = (n_reads + 63u) >> 6;
     u64 grid = (u64)n_cu * (u64)bpc;

@@ -8,7 +8,7 @@ ctx = Context(0)
 n, L, k = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000, 150, 31
 bases = ctx.gen_reads(n * L)
 NWV = 4096
-out = torch.zeros(8 + NWV * 8, dtype=torch.int64, device="cuda")
+out = torch.zeros(8 + NWV * 10, dtype=torch.int64, device="cuda")
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"   # the same reads behind an offsets array (frame 160)
 d_off = ctx.to_device((np.arange(n + 1, dtype=np.uint64) * np.uint64(L))) if ragged else None
@@ -24,8 +24,8 @@ torch.cuda.synchronize()
 ms = [a.elapsed_time(b) for a, b in ev]
 print("kernel ms per launch (events): min %.3f median %.3f max %.3f -> %.0f GB/s at median" % (min(ms), sorted(ms)[len(ms)//2], max(ms), n * L / sorted(ms)[len(ms)//2] / 1e6))
 v = out.cpu().numpy().view(np.uint64)
-d = v[8:8 + NWV * 8].reshape(NWV, 8).astype(np.float64)
-raw5 = v[8:8 + NWV * 8].reshape(NWV, 8)[:, 5]
+d = v[8:8 + NWV * 10].reshape(NWV, 10).astype(np.float64)
+raw5 = v[8:8 + NWV * 10].reshape(NWV, 10)[:, 5]
 start_abs = (raw5 >> np.uint64(20)).astype(np.float64)
 d[:, 5] = (raw5 & np.uint64((1 << 20) - 1)).astype(np.float64)
 keep = d[:, 5] > 0
@@ -37,10 +37,12 @@ print("waves", len(d), "start ms: min %.3f p50 %.3f p90 %.3f max %.3f | end ms: 
 print("late starters (>0.1 ms):", int((st > 0.1).sum()))
 print("per-wave lifetime ms (first 64 waves): min %.3f max %.3f" % (d[:,7].min()/1e5, d[:,7].max()/1e5))
 tiles = d[:, 5]
-names = ["A0 wait loads", "A encode+lds", "ticket take/issue", "B+C realign+transpose", "D main loop"]
+names = ["A0 wait loads", "A encode+lds", "ticket take/issue", "B+C realign+transpose", "D pass 2", "", "", "", "D pass 1 + late rows"]
 print("tiles per wave", tiles.mean())
 tot = 0
 for i, nme in enumerate(names):
+    if not nme:
+        continue
     c = (d[:, i] / tiles).mean()
     tot += c
     print(f"{nme:16s} {c:10.0f} cycles/tile")
