@@ -103,6 +103,13 @@ int kmx_ctx_create_on_stream(int device, void *hip_stream, kmx_ctx **out); /* bo
 void kmx_ctx_destroy(kmx_ctx *ctx);
 int kmx_ctx_synchronize(kmx_ctx *ctx);                         /* also reports what the asynchronous scans could not: KMX_E_ARG after a read of >= 2^31 bases was skipped */
 int kmx_ctx_device(const kmx_ctx *ctx);
+/* The context owns ONE grow-only device work buffer (bucket-id streams of kmx_histogram above 2^14 buckets, chunk prefixes of
+ * kmx_fastx_parse); reads are processed in as many chunks as it takes.  Its size is chosen per call -- an eighth of the device
+ * memory, at most half of what is free -- unless a limit is set here (bytes; 0 = automatic again).  A server that shares the
+ * device caps it; a small limit forces the chunked paths. */
+int kmx_ctx_set_work_buffer_limit(kmx_ctx *ctx, size_t bytes);
+/* what the context holds now, and how often the buffer has been (re)allocated since kmx_ctx_create (either pointer may be NULL) */
+int kmx_ctx_work_buffer_info(const kmx_ctx *ctx, size_t *bytes_held, uint64_t *n_allocations);
 const char *kmx_strerror(int status);
 const char *kmx_last_error(const kmx_ctx *ctx); /* text of the last HIP failure on this ctx */
 int kmx_version(void);

@@ -55,6 +55,8 @@ SIGNATURES = {
     "kmx_ctx_destroy": (None, [_vp]),
     "kmx_ctx_synchronize": (_int, [_vp]),
     "kmx_ctx_device": (_int, [_vp]),
+    "kmx_ctx_set_work_buffer_limit": (_int, [_vp, C.c_size_t]),
+    "kmx_ctx_work_buffer_info": (_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "kmx_last_error": (C.c_char_p, [_vp]),
     "kmx_malloc": (_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "kmx_free": (_int, [_vp, _vp]),

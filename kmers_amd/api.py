@@ -88,6 +88,16 @@ class Context:
     def synchronize(self):
         self._ck(self.lib.kmx_ctx_synchronize(self._h))
 
+    def set_work_buffer_limit(self, nbytes: int):
+        """cap (bytes; 0 = automatic) on the context's device work buffer: kmx_ctx_set_work_buffer_limit"""
+        self._ck(self.lib.kmx_ctx_set_work_buffer_limit(self._h, int(nbytes)))
+
+    def work_buffer_info(self):
+        """(bytes held, number of (re)allocations so far): kmx_ctx_work_buffer_info"""
+        held, n = C.c_size_t(0), C.c_uint64(0)
+        self._ck(self.lib.kmx_ctx_work_buffer_info(self._h, C.byref(held), C.byref(n)))
+        return int(held.value), int(n.value)
+
     # ------------------------------------------------------------- helpers
     @_on_ctx_stream
     def empty(self, n, dtype):

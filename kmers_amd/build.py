@@ -26,7 +26,7 @@ SOURCES = ["kmx_hist.hip", "kmx_hist32.hip", "kmx_bitslice.hip", "kmx_scan.hip",
            "kmx_bitslice_k57_61.hip", "kmx_bitslice_k34_40.hip", "kmx_bitslice_k42_48.hip", "kmx_bitslice_k50_56.hip", "kmx_bitslice_k58_64.hip",
            "kmx_bitslice_ragged_k13_16.hip", "kmx_bitslice_ragged_k17_20.hip", "kmx_bitslice_ragged_k21_24.hip", "kmx_bitslice_ragged_k25_28.hip",
            "kmx_bitslice_ragged_k29_31.hip", "kmx_generic.hip", "kmx_elem.hip", "kmx_seqvec.hip", "kmx_fastx.hip", "kmx_comm.hip", "kmx_api.hip"]
-HEADERS = [os.path.join(CSRC, "kmx_device.h"), os.path.join(CSRC, "kmx_hist_part.h"), os.path.join(CSRC, "kmx_bitslice_pc.h"), os.path.join(CSRC, "kmx_bitslice_kernel.h"), os.path.join(CSRC, "kmx_internal.h"), os.path.join(CSRC, "kmx_scan_kernel.h"),
+HEADERS = [os.path.join(CSRC, "kmx_device.h"), os.path.join(CSRC, "kmx_hist_part.h"), os.path.join(CSRC, "kmx_bitslice_kernel.h"), os.path.join(CSRC, "kmx_internal.h"), os.path.join(CSRC, "kmx_scan_kernel.h"),
            os.path.join(HERE, "..", "include", "kmx.h")]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
@@ -57,7 +57,7 @@ def _headers_of(src: str) -> list[str]:
     out = []
     for h in HEADERS:
         base = os.path.basename(h)
-        if base in ("kmx_bitslice_kernel.h", "kmx_bitslice_pc.h") and not src.startswith("kmx_bitslice"):
+        if base == "kmx_bitslice_kernel.h" and not src.startswith("kmx_bitslice"):
             continue
         if base in ("kmx_scan_kernel.h", "kmx_hist_part.h") and src not in ("kmx_scan.hip", "kmx_hist.hip", "kmx_hist32.hip"):
             continue

@@ -169,23 +169,23 @@ void* big_scratch(void* user, size_t bytes) {
         (void)hipGetLastError();
         return nullptr;
     }
-    if (std::getenv("KMX_DEBUG_ALLOC")) std::fprintf(stderr, "kmx: work buffer (re)allocated, %zu bytes\n", bytes);   // (tests count these)
+    ctx->big_allocs += 1;
     ctx->d_big = q;
     ctx->big_bytes = bytes;
     return q;
 }
 
-// an eighth of the device memory, at least 8 GiB (KMX_HIST_SCRATCH_MB overrides), and at most half of what is free: fewer,
+// an eighth of the device memory, at least 8 GiB (kmx_ctx_set_work_buffer_limit overrides), and at most half of what is free: fewer,
 // larger chunks of reads per call (configs[4], 1.25e8 reads: 6 chunks at 8 GiB 19.3 ms, 2 at 36 GiB 18.6 ms)
 // (`held`: the work buffer the context already owns -- it is not part of "free" any more, but it IS available: without adding
 // it back a second call under memory pressure got a smaller budget than the buffer it holds, cut the reads into more chunks
 // than the first call had, and timing depended on call order)
-size_t hist_scratch_budget(size_t held) {
+size_t hist_scratch_budget(size_t held, size_t limit) {
+    if (limit) return limit;
     size_t free_b = 0, total_b = 0;
     const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
     size_t budget = (size_t)8 << 30;
     if (have && total_b / 8u > budget) budget = total_b / 8u;
-    if (const char* e = std::getenv("KMX_HIST_SCRATCH_MB")) return (size_t)std::strtoull(e, nullptr, 10) << 20;   // (tests: forces chunks)
     if (have && budget > (free_b + held) / 2) budget = (free_b + held) / 2;
     if (budget < held) budget = held;
     return budget;
@@ -268,6 +268,8 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, kmx_ctx*
     c->d_scratch = nullptr;
     c->d_big = nullptr;
     c->big_bytes = 0;
+    c->big_limit = 0;
+    c->big_allocs = 0;
     c->dirty_desc = 0;
     c->d_flags = nullptr;
     c->flags_bytes = 0;
@@ -326,6 +328,19 @@ int kmx_ctx_synchronize(kmx_ctx* ctx) {
 }
 
 int kmx_ctx_device(const kmx_ctx* ctx) { return ctx ? ctx->device : -1; }
+
+int kmx_ctx_set_work_buffer_limit(kmx_ctx* ctx, size_t bytes) {
+    if (!ctx) return KMX_E_ARG;
+    ctx->big_limit = bytes;
+    return KMX_OK;
+}
+
+int kmx_ctx_work_buffer_info(const kmx_ctx* ctx, size_t* bytes_held, uint64_t* n_allocations) {
+    if (!ctx) return KMX_E_ARG;
+    if (bytes_held) *bytes_held = ctx->big_bytes;
+    if (n_allocations) *n_allocations = ctx->big_allocs;
+    return KMX_OK;
+}
 
 const char* kmx_last_error(const kmx_ctx* ctx) { return ctx ? ctx->last_error : "null ctx"; }
 
@@ -522,7 +537,7 @@ int kmx_histogram(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t has
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
         KMX_HIP(ctx, kmx::launch_hist_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, hasher, hasher_k,
                                               log2_buckets, d_counts, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled,
-                                              &big_scratch, ctx, hist_scratch_budget(ctx->big_bytes), reads->d_offsets));
+                                              &big_scratch, ctx, hist_scratch_budget(ctx->big_bytes, ctx->big_limit), reads->d_offsets));
         if (handled) return KMX_OK;
     }
     KMX_HIP(ctx, kmx::launch_histogram_generic(reads, k, hasher, hasher_k, log2_buckets, d_counts, ctx->n_cu, ctx->stream, ctx->d_scratch + 8));

@@ -1,23 +1,8 @@
 // kmx_bitslice.hip -- launchers of the bit-sliced canonical k-mer scan (kernel: kmx_bitslice_kernel.h); this
 // translation unit holds the k = 31 and k = 63 instantiations, kmx_bitslice_k*.hip hold the other k.
 #include "kmx_bitslice_kernel.h"
-#include "kmx_bitslice_pc.h"
 
 namespace kmx {
-
-// The producer/consumer form of the scan (kmx_bitslice_pc.h), k = 31 on the 10-word frame with 4 windows per lane.  Opt-in
-// (KMX_BS_PC=1: 3 producers + 5 consumers per block, 6 waves/SIMD; KMX_BS_PC=2: 3 + 3, 4.5 waves/SIMD): bit-exact with the
-// one-role kernel, 1-3 % slower on every box measured (profiles/r03_pc_variants.txt) -- the scan runs at the package's power
-// cap, and there more waves per SIMD buy nothing while the hand-off polls cost instructions.  Kept as the measured answer
-// to "would wave specialisation help" and as a test vehicle (tests/test_gpu_round3.py runs the parity cases through it).
-static hipError_t launch_pc_k31(int cfg, const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, kmx_summary* out,
-                                unsigned long long* queue, int n_cu, hipStream_t stream) {
-    switch (cfg) {
-        case 1: return launch_bs_pc<31, 10, 4, 3, 5, 6, 3>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
-        case 2: return launch_bs_pc<31, 10, 4, 3, 3, 6, 3>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
-        default: return hipErrorInvalidValue;
-    }
-}
 
 KMX_BS_DEFINE_K(31, true)
 
@@ -42,13 +27,6 @@ hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
     if (!bs_domain(bases, n_reads, L, k, false)) return hipSuccess;
-    if (const char* e = getenv("KMX_BS_PC")) {
-        const u32 W = L - k + 1u;
-        if (k == 31 && atoi(e) > 0 && W > 96u && W <= 128u && L <= 160 && 4u * L + 1u > 64u * 7u) {
-            *handled = true;
-            return launch_pc_k31(atoi(e), bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
-        }
-    }
     switch (k) {
         KMX_BS_FOR_EACH_K(KMX_BS_CASE)
         default:
@@ -83,9 +61,6 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
                                         bool want_sumfw) {
     *handled = false;
     if (!offsets || (reinterpret_cast<uintptr_t>(bases) & 15u) || L_hint > 256) return hipSuccess;
-    if (const char* e = getenv("KMX_BS_RAGGED")) {   // dev knob: 0 = leave ragged reads to the word-domain kernel
-        if (e[0] == '0') return hipSuccess;
-    }
     u32 Lf = L_hint ? L_hint : 160u;
     if (Lf < k + 15u) Lf = k + 15u;       // keep at least 16 windows in the frame
     if (Lf > 256u) return hipSuccess;

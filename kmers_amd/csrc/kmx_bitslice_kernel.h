@@ -1,159 +1,36 @@
-// kmx_bitslice_kernel.h -- K1b: bit-sliced canonical k-mer scan (the headline kernel for k=31 / k=21).
+// kmx_bitslice_kernel.h -- K1b: bit-sliced canonical k-mer scan (the headline kernel: every k from 13 to 64).
 //
 // Why: on gfx950 only the simplest VALU ops (v_and/or/xor/not, v_lshrrev, v_add_u32, v_bitop3_b32)
 // issue at 32 lanes/clk; v_alignbit, v_perm, v_cmp*, v_cndmask, carry adds, 64-bit ops and v_bcnt
 // run at half that (measured, tools/ubench2.hip, profiles/r01_valu_rates.txt).  A word-per-k-mer
 // window costs >= 16 full-rate issue slots, which caps the scan near 45 % of the HBM roofline.
-// Bit-slicing ACROSS 32 READS turns the per-window work into ~7 slots per k-mer:
+// Bit-slicing ACROSS 32 READS, with the counting on the matrix pipe, brings it to ~5 lane-operations per k-mer:
 //
 //   * a register holds ONE bit (base i, bit b) of 32 different reads ("plane");
 //   * fw < rc is a ripple of v_bitop3_b32 over the top ceil(k/2) base pairs only, because rc is the
 //     complemented mirror of fw: fw base k-1-j meets rc base = ~(fw base j)   (kmer.rs:124-136);
 //   * the wrapping sum of canonical words needs no select and no 64-bit add: with m = (fw < rc),
 //       sum(canon) = sum_{t,b} 2^(2t+b) * (C[t][b] + C[k-1-t][b]) - popcount(m)*MASK[k] + sum(all rc)
-//     where C[t][b] += popcount(m & plane(t,b)) (v_and + v_bcnt_u32_b32 with accumulate) and
-//     sum(all rc), sum(all fw) and the LexHasher xor-fold follow from per-plane popcount totals.
+//     where C[t][b] = sum over windows o and reads r of m[o][r] * plane(o+t,b)[r], and sum(all rc), sum(all fw) and the
+//     LexHasher xor-fold follow from per-plane popcount totals;
+//   * C is a 0/1 correlation: the diagonal sums of G[o][beta] = sum_r m[o][r] * plane(beta)[r], a matrix product over the
+//     tile's 64 reads that v_mfma_scale_f32_32x32x64_f8f6f4 computes exactly from FP4 operands made with one v_and per dword
+//     (round 4; rounds 1-3 spent a v_and + v_bcnt per (window, plane) pair on it, half of the kernel's instructions).
 //
 // Data flow per 64-read tile (one wave, no block barrier):
-//   A. coalesced 16 B/lane global loads -> encode16 (v_dot4_u32_u8 pack, v_perm_b32 validate) -> LDS
+//   A. coalesced 16 B/lane buffer loads -> encode16 (v_dot4_u32_u8 pack, v_perm_b32 validate) -> LDS
 //   B. lane r pulls read r's packed words back (ds_read_b32) and realigns them (v_alignbit_b32)
-//   C. 32x32 bit transposes across lanes, 5 x (ds_swizzle xor-d, rotate, bit-select) per 16 bases:
+//   C. 32x32 bit transposes across lanes, 5 x (exchange with lane^d, rotate, bit-select) per 16 bases:
 //      lane p of each half-wave ends with plane p -> LDS plane array of the half's 32 reads
-//   D. the 64 lanes split the 2*(L-k+1) (set, window) items; each item = 2k plane loads
-//      (ds_read_b64), a k-step v_bitop3 ripple and 2k masked popcounts.
+//   D. pass 1: lane = (set, WPL adjacent windows): the ripples over 2 ceil(k/2) plane pairs (ds_read_b64) -> mask words m;
+//      pass 2: mask words and planes become matrix operands, <= 4 WPL matrix instructions accumulate G for every tile.
 // The final partial tile takes roll_read (exact iterator semantics, canonical_kmer_iterator.rs:42-70).  A tile with a
 // non-ACGTacgt byte is scanned with the offending reads blanked out; those are rolled separately, 64 at a time, by
 // roll_flagged_kernel -- see "reads with an invalid byte" in the kernel.
 #pragma once
 #include "kmx_device.h"
 
-#include <cstdio>
-#include <cstdlib>
 #include <type_traits>
-
-#ifndef KMX_BS_WAVES16
-#define KMX_BS_WAVES16 3   // waves per SIMD of the 16-word frame (reads of 161..256 bases; 64 prefetch registers, 64 B of spills: +1..3 % over 2 waves)
-#endif
-#ifndef KMX_BSP_WAVES
-#define KMX_BSP_WAVES 3   // waves per SIMD of the packed-input variant
-#endif
-#ifndef KMX_BSR_WAVES
-#define KMX_BSR_WAVES 3   // waves per SIMD of the ragged variant (with its late prefetch rows: 149..162 registers, no spills; 2 before)
-#endif
-#ifndef KMX_BS_WAVES
-#define KMX_BS_WAVES 3      // waves per SIMD the register allocation is sized for
-#endif
-#ifndef KMX_BS_P1D
-#define KMX_BS_P1D 2      // pass 1: ripple steps between the LDS request of a plane and its use
-#endif
-#ifndef KMX_BS_RUNR
-#define KMX_BS_RUNR 2      // pass 2: planes per run when KMX_BS_RUN2 (3 and 4 measured 0.3 % slower)
-#endif
-#ifndef KMX_BS_RUN2
-#define KMX_BS_RUN2 1      // pass 2: two planes per (v_and run, v_bcnt run) pair when WPL <= 4
-#endif
-#ifndef KMX_BS_PRIO
-#define KMX_BS_PRIO 2      // raise the wave priority around runs of half-rate VALU instructions (1: phases A and D, 2: also B/C stage-major)
-#endif
-#ifndef KMX_BS_SWZ
-#define KMX_BS_SWZ 1   // butterfly stages d=16,8,4 through ds_swizzle (LDS crossbar) instead of permlane/DPP: the kernel is VALU-issue-bound
-#endif
-#ifndef KMX_BS_LATE7
-#define KMX_BS_LATE7 3    // late prefetch rows (of 7) of the 7-word frame (ASCII reads of up to 112 bases, uniform or ragged)
-#endif
-#ifndef KMX_BS_LATE16
-#define KMX_BS_LATE16 8   // late prefetch rows (of 16) of the 16-word frame (uniform ASCII reads of 161..256 bases): 160 registers, no spills (168 with 10 spilled before)
-#endif
-#ifndef KMX_BSR_VAL
-#define KMX_BSR_VAL 1    // ragged: 1 = validity planes from per-read end marks + a prefix-OR across the lanes, bases past a read's end masked out of
-                         // the plane totals only; 0 = (round 1) NV thermometer words per read through the 32x32 transposes, bases zeroed per group
-#endif
-#ifndef KMX_BSR_LATE
-#define KMX_BSR_LATE 5   // late prefetch rows of the ragged variant
-#endif
-#ifndef KMX_BS_WAVES2
-#define KMX_BS_WAVES2 2   // waves per SIMD the two-word kernels (k = 33..63) are compiled for
-#endif
-#ifndef KMX_BS_LATE2
-#define KMX_BS_LATE2 5   // late prefetch rows of the two-word k (33..63): k = 33 then fits 128 registers (4 waves/SIMD), k = 45..53 fit 168 (3 waves instead of 2)
-#endif
-#ifndef KMX_BS_P1TIE
-#define KMX_BS_P1TIE 2   // pass 1: how a plane request is tied to the ripple step it belongs to (1: opaque copy of the LDS address, a v_mov per step; 2: compiler fence, no instruction)
-#endif
-#ifndef KMX_BS_RELANE
-#define KMX_BS_RELANE 0   // 1: every phase derives its lane-dependent indices and LDS addresses afresh from an opaque copy of the lane id (a few VALU per tile) instead of keeping ~10 of them in registers across the tile loop
-#endif
-#ifndef KMX_BS_TRC_LDS
-#define KMX_BS_TRC_LDS 0   // 1: the eight per-lane constants of the transposes (phase C) live in a 1 KB table in LDS, fetched per tile, instead of in registers across the loop
-#endif
-#ifndef KMX_BS_LATE_ROWS
-// uniform ASCII main pass on the 10-word frame: this many of the NW prefetch rows are requested between pass 1 and pass 2
-// of phase D instead of right after phase A -- their 4 registers each are free until then, and with half of the tile's
-// rows out of the way every k from 13 to 31 fits 128 registers without a spill: 4 waves/SIMD (k = 31: 0.648 -> 0.676 of the
-// roofline; 5 or 6 late rows measure the same, 3 or 4 need more help and lose what they gain)
-#define KMX_BS_LATE_ROWS 5
-#endif
-#ifndef KMX_BS_BANKFIX
-// 1: (round 3) the plane array of set 1 starts where set 0's lanes stop on the 64 LDS banks (a runtime set stride), the idle
-// lanes of phase D continue set 1's sequence instead of all reading set 0's first plane, and the rotated layout of WPL = 4
-// is used for WPL = 2 and 8 as well.  Before, every ds_read_b64 of phase D had a 2-way conflict in each half-wave (lanes 30/31
-// = set 1 on the banks of lanes 4/5; the idle lanes on the banks of lane 32): 136 of ~600 LDS cycles per tile at k = 31.
-#define KMX_BS_BANKFIX 1
-#endif
-#ifndef KMX_BS_LDS64
-// 1: (round 3) phase D requests its planes one ds_read_b64 at a time (volatile loads): hipcc otherwise pairs them into
-// ds_read2_b64, which the LDS serves in 4 x 16-lane groups on 32 banks -- 8 cycles per instruction against 2 x 2 for two
-// ds_read_b64 (2 x 32 lanes on 64 banks; MI355X_MICROARCH.md, LDS table): 272 of the tile's ~460 LDS cycles at k = 31.
-#define KMX_BS_LDS64 1
-#endif
-#ifndef KMX_BS_EXECMASK
-// 1: (round 3) the lanes of phase D that hold no (set, group) item (4 of 64 at k = 31 / 150 bp, 12 at k = 21) are masked out of
-// both passes (exec) instead of computing on zeros: the kernel runs at the package's power cap, idle lanes still cost energy
-#define KMX_BS_EXECMASK 0
-#endif
-#ifndef KMX_BS_BUFLOAD
-// 1: (round 3) the rows of a uniform ASCII tile are raw buffer loads from a per-tile descriptor (base = the tile, num_records =
-// its bytes): lanes past the tile's end are out of range and read zeros -- no per-row v_min clamp (10 half-rate VALU a tile) --
-// and the cache policy is a compile-time constant (KMX_BS_LOAD_AUX: 1 = sc0, 2 = nt, 16 = sc1)
-#define KMX_BS_BUFLOAD 1
-#endif
-#ifndef KMX_BS_LOAD_AUX
-#define KMX_BS_LOAD_AUX 2
-#endif
-#ifndef KMX_BS_LATE13
-#define KMX_BS_LATE13 7   // late prefetch rows (of 13) of the 13-word frame (uniform ASCII reads of 161..208 bases)
-#endif
-#ifndef KMX_BS_WAVES5
-#define KMX_BS_WAVES5 5   // waves per SIMD of the 5-word frame (uniform ASCII reads of up to 80 bases): 92..96 registers, at most 52 bytes spilled; 75 bp k=31: 0.609 -> 0.627
-#endif
-#ifndef KMX_BS_WAVES13
-#define KMX_BS_WAVES13 4  // waves per SIMD of the 13-word frame
-#endif
-#ifndef KMX_BS_XORC
-// 1: (round 3) phase A leaves the packed words in the internal ACTG codes ((byte >> 1) & 3); the conversion to naive_impl's
-// ACGT codes (bit 0 ^= bit 1) happens on the PLANES after the transposes, where the two bits of a base sit in neighbouring
-// lanes: the even lanes fetch the odd lane's plane through the LDS crossbar (ds_swizzle, no VALU) and one v_bitop3 per word
-// applies it -- 10 VALU instructions a tile instead of a shift and a v_bitop3 per 16-byte row of phase A (20).  Bit-exact, and
-// 0.7 % SLOWER at k = 31 / 150 bp (profiles/r03_swizzle_variants.txt): the ten crossbar trips cost more than the ten full-rate
-// VALU instructions they replace; so does KMX_BS_SWZ = 2 (-20 VALU, +20 ds_swizzle: -0.9 %).  Off.
-#define KMX_BS_XORC 0
-#endif
-#ifndef KMX_BS_ABLATE
-#define KMX_BS_ABLATE 0   // dev: bitmask of phases to skip (timing experiments only; results become wrong)
-#endif
-#ifndef KMX_BS_MFMA
-// 1: (round 4) pass 2 of phase D -- C[t][b] = sum over windows o and reads r of m[o][r] * plane[o+t][b][r], a 0/1 correlation --
-// runs on the matrix pipe: G[o][beta] = sum_r m[o][r] * plane[beta][r] as v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands
-// (K = the tile's 64 reads), all window blocks accumulating into the same NAB x 16 fp32 registers; the diagonals beta - o = t
-// are summed once per wave.  See "pass 2 on the matrix pipe" in phase D.
-#define KMX_BS_MFMA 1
-#endif
-#ifndef KMX_BS_MFMA_WAVES
-#define KMX_BS_MFMA_WAVES 3   // waves per SIMD of the KMX_BS_MFMA build (NAB x 16 accumulators instead of K + 1 counters)
-#endif
-#ifndef KMX_BS_MFMA_FLUSH
-#define KMX_BS_MFMA_FLUSH 256    // tiles between two folds of the fp32 accumulators into the 64-bit sums (a power of two; far below the 2^24 / (8 blocks x 64 reads) the sums stay exact for: the full-size runs -- ~500 tiles per wave -- exercise the fold, at ~1.5 instructions per tile)
-#endif
 
 namespace kmx {
 
@@ -215,28 +92,6 @@ __device__ __forceinline__ bs_v8i fp4_operand_a(u32 m) {
     return r;
 }
 
-// The weighted form: nibble = the 2-bit code of a base (bit 0 from plane p0, bit 1 from p1) = 0, 0.5, 1 or 1.5; against mask
-// nibbles of 2.0 the products are the codes 0..3 themselves, so ONE product sums C[t][0] + 2 C[t][1] -- all the wrapping sum
-// of canonical words needs (the xor-fold of the hashes needs the two parities apart).  K-slot (dword c, nibble n) = read 4n + c.
-__device__ __forceinline__ bs_v8i fp4_operand_codes(u32 p0, u32 p1) {
-    const u32 ev = __builtin_amdgcn_bitop3_b32(p0, p1 << 1, 0x55555555u, 0xE4);    // bits (2m, 2m+1) = code of read 2m
-    const u32 od = __builtin_amdgcn_bitop3_b32(p0 >> 1, p1, 0x55555555u, 0xE4);    //                = code of read 2m + 1
-    bs_v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
-    r[0] = (int)(ev & 0x33333333u);
-    r[1] = (int)(od & 0x33333333u);
-    r[2] = (int)((ev >> 2) & 0x33333333u);
-    r[3] = (int)((od >> 2) & 0x33333333u);
-    return r;
-}
-__device__ __forceinline__ bs_v8i fp4_operand_mask2(u32 m) {
-    bs_v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
-    r[0] = (int)(alignbit(m, m, 30) & 0x44444444u);
-    r[1] = (int)(alignbit(m, m, 31) & 0x44444444u);
-    r[2] = (int)(m & 0x44444444u);
-    r[3] = (int)(alignbit(m, m, 1) & 0x44444444u);
-    return r;
-}
-
 // PACKED: `bases` is a SeqVector (kmx_seqvec.hip), read r = its bases [r*L, (r+1)*L): a tile is 16*L bytes of ready-made
 // 2-bit codes that go from HBM straight into the packed LDS buffer -- no phase A, nothing to validate.
 // RAGGED: reads of different lengths, read r = bases[offsets[r], offsets[r+1]); L is then the frame: the longest read a
@@ -249,29 +104,27 @@ __device__ __forceinline__ bs_v8i fp4_operand_mask2(u32 m) {
 //     a read instead of stopping t bases before ITS end, and these per-base totals take the excess back out.
 // A tile whose span or longest read leaves the frame, or that would load past the end of the buffer, and tiles with
 // an invalid byte, take the per-lane rolling path as before.
-#ifndef KMX_BS_DIRTY
-#define KMX_BS_DIRTY 1
-#endif
-// dwords of one set's plane area (the kernel and launch_bs size the LDS from it); the set stride adds up to 63 dwords
-constexpr int bs_plane_dwords(int NW) { return KMX_BS_BANKFIX ? 32 * NW + 16 : 8 * (4 * NW + 1); }
-constexpr unsigned BS_SET_SLACK = KMX_BS_BANKFIX ? 64u : 0u;
-template <int K> constexpr bool bs_has_dirty_pass() { return KMX_BS_DIRTY != 0; }   // (0, a dev switch: tiles with an invalid byte roll per lane as a whole)
-// Waves per SIMD of the ASCII kernel on the 10-word frame: 4 for every k now that half of the prefetch rows are requested
-// late (KMX_BS_LATE_ROWS).  Before that the counters D[] decided: up to k = 23 (k = 26 with <= 4 windows per lane) the
-// kernel fit 128 registers with at most 16 bytes of spills, k = 27 / 28 were neutral, k = 29 / 30 lost 3-6 % and k = 31
-// spilled a row of the prefetch (-15 %).
-template <int K, int WPL> constexpr int bs_waves_ascii() {
-#ifdef KMX_BS_WAVES_FORCE
-    return KMX_BS_WAVES_FORCE;
-#else
-    return (KMX_BS_LATE_ROWS >= 5 || K <= 23 || (K <= 26 && WPL <= 4)) ? 4 : KMX_BS_WAVES;
-#endif
-}
-// waves per SIMD a variant is compiled for (64 prefetch registers at NW = 16; 2 x counters at K > 32)
+// dwords of one set's plane area (the kernel and launch_bs size the LDS from it)
+constexpr int bs_plane_dwords(int NW) { return 32 * NW + 16; }
+constexpr int BS_LOAD_NT = 2;   // cache policy of the tile loads (aux bit 1 = nt: streamed once; +1.6 % over none, sc0 / sc1 nothing -- profiles/r03_load_policy_variants.txt)
+// fp32 accumulator blocks (16 registers each) of pass 2: window block i (32 windows) meets the planes of bases 32i .. 32i+K+30,
+// i.e. the blocks of 16 bases (32 planes) 2i .. 2i + bs_acc_blocks(K) - 1
+constexpr int bs_acc_blocks(int K) { return (K + 30) / 16 + 1; }
+// Waves per SIMD a variant is compiled for.  With 16 bs_acc_blocks(K) accumulators and the prefetch rows of a tile in
+// registers the kernels need 130..168 registers: three waves (measured round 4: a 32-accumulator form at four waves was 3 %
+// slower than this one at three -- profiles/r04_mfma_variants.txt).  The two-word k (5..6 accumulator blocks), the ragged
+// variants (190..214 registers: at three waves they spill 30..170 bytes and run 30 % slower) and the 16-word frame below 8
+// windows per lane run at two.
 template <int K, int NW, int WPL, bool PACKED, bool RAGGED> constexpr int bs_waves() {
-    const int w = K > 32 ? KMX_BS_WAVES2 : RAGGED ? (NW > 10 ? 2 : KMX_BSR_WAVES) : (NW == 5 && !PACKED) ? KMX_BS_WAVES5 : NW == 13 ? KMX_BS_WAVES13 : NW > 10 ? KMX_BS_WAVES16 : PACKED ? KMX_BSP_WAVES : bs_waves_ascii<K, WPL>();
-    return (KMX_BS_MFMA && w > KMX_BS_MFMA_WAVES) ? KMX_BS_MFMA_WAVES : w;
+#ifdef KMX_TMP_WAVES   // (temporary, round-4 tuning)
+    if (K > 32 && (KMX_TMP_WAVES & 4)) return 3;
+#endif
+    return (K > 32 || RAGGED || (NW == 16 && WPL < 8)) ? 2 : 3;
 }
+// tiles between two folds of the fp32 accumulators into the 64-bit class sums: a power of two, far below the 2^24 / (8 window
+// blocks x 64 reads) the sums stay exact integers for, and small enough that the full-size runs (~500 tiles per wave) exercise
+// the fold (~1.5 instructions per tile)
+constexpr unsigned BS_FOLD_TILES = 256;
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
 __global__ void __launch_bounds__(256, (bs_waves<K, NW, WPL, PACKED, RAGGED>()))
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
@@ -280,14 +133,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // `lead` (uniform ASCII input whose first byte is not 16-byte aligned): `bases` is the aligned address below it and
     // read r starts at byte lead + r*L.  A tile then spans one more chunk (its first holds the tail of the tile before
     // it), exactly like a ragged tile streamed from its aligned start; 0 for every other input.
-    static_assert(!RAGGED || (!PACKED && K <= 32 && KMX_BS_PRIO >= 2), "ragged input: ASCII, single-word k-mers");
+    static_assert(!RAGGED || (!PACKED && K <= 32), "ragged input: ASCII, single-word k-mers");
     static_assert(WPL <= 8, "the zero words behind the validity planes cover a lane's windows");
-    static_assert(!KMX_BS_XORC || KMX_BS_PRIO >= 2, "the plane-domain code conversion lives in the stage-major transposes");
     constexpr int NE = RAGGED ? (K - 1 + 15) / 16 : 0;            // dwords holding the last K-1 bases of a read
     constexpr int NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;  // validity words per read (one bit per window of the frame)
     constexpr u32 VS = RAGGED ? 32u * NV + 8u : 0u;             // validity planes of one set + 8 always-zero words (a lane's windows past the frame, idle lanes)
-    constexpr int NVT = KMX_BSR_VAL ? 0 : NV;                    // validity words that go through the transposes
-    constexpr int NXT = NW + NE + NVT;                           // 32x32 transposes per half-wave and tile
+    constexpr int NXT = NW + NE;                                 // 32x32 transposes per half-wave and tile
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     // Gate (queue[513], zero unless kmx_canonical_reduce is deciding on the device whether reads behind an offsets array are
     // in fact uniform -- offsets_uniform_gate_kernel): 1 = only the uniform kernels run, 2 = only the ragged ones.
@@ -302,27 +153,20 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // (For an odd number of windows per lane the lane stride is an odd number of u64s and the plain linear
     // layout is already conflict-free.)
     // (Rotated layout, generally: base beta at u64 index (beta % WPL) * S2 + beta / WPL, for the WPL that divide 16.)
-    constexpr bool ROT = KMX_BS_BANKFIX ? (WPL == 2 || WPL == 4 || WPL == 8) : (WPL == 4);
+    constexpr bool ROT = WPL == 2 || WPL == 4 || WPL == 8;
     constexpr int RW = ROT ? WPL : 4;                // rows of the rotated layout
     constexpr int S2 = (16 * NW) / RW + 1;           // u64 row pitch (4*NW + 1 at WPL = 4)
     constexpr int PLANES = bs_plane_dwords(NW);      // dwords per set (>= 2 * RW * S2, >= 32*NW)
     static_assert(PLANES >= 2 * RW * S2 && PLANES >= 32 * NW, "plane area");
     const u32 lane = threadIdx.x & 63u;
     const u32 half = lane >> 5, p = lane & 31u;
-    const u32 wib = KMX_BS_RELANE ? (u32)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (threadIdx.x >> 6);
-    // KMX_BS_RELANE: an opaque copy of the lane id; what a phase derives from it cannot be hoisted out of the tile loop
-    auto relane = [&]() -> u32 {
-        u32 v = lane;
-        if (KMX_BS_RELANE) asm volatile("" : "+v"(v));
-        return v;
-    };
+    const u32 wib = threadIdx.x >> 6;
     const u32 chunks = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);   // 16-byte chunks a tile may span (+1 for an unaligned start)
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
     u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
-    if (KMX_BS_MFMA && ldsw < 64u * WPL) ldsw = 64u * WPL;   // (it holds the m words of pass 2 afterwards)
-    constexpr u32 CSA_DW = KMX_BS_MFMA ? 4u * ((K + 1) / 2) : 0u;   // KMX_BS_MFMA: 2 * NT 64-bit sums of the counter classes
-    constexpr u32 TRC_DW = KMX_BS_TRC_LDS ? 256u : 0u;     // [32 lanes of a half-wave][8] transpose constants, shared by the block
-    u32* P = lds + TRC_DW + wib * (ldsw + 4u * PLANES + BS_SET_SLACK + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW);
+    if (ldsw < 64u * WPL) ldsw = 64u * WPL;            // (it holds the mask words of pass 2 afterwards)
+    constexpr u32 CSA_DW = 4u * ((K + 1) / 2);         // 2 * NT 64-bit sums of the counter classes
+    u32* P = lds + wib * (ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW);
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
     const u64 n_full = n_reads >> 6;
@@ -331,13 +175,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u32 posF = lane * L + lead + 16u * PAD;    // (ragged: set per tile from the lane's own offset)
     u32 qF = posF >> 4, aF = 2u * (posF & 15u);
     const u32 W = L - (u32)K + 1u;      // windows per read
-    const u32 NG = (W + WPL - 1u) / WPL; // groups of WPL adjacent windows per read
-    const u32 rounds = (2u * NG + 63u) >> 6;   // (set, group) items per tile, 64 per round
-    // Set stride (dwords).  In phase D lane g of a set reads u64 index g (rotated layout) or WPL*g (linear, odd WPL): LS dwords per
-    // lane, a permutation of the 64 banks over 32 lanes.  Set 1 is placed so that its first lane lands on the banks right behind
-    // set 0's last lane: SP = LS*NG (mod 64).
-    constexpr u32 LS = ROT ? 2u : 2u * (u32)WPL;
-    const u32 SP = KMX_BS_BANKFIX ? (u32)PLANES + ((LS * NG - (u32)PLANES) & 63u) : (u32)PLANES;
+    const u32 NG = (W + WPL - 1u) / WPL; // groups of WPL adjacent windows per read (<= 32: launch_bs checks it)
+    const u32 rounds = (2u * NG + 63u) >> 6;   // == 1; a runtime value on purpose (the trip count of phase D's loop, see there)
+    constexpr u32 SP = (u32)PLANES;      // set stride (dwords): each half-wave reads its own set, 32 lanes over the 64 banks
 
     // transpose stage constants: rotate amount and keep-mask per butterfly distance
     u32 tr_sh[5], tr_keep[5];
@@ -349,30 +189,16 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         tr_keep[s] = (p & d) ? ~md : md;
     }
 
-    // D[2t+b], t <= (K-1)/2: sum of popcount(m & plane(t,b)) + popcount(m & plane(K-1-t,b)) -- the two
-    // always enter the result as a sum (weights are symmetric under t <-> K-1-t), so they share a counter
+    // counter class min(t, K-1-t): C[t][b] = sum over windows and reads of (m & plane(t,b)) and C[K-1-t][b] always enter the result
+    // as a sum (the weights are symmetric under t <-> K-1-t)
     constexpr int NT = (K + 1) / 2;     // distinct t classes (the middle one of odd K pairs with itself)
     // v_perm_b32 selectors of the byte-granular stages ({S0=y: bytes 4-7, S1=x: bytes 0-3})
     const u32 tr_sel16 = (p & 16u) ? 0x03020706u : 0x05040100u;   // keep x.hi, take y.hi>>16  |  keep x.lo, take y.lo<<16
     const u32 tr_sel8 = (p & 8u) ? 0x03070105u : 0x06020400u;     // odd bytes kept, even from y.odd | even kept, odd from y.even
-    if constexpr (KMX_BS_TRC_LDS) {
-        // every wave writes the same values (no block barrier needed: a wave reads them after its own, fenced, writes)
-        if (half == 0) {
-            uint4* t = reinterpret_cast<uint4*>(lds + 8u * p);
-            t[0] = make_uint4(tr_sh[2], tr_sh[3], tr_sh[4], tr_sel16);
-            t[1] = make_uint4(tr_keep[2], tr_keep[3], tr_keep[4], tr_sel8);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    u32 D[2 * NT];
-#pragma unroll
-    for (int q = 0; q < 2 * NT; ++q) D[q] = 0;
     u32 mcnt = 0;                       // sum popcount(m)
     // per-plane popcount totals of the planes this lane produces live in LDS (TOT[g][lane]); only this
     // lane ever touches its own slots, so plain read-modify-write is enough
-    u32* TOT = PL + 2u * PLANES + BS_SET_SLACK;
+    u32* TOT = PL + 2u * PLANES;
 #pragma unroll
     for (int g = 0; g < NW; ++g) TOT[64u * g + lane] = 0;   // (indexed [group][lane]: one address register, a compile-time offset per group)
     u32* VAL = TOT + 2u * PLANES;       // ragged: [2][32*NV] validity planes of the current tile
@@ -438,31 +264,29 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         m.fits = nch <= (u64)chunks && nch <= 64u * NW && !__any(m.len > L) && m.base + 16u * nch <= total_bytes;   // (one compare + a scalar test: a wave-wide max costs ten instructions)
     };
     u32 n_bs_tiles = 0;
-#if KMX_BS_MFMA
-    // pass 2 on the matrix pipe: window block i (windows 32i .. 32i+31) meets the planes of bases 32i .. 32i+K+30, i.e. the NAB
-    // blocks of 16 bases (32 planes) from 2i on; acc[q] collects block pair (i, 2i + q) of EVERY i and every tile.
-    constexpr bool WSUM = KMX_BS_MFMA == 2;     // the weighted form: columns = bases, one accumulator block per 32 of them (no hash fold)
-    constexpr int NAB = WSUM ? (K + 30) / 32 + 1 : (K + 30) / 16 + 1;
+    // pass 2 on the matrix pipe (see phase D): acc[q] collects the block pair (window block i, plane block 2i + q) of EVERY i and
+    // every tile
+    constexpr int NAB = bs_acc_blocks(K);
     bs_v16f acc[NAB];
 #pragma unroll
     for (int q = 0; q < NAB; ++q)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
-    u64* const CSA = reinterpret_cast<u64*>(P + ldsw + 4u * PLANES + BS_SET_SLACK + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u));
+    u64* const CSA = reinterpret_cast<u64*>(P + ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u));
     for (u32 i = lane; i < 2u * NT; i += 64u) CSA[i] = 0ull;
     // acc[q][j] of lane (half, p) is G[o][beta] for o = (j & 3) + 8 (j >> 2) + 4 half (mod 32), plane 32 q + p relative to the
     // window block: base o_blk + 16 q + p / 2, bit p & 1.  The diagonal t = beta - o in [0, K) is base t of the window; t and
-    // K-1-t share a counter class as D[] does.
+    // K-1-t share a counter class.
     auto fold_acc = [&]() {
         u32 ln_ = lane;
         asm volatile("" : "+v"(ln_));   // (opaque: hipcc otherwise hoists the 16 NAB addresses and conditions of this rare path out of the tile loop -- and spills them)
-        const int pb = (WSUM ? (int)(ln_ & 31u) : (int)((ln_ & 31u) >> 1)) - 4 * (int)(ln_ >> 5);
-        u64* const cs_b = CSA + (WSUM ? 0u : (ln_ & 1u));
+        const int pb = (int)((ln_ & 31u) >> 1) - 4 * (int)(ln_ >> 5);
+        u64* const cs_b = CSA + (ln_ & 1u);
 #pragma unroll
         for (int q = 0; q < NAB; ++q) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int t = (WSUM ? 32 : 16) * q + pb - ((j & 3) + 8 * (j >> 2));
+                const int t = 16 * q + pb - ((j & 3) + 8 * (j >> 2));
                 if (t >= 0 && t <= K - 1) {
                     const int tc = t < K - 1 - t ? t : K - 1 - t;
                     atomicAdd(reinterpret_cast<unsigned long long*>(cs_b + 2 * tc), (unsigned long long)(u32)acc[q][j]);
@@ -471,7 +295,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
         }
     };
-#endif
     // ---- reads with an invalid byte (ASCII input, uniform or ragged).  A tile that holds one used to go to the per-lane path
     // as a whole -- 64 reads rolled at 6.5x the cost of a bit-sliced tile, so 0.5 % of reads with an N (27 % of the tiles)
     // made the scan 3.4x slower.  Rounds 1-2 had a second instantiation of this kernel scan the flagged tiles again with the
@@ -481,17 +304,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // those reads, 64 at a time: blanked in place such a tile costs what every tile costs.
     // queue[515] == 0: no array, such tiles roll as a whole here; queue[512] = "a tile was marked" (lets roll_flagged_kernel
     // return at once on clean input).
-    constexpr bool DIRTY_LIST = !PACKED && bs_has_dirty_pass<K>();
-    constexpr bool INLINE = DIRTY_LIST;           // (kept as a name: the blanking code is fenced by it)
+    constexpr bool INLINE = !PACKED;              // (packed input has no invalid codes)
     u64 valid_reads = ~0ull;                      // reads of the current tile that are not blanked (bit = lane = read)
     u32 n_blanked = 0;                            // reads blanked in this wave's tiles
     // word-domain accumulators of the fallback path (tiles with invalid bytes, the final partial tile)
-#ifndef KMX_BS_FB_FLUSH
-#define KMX_BS_FB_FLUSH 1   // 1: the fallback path adds its sums to the output per tile (12 registers less across the main loop: +1.7 % at k=31)
-#endif
     struct FbAcc { u64 n = 0, s0 = 0, s1 = 0, x0 = 0, x1 = 0, fw = 0; };
     auto emit_sums = [&](u64 n, u64 r0, u64 r1, u64 h0, u64 h1, u64 f) {   // wave-uniform values, one set of atomics
-        if ((KMX_BS_ABLATE & 256) && wave_id != 0) return;   // (dev: timing of the end-of-kernel atomics)
         if (lane == 0) {
             if constexpr (K <= 32) {
                 kmx_summary* o = static_cast<kmx_summary*>(out);
@@ -511,7 +329,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
         }
     };
-    constexpr bool FB_FLUSH = KMX_BS_FB_FLUSH && K <= 32;   // (two-word k-mers: the per-tile sums then live in scratch, 0.46 -> 0.37 of the roofline at k=63)
+    constexpr bool FB_FLUSH = K <= 32;   // (two-word k-mers: the per-tile sums then live in scratch, 0.46 -> 0.37 of the roofline at k=63)
     FbAcc fb_all;                                             // !FB_FLUSH: summed over the whole run of the wave
     auto fallback_read_acc = [&](u64 read, FbAcc& fb) {
         const uint8_t* s = bases + lead + read * (u64)L;
@@ -591,30 +409,20 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         const u32 lo = m.fits ? (m.n_ch - 1u) * 16u : 0u;
         u32 l16 = lane16;                       // (opaque copy: see issue_loads)
         asm volatile("" : "+v"(l16));
-        if constexpr (KMX_BS_BUFLOAD) {         // per-tile descriptor over the tile's chunks: lanes past its end read zeros (see issue_loads)
-            uint8_t* const tbu = reinterpret_cast<uint8_t*>(uniform_u64(reinterpret_cast<u64>(tb)));
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tbu, 0, (int)__builtin_amdgcn_readfirstlane(lo + 16u), 0x00020000);
-#pragma unroll
-            for (int it = 0; it < NLD; ++it) {
-                if (it < row0 || it >= row1) continue;
-                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, l16 + (u32)it * 1024u, 0, KMX_BS_LOAD_AUX);
-                w[it] = make_uint4(v.x, v.y, v.z, v.w);
-            }
-            return;
-        }
+        // per-tile descriptor over the tile's chunks: lanes past its end read zeros (see issue_loads)
+        uint8_t* const tbu = reinterpret_cast<uint8_t*>(uniform_u64(reinterpret_cast<u64>(tb)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tbu, 0, (int)__builtin_amdgcn_readfirstlane(lo + 16u), 0x00020000);
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             if (it < row0 || it >= row1) continue;
-            u32 off = l16 + (u32)it * 1024u;
-            off = off < lo ? off : lo;
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb + off));
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, l16 + (u32)it * 1024u, 0, BS_LOAD_NT);
             w[it] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    constexpr int LATE = PACKED ? 0 : NW == 10 ? (RAGGED ? KMX_BSR_LATE : K <= 32 ? KMX_BS_LATE_ROWS : KMX_BS_LATE2)
-                         : NW < 10 ? (K > 32 ? 0 : KMX_BS_LATE7) : (RAGGED || K > 32) ? 0 : NW == 13 ? KMX_BS_LATE13 : KMX_BS_LATE16;   // rows of the prefetch requested late
+    // rows of the prefetch requested late (between the passes of phase D; their registers are free until then): half of a tile's
+    // rows -- 5 of 10, 7 of 13, 8 of 16 --, 3 of the 7 (5) rows of the short frames
+    constexpr int LATE = PACKED ? 0 : NW == 10 ? 5 : NW < 10 ? (K > 32 ? 0 : 3) : K > 32 ? 0 : NW == 13 ? 7 : 8;
     u64 tile = ~0ull, next_tile = ~0ull;
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
@@ -622,9 +430,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         // NLD of them out of the tile loop as zero-extended 64-bit values (24 registers at NLD = 10, and a 64-bit add per
         // row per tile); recomputed they are one 32-bit op each and the loads take the SGPR-base + VGPR-offset form
         // (168 -> 152 registers at k = 31, 240 -> 220 at k = 63; same speed).
-        u32 l16 = KMX_BS_RELANE ? relane() * 16u : lane16;
+        u32 l16 = lane16;
         asm volatile("" : "+v"(l16));
-        if constexpr (KMX_BS_BUFLOAD && !PACKED) {
+        if constexpr (!PACKED) {
             // (the tile index is wave-uniform, but only readfirstlane tells hipcc so: a descriptor it takes for lane-dependent is
             // fed to every load through a waterfall loop)
             uint8_t* const tbu = reinterpret_cast<uint8_t*>(uniform_u64(reinterpret_cast<u64>(tb)));
@@ -633,11 +441,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             for (int it = 0; it < NLD; ++it) {
                 if (it < row0 || it >= row1) continue;
                 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, l16 + (u32)it * 1024u, 0, KMX_BS_LOAD_AUX);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, l16 + (u32)it * 1024u, 0, BS_LOAD_NT);
                 w[it] = make_uint4(v.x, v.y, v.z, v.w);
             }
             return;
         }
+        // (packed input: plain loads)
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             if (it < row0 || it >= row1) continue;
@@ -699,7 +508,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     auto prefetch = [&](u64 t, u64 fallback_t, int row0 = 0, int row1 = 64) {   // clamped => unconditional, one basic block, pinned by sched barriers
         const u64 nxt = t < n_full ? t : fallback_t;
         __builtin_amdgcn_sched_barrier(0);
-        if (!(KMX_BS_ABLATE & 128)) issue_loads(nxt, row0, row1);   // (dev) 128: compute-only
+        issue_loads(nxt, row0, row1);
         __builtin_amdgcn_sched_barrier(0);
     };
     // ---- per-tile phases
@@ -739,20 +548,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                      "s_setprio 0"
                      : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3)
                      : "s"(W4));
-        if constexpr (KMX_BS_XORC && !PACKED) return t0;               // (converted on the planes, end of phase C)
         return __builtin_amdgcn_bitop3_b32(t0 >> 1, t0, k55, 0x6c);   // internal (ACTG) -> naive_impl (ACGT) codes
     };
-    auto enc16_p = [&](const uint4& wv, u32& bad) -> u32 {   // encode16 for the packed buffer (KMX_BS_XORC: back to ACTG codes -- c ^ (c >> 1) on 2-bit codes is an involution)
-        const u32 v = encode16(wv, bad);
-        if constexpr (KMX_BS_XORC && !PACKED) return __builtin_amdgcn_bitop3_b32(v >> 1, v, k55, 0x6c);
-        return v;
-    };
     auto phase_A = [&]() -> bool {   // pack + validate the tile sitting in w[] into the packed LDS buffer
-        const u32 ln_ = relane();
-        const u32 lane = ln_;
         u32 bad = 0;
         if constexpr (RAGGED) {      // the tile spans cur_m.n_ch chunks from its aligned start (neighbouring tiles' bytes at both ends)
-            if (KMX_BSR_VAL && cur_m.n_ch >= 64u * (NW - 1)) {   // wave-uniform: only the last row is partial (64 reads of 150: 600 or 601 chunks)
+            if (cur_m.n_ch >= 64u * (NW - 1)) {   // wave-uniform: only the last row is partial (64 reads of 150: 600 or 601 chunks)
 #pragma unroll
                 for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
                 const u32 c = (NW - 1) * 64u + lane;
@@ -774,26 +575,20 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             return false;
         } else {
-        if (KMX_BS_PRIO && !(KMX_BS_ABLATE & 24) && chunks >= 64u * (NW - 1)) {
-            // wave-uniform: only the last row of chunks is partial (L = 150: 600 = 9*64 + 24)
+            if (chunks >= 64u * (NW - 1)) {
+                // wave-uniform: only the last row of chunks is partial (L = 150: 600 = 9*64 + 24)
 #pragma unroll
-            for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
-            const u32 c = (NW - 1) * 64u + lane;
-            if (c < chunks) P[1u + c] = encode_prio(w[NW - 1], bad);
-
-        } else if (chunks >= 64u * (NW - 1)) {
+                for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
+                const u32 c = (NW - 1) * 64u + lane;
+                if (c < chunks) P[1u + c] = encode_prio(w[NW - 1], bad);
+            } else {
 #pragma unroll
-            for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = enc16_p(w[it], bad);
-            const u32 c = (NW - 1) * 64u + lane;
-            if (c < chunks) P[1u + c] = enc16_p(w[NW - 1], bad);
-        } else {
-#pragma unroll
-            for (int it = 0; it < NW; ++it) {
-                const u32 c = it * 64u + lane;
-                if (c < chunks) P[1u + c] = enc16_p(w[it], bad);
+                for (int it = 0; it < NW; ++it) {
+                    const u32 c = it * 64u + lane;
+                    if (c < chunks) P[1u + c] = encode_prio(w[it], bad);
+                }
             }
-        }
-        return __any(chunk_has_invalid(bad));
+            return __any(chunk_has_invalid(bad));
         }
     };
     auto lds_fence = [&]() {
@@ -802,16 +597,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     auto phase_BC = [&]() {
-        const u32 ln_ = relane();
-        const u32 lane = ln_, half = ln_ >> 5, p = ln_ & 31u;
         // ---- B. this lane's read, realigned: F[g] = bases [16g, 16g+16)
         u32 F[NXT];
         if constexpr (RAGGED) {
             posF = cur_m.rel + 16u * PAD;
-            qF = posF >> 4;
-            aF = 2u * (posF & 15u);
-        } else if constexpr (KMX_BS_RELANE != 0) {
-            posF = lane * L + lead + 16u * PAD;
             qF = posF >> 4;
             aF = 2u * (posF & 15u);
         }
@@ -819,10 +608,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             u32 R[NW + 1];
 #pragma unroll
             for (int j = 0; j <= NW; ++j) R[j] = P[qF + j];
-            if (KMX_BS_PRIO >= 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int g = 0; g < NW; ++g) F[g] = alignbit(R[g + 1], R[g], aF);
-            if (KMX_BS_PRIO >= 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
         }
         if constexpr (INLINE) {
             if (valid_reads != ~0ull) {
@@ -845,15 +636,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 }
             }
             const u32 len = (cur_m.len >= (u32)K && !set_aside) ? cur_m.len : 0u;   // a read shorter than k owns no window: it is blanked out entirely
-            // bases past the end of the read belong to the next read.  KMX_BSR_VAL: they stay -- a window that holds one is masked
-            // out of m by its validity plane, and the plane totals count a plane through the validity plane of its base (below)
-            if constexpr (!KMX_BSR_VAL) {
-#pragma unroll
-                for (int g = 0; g < NW; ++g) {
-                    const u32 keep = len > 16u * g ? (len - 16u * g < 16u ? len - 16u * g : 16u) : 0u;
-                    F[g] = keep >= 16u ? F[g] : (F[g] & ((1u << (2u * keep)) - 1u));
-                }
-            }
+            // bases past the end of the read belong to the next read.  They stay: a window that holds one is masked out of m by
+            // its validity plane, and the plane totals count a plane through the validity plane of its base (below)
             // the last K-1 bases of the read, base len-K+1+i at position i of the NE dwords
             const u32 posE = len ? posF + len - (u32)(K - 1) : posF;
             const u32 qE = posE >> 4, aE = 2u * (posE & 15u);
@@ -867,11 +651,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             // validity: bit o of word o/32 = window o lies inside the read
             const u32 wr = len ? len - (u32)K + 1u : 0u;
             atomicAdd(reinterpret_cast<unsigned long long*>(&NVR[lane]), (unsigned long long)wr);   // ds_add_u64, no return
-            if constexpr (!KMX_BSR_VAL) {
-#pragma unroll
-                for (int j = 0; j < NV; ++j)
-                    F[NW + NE + j] = wr >= 32u * (j + 1) ? ~0u : (wr > 32u * j ? (1u << (wr - 32u * j)) - 1u : 0u);
-            } else {
+            {
                 // Validity planes without transposes: V_o (bit r = read r owns window o <=> wr_r > o) = OR over i > o of E_i,
                 // E_i = the reads with wr == i.  The reads mark E (in the plane area, free until the planes are stored at the end
                 // of this phase); lane p of a half-wave then takes the NV planes o = NV*(31-p) .. +NV-1 -- the lanes below it hold
@@ -909,26 +689,17 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 lds_fence();
             }
         }
-        // ---- C. transpose each 32 reads x 32 bits block across the 32 lanes of the half-wave, entirely in
-        //      the VALU (no LDS round trips): butterfly stage d exchanges with lane^d and keeps/merges the
-        //      bits whose index has bit d clear/set.
-        //        d=16: v_permlane16_swap_b32 (rows of 16 lanes) + byte merge (v_perm_b32)
-        //        d=8 : two bank-masked DPP row shifts            + byte merge (v_perm_b32)
-        //        d=4 : two bank-masked DPP row shifts            + rotate (v_alignbit) + bit select (v_bitop3)
-        //        d=2,1: DPP quad_perm                             + rotate + bit select
-#if KMX_BS_PRIO >= 2
+        // ---- C. transpose each 32 reads x 32 bits block across the 32 lanes of the half-wave (no LDS round trips):
+        //      butterfly stage d exchanges with lane^d and keeps/merges the bits whose index has bit d clear/set.
+        //        d=16, 8: ds_swizzle xor-d (the LDS crossbar, no VALU) + byte merge (v_perm_b32)
+        //        d=4    : ds_swizzle xor-4                             + rotate (v_alignbit) + bit select (v_bitop3)
+        //        d=2, 1 : DPP quad_perm                                + rotate + bit select
         // Stage-major order: every butterfly stage runs over all NW groups, with its half-rate instructions
         // (v_perm_b32 / v_alignbit_b32 / DPP moves) as one raised-priority run and its full-rate bit selects after it.
         {
             u32 Y[NXT];
-            u32 c_sh2 = tr_sh[2], c_sh3 = tr_sh[3], c_sh4 = tr_sh[4], c_sel16 = tr_sel16;
-            u32 c_keep2 = tr_keep[2], c_keep3 = tr_keep[3], c_keep4 = tr_keep[4], c_sel8 = tr_sel8;
-            if constexpr (KMX_BS_TRC_LDS) {
-                const uint4* t = reinterpret_cast<const uint4*>(lds + 8u * p);
-                const uint4 a = t[0], b = t[1];
-                c_sh2 = a.x; c_sh3 = a.y; c_sh4 = a.z; c_sel16 = a.w;
-                c_keep2 = b.x; c_keep3 = b.y; c_keep4 = b.z; c_sel8 = b.w;
-            }
+            const u32 c_sh2 = tr_sh[2], c_sh3 = tr_sh[3], c_sh4 = tr_sh[4], c_sel16 = tr_sel16;
+            const u32 c_keep2 = tr_keep[2], c_keep3 = tr_keep[3], c_keep4 = tr_keep[4], c_sel8 = tr_sel8;
 #define KMX_HRUN_BEGIN __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(3);
 #define KMX_HRUN_END __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -953,36 +724,16 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             for (int g = 0; g < NXT; ++g) F[g] = bitsel(F[g], Y[g], c_keep2);
 #pragma unroll
             for (int st = 3; st < 5; ++st) {
-#if KMX_BS_SWZ == 2
-#pragma unroll
-                for (int g = 0; g < NXT; ++g)
-                    Y[g] = st == 3 ? (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (2 << 10) | 0x1f)
-                                   : (u32)__builtin_amdgcn_ds_swizzle((int)F[g], (1 << 10) | 0x1f);
-                KMX_HRUN_BEGIN
-#else
                 KMX_HRUN_BEGIN
 #pragma unroll
                 for (int g = 0; g < NXT; ++g)
                     Y[g] = st == 3 ? (u32)__builtin_amdgcn_update_dpp(0, (int)F[g], 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true)
                                    : (u32)__builtin_amdgcn_update_dpp(0, (int)F[g], 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
-#endif
 #pragma unroll
                 for (int g = 0; g < NXT; ++g) Y[g] = alignbit(Y[g], Y[g], st == 3 ? c_sh3 : c_sh4);
                 KMX_HRUN_END
 #pragma unroll
                 for (int g = 0; g < NXT; ++g) F[g] = bitsel(F[g], Y[g], st == 3 ? c_keep3 : c_keep4);
-            }
-            if constexpr (KMX_BS_XORC && !PACKED) {
-                // ACTG -> ACGT on the planes: lane 2j holds bit 0 and lane 2j + 1 bit 1 of base j.  Every lane fetches the odd
-                // lane of its pair (quad_perm [1,1,3,3] of ds_swizzle); the even lanes xor it in, the odd lanes keep their plane
-                // (evn = all ones on even lanes, from the rotate amount of the last stage: 31 on even, 1 on odd lanes)
-                u32 sh_o = c_sh4;
-                asm volatile("" : "+v"(sh_o));
-                const u32 evn = (u32)__builtin_amdgcn_sbfe((int)sh_o, 1u, 1u);
-#pragma unroll
-                for (int g = 0; g < NW + NE; ++g) Y[g] = (u32)__builtin_amdgcn_ds_swizzle((int)F[g], 0x80F5);
-#pragma unroll
-                for (int g = 0; g < NW + NE; ++g) F[g] = __builtin_amdgcn_bitop3_b32(F[g], Y[g], evn, 0x78);   // F ^ (Y & evn)
             }
             {
                 // plane q = 32g + p  <->  base beta = 16g + p/2, bit p & 1.  One lane-dependent base and a compile-time offset per
@@ -994,9 +745,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
                 for (int g = 0; g < NW; ++g) pst[ROT ? (32 / RW) * g : 32 * g] = F[g];
             }
-#pragma unroll
-            for (int j = 0; j < NVT; ++j) VAL[half * VS + 32u * j + p] = F[NW + NE + j];   // ragged: plane V_(32j+p) of this set
-            if constexpr (RAGGED && KMX_BSR_VAL) {
+            if constexpr (RAGGED) {
                 // plane (g, p) holds base beta = 16g + p/2 of the set's reads: only the reads that HAVE a base beta count
                 // (len > beta <=> wr > beta - (K-1): validity plane V_(beta-K+1); below K-1 every read that owns a window at all)
                 const u32* const vh = VAL + half * VS;
@@ -1031,82 +780,23 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #undef KMX_HRUN_BEGIN
 #undef KMX_HRUN_END
         }
-#else
-#pragma unroll
-        for (int g = 0; g < NW; ++g) {
-            u32 x = F[g];
-            if (!(KMX_BS_ABLATE & 4)) {
-#if KMX_BS_SWZ
-#pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {   // d = 16, 8, 4 through the LDS crossbar (no VALU for the exchange)
-                const u32 y = s3 == 0 ? (u32)__builtin_amdgcn_ds_swizzle((int)x, (16 << 10) | 0x1f)
-                            : s3 == 1 ? (u32)__builtin_amdgcn_ds_swizzle((int)x, (8 << 10) | 0x1f)
-                                      : (u32)__builtin_amdgcn_ds_swizzle((int)x, (4 << 10) | 0x1f);
-                if (s3 == 0) x = __builtin_amdgcn_perm(y, x, tr_sel16);
-                else if (s3 == 1) x = __builtin_amdgcn_perm(y, x, tr_sel8);
-                else { const u32 rot = alignbit(y, y, tr_sh[2]); x = bitsel(x, rot, tr_keep[2]); }
-            }
-#else
-            {   // d = 16
-                typedef u32 v2u __attribute__((ext_vector_type(2)));
-                const v2u sw = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-                const u32 y = (p & 16u) ? sw.x : sw.y;          // value held by lane ^ 16
-                x = __builtin_amdgcn_perm(y, x, tr_sel16);      // low half from x / high from y<<16, or mirrored
-            }
-            {   // d = 8
-                u32 y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x108 /* row_shl:8 */, 0xF, 0x3, false);
-                y = (u32)__builtin_amdgcn_update_dpp((int)y, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xC, false);
-                x = __builtin_amdgcn_perm(y, x, tr_sel8);
-            }
-            {   // d = 4
-                u32 y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
-                y = (u32)__builtin_amdgcn_update_dpp((int)y, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
-                const u32 rot = alignbit(y, y, tr_sh[2]);
-                x = bitsel(x, rot, tr_keep[2]);
-            }
-#endif
-#pragma unroll
-            for (int s = 3; s < 5; ++s) {
-#if KMX_BS_SWZ == 2
-                const u32 y = s == 3 ? (u32)__builtin_amdgcn_ds_swizzle((int)x, (2 << 10) | 0x1f)
-                                     : (u32)__builtin_amdgcn_ds_swizzle((int)x, (1 << 10) | 0x1f);
-#else
-                const u32 y = s == 3 ? (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, true)
-                                     : (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
-#endif
-                const u32 rot = alignbit(y, y, tr_sh[s]);
-                x = bitsel(x, rot, tr_keep[s]);
-            }
-            }
-            {   // plane index q = 32g+p  <->  base beta = 16g + p/2, bit p&1
-                const u32 beta = 16u * g + (p >> 1);
-                const u32 slot = ROT ? (beta % (u32)RW) * S2 + (beta / (u32)RW) : beta;
-                PL[half * SP + 2u * slot + (p & 1u)] = x;
-            }
-            atomicAdd(&TOT[64u * g + lane], (u32)__builtin_popcount(x));   // ds_add_u32, no return: no LDS round trip
-        }
-#endif
         lds_fence();
 
     };
     auto phase_D = [&](const bool run) {
         // ---- D. a lane handles the WPL windows o..o+WPL-1 of one set (o = WPL*group): they share the planes of
-        //      bases o..o+K+WPL-2, streamed twice from LDS as u64 (2 planes per base):
-        //      pass 1 = four interleaved fw<rc ripples, pass 2 = masked popcounts.
+        //      bases o..o+K+WPL-2, streamed from LDS as u64 (2 planes per base):
+        //      pass 1 = WPL interleaved fw<rc ripples -> the mask words m; pass 2 = the masked plane counts, on the matrix pipe.
         // `run` (wave-uniform) = false: a tile that is not scanned here (it rolled per lane); with LATE > 0 the call
         // is still made, for the ONE static site of the late prefetch rows between the passes (a second site in another
         // branch gets its own registers and is hoisted above the branch).
-        // The launchers pick WPL so that the 2 * NG (set, group) items of a tile fit the 64 lanes: ONE round, always
-        // (launch_bs checks it).  LATE > 0 relies on it: with a compile-time single trip the late prefetch rows have one
-        // definition on every path.  Otherwise the round loop stays a real loop (runtime bound): as straight-line code hipcc
-        // hoists the plane requests of pass 1 across phase C and the kernels gain 20-60 registers.
+        // The launchers pick WPL = ceil(W / 32): the 32 lanes of a half-wave hold all windows of a set, ONE round (launch_bs
+        // checks it).  LATE > 0 relies on it: with a compile-time single trip the late prefetch rows have one definition on
+        // every path.  Otherwise the round stays a real loop (runtime bound, one trip): as straight-line code hipcc hoists
+        // the plane requests of pass 1 across phase C and the kernels gain 20-60 registers.
         const u32 n_rounds = LATE > 0 ? 1u : (run ? rounds : 0u);
-        const u32 ln_ = relane();
-        const u32 lane = ln_;
 #pragma unroll 1
         for (u32 r = 0; LATE > 0 ? r < 1u : r < n_rounds; ++r) {
-            if (KMX_BS_ABLATE & 64) break;
-#if KMX_BS_MFMA
             // a half-wave per set, lane p of it the windows WPL p .. WPL p + WPL - 1 (the launchers pick WPL = ceil(W / 32)): the
             // lanes past the last group compute on whatever lies behind the planes and count nothing (nwin = 0), but they write
             // the zero words that complete the set's 32 WPL mask words -- the A operands of the matrix products.
@@ -1114,60 +804,26 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             const bool active = (lane & 31u) < NG;
             const u32 o = (u32)WPL * (lane & 31u);
             const u32 nwin = active ? (W - o < (u32)WPL ? W - o : (u32)WPL) : 0u;   // valid windows in this group
-#else
-            const u32 gidx = r * 64u + lane;
-            const bool active = gidx < 2u * NG;
-            // (KMX_BS_BANKFIX: the idle lanes continue set 1's sequence -- their reads land on banks no active lane of their
-            // half-wave uses, inside the wave's own plane / totals area; nothing they read is counted: nwin = 0)
-            const u32 set = (gidx >= NG && (active || KMX_BS_BANKFIX)) ? 1u : 0u;
-            const u32 o = (active || KMX_BS_BANKFIX) ? (u32)WPL * (gidx - set * NG) : 0u;
-            const u32 nwin = active ? (W - o < (u32)WPL ? W - o : (u32)WPL) : 0u;   // valid windows in this group
-#endif
             // base o+i  ->  u64 index (i % WPL) * S2 + o / WPL + i / WPL in the rotated layout (o is a multiple of WPL), else o + i
-#if KMX_BS_LDS64
             // (an address-space-3 pointer: a volatile access through a generic pointer stays a flat load)
             typedef const volatile u64 __attribute__((address_space(3))) * lds_cvu64p;
             const lds_cvu64p src = (lds_cvu64p)(reinterpret_cast<const u64*>(PL + set * SP) + (ROT ? (o / (u32)RW) : o));
-#else
-            const u64* __restrict__ src = reinterpret_cast<const u64*>(PL + set * SP) + (ROT ? (o / (u32)RW) : o);
-#endif
 #define KMX_PLANE(i) src[ROT ? (((i) % RW) * S2 + ((i) / RW)) : (i)]
             u32 lt[WPL];
 #pragma unroll
             for (int w = 0; w < WPL; ++w) lt[w] = 0u;
-            if (run && (!KMX_BS_EXECMASK || active)) {
-#if KMX_BS_P1D == 0
-                // (dev) plane loads left to the compiler
-                u64 Pv[K + WPL - 1];
-                bool have[K + WPL - 1];
-#pragma unroll
-                for (int i = 0; i < K + WPL - 1; ++i) have[i] = false;
-#pragma unroll
-                for (int j = (K + 1) / 2 - 1; j >= ((KMX_BS_ABLATE & 2) ? (K + 1) / 2 - 1 : 0); --j) {
-#pragma unroll
-                    for (int w = 0; w < WPL; ++w) {
-                        const int ia = K - 1 - j + w, iq = j + w;
-                        if (!have[ia]) { Pv[ia] = KMX_PLANE(ia); have[ia] = true; }
-                        if (!have[iq]) { Pv[iq] = KMX_PLANE(iq); have[iq] = true; }
-                        const u32 a0 = (u32)Pv[ia], a1 = (u32)(Pv[ia] >> 32);
-                        const u32 q0 = (u32)Pv[iq], q1 = (u32)(Pv[iq] >> 32);
-                        lt[w] = ripple(lt[w], a0, q0);
-                        lt[w] = ripple(lt[w], a1, q1);
-                    }
-                }
-            }
-#else
+            if (run) {
                 u64 Pv[K + WPL - 1];
                 // ripple from the least significant deciding pair (j = ceil(K/2)-1) to the most significant (j = 0);
                 // window w compares fw base K-1-j (plane o+w+K-1-j) with rc base = ~(fw base j) (plane o+w+j).
                 // Step J0 needs the planes J0 .. K-1-J0+WPL-1, every later step one more on either side (j and
-                // K-1-j+WPL-1).  They are requested KMX_BS_P1D steps ahead (one step = 2*WPL bit ops, far less than an LDS
+                // K-1-j+WPL-1).  They are requested P1D steps ahead (one step = 2*WPL bit ops, far less than an LDS
                 // round trip): left to hipcc, every second step ended in `ds_read ... s_waitcnt lgkmcnt(0)`.
-                constexpr int J0 = (K + 1) / 2 - 1, JEND = (KMX_BS_ABLATE & 2) ? J0 : 0;
+                constexpr int J0 = (K + 1) / 2 - 1, JEND = 0, P1D = 2;
 #pragma unroll
                 for (int i = J0; i <= K - 1 - J0 + WPL - 1; ++i) Pv[i] = KMX_PLANE(i);
 #pragma unroll
-                for (int d = 1; d < KMX_BS_P1D; ++d) {
+                for (int d = 1; d < P1D; ++d) {
                     if (J0 - d >= JEND) {
                         Pv[J0 - d] = KMX_PLANE(J0 - d);
                         Pv[K - 1 - (J0 - d) + WPL - 1] = KMX_PLANE(K - 1 - (J0 - d) + WPL - 1);
@@ -1180,22 +836,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     // (an index, not the pointer: an opaque pointer would lose its LDS address space and turn the reads into flat loads)
                     // (the LDS byte address itself goes through the asm and comes back as an address-space-3 pointer: a zero
                     // offset added to `src` costs a v_mov and a v_lshl_add per step, 30 VALU instructions a tile)
-#if KMX_BS_P1TIE == 2
                     asm volatile("" : : "v"(lt[0]) : "memory");   // a compiler-level fence only: no instruction, no copy
                     Pv[j] = KMX_PLANE_AT(src, j);
                     Pv[K - 1 - j + WPL - 1] = KMX_PLANE_AT(src, K - 1 - j + WPL - 1);
-#else
-                    typedef const u64 __attribute__((address_space(3))) * lds_cu64p;
-                    u32 a = (u32)(uintptr_t)(lds_cu64p)src;
-                    asm volatile("" : "+v"(a) : "v"(lt[0]));
-                    const lds_cu64p sj = (lds_cu64p)(uintptr_t)a;
-                    Pv[j] = KMX_PLANE_AT(sj, j);
-                    Pv[K - 1 - j + WPL - 1] = KMX_PLANE_AT(sj, K - 1 - j + WPL - 1);
-#endif
                 };
 #pragma unroll
                 for (int j = J0; j >= JEND; --j) {
-                    if (j - KMX_BS_P1D >= JEND) fetch(j - KMX_BS_P1D);
+                    if (j - P1D >= JEND) fetch(j - P1D);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int w = 0; w < WPL; ++w) {
@@ -1207,7 +854,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     }
                 }
             }
-#endif
             u32 m[WPL];
 #pragma unroll
             for (int w = 0; w < WPL; ++w) {
@@ -1238,8 +884,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             if (!run) break;
             KMX_T(5)
-            asm volatile("" ::: "memory");   // pass 2 re-reads the planes instead of keeping 2K+6 registers live
-#if KMX_BS_MFMA
+            asm volatile("" ::: "memory");
             {
                 // ---- pass 2 on the matrix pipe.  C[t][b] = sum_o sum_r m[o][r] & plane[o+t][b][r] is the sum along the diagonal
                 // beta - o = t of G[o][beta] = sum_r m[o][r] * plane[beta][r], a 0/1 matrix product over the tile's 64 reads:
@@ -1247,8 +892,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 // block, columns = the 32 planes of 16 bases, K = reads: lanes 0..31 carry set 0, lanes 32..63 set 1 -- which is
                 // how phase C left the planes (lane (half, p) holds plane 32 g + p of set `half`) and how the mask words come back
                 // from LDS below.  Per tile: WPL + NW ds_read_b32, 7 WPL + 5 NW VALU instructions for the operands and at most
-                // NAB WPL matrix instructions, instead of 2 (v_and + v_bcnt) per (window, plane) pair (504 VALU instructions at
-                // k = 31, L = 150).
+                // NAB WPL matrix instructions (16 at k = 31, L = 150), instead of a v_and + v_bcnt pair per (window, plane) -- 504 of
+                // the tile's 1007 VALU instructions in rounds 1-3 (597 now).  A weighted form (nibble = the 2-bit code of a base,
+                // half the matrix instructions and accumulators, no hash fold) measured 3 % slower at three or four waves per SIMD
+                // (profiles/r04_mfma_variants.txt).
                 u32* const MW = P;          // the packed reads are dead since phase B
                 u32* const mwr = MW + set * (32u * WPL) + (u32)WPL * (lane & 31u);
                 if constexpr (WPL == 4) {
@@ -1273,23 +920,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 const u32* const prd = PL + (set * SP + 2u * slot0 + (pp & 1u));
                 const int unit = 0x7F7F7F7F;    // E8M0 scale 2^0 in every byte
                 bs_v8i A[WPL];
-                if constexpr (WSUM) {
-                    // columns = the 32 bases of a block (both planes of a base in one operand), window block i meets the base blocks i .. i + NAB - 1
-                    const u32 slot64 = ROT ? (pp % (u32)RW) * S2 + (pp / (u32)RW) : pp;
-                    const u64* const prd64 = reinterpret_cast<const u64*>(PL + set * SP) + slot64;
-#pragma unroll
-                    for (int j = 0; 32 * j < 16 * NW; ++j) {
-                        const u64 pv = prd64[ROT ? (32 / RW) * j : 32 * j];
-                        const bs_v8i B = fp4_operand_codes((u32)pv, (u32)(pv >> 32));
-#pragma unroll
-                        for (int i = 0; i < WPL; ++i) {
-                            const int q = j - i;
-                            if (q < 0 || q >= NAB) continue;
-                            if (q == 0) A[i] = fp4_operand_mask2(ab[i]);
-                            acc[q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[i], B, acc[q], 4, 4, 0, unit, 0, unit);
-                        }
-                    }
-                } else
 #pragma unroll
                 for (int g = 0; g < NW; ++g) {
                     const bs_v8i B = fp4_operand_b(prd[ROT ? (32 / RW) * g : 32 * g]);
@@ -1298,114 +928,15 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                         const int q = g - 2 * i;
                         if (q < 0 || q >= NAB) continue;
                         if (q == 0) A[i] = fp4_operand_a(ab[i]);     // first use of window block i
-#ifdef KMX_BS_MFMA_PROBE2   // (dev, timing only: two accumulator blocks -- the register need of a 32-accumulator form; results are wrong)
-                        acc[q & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[i], B, acc[q & 1], 4, 4, 0, unit, 0, unit);
-#else
                         acc[q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[i], B, acc[q], 4, 4, 0, unit, 0, unit);
-#endif
                     }
                 }
             }
-#else
-            constexpr int NPL = (KMX_BS_ABLATE & 1) ? 1 : K + WPL - 1;
-            if (!KMX_BS_EXECMASK || active) {
-#if KMX_BS_PRIO
-            if constexpr (KMX_BS_RUN2 && WPL <= 4) {
-            // R planes per run (2*R*WPL v_and, then 2*R*WPL v_bcnt at raised priority): two planes are 0.8 % over one
-            constexpr int R = KMX_BS_RUNR;
-            u64 vcur[R];
-#pragma unroll
-            for (int h = 0; h < R; ++h) vcur[h] = KMX_PLANE(h < NPL ? h : 0);
-#pragma unroll
-            for (int i = 0; i < NPL; i += R) {
-                // (requesting the planes two runs ahead instead of one changed nothing: pass 2 does not wait on LDS)
-                u64 vnext[R];
-#pragma unroll
-                for (int h = 0; h < R; ++h) vnext[h] = KMX_PLANE(i + R + h < NPL ? i + R + h : i);
-                __builtin_amdgcn_sched_barrier(0);
-                u32 x[2 * R * WPL];
-#pragma unroll
-                for (int h = 0; h < R; ++h) {
-#pragma unroll
-                    for (int w = 0; w < WPL; ++w) {
-                        x[2 * WPL * h + 2 * w] = m[w] & (u32)vcur[h];
-                        x[2 * WPL * h + 2 * w + 1] = m[w] & (u32)(vcur[h] >> 32);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-                for (int h = 0; h < R; ++h) {
-                    if (i + h >= NPL) continue;
-#pragma unroll
-                    for (int w = 0; w < WPL; ++w) {
-                        const int t = i + h - w;
-                        if (t < 0 || t > K - 1) continue;
-                        const int tc = t < K - 1 - t ? t : K - 1 - t;
-                        pc_acc(D[2 * tc], x[2 * WPL * h + 2 * w]);
-                        pc_acc(D[2 * tc + 1], x[2 * WPL * h + 2 * w + 1]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                for (int h = 0; h < R; ++h) vcur[h] = vnext[h];
-            }
-            } else
-#endif
-            {
-#if KMX_BS_PRIO
-            u64 vcur = KMX_PLANE(0);
-#endif
-#pragma unroll
-            for (int i = 0; i < NPL; ++i) {
-#if KMX_BS_PRIO
-                // Hand-scheduled: [LDS read of the next plane] [full-rate v_and of this plane] [half-rate v_bcnt run at
-                // raised wave priority].  gfx950 co-issues another wave's full-rate instructions next to a half-rate
-                // run only when the wave running it outranks the others (tools/ubench7.hip: 108 -> 65 ns per
-                // 32 and + 32 bcnt), so the runs are kept apart and bracketed by s_setprio.
-                const u64 vnext = KMX_PLANE(i + 1 < NPL ? i + 1 : i);
-                __builtin_amdgcn_sched_barrier(0);
-                const u32 p0 = (u32)vcur, p1 = (u32)(vcur >> 32);
-                u32 x[2 * WPL];
-#pragma unroll
-                for (int w = 0; w < WPL; ++w) { x[2 * w] = m[w] & p0; x[2 * w + 1] = m[w] & p1; }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-                for (int w = 0; w < WPL; ++w) {
-                    const int t = i - w;                 // plane i is base t of window w
-                    if (t < 0 || t > K - 1) continue;
-                    const int tc = t < K - 1 - t ? t : K - 1 - t;
-                    pc_acc(D[2 * tc], x[2 * w]);
-                    pc_acc(D[2 * tc + 1], x[2 * w + 1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(0);
-                vcur = vnext;
-#else
-                const u64 v = KMX_PLANE(i);
-                const u32 p0 = (u32)v, p1 = (u32)(v >> 32);
-#pragma unroll
-                for (int w = 0; w < WPL; ++w) {
-                    const int t = i - w;                 // plane i is base t of window w
-                    if (t < 0 || t > K - 1) continue;
-                    const int tc = t < K - 1 - t ? t : K - 1 - t;
-                    pc_acc(D[2 * tc], m[w] & p0);
-                    pc_acc(D[2 * tc + 1], m[w] & p1);
-                }
-#endif
-            }
-            }
-            }
-#endif
         }
 #undef KMX_PLANE
 #undef KMX_PLANE_AT
         if (run) n_bs_tiles += 1;
-#if KMX_BS_MFMA
-        if (run && (n_bs_tiles & (u32)(KMX_BS_MFMA_FLUSH - 1)) == 0u) fold_acc();   // (wave-uniform, rare: keeps every fp32 accumulator an exact integer)
-#endif
+        if (run && (n_bs_tiles & (BS_FOLD_TILES - 1u)) == 0u) fold_acc();   // (wave-uniform, rare: keeps every fp32 accumulator an exact integer)
     };
 
     // Pipeline order 1: [A of tile t] [issue loads of tile t+1] [B,C,D of tile t]
@@ -1497,16 +1028,15 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
         lds_fence();
         KMX_T(1)
-        if (bad_tile) {   // not blanked in place: packed input has no such tiles; a ragged tile outside the frame; KMX_BS_DIRTY = 0
-            if constexpr (!(DIRTY_LIST && !RAGGED)) fallback_read(tile * 64u + lane, true);   // (uniform ASCII reads never get here)
+        if (bad_tile) {   // not blanked in place: a ragged tile outside the frame (packed input has no such tiles, uniform ASCII reads never get here)
+            if constexpr (RAGGED) fallback_read(tile * 64u + lane, true);
         }
         {
-            const bool run = !bad_tile && !(KMX_BS_ABLATE & 32);
+            const bool run = !bad_tile;
             if (run) phase_BC();
             KMX_T(3)
             if (run || LATE > 0) phase_D(run);
             KMX_T(4)
-            if (!bad_tile && (KMX_BS_ABLATE & 32)) n_bs_tiles += 1;
         }
         tile = next_tile;
         next_tile = uniform_u64(ticket_take());     // requested one whole iteration ago (kept in scalar registers)
@@ -1563,22 +1093,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         u32 mcnt_c;
         asm volatile("v_mov_b32 %0, %1" : "=&v"(mcnt_c) : "v"(mcnt));
         const u64 mc = wave_sum((u64)mcnt_c);
-#if KMX_BS_MFMA
         fold_acc();
         const u64* const CS = CSA;
-#else
-        u64* CS = reinterpret_cast<u64*>(PL + PLANES);      // set-1 plane area is free now
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 2 * NT; ++q) {
-            // (through an opaque 32-bit copy: zero-extended directly, D[q] becomes the low half of a 64-bit register for its
-            // whole life -- even-aligned on gfx950 -- and the allocator needs ~35 registers more for the same live values)
-            u32 dq;
-            asm volatile("v_mov_b32 %0, %1" : "=&v"(dq) : "v"(D[q]));   // (early clobber: a register of its own)
-            const u64 v = wave_sum((u64)dq);
-            if (lane == 0) CS[q] = v;
-        }
-#endif
 #pragma unroll
         for (int g = 0; g < NW; ++g)
             if (half == 0) PL[32u * g + p] = tot[g];        // PL[2*base + bit] = popcount total of that plane
@@ -1646,7 +1162,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 }
 
 // ------------------------------------------------------------------ the reads the main pass blanked out
-// KMX_BS_INLINE_DIRTY: masks[t] (behind queue[515]) = the reads of tile t that hold an invalid byte, left by the main pass,
+// masks[t] (behind queue[515]) = the reads of tile t that hold an invalid byte, left by the main pass,
 // which scanned the tile without them.  A lane takes the mask of one tile, the wave gathers the reads 64 at a time (one
 // ballot + one v_mbcnt per round: no list in memory, no atomics) and rolls them, one lane per read, with the reference's
 // iterator semantics (roll_read).  Every mask goes back to zero: the caller never clears the array.
@@ -1676,7 +1192,7 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
         // exactly the read's windows, and the walk, whose length is what this kernel costs, is 45-90 bases instead of 150.
         const u32 sh = n_aside <= 8u ? 3u : n_aside <= 16u ? 2u : n_aside <= 32u ? 1u : 0u;   // (wave-uniform)
         const u32 slot = lane >> sh, part = lane & ((1u << sh) - 1u);
-        if (slot < n_aside && !(KMX_BS_ABLATE & 512)) {
+        if (slot < n_aside) {
             const u64 read = aside[slot];
             const uint8_t* sp = bases + lead + read * (u64)L;
             u32 len = L;
@@ -1760,7 +1276,7 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
     __syncthreads();
     if (threadIdx.x != 0) return;
     const u64 n = part[0][0] + part[1][0] + part[2][0] + part[3][0];
-    if (n == 0 || (KMX_BS_ABLATE & 1024)) return;   // nothing rolled: no atomics
+    if (n == 0) return;   // nothing rolled: no atomics
     const u64 s0 = part[0][1] + part[1][1] + part[2][1] + part[3][1], s1 = part[0][2] + part[1][2] + part[2][2] + part[3][2];
     const u64 x0 = part[0][3] ^ part[1][3] ^ part[2][3] ^ part[3][3], x1 = part[0][4] ^ part[1][4] ^ part[2][4] ^ part[3][4];
     const u64 f = part[0][5] + part[1][5] + part[2][5] + part[3][5];
@@ -1801,13 +1317,11 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     }
     const u32 chunks = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);
     u32 ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
-    if (KMX_BS_MFMA && ldsw < 64u * (u32)WPL) ldsw = 64u * (u32)WPL;
+    if (ldsw < 64u * (u32)WPL) ldsw = 64u * (u32)WPL;
     constexpr u32 NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;
     constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
-    constexpr u32 CSA_DW = KMX_BS_MFMA ? 4u * ((K + 1) / 2) : 0u;
-    size_t lds_bytes = (size_t)(ldsw + 4u * (u32)bs_plane_dwords(NW) + BS_SET_SLACK + (RAGGED ? 2u * (32u * NV + 8u) : 0u) + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW) * 4u * 4u;
-    if (KMX_BS_TRC_LDS) lds_bytes += 1024u;
-    if (const char* e = getenv("KMX_BS_EXTRA_LDS")) lds_bytes += (size_t)atol(e);   // dev knob: caps blocks per CU
+    constexpr u32 CSA_DW = 4u * ((K + 1) / 2);
+    const size_t lds_bytes = (size_t)(ldsw + 4u * (u32)bs_plane_dwords(NW) + (RAGGED ? 2u * (32u * NV + 8u) : 0u) + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW) * 4u * 4u;
     // blocks per CU, cached per host thread and device (one thread per context / GPU is the ABI's model: a plain static
     // would be shared, and written, by all of them)
     static thread_local int bpc = 0, bpc_dev = -1;
@@ -1821,10 +1335,8 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
         if (e != hipSuccess) return e;
         bpc = b > 0 ? b : 1;
         bpc_lds = lds_bytes;
-        if (getenv("KMX_BS_PRINT_BPC")) fprintf(stderr, "kmx: bit-sliced K=%d NW=%d WPL=%d: %d blocks per CU, %zu B of LDS each\n", K, NW, WPL, bpc, lds_bytes);
     }
-    if (L < (u32)K || 2u * ((L - (u32)K + 1u + (u32)WPL - 1u) / (u32)WPL) > 64u) return hipErrorInvalidValue;   // phase D runs ONE round of 64 items
-    if (KMX_BS_MFMA && L - (u32)K + 1u > 32u * (u32)WPL) return hipErrorInvalidValue;   // a half-wave per set: the 32 lanes hold all of a read's windows
+    if (L < (u32)K || L - (u32)K + 1u > 32u * (u32)WPL) return hipErrorInvalidValue;   // phase D runs ONE round: a half-wave per set, its 32 lanes hold all of a read's windows
     if ((n_reads >> 6) >= (1ull << 36)) return hipErrorInvalidValue;   // tickets are kept as 32-bit values (32 heads x 2^32 tiles; 2^42 reads is far past any HBM)
     const u64 n_tiles = (n_reads + 63u) >> 6;
     u64 grid = (u64)n_cu * (u64)bpc;
@@ -1832,7 +1344,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets, lead);
-    if constexpr (!PACKED && bs_has_dirty_pass<K>()) {
+    if constexpr (!PACKED) {
         // the reads the main pass blanked out (none on clean input: the waves return at once)
         u64 grid1 = (u64)n_cu * 4u;
         const u64 need1 = ((n_reads >> 6) + 255u) / 256u;   // a wave takes 64 masks at a time

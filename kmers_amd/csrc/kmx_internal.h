@@ -16,6 +16,8 @@ struct kmx_ctx {
     unsigned long long* d_scratch;  // 8 KiB: [0] first_bad, [2..3] fastx totals, [4] length range, [16..] tile-queue heads
     void* d_big;                    // grow-only work buffer of the partitioned histogram (bucket-id streams)
     size_t big_bytes;
+    size_t big_limit;               // kmx_ctx_set_work_buffer_limit: 0 = automatic (an eighth of the device memory, at most half of what is free)
+    unsigned long long big_allocs;  // how often the work buffer was (re)allocated (kmx_ctx_work_buffer_info)
     unsigned long long dirty_desc;  // address of the dirty-tile flags as last written behind the queue heads
     uint8_t* d_flags;               // one byte per tile, all zero between calls
     size_t flags_bytes;

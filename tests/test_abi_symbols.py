@@ -72,3 +72,20 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 txt = open(os.path.join(dp, fn)).read()
                 assert "kmx_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+
+
+def test_no_development_knobs_in_the_product():
+    """Experiments live in git history and profiles/, not in the shipped library: no environment variable steers kernel
+    selection or chunking (round 3 read KMX_BS_PC, KMX_BS_RAGGED, KMX_BS_EXTRA_LDS, KMX_BS_PRINT_BPC, KMX_HIST_SCRATCH_MB and
+    KMX_DEBUG_ALLOC on every launch); the work-buffer cap is an ABI call (kmx_ctx_set_work_buffer_limit)."""
+    from kmers_amd import _lib
+
+    blob = open(_lib.lib_path() if hasattr(_lib, "lib_path") else os.path.join(ROOT, "kmers_amd", "libkmx.so"), "rb").read()
+    for needle in (b"KMX_BS_", b"KMX_HIST_SCRATCH", b"KMX_DEBUG_ALLOC"):
+        assert needle not in blob, needle
+    for dp, _, fns in os.walk(os.path.join(ROOT, "kmers_amd", "csrc")):
+        if os.path.basename(dp).startswith("_obj"):
+            continue
+        for fn in fns:
+            if fn.endswith((".hip", ".h")):
+                assert "getenv" not in open(os.path.join(dp, fn)).read(), fn

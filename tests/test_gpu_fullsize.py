@@ -264,24 +264,22 @@ def test_full_size_fastq_image_roundtrip(ctx):
     assert torch.equal(out, bases.view(-1))
 
 
-def test_full_size_chunked_histogram_keeps_its_work_buffer(ctx, big, capfd):
+def test_full_size_chunked_histogram_keeps_its_work_buffer(ctx, big):
     """1e8 x 150 bp at k = 13 need more id space than an eighth of the device memory: the reads go in chunks.  The context's work
     buffer must be allocated once and then stay -- a request a little above the budget used to raise the next call's budget, and
     every call re-allocated 36 GB (1.1 s of host time per call; round 3)"""
     from kmers_amd import _lib
 
     k, b = 13, 20
-    os.environ["KMX_DEBUG_ALLOC"] = "1"
-    try:
-        capfd.readouterr()
-        first = ctx.histogram(big, N_FULL, L, k, _lib.HASH_LEX, k, b)
-        n_first = capfd.readouterr().err.count("work buffer (re)allocated")
-        again = None
-        for _ in range(3):
-            again = ctx.histogram(big, N_FULL, L, k, _lib.HASH_LEX, k, b)
-        n_later = capfd.readouterr().err.count("work buffer (re)allocated")
-    finally:
-        os.environ.pop("KMX_DEBUG_ALLOC", None)
+    n0 = ctx.work_buffer_info()[1]
+    first = ctx.histogram(big, N_FULL, L, k, _lib.HASH_LEX, k, b)
+    held, n1 = ctx.work_buffer_info()
+    n_first = n1 - n0
+    again = None
+    for _ in range(3):
+        again = ctx.histogram(big, N_FULL, L, k, _lib.HASH_LEX, k, b)
+    n_later = ctx.work_buffer_info()[1] - n1
+    assert held > 0
     assert n_first <= 1 and n_later == 0
     assert int(first.sum().item()) == N_FULL * (L - k + 1)
     import torch

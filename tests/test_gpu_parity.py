@@ -499,19 +499,22 @@ def test_histogram_fast_kernel_many_tiles(ctx, orc, b):
 
 
 @pytest.mark.parametrize("b", [10, 14, 15, 18, 21, 22, 23])
-def test_histogram_three_regimes(ctx, orc, b, monkeypatch):
+def test_histogram_three_regimes(ctx, orc, b):
     """2^b <= 2^14: block-private LDS tables; 2^15..2^22: 64-way partition + LDS tables (2^22: two half tables per partition; here in several chunks of reads,
     forced by a 4 MiB work buffer); above: device atomics.  All three must equal the oracle, dirty tiles included."""
-    monkeypatch.setenv("KMX_HIST_SCRATCH_MB", "4")
     rng = np.random.default_rng(100 + b)
     L, n, k = 150, 64 * 400 + 37, 31
     host = _dirty(rng, n * L, 0.0003)
     bases = ctx.to_device(host)
     o = orc.histogram(host, n, L, k, k, b)
-    g = ctx.histogram(bases, n, L, k, 1, k, b)
-    assert (g.cpu().numpy().view(np.uint64) == o).all()
-    g = ctx.histogram(bases, n, L, k, 1, k, b, counts=g)
-    assert (g.cpu().numpy().view(np.uint64) == 2 * o).all()
+    ctx.set_work_buffer_limit(4 << 20)
+    try:
+        g = ctx.histogram(bases, n, L, k, 1, k, b)
+        assert (g.cpu().numpy().view(np.uint64) == o).all()
+        g = ctx.histogram(bases, n, L, k, 1, k, b, counts=g)
+        assert (g.cpu().numpy().view(np.uint64) == 2 * o).all()
+    finally:
+        ctx.set_work_buffer_limit(0)
 
 
 @pytest.mark.parametrize("b", [12, 16, 20])

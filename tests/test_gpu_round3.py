@@ -1,6 +1,6 @@
 """Round-3 GPU parity tests (all through the C ABI, bit-exact against the CPU oracle):
-  * the producer/consumer form of the k = 31 scan (kmx_bitslice_pc.h, opt-in through KMX_BS_PC) on the same inputs as the
-    one-role kernel: clean, dirty, unaligned base, partial tiles, every read length of its frame;
+  * the k = 31 scan on the inputs written for round 3's producer/consumer variant (removed in round 4: measured 1-3 % slower;
+    the cases stay): clean, dirty, unaligned base, partial tiles, every read length of the 10-word frame with 4 windows per lane;
   * the error path of kmx_comm_create: two ranks on ONE device -- RCCL refuses the duplicate GPU, both processes must come
     back with KMX_E_HIP and a text in kmx_last_error, without hanging;
   * libkmx.so loads without librccl on the link line (RCCL is resolved at the first kmx_comm_* call)."""
@@ -28,18 +28,6 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["1", "2"])
-def pc_mode(request):
-    """KMX_BS_PC is read by the launcher at every call (kmx_bitslice.hip): set for the test, restored after"""
-    old = os.environ.get("KMX_BS_PC")
-    os.environ["KMX_BS_PC"] = request.param
-    yield request.param
-    if old is None:
-        os.environ.pop("KMX_BS_PC", None)
-    else:
-        os.environ["KMX_BS_PC"] = old
-
-
 def _dirty(rng, n, p_bad):
     alpha = np.frombuffer(b"ACGTacgt", np.uint8)
     a = alpha[rng.integers(0, 8, n)].copy()
@@ -56,7 +44,7 @@ def _same(g, o, want_hash, want_sumfw):
 
 
 @pytest.mark.parametrize("n_reads", [1, 63, 64, 65, 64 * 7 + 5, 20_000, 200_003])
-def test_pc_clean_reads(ctx, orc, pc_mode, n_reads):
+def test_scan_r3_clean_reads(ctx, orc, n_reads):
     from kmers_amd import _lib
 
     L, k = 150, 31
@@ -68,8 +56,8 @@ def test_pc_clean_reads(ctx, orc, pc_mode, n_reads):
 
 
 @pytest.mark.parametrize("L", [127, 128, 131, 140, 149, 151, 157, 158])
-def test_pc_every_length_of_the_frame(ctx, orc, pc_mode, L):
-    """k = 31 with 97..128 windows per read is what the producer/consumer kernel is instantiated for (4 windows per lane)"""
+def test_scan_r3_every_length_of_the_frame(ctx, orc, L):
+    """k = 31 with 97..128 windows per read: 4 windows per lane, four window blocks of pass 2"""
     from kmers_amd import _lib
 
     k, n_reads = 31, 64 * 11 + 9
@@ -79,8 +67,8 @@ def test_pc_every_length_of_the_frame(ctx, orc, pc_mode, L):
 
 
 @pytest.mark.parametrize("p_bad", [0.0002, 0.002, 0.02])
-def test_pc_dirty_reads(ctx, orc, pc_mode, p_bad):
-    """reads with an invalid byte: the producers blank them, the consumers mask them out of m, roll_flagged_kernel rolls them"""
+def test_scan_r3_dirty_reads(ctx, orc, p_bad):
+    """reads with an invalid byte: blanked in phase B, masked out of m, rolled by roll_flagged_kernel"""
     from kmers_amd import _lib
 
     L, k, n_reads = 150, 31, 64 * 300 + 17
@@ -96,7 +84,7 @@ def test_pc_dirty_reads(ctx, orc, pc_mode, p_bad):
 
 
 @pytest.mark.parametrize("lead", [1, 5, 8, 15])
-def test_pc_unaligned_base(ctx, orc, pc_mode, lead):
+def test_scan_r3_unaligned_base(ctx, orc, lead):
     from kmers_amd import _lib
 
     L, k, n_reads = 150, 31, 64 * 40 + 3
@@ -108,16 +96,14 @@ def test_pc_unaligned_base(ctx, orc, pc_mode, lead):
     _same(g, o, True, True)
 
 
-def test_pc_matches_the_one_role_kernel_at_size(ctx, pc_mode):
-    """2e6 reads (31 250 tiles: every producer of every block runs many tiles, the hand-off rings wrap): same summary"""
+def test_scan_r3_repeatable_at_size(ctx):
+    """2e6 reads (31 250 tiles: every wave runs many tiles; the accumulators of pass 2 are folded and carried): two calls, same summary"""
     from kmers_amd import _lib
 
     L, k, n_reads = 150, 31, 2_000_000
     bases = ctx.gen_reads(n_reads * L)
     g = ctx.canonical_reduce(bases, n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
-    os.environ.pop("KMX_BS_PC")
     r = ctx.canonical_reduce(bases, n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
-    os.environ["KMX_BS_PC"] = pc_mode
     assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (r.n_valid, r.sum_canon, r.xor_hash, r.sum_fw)
     assert g.n_valid == n_reads * (L - k + 1)
 

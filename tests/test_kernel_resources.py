@@ -40,19 +40,22 @@ def test_bitsliced_kernels_stay_out_of_scratch(kernels):
             continue
         seen += 1
         assert d["Dynamic Stack"] == "False", name
-        assert int(d["ScratchSize [bytes/lane]"]) <= 64, (name, d["ScratchSize [bytes/lane]"])
+        # (round 4: the 16-word frame at 8 windows per lane -- reads of 256 bases -- keeps 72 bytes of spills at three waves per
+        # SIMD, measured 4 % faster than two waves without any)
+        assert int(d["ScratchSize [bytes/lane]"]) <= 80, (name, d["ScratchSize [bytes/lane]"])
     assert seen >= 100   # every k of the three families, every frame
 
 
 def test_headline_kernel_occupancy(kernels):
-    """k = 31, 150 bp (10-word frame, 4 windows per lane): 4 waves per SIMD; the ragged variant 3; two-word k = 63 3"""
+    """k = 31, 150 bp (10-word frame, 4 windows per lane): 3 waves per SIMD since pass 2 runs on the matrix pipe (64 fp32
+    accumulators; four waves of a 32-accumulator form measured slower); the ragged variant and two-word k = 63: 2"""
     def occ(pattern):
         hits = [d for n, d in kernels.items() if re.search(pattern, n)]
         assert len(hits) == 1, (pattern, len(hits))
         return int(hits[0]["Occupancy [waves/SIMD]"])
-    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0EEEv") == 4
-    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb1EEEv") == 3
-    assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb0EEEv") == 3
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0EEEv") == 3
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb1EEEv") == 2
+    assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb0EEEv") >= 2
 
 
 def test_scan_and_histogram_kernels_do_not_call(kernels):

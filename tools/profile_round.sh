@@ -35,10 +35,6 @@ python3 bench.py --packed --no-cpu-baseline --no-traffic > $out/bench_packed.jso
 for k in 13 17 21 25 27 29 31 33 41 47 51 55 63; do python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 200 -k $k 2>/dev/null | python3 tools/bench_line.py "k=$k"; done > $out/k_sweep.txt
 for spec in "36 400000000" "50 300000000" "62 240000000" "75 200000000" "100 150000000" "125 120000000" "150 100000000" "161 93000000" "170 88000000" "200 75000000" "208 72000000" "250 60000000" "256 58000000" "300 50000000" "1000 15000000" "10000 1500000"; do set -- $spec
   python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len $1 --reads-per-gpu $2 2>/dev/null | python3 tools/bench_line.py "L=$1"; done > $out/len_sweep.txt
-# the producer/consumer form of the k=31 scan (opt-in) next to the one-role kernel, same box
-for c in 0 1 2; do if [ $c == 0 ]; then unset KMX_BS_PC; else export KMX_BS_PC=$c; fi
-  python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-traffic --sustain-steps 400 2>/dev/null | python3 tools/bench_line.py "[KMX_BS_PC=$c]"; done > $out/pc_bench.txt
-unset KMX_BS_PC
 python3 tools/bench_windows2.py > $out/windows2_bench.txt 2>/dev/null
 python3 tools/bench_ragged.py 100000000 31 > $out/ragged_bench.txt 2>/dev/null
 python3 tools/bench_ragged.py 100000000 21 >> $out/ragged_bench.txt 2>/dev/null
