@@ -266,6 +266,7 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, kmx_ctx*
     c->stream = stream;
     c->owns_stream = owns;
     c->d_scratch = nullptr;
+    c->h_pinned = nullptr;
     c->d_big = nullptr;
     c->big_bytes = 0;
     c->big_limit = 0;
@@ -279,12 +280,14 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, kmx_ctx*
     hipError_t e = g.ok ? hipGetDeviceProperties(&prop, device) : hipErrorInvalidDevice;
     if (e == hipSuccess && owns) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_scratch), 8192);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 64, hipHostMallocDefault);
     // (the dirty-list descriptor behind the queue heads starts as "no list"; cleared on the context's own stream so that
     // the clear is ordered before every kernel the context launches)
     if (e == hipSuccess) e = hipMemsetAsync(c->d_scratch, 0, 8192, c->stream);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (c->d_scratch) (void)hipFree(c->d_scratch);
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
         if (owns && c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return KMX_E_HIP;
@@ -304,6 +307,7 @@ void kmx_ctx_destroy(kmx_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_big) (void)hipFree(ctx->d_big);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -313,10 +317,12 @@ void kmx_ctx_destroy(kmx_ctx* ctx) {
 int kmx_ctx_synchronize(kmx_ctx* ctx) {
     if (!ctx) return KMX_E_ARG;
     DeviceGuard g(ctx->device);
+    // the sticky flag of the scans: a ragged read of 2^31 bases or more was skipped (kmx.h "Limits").  Read back on the context's
+    // own stream into pinned memory, ahead of the one wait: no blocking copy on the null stream (which would also synchronise
+    // with every other blocking stream of the process)
+    KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
     KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // the sticky flag of the scans: a ragged read of 2^31 bases or more was skipped (kmx.h "Limits")
-    unsigned long long too_long = 0;
-    KMX_HIP(ctx, hipMemcpy(&too_long, ctx->d_scratch + 8, 8, hipMemcpyDeviceToHost));
+    const unsigned long long too_long = *ctx->h_pinned;
     if (too_long) {
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 8, 0, 8, ctx->stream));
         KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -412,8 +418,10 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
         // untrimmed -- every read exactly L bases -- and the uniform kernel is ~1.4x the ragged one.  Decided on the device:
         // a small kernel checks offsets[i] == i*L, both scans are launched behind its verdict, the one it names runs.
         const uint32_t Lh = reads->read_len;
+        // (only where BOTH bit-sliced launchers take the call: the ragged one needs a 16-byte aligned base -- with a misaligned
+        // base the uniform scan used to be enqueued behind the gate and the generic kernel then counted the batch a second time)
         if (reads->d_offsets && !want_sumfw && k >= 13 && k <= 31 && Lh >= k && Lh <= 256 &&
-            !((reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) && (Lh == 160 || Lh == 256))) {
+            (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
             uint32_t* gate = reinterpret_cast<uint32_t*>(ctx->d_scratch + 16 + 513);
             KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 1, 1, ctx->stream));
             KMX_HIP(ctx, kmx::launch_offsets_uniform_gate(reads->d_offsets, reads->n_reads, Lh, gate, ctx->n_cu, ctx->stream));
@@ -430,9 +438,12 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
                     if (fix_fold) KMX_HIP(ctx, kmx::launch_fix_hash_fold(d_out, k, hasher, hasher_k, ctx->stream));
                     return KMX_OK;
                 }
-                // (cannot happen -- the ragged launcher takes every (k, L) the uniform one takes -- but if it did, the gate
-                // must not stay armed for what follows: finish on the ragged word-domain path with the gate cleared)
-                KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 2, 1, ctx->stream));
+                // The ragged launcher takes every aligned (k, L) the uniform one takes.  Should that ever stop being true, the uniform
+                // scan is already enqueued behind the gate and nothing may run after it: fail loudly, never count twice.
+                KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));
+                KMX_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(kmx_summary), ctx->stream));
+                std::snprintf(ctx->last_error, sizeof ctx->last_error, "kmx: internal -- the ragged scan refused k=%u, L<=%u that the uniform scan accepted", k, Lh);
+                return KMX_E_HIP;
             } else {
                 KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));
             }
@@ -516,8 +527,9 @@ int kmx_canonical_windows2(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t*
     if (reads->d_offsets && !d_win_offsets) return KMX_E_ARG;
     if (reads->n_reads == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
-    bool handled = false;   // uniform reads of up to 256 bases: the tiled kernel (kmx_generic.hip)
-    KMX_HIP(ctx, kmx::launch_windows2_tiled(reads, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled));
+    bool handled = false;   // uniform reads of up to 256 bases in the dense layout (slot r*W + p): the tiled kernel (kmx_generic.hip)
+    if (!reads->d_offsets && !d_win_offsets)   // (a caller's win_offsets for uniform reads are honoured by the lane-per-read kernel, as kmx_canonical_windows does)
+        KMX_HIP(ctx, kmx::launch_windows2_tiled(reads, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled));
     if (handled) return KMX_OK;
     KMX_HIP(ctx, kmx::launch_windows2_generic(reads, d_win_offsets, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, ctx->d_scratch + 8));
     return KMX_OK;

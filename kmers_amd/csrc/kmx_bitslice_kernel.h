@@ -112,14 +112,11 @@ constexpr int BS_LOAD_NT = 2;   // cache policy of the tile loads (aux bit 1 = n
 constexpr int bs_acc_blocks(int K) { return (K + 30) / 16 + 1; }
 // Waves per SIMD a variant is compiled for.  With 16 bs_acc_blocks(K) accumulators and the prefetch rows of a tile in
 // registers the kernels need 130..168 registers: three waves (measured round 4: a 32-accumulator form at four waves was 3 %
-// slower than this one at three -- profiles/r04_mfma_variants.txt).  The two-word k (5..6 accumulator blocks), the ragged
+// slower than this one at three -- profiles/r04_mfma_variants.txt).  The two-word k above 48 (six accumulator blocks; k = 41 / 47 at three waves 0.69 / 0.68 of the roofline against 0.64 / 0.63 at two, k = 55 / 63 spill and fall from 0.64 / 0.63 to 0.48), the ragged
 // variants (190..214 registers: at three waves they spill 30..170 bytes and run 30 % slower) and the 16-word frame below 8
 // windows per lane run at two.
 template <int K, int NW, int WPL, bool PACKED, bool RAGGED> constexpr int bs_waves() {
-#ifdef KMX_TMP_WAVES   // (temporary, round-4 tuning)
-    if (K > 32 && (KMX_TMP_WAVES & 4)) return 3;
-#endif
-    return (K > 32 || RAGGED || (NW == 16 && WPL < 8)) ? 2 : 3;
+    return (K > 48 || RAGGED || (NW == 16 && WPL < 8)) ? 2 : 3;
 }
 // tiles between two folds of the fp32 accumulators into the 64-bit class sums: a power of two, far below the 2^24 / (8 window
 // blocks x 64 reads) the sums stay exact integers for, and small enough that the full-size runs (~500 tiles per wave) exercise

@@ -226,7 +226,13 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
         // entries (2^16 at b = 28: two halves).  Scratch per window: 1.5 x (4 + 2) bytes.
         const u32 Lb = offsets ? (L ? L : 256u) : L;
         const u64 W = Lb >= k ? Lb - k + 1u : 1u;
-        u64 chunk = scratch_budget / (10u * W);
+        // scratch per window: 1.5 x (4 + 2) bytes, plus the fixed pads of the segments (<= 319 entries for each of the 64 x waves
+        // first-level and 64 x 64 x waves second-level segments, ~0.8 GB on 256 CUs) -- taken off the budget first, as the
+        // one-level path does: a request above the budget grows the context's buffer past it, and the next call asks for
+        // slightly more again (a re-allocation per call)
+        const u64 fixed_max = (u64)n_cu * 16u * 64u * 319u * 4u + 64ull * (u64)((n_cu * 4 + 63) / 64 > 0 ? (n_cu * 4 + 63) / 64 : 1) * 4u * 64u * 319u * 2u + (64u << 20);
+        const u64 fixed = fixed_max < scratch_budget / 4u ? fixed_max : scratch_budget / 4u;
+        u64 chunk = (scratch_budget - fixed) / (9u * W);
         if (chunk > n_reads) chunk = n_reads;
         chunk &= ~63ull;
         if (chunk >= 4096u) {

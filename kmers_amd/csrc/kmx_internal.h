@@ -13,6 +13,7 @@ struct kmx_ctx {
     hipStream_t stream;
     bool owns_stream;
     int n_cu;
+    unsigned long long* h_pinned;   // one pinned host word: the sticky flag read back by kmx_ctx_synchronize on the context's own stream
     unsigned long long* d_scratch;  // 8 KiB: [0] first_bad, [2..3] fastx totals, [4] length range, [16..] tile-queue heads
     void* d_big;                    // grow-only work buffer of the partitioned histogram (bucket-id streams)
     size_t big_bytes;

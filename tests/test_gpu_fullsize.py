@@ -285,3 +285,36 @@ def test_full_size_chunked_histogram_keeps_its_work_buffer(ctx, big):
     import torch
 
     assert torch.equal(first, again)
+
+
+@pytest.mark.parametrize("k,two_word", [(31, False), (21, False), (47, True), (63, True)])
+def test_full_size_identical_reads_through_the_accumulator_folds(ctx, orc, k, two_word):
+    """6e7 copies of ONE read (round 4): every tile adds the same 0/1 pattern from all 64 reads to the fp32 accumulators of
+    pass 2 -- the largest per-entry counts there are -- and every wave runs ~300 tiles, i.e. across at least one fold into the
+    64-bit class sums (every 256 tiles).  The summary is the one read's, times the number of reads (wrapping); xor folds of an
+    even number of equal hashes cancel."""
+    import torch
+    from kmers_amd import _lib
+
+    n = min(N_FULL, 60_000_000)
+    rng = np.random.default_rng(k)
+    one = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].copy()
+    d_one = ctx.to_device(one)
+    bases = d_one.repeat(n)
+    torch.cuda.synchronize()
+    if not two_word:
+        o = orc.canonical_reduce(one, 1, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        assert g.n_valid == n * o.n_valid
+        assert g.sum_canon == (n * o.sum_canon) & M64
+        assert g.sum_fw == (n * o.sum_fw) & M64
+        assert g.xor_hash == (o.xor_hash if n % 2 else 0)
+    else:
+        o = orc.canonical_reduce2(one, 1, L, k, with_hash=True)
+        g = ctx.canonical_reduce2(bases, n, L, k, with_hash=True)
+        assert g.n_valid == n * o.n_valid
+        tot = n * ((o.sum_hi << 64) | o.sum_lo)      # the two sums wrap independently (kmx_summary2: per-word sums)
+        assert g.sum_lo == (n * o.sum_lo) & M64 and g.sum_hi == (n * o.sum_hi) & M64, tot
+        assert (g.xor_lo, g.xor_hi) == ((o.xor_lo, o.xor_hi) if n % 2 else (0, 0))
+    del bases
+    torch.cuda.empty_cache()

@@ -1,0 +1,193 @@
+"""Round-4 GPU parity tests (all through the C ABI, bit-exact against the CPU oracle):
+  * kmx_canonical_reduce behind an offsets array from a base that is NOT 16-byte aligned (the device-gated
+    uniform / ragged pair used to be entered with a base only the uniform launcher takes, and the generic kernel then counted
+    the batch a second time);
+  * kmx_canonical_windows2 with a caller's win_offsets on uniform reads (the tiled kernel ignored them);
+  * the work-buffer ABI (kmx_ctx_set_work_buffer_limit / kmx_ctx_work_buffer_info) that replaced two environment knobs;
+  * pass 2 of the bit-sliced scan on the matrix pipe: inputs that put extreme counts into its fp32 accumulators
+    (every window canonical-forward on every read, every read identical) and every k / frame it is instantiated for."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from kmers_amd.api import Context
+
+    c = Context()
+    yield c
+    c.close()
+
+
+def _dirty(rng, n, p_bad):
+    alpha = np.frombuffer(b"ACGTacgt", np.uint8)
+    a = alpha[rng.integers(0, 8, n)].copy()
+    bad = rng.random(n) < p_bad
+    a[bad] = rng.integers(0, 256, int(bad.sum()), dtype=np.uint8)
+    return a
+
+
+def _same(g, o, want_hash=True):
+    assert g.n_valid == o.n_valid
+    assert g.sum_canon == o.sum_canon
+    assert g.xor_hash == (o.xor_hash if want_hash else 0)
+
+
+# ------------------------------------------------------------------ offsets + a misaligned base
+
+@pytest.mark.parametrize("k", [13, 31])
+@pytest.mark.parametrize("lead", [1, 7, 8, 15])
+@pytest.mark.parametrize("case", ["uniform", "one_trimmed"])
+def test_reduce_offsets_from_a_misaligned_base(ctx, orc, k, lead, case):
+    from kmers_amd import _lib
+
+    L, n_reads = 150, 64 * 50 + 11
+    rng = np.random.default_rng(1000 * k + lead)
+    lens = np.full(n_reads, L, np.int64)
+    if case == "one_trimmed":
+        lens[n_reads // 3] = L - 9
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, lead + int(offsets[-1]), 0.0005)
+    dev = ctx.to_device(host)
+    o = orc.canonical_reduce(host[lead:], n_reads, 0, k, hasher_k=k, offsets=offsets)
+    d_off = ctx.to_device(offsets)
+    for hint in (L, 0, 160):
+        g = ctx.canonical_reduce(dev[lead:], n_reads, hint, k, _lib.HASH_LEX, k, 0, offsets=d_off)
+        _same(g, o)
+    # and the summary is not doubled on the second call either
+    g = ctx.canonical_reduce(dev[lead:], n_reads, L, k, _lib.HASH_NONE, 0, 0, offsets=d_off)
+    _same(g, o, False)
+
+
+# ------------------------------------------------------------------ windows2: a caller's win_offsets on uniform reads
+
+@pytest.mark.parametrize("k", [33, 63])
+def test_windows2_honours_win_offsets_on_uniform_reads(ctx, orc, k):
+    import torch
+    from kmers_amd.api import _ptr
+
+    L, n_reads, gap = 150, 64 * 3 + 5, 5
+    W = L - k + 1
+    rng = np.random.default_rng(k)
+    host = _dirty(rng, n_reads * L, 0.001)
+    bases = ctx.to_device(host)
+    dense = ctx.canonical_windows2(bases, n_reads, L, k)
+    wo = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(W + gap))
+    d_wo = ctx.to_device(wo)
+    total = int(wo[-1])
+    outs = {n: torch.full((2 * total,), -1, dtype=torch.int64, device=bases.device) for n in ("fw", "rc", "canon")}
+    flags = torch.full((total,), 0x7F, dtype=torch.uint8, device=bases.device)
+    r = ctx._reads(bases, n_reads, L, None)
+    ctx._ck(ctx.lib.kmx_canonical_windows2(ctx._h, C.byref(r), _ptr(d_wo), k, _ptr(outs["fw"]), _ptr(outs["rc"]), _ptr(outs["canon"]), _ptr(flags)))
+    ctx.synchronize()
+    for name in ("fw", "rc", "canon"):
+        got = outs[name].cpu().numpy().reshape(total, 2)
+        want = dense[name].cpu().numpy().reshape(n_reads * W, 2)
+        for rd in (0, 1, n_reads // 2, n_reads - 1):
+            assert (got[rd * (W + gap): rd * (W + gap) + W] == want[rd * W: (rd + 1) * W]).all(), (name, rd)
+            assert (got[rd * (W + gap) + W: (rd + 1) * (W + gap)] == -1).all()      # the gap is the caller's: untouched
+    gf = flags.cpu().numpy()
+    df = dense["flags"].cpu().numpy()
+    for rd in (0, n_reads - 1):
+        assert (gf[rd * (W + gap): rd * (W + gap) + W] == df[rd * W: (rd + 1) * W]).all()
+
+
+# ------------------------------------------------------------------ the work buffer as ABI
+
+def test_work_buffer_limit_and_info(ctx, orc):
+    """a small limit forces the chunked histogram (several chunks, same table); 0 restores the automatic budget; the context
+    reports what it holds and how often it allocated"""
+    L, k, b, n_reads = 150, 31, 18, 64 * 600 + 7
+    rng = np.random.default_rng(5)
+    host = _dirty(rng, n_reads * L, 0.0003)
+    bases = ctx.to_device(host)
+    o = orc.histogram(host, n_reads, L, k, k, b)
+    held0, n0 = ctx.work_buffer_info()
+    ctx.set_work_buffer_limit(8 << 20)
+    try:
+        g = ctx.histogram(bases, n_reads, L, k, 1, k, b)
+        assert (g.cpu().numpy().view(np.uint64) == o).all()
+        held1, n1 = ctx.work_buffer_info()
+        assert held1 >= held0 and n1 >= n0
+        g = ctx.histogram(bases, n_reads, L, k, 1, k, b)
+        assert ctx.work_buffer_info()[1] == n1          # the second call re-uses the buffer
+        assert (g.cpu().numpy().view(np.uint64) == o).all()
+    finally:
+        ctx.set_work_buffer_limit(0)
+    g = ctx.histogram(bases, n_reads, L, k, 1, k, b)
+    assert (g.cpu().numpy().view(np.uint64) == o).all()
+    lib = ctx.lib
+    assert lib.kmx_ctx_set_work_buffer_limit(None, 0) != 0 and lib.kmx_ctx_work_buffer_info(None, None, None) != 0
+
+
+# ------------------------------------------------------------------ pass 2 on the matrix pipe: extreme accumulator contents
+
+@pytest.mark.parametrize("k", [13, 17, 18, 21, 31])
+@pytest.mark.parametrize("pattern", ["all_A", "all_T", "identical_reads", "alternating_AT", "poly_ACGT"])
+def test_scan_extreme_counts(ctx, orc, k, pattern):
+    """every accumulator entry of a window block gets the same sign of contribution from all 64 reads of every tile: all-A reads
+    (fw < rc in every window, every plane zero), all-T (never), 64 identical random reads per tile, and periodic reads whose
+    windows tie (fw == rc never happens for odd k; even k is not instantiated below 33 ... 64 either way the iterator's rule
+    `fw < rc` decides)"""
+    from kmers_amd import _lib
+
+    L, n_reads = 150, 64 * 40 + 9
+    rng = np.random.default_rng(k)
+    if pattern == "all_A":
+        host = np.full(n_reads * L, ord("A"), np.uint8)
+    elif pattern == "all_T":
+        host = np.full(n_reads * L, ord("T"), np.uint8)
+    elif pattern == "identical_reads":
+        one = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)]
+        host = np.tile(one, n_reads)
+    elif pattern == "alternating_AT":
+        host = np.tile(np.frombuffer(b"AT", np.uint8), n_reads * L // 2)
+    else:
+        host = np.tile(np.frombuffer(b"ACGT", np.uint8), (n_reads * L + 3) // 4)[: n_reads * L].copy()
+    o = orc.canonical_reduce(host, n_reads, L, k, hasher_k=k)
+    g = ctx.canonical_reduce(ctx.to_device(host), n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _same(g, o)
+    assert g.sum_fw == o.sum_fw
+
+
+@pytest.mark.parametrize("k", [33, 34, 48, 49, 50, 63, 64])
+@pytest.mark.parametrize("pattern", ["all_A", "identical_reads", "random"])
+def test_scan2_extreme_counts(ctx, orc, k, pattern):
+    L, n_reads = 150, 64 * 30 + 3
+    rng = np.random.default_rng(k)
+    if pattern == "all_A":
+        host = np.full(n_reads * L, ord("A"), np.uint8)
+    elif pattern == "identical_reads":
+        host = np.tile(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)], n_reads)
+    else:
+        host = _dirty(rng, n_reads * L, 0.0005)
+    o = orc.canonical_reduce2(host, n_reads, L, k, with_hash=True)
+    g = ctx.canonical_reduce2(ctx.to_device(host), n_reads, L, k, with_hash=True)
+    assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+
+@pytest.mark.parametrize("L", [36, 50, 64, 75, 80, 81, 100, 112, 113, 128, 129, 150, 160, 161, 200, 208, 209, 224, 250, 256])
+def test_scan_every_frame(ctx, orc, L):
+    """the six frames (5, 7, 8, 10, 13, 16 words) at the ends of their length ranges, k = 31 and 21, dirty"""
+    from kmers_amd import _lib
+
+    n_reads = 64 * 20 + 33
+    for k in (31, 21):
+        if L < k:
+            continue
+        rng = np.random.default_rng(L * 100 + k)
+        host = _dirty(rng, n_reads * L, 0.0004)
+        o = orc.canonical_reduce(host, n_reads, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(ctx.to_device(host), n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        _same(g, o)
+        assert g.sum_fw == o.sum_fw
