@@ -651,7 +651,9 @@ def worker(args, traffic_raw=None, traffic_err=None):
         if hist_mode:
             kernel_name = "kmx::scan_uniform_kernel<SinkHist*> (partition pass + per-partition tables)"
         elif bs_kernel:
-            kernel_name = "kmx::scan_bitsliced_kernel<%d,%d,*>" % (k, 7 if (L <= 112 and k <= 32) else 10 if L <= 160 else 16)
+            # the frame (packed dwords per read) launch_bs_any picks: 5 / 7 / 8 / 10 / 13 / 16 words for reads of up to 80 / 112 / 128 / 160 / 208 / 256 bases
+            frame = 10 if (k > 32 or args.packed) and L <= 160 else 16 if args.packed else next(nw for nw, lmax in ((5, 80), (7, 112), (8, 128), (10, 160), (13, 208), (16, 256)) if L <= lmax)
+            kernel_name = "kmx::scan_bitsliced_kernel<%d,%d,*>" % (k, frame)
         else:
             kernel_name = "kmx::scan_uniform_kernel" if k <= 31 else "kmx::reduce2_generic_kernel"
         cfg_names = {"1": "BASELINE configs[1]", "2": "BASELINE configs[2]", "3": "BASELINE configs[3]", "4": "BASELINE configs[4]"}
