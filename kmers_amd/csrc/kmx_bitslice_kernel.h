@@ -110,13 +110,13 @@ constexpr int BS_LOAD_NT = 2;   // cache policy of the tile loads (aux bit 1 = n
 // fp32 accumulator blocks (16 registers each) of pass 2: window block i (32 windows) meets the planes of bases 32i .. 32i+K+30,
 // i.e. the blocks of 16 bases (32 planes) 2i .. 2i + bs_acc_blocks(K) - 1
 constexpr int bs_acc_blocks(int K) { return (K + 30) / 16 + 1; }
-// Waves per SIMD a variant is compiled for.  With 16 bs_acc_blocks(K) accumulators and the prefetch rows of a tile in
-// registers the kernels need 130..168 registers: three waves (measured round 4: a 32-accumulator form at four waves was 3 %
-// slower than this one at three -- profiles/r04_mfma_variants.txt).  The two-word k above 48 (six accumulator blocks; k = 41 / 47 at three waves 0.69 / 0.68 of the roofline against 0.64 / 0.63 at two, k = 55 / 63 spill and fall from 0.64 / 0.63 to 0.48), the ragged
-// variants (190..214 registers: at three waves they spill 30..170 bytes and run 30 % slower) and the 16-word frame below 8
-// windows per lane run at two.
+// Waves per SIMD a variant is compiled for.  With 16 (bs_acc_blocks(K) - 1) accumulators and the prefetch rows of a tile in
+// registers the kernels need 100..168 registers: three waves (measured round 4: a 32-accumulator form at four waves was 3 %
+// slower than the 64-accumulator one at three -- profiles/r04_mfma_variants.txt; the short frames that fit 128 registers run
+// at four).  The ragged variants on the 16-word frame and at 5 windows per lane (176..248 registers) run at two: at three they
+// spill up to 68 bytes and lose 1..3 %.
 template <int K, int NW, int WPL, bool PACKED, bool RAGGED> constexpr int bs_waves() {
-    return (K > 48 || RAGGED || (NW == 16 && WPL < 8)) ? 2 : 3;
+    return (RAGGED && (NW > 10 || WPL > 4)) ? 2 : 3;
 }
 // tiles between two folds of the fp32 accumulators into the 64-bit class sums: a power of two, far below the 2^24 / (8 window
 // blocks x 64 reads) the sums stay exact integers for, and small enough that the full-size runs (~500 tiles per wave) exercise
@@ -261,12 +261,17 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         m.fits = nch <= (u64)chunks && nch <= 64u * NW && !__any(m.len > L) && m.base + 16u * nch <= total_bytes;   // (one compare + a scalar test: a wave-wide max costs ten instructions)
     };
     u32 n_bs_tiles = 0;
-    // pass 2 on the matrix pipe (see phase D): acc[q] collects the block pair (window block i, plane block 2i + q) of EVERY i and
-    // every tile
+    // pass 2 on the matrix pipe (see phase D): block pair q = (window block i, plane block 2i + q) of EVERY i and every tile goes
+    // to the same accumulator block.  The first and the last pair share ONE: of pair 0 (bases 0..15 past the window block's
+    // first) only the windows 0..15 can lie on a diagonal 0 <= t < K, of pair NAB-1 only the windows 16..31 (16 NAB - 31 >= K).
+    // The rows that do not count are switched off through the A operand's per-lane E8M0 scale (0 = 2^-127: what they add
+    // vanishes next to an integer and truncates to 0 where there is none -- tools/mfma/fp4_share_probe.hip).
     constexpr int NAB = bs_acc_blocks(K);
-    bs_v16f acc[NAB];
+    constexpr int NAR = NAB - 1;       // accumulator blocks in registers
+    static_assert(NAB >= 3 && 16 * NAB - 31 >= K, "the first and the last block pair share an accumulator block");
+    bs_v16f acc[NAR];
 #pragma unroll
-    for (int q = 0; q < NAB; ++q)
+    for (int q = 0; q < NAR; ++q)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
     u64* const CSA = reinterpret_cast<u64*>(P + ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u));
@@ -280,10 +285,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         const int pb = (int)((ln_ & 31u) >> 1) - 4 * (int)(ln_ >> 5);
         u64* const cs_b = CSA + (ln_ & 1u);
 #pragma unroll
-        for (int q = 0; q < NAB; ++q) {
+        for (int q = 0; q < NAR; ++q) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int t = 16 * q + pb - ((j & 3) + 8 * (j >> 2));
+                // (registers 8..15 of the shared block are the rows 16..31: block pair NAB - 1)
+                const int t = 16 * ((q == 0 && j >= 8) ? NAB - 1 : q) + pb - ((j & 3) + 8 * (j >> 2));
                 if (t >= 0 && t <= K - 1) {
                     const int tc = t < K - 1 - t ? t : K - 1 - t;
                     atomicAdd(reinterpret_cast<unsigned long long*>(cs_b + 2 * tc), (unsigned long long)(u32)acc[q][j]);
@@ -916,16 +922,25 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 const u32 slot0 = ROT ? (b0 % (u32)RW) * S2 + (b0 / (u32)RW) : b0;
                 const u32* const prd = PL + (set * SP + 2u * slot0 + (pp & 1u));
                 const int unit = 0x7F7F7F7F;    // E8M0 scale 2^0 in every byte
+                const int rows_lo = pp < 16u ? unit : 0, rows_hi = pp < 16u ? 0 : unit;   // the shared accumulator block: which rows of A count
                 bs_v8i A[WPL];
 #pragma unroll
                 for (int g = 0; g < NW; ++g) {
                     const bs_v8i B = fp4_operand_b(prd[ROT ? (32 / RW) * g : 32 * g]);
+                    // (window blocks in ascending order for even g, descending for odd g: two products into the shared block are then
+                    // never back to back)
 #pragma unroll
-                    for (int i = 0; i < WPL; ++i) {
+                    for (int ii = 0; ii < WPL; ++ii) {
+                        const int i = (g & 1) ? WPL - 1 - ii : ii;
                         const int q = g - 2 * i;
                         if (q < 0 || q >= NAB) continue;
                         if (q == 0) A[i] = fp4_operand_a(ab[i]);     // first use of window block i
-                        acc[q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[i], B, acc[q], 4, 4, 0, unit, 0, unit);
+                        if (q == 0)
+                            acc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[i], B, acc[0], 4, 4, 0, rows_lo, 0, unit);
+                        else if (q == NAB - 1)
+                            acc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[i], B, acc[0], 4, 4, 0, rows_hi, 0, unit);
+                        else
+                            acc[q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[i], B, acc[q], 4, 4, 0, unit, 0, unit);
                     }
                 }
             }
