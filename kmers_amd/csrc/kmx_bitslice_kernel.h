@@ -475,6 +475,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     constexpr u32 NQ = 32;
     u32 qid = (blockIdx.x & 255u) >> 3;
     u32 heads_left = NQ;                                // heads this wave has not yet seen exhausted
+    // Every ticket from the NEXT head (round 4): a wave that stayed with "its" head tied the head's pace to the 24 blocks that
+    // share it, the heads drifted apart, and with them the addresses in flight -- the HBM stream is measurably better when the
+    // tiles being read lie close together (+1..2 %; tools/stream_patterns.hip).  Until the first head is seen exhausted: from
+    // then on the heads are swept once, in order, as before.
+    bool rot = true;
     auto dequeue = [&]() -> u64 {
         while (heads_left != 0u) {
             unsigned long long v = 0;
@@ -482,6 +487,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
             const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
             if (t < n_full) return t;
+            rot = false;
             qid = (qid + 1u) & (NQ - 1u);               // this head is drained: help with the next one
             heads_left -= 1u;
         }
@@ -498,12 +504,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             asm volatile("" : "+v"(one));
             pend = (u32)atomicAdd(queue + qid * 16u, one);
         }
+        if (rot) qid = (qid + 1u) & (NQ - 1u);
     };
     auto ticket_take = [&]() -> u64 {
         if (heads_left == 0u) return ~0ull;
         const u32 lo = __builtin_amdgcn_readfirstlane(pend);
         const u64 t = (u64)lo * NQ + pend_qid;
         if (t < n_full) return t;
+        rot = false;
         qid = (pend_qid + 1u) & (NQ - 1u);   // that head is drained: move on, synchronously (rare)
         heads_left -= 1u;
         return dequeue();

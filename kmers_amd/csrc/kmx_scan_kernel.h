@@ -108,13 +108,18 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     constexpr u32 NQ = 32;
     u32 qid = (blockIdx.x & 255u) >> 3;
     u32 heads_left = NQ;
+    bool rot = true;   // every ticket from the next head until the first head is seen exhausted (kmx_bitslice_kernel.h: the heads keep pace, the tiles in flight stay close together)
     auto dequeue = [&]() -> u64 {
         while (heads_left != 0u) {
             unsigned long long v = 0;
             if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);
             const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
             const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
-            if (t < n_full) return t;
+            if (t < n_full) {
+                if (rot) qid = (qid + 1u) & (NQ - 1u);
+                return t;
+            }
+            rot = false;
             qid = (qid + 1u) & (NQ - 1u);
             heads_left -= 1u;
         }
