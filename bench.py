@@ -647,12 +647,13 @@ def worker(args, traffic_raw=None, traffic_err=None):
             td = traffic_from_counters(traffic_raw, float(nbytes), 3)
             if td is not None:
                 traffic, traffic_detail = td["bytes_per_step"], td
-        bs_kernel = (13 <= k <= 31 or (33 <= k <= 63 and L <= 160)) and L <= 256
+        bs_kernel = (13 <= k <= 31 or 33 <= k <= 64) and L <= 256
         if hist_mode:
             kernel_name = "kmx::scan_uniform_kernel<SinkHist*> (partition pass + per-partition tables)"
         elif bs_kernel:
             # the frame (packed dwords per read) launch_bs_any picks: 5 / 7 / 8 / 10 / 13 / 16 words for reads of up to 80 / 112 / 128 / 160 / 208 / 256 bases
-            frame = 10 if (k > 32 or args.packed) and L <= 160 else 16 if args.packed else next(nw for nw, lmax in ((5, 80), (7, 112), (8, 128), (10, 160), (13, 208), (16, 256)) if L <= lmax)
+            frame = 10 if (k > 32 or args.packed) and L <= 160 else 16 if args.packed else (13 if L <= 208 else 16) if k > 32 else \
+                next(nw for nw, lmax in ((5, 80), (7, 112), (8, 128), (10, 160), (13, 208), (16, 256)) if L <= lmax)
             kernel_name = "kmx::scan_bitsliced_kernel<%d,%d,*>" % (k, frame)
         else:
             kernel_name = "kmx::scan_uniform_kernel" if k <= 31 else "kmx::reduce2_generic_kernel"

@@ -79,7 +79,7 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
-    if (L < k || L > 160 || ((reinterpret_cast<uintptr_t>(bases) & 15u) && L == 160)) return hipSuccess;
+    if (L < k || L > 256 || ((reinterpret_cast<uintptr_t>(bases) & 15u) && (L == 160 || L == 256))) return hipSuccess;
     if (n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
 #define KMX_BS2_CASE(K) \
     case K:             \

@@ -114,9 +114,9 @@ constexpr int bs_acc_blocks(int K) { return (K + 30) / 16 + 1; }
 // registers the kernels need 100..168 registers: three waves (measured round 4: a 32-accumulator form at four waves was 3 %
 // slower than the 64-accumulator one at three -- profiles/r04_mfma_variants.txt; the short frames that fit 128 registers run
 // at four).  The ragged variants on the 16-word frame and at 5 windows per lane (176..248 registers) run at two: at three they
-// spill up to 68 bytes and lose 1..3 %.
+// spill up to 68 bytes and lose 1..3 %; so do the two-word k on the 13- and 16-word frames (200+ bytes of spills at three).
 template <int K, int NW, int WPL, bool PACKED, bool RAGGED> constexpr int bs_waves() {
-    return (RAGGED && (NW > 10 || WPL > 4)) ? 2 : 3;
+    return ((RAGGED && (NW > 10 || WPL > 4)) || (K > 32 && NW > 10)) ? 2 : 3;
 }
 // tiles between two folds of the fp32 accumulators into the 64-bit class sums: a power of two, far below the 2^24 / (8 window
 // blocks x 64 reads) the sums stay exact integers for, and small enough that the full-size runs (~500 tiles per wave) exercise
@@ -425,7 +425,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     // rows of the prefetch requested late (between the passes of phase D; their registers are free until then): half of a tile's
     // rows -- 5 of 10, 7 of 13, 8 of 16 --, 3 of the 7 (5) rows of the short frames
-    constexpr int LATE = PACKED ? 0 : NW == 10 ? 5 : NW < 10 ? (K > 32 ? 0 : 3) : K > 32 ? 0 : NW == 13 ? 7 : 8;
+    constexpr int LATE = PACKED ? 0 : NW == 10 ? 5 : NW < 10 ? (K > 32 ? 0 : 3) : NW == 13 ? 7 : 8;
     u64 tile = ~0ull, next_tile = ~0ull;
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
         const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
@@ -942,6 +942,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                         const int i = (g & 1) ? WPL - 1 - ii : ii;
                         const int q = g - 2 * i;
                         if (q < 0 || q >= NAB) continue;
+                        if (32u * (u32)i >= W) continue;             // (wave-uniform: a window block past the last window -- the two-word k on the long frames run with more windows per lane than their reads have)
                         if (q == 0) A[i] = fp4_operand_a(ab[i]);     // first use of window block i
                         if (q == 0)
                             acc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[i], B, acc[0], 4, 4, 0, rows_lo, 0, unit);
@@ -1425,11 +1426,18 @@ static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
     return launch_bs<K, 10, 5, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
 }
 
-// [u64;2] k-mers (k in 33..64, L <= 160): WPL so that 2*ceil(W/WPL) <= 64
+// [u64;2] k-mers (k in 33..64): WPL = ceil(W / 32) on the 10-word frame; reads of 161..208 / 209..256 bases (round 4) take the
+// 13- / 16-word frame with ONE instantiation each -- 6 / 7 windows per lane hold every W a two-word k leaves there (<= 176 / 224),
+// the window blocks past W are skipped at run time
 template <int K>
 static hipError_t launch_bs2_any(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, void* out, unsigned long long* queue,
                                  int n_cu, hipStream_t stream) {
     const u32 W = L - (u32)K + 1u;
+    if (L > 160) {
+        const u32 mis = (reinterpret_cast<uintptr_t>(bases) & 15u) ? 1u : 0u;
+        if (4u * L + mis <= 64u * 13u) return launch_bs<K, 13, 6>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
+        return launch_bs<K, 16, 7>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
+    }
     if (W <= 64u) return launch_bs<K, 10, 2>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
     if (W <= 96u) return launch_bs<K, 10, 3>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
     return launch_bs<K, 10, 4>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);

@@ -191,3 +191,29 @@ def test_scan_every_frame(ctx, orc, L):
         g = ctx.canonical_reduce(ctx.to_device(host), n_reads, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
         _same(g, o)
         assert g.sum_fw == o.sum_fw
+
+
+# ------------------------------------------------------------------ two-word k on the 13- and 16-word frames
+
+@pytest.mark.parametrize("k", [33, 47, 48, 49, 63, 64])
+@pytest.mark.parametrize("L", [161, 176, 200, 208, 209, 224, 250, 256])
+def test_reduce2_on_the_long_frames(ctx, orc, k, L):
+    """kmx_canonical_reduce2 on reads of 161..256 bases took the lane-per-read kernel (0.4 TB/s) until round 4; now the bit-sliced
+    kernel's 13- / 16-word frames with 6 / 7 windows per lane (window blocks past the read's last window are skipped)"""
+    n_reads = 64 * 9 + 21
+    rng = np.random.default_rng(k * 1000 + L)
+    host = _dirty(rng, n_reads * L, 0.0004)
+    o = orc.canonical_reduce2(host, n_reads, L, k, with_hash=True)
+    g = ctx.canonical_reduce2(ctx.to_device(host), n_reads, L, k, with_hash=True)
+    assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+
+@pytest.mark.parametrize("lead", [3, 8])
+def test_reduce2_long_frames_unaligned_base(ctx, orc, lead):
+    k, L, n_reads = 63, 250, 64 * 5 + 2
+    rng = np.random.default_rng(lead)
+    host = _dirty(rng, lead + n_reads * L, 0.0005)
+    dev = ctx.to_device(host)
+    o = orc.canonical_reduce2(host[lead:], n_reads, L, k, with_hash=True)
+    g = ctx.canonical_reduce2(dev[lead:], n_reads, L, k, with_hash=True)
+    assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
