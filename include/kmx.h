@@ -61,7 +61,10 @@ typedef struct kmx_ctx kmx_ctx;
  *   then carry an upper bound of the read lengths (0 = unknown): a bound <= 160 selects the smaller, faster frame of the
  *   tiled kernels, and the tighter it is the fewer windows a lane carries (150 bp reads: 7 % faster at k = 31 with 150
  *   than with 160 or 0).  It is only a hint -- tiles with a longer read take the exact per-read path, and the
- *   histogram's work buffer, sized from it, overflows into exact (slow) global atomics.
+ *   histogram's work buffer, sized from it, overflows into exact (slow) global atomics.  A bound ABOVE 256 says "long reads"
+ *   (PacBio / ONT reads, contigs): kmx_canonical_reduce (13 <= k <= 31, 16-byte aligned d_bases) then cuts every read into
+ *   overlapping segments on the device and scans those (one host round trip for the batch's first and last offset; the segment
+ *   arrays live in the context's work buffer); with 0 or a bound <= 256 a long read costs its tile the per-read path.
  * d_bases must be a device pointer whenever n_reads > 0, also when every read is empty (KMX_E_ARG otherwise). */
 typedef struct {
     const uint8_t *d_bases;

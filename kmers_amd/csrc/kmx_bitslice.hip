@@ -58,7 +58,7 @@ KMX_BS2_DEFINE_K(63)
 // segments of long uniform reads (offsets == nullptr there).
 hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 L_hint, u32 k, bool want_hash,
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
-                                        bool want_sumfw) {
+                                        bool want_sumfw, const u64* ends) {
     *handled = false;
     if (!offsets || (reinterpret_cast<uintptr_t>(bases) & 15u) || L_hint > 256) return hipSuccess;
     u32 Lf = L_hint ? L_hint : 160u;
@@ -67,7 +67,7 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
 #define KMX_BSR_CASE(K) \
     case K:             \
         *handled = true; \
-        return launch_bs_ragged_k##K(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, 0, want_sumfw ? 1u : 0u);
+        return launch_bs_ragged_k##K(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, 0, want_sumfw ? 1u : 0u, ends);
     switch (k) {
         KMX_BSR_FOR_EACH_K(KMX_BSR_CASE)
         default:
@@ -110,7 +110,7 @@ hipError_t launch_scan_bitsliced_long(const uint8_t* bases, u64 n_reads, u32 L, 
 #define KMX_BSL_CASE(K) \
     case K:             \
         *handled = true; \
-        return launch_bs_ragged_k##K(bases, nullptr, n_seg, Lf, want_hash, out, queue, n_cu, stream, T, L);
+        return launch_bs_ragged_k##K(bases, nullptr, n_seg, Lf, want_hash, out, queue, n_cu, stream, T, L, nullptr);
     switch (k) {
         KMX_BSR_FOR_EACH_K(KMX_BSL_CASE)
         default:

@@ -126,7 +126,10 @@ template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
 __global__ void __launch_bounds__(256, (bs_waves<K, NW, WPL, PACKED, RAGGED>()))
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
-                      unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead) {
+                      unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead,
+                      const u64* __restrict__ ends) {
+    // `ends` (RAGGED with offsets): read r = bases[offsets[r], ends[r]) -- offsets + 1 for reads stored back to back, an array of
+    // its own for the overlapping SEGMENTS a batch of long ragged reads was cut into (kmx_segments.hip, round 4).
     // `lead` (uniform ASCII input whose first byte is not 16-byte aligned): `bases` is the aligned address below it and
     // read r starts at byte lead + r*L.  A tile then spans one more chunk (its first holds the tail of the tile before
     // it), exactly like a ragged tile streamed from its aligned start; 0 for every other input.
@@ -226,7 +229,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         const u64 e = o0 + seg_T + (u32)(K - 1), re = (i + 1u) * (u64)seg_L;
         o1 = e < re ? e : re;
     };
-    const u64 total_bytes = !RAGGED ? 0 : seg_mode ? (n_reads / seg_J) * (u64)seg_L : offsets[n_reads];
+    const u64 total_bytes = !RAGGED ? 0 : seg_mode ? (n_reads / seg_J) * (u64)seg_L : ends[n_reads - 1u];
     // ragged: per-tile geometry of the current and of the next tile (rel/len per lane, the rest wave-uniform)
     struct TileMeta { u32 rel = 0, len = 0, n_ch = 0; u64 base = 0; bool fits = true; };
     TileMeta cur_m, nx_m;
@@ -243,7 +246,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             raw_o1 = e < re ? e : re;
         } else {
             raw_o0 = offsets[t * 64u + lane];
-            raw_o1 = offsets[t * 64u + lane + 1u];
+            raw_o1 = ends[t * 64u + lane];
         }
     };
     auto meta_finish = [&](TileMeta& m) {
@@ -339,7 +342,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         if constexpr (RAGGED) {
             u64 o0, o1;
             if (seg_mode) seg_bounds(read, o0, o1);
-            else { o0 = offsets[read]; o1 = offsets[read + 1u]; }
+            else { o0 = offsets[read]; o1 = ends[read]; }
             if (read_too_long(o1 - o0, queue + KMX_TOOLONG_FROM_QUEUE)) return;   // (not scanned; kmx_ctx_synchronize reports it)
             roll_read(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
                 const u64 canon = fw < rc ? fw : rc;
@@ -1192,7 +1195,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 template <int K, bool RAGGED>
 __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash,
                                                            u32 want_sumfw, void* __restrict__ out, unsigned long long* __restrict__ queue,
-                                                           const u64* __restrict__ offsets, u32 lead) {
+                                                           const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends) {
     u64* const masks = reinterpret_cast<u64*>(queue[515]);
     if (masks == nullptr || queue[512] == 0) return;   // queue[512]: "a tile was marked" (zeroed by the caller with the heads)
     __shared__ u64 aside_all[4][64];
@@ -1227,7 +1230,7 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
                     o1 = e < re ? e : re;
                 } else {
                     o0 = offsets[read];
-                    o1 = offsets[read + 1u];
+                    o1 = ends[read];
                 }
                 sp = bases + o0;
                 len = (u32)(o1 - o0);
@@ -1326,7 +1329,9 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
 static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
                             unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets = nullptr,
-                            u32 seg_T = 0 /* RAGGED, offsets == nullptr: segments of long uniform reads, see the kernel */) {
+                            u32 seg_T = 0 /* RAGGED, offsets == nullptr: segments of long uniform reads, see the kernel */,
+                            const u64* ends = nullptr /* RAGGED with offsets: the reads' ends (nullptr: offsets + 1) */) {
+    if (offsets != nullptr && ends == nullptr) ends = offsets + 1;
     auto kern = scan_bitsliced_kernel<K, NW, WPL, PACKED, RAGGED>;
     // uniform ASCII reads from a base that is not 16-byte aligned: the kernel streams from the aligned address below it
     u32 lead = 0;
@@ -1364,14 +1369,14 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     const u64 need = (n_tiles + 3u) / 4u;
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets, lead);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets, lead, ends);
     if constexpr (!PACKED) {
         // the reads the main pass blanked out (none on clean input: the waves return at once)
         u64 grid1 = (u64)n_cu * 4u;
         const u64 need1 = ((n_reads >> 6) + 255u) / 256u;   // a wave takes 64 masks at a time
         if (grid1 > need1) grid1 = need1;
         hipLaunchKernelGGL((roll_flagged_kernel<K, RAGGED>), dim3((unsigned)(grid1 ? grid1 : 1)), dim3(256), 0, stream, bases, n_reads, L, want_hash,
-                           want_sumfw, out, queue, offsets, lead);
+                           want_sumfw, out, queue, offsets, lead, ends);
     }
     return hipGetLastError();
 }
@@ -1458,29 +1463,29 @@ static hipError_t launch_bs2_any(const uint8_t* bases, u64 n_reads, u32 L, u32 w
 // offsets == nullptr: segments of uniform reads of seg_L bases, seg_T windows each (n_reads = segments, Lf = seg_T + K - 1)
 template <int K>
 static hipError_t launch_bs_ragged_any(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out,
-                                       unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L) {
+                                       unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L, const u64* ends) {
     const u32 W = Lf - (u32)K + 1u;
     if (Lf > 160) {
-        if (W <= 160u) return launch_bs<K, 16, 5, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
-        if (W <= 192u) return launch_bs<K, 16, 6, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
-        if (W <= 224u) return launch_bs<K, 16, 7, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
-        return launch_bs<K, 16, 8, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+        if (W <= 160u) return launch_bs<K, 16, 5, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
+        if (W <= 192u) return launch_bs<K, 16, 6, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
+        if (W <= 224u) return launch_bs<K, 16, 7, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
+        return launch_bs<K, 16, 8, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
     }
     if (Lf <= 111u && Lf >= (u32)K) {   // short reads (a tile of 64 spans at most 448 chunks): the 7-word frame
-        if (W <= 96u) return launch_bs<K, 7, 3, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
-        return launch_bs<K, 7, 4, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+        if (W <= 96u) return launch_bs<K, 7, 3, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
+        return launch_bs<K, 7, 4, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
     }
-    if (W <= 96u) return launch_bs<K, 10, 3, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
-    if (W <= 128u) return launch_bs<K, 10, 4, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
-    return launch_bs<K, 10, 5, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T);
+    if (W <= 96u) return launch_bs<K, 10, 3, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
+    if (W <= 128u) return launch_bs<K, 10, 4, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
+    return launch_bs<K, 10, 5, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
 }
 #define KMX_BSR_DECLARE_K(K) \
     hipError_t launch_bs_ragged_k##K(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out, \
-                                     unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L);
+                                     unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L, const u64* ends);
 #define KMX_BSR_DEFINE_K(K)                                                                                                  \
     hipError_t launch_bs_ragged_k##K(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out, \
-                                     unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L) {         \
-        return launch_bs_ragged_any<K>(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, seg_T, seg_L);       \
+                                     unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L, const u64* ends) { \
+        return launch_bs_ragged_any<K>(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, seg_T, seg_L, ends);  \
     }
 // k with a bit-sliced kernel for ragged reads: 13..31, like the uniform kernel
 #define KMX_BSR_FOR_EACH_K(X) \

@@ -217,3 +217,41 @@ def test_reduce2_long_frames_unaligned_base(ctx, orc, lead):
     o = orc.canonical_reduce2(host[lead:], n_reads, L, k, with_hash=True)
     g = ctx.canonical_reduce2(dev[lead:], n_reads, L, k, with_hash=True)
     assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+
+# ------------------------------------------------------------------ long ragged reads: segments built on the device
+
+@pytest.mark.parametrize("k", [13, 21, 31])
+@pytest.mark.parametrize("case", ["long", "mixed", "few_huge", "with_empty"])
+def test_reduce_long_ragged_reads(ctx, orc, k, case):
+    """a length bound above 256 = "long reads": every read is cut into overlapping segments on the device (kmx_segments.hip) and
+    the ragged bit-sliced kernel scans those; the summary is the per-read iterator's"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(k * 31 + len(case))
+    if case == "long":
+        lens = rng.integers(300, 5000, 700)
+    elif case == "mixed":
+        lens = np.where(rng.random(3000) < 0.3, rng.integers(257, 3000, 3000), rng.integers(0, 257, 3000))
+    elif case == "few_huge":
+        lens = np.array([250_000, 17, 131_313, k, k - 1, 90_001])
+    else:
+        lens = rng.integers(200, 2000, 900)
+        lens[rng.integers(0, 900, 60)] = 0
+        lens[rng.integers(0, 900, 60)] = k - 1
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n_reads = len(lens)
+    host = _dirty(rng, int(offsets[-1]), 0.0002)
+    o = orc.canonical_reduce(host, n_reads, 0, k, hasher_k=k, offsets=offsets)
+    dev, d_off = ctx.to_device(host), ctx.to_device(offsets)
+    for _ in range(2):   # (twice: the work buffer and the masks of the dirty reads are re-used)
+        g = ctx.canonical_reduce(dev, n_reads, 1 << 20, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=d_off)
+        _same(g, o)
+        assert g.sum_fw == o.sum_fw
+    g = ctx.canonical_reduce(dev, n_reads, 300, k, _lib.HASH_NONE, 0, 0, offsets=d_off)
+    _same(g, o, False)
+    # and from an offsets array that does not start at 0 (a slice of a larger batch)
+    cut = n_reads // 3
+    o2 = orc.canonical_reduce(host, n_reads - cut, 0, k, hasher_k=k, offsets=offsets[cut:])
+    g2 = ctx.canonical_reduce(dev, n_reads - cut, 100_000_000, k, _lib.HASH_LEX, k, 0, offsets=d_off[cut:])
+    _same(g2, o2)
