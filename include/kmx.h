@@ -63,8 +63,8 @@ typedef struct kmx_ctx kmx_ctx;
  *   than with 160 or 0).  It is only a hint -- tiles with a longer read take the exact per-read path, and the
  *   histogram's work buffer, sized from it, overflows into exact (slow) global atomics.  A bound ABOVE 256 says "long reads"
  *   (PacBio / ONT reads, contigs): kmx_canonical_reduce (13 <= k <= 31, 16-byte aligned d_bases) then cuts every read into
- *   overlapping segments on the device and scans those (one host round trip for the batch's first and last offset; the segment
- *   arrays live in the context's work buffer); with 0 or a bound <= 256 a long read costs its tile the per-read path.
+ *   overlapping segments on the device and scans those (two host round trips: the batch's first and last offset, the number of
+ *   segments; the segment arrays live in the context's work buffer); with 0 or a bound <= 256 a long read costs its tile the per-read path.
  * d_bases must be a device pointer whenever n_reads > 0, also when every read is empty (KMX_E_ARG otherwise). */
 typedef struct {
     const uint8_t *d_bases;

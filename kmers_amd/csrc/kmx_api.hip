@@ -36,8 +36,9 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
 // kmx_segments.hip
 size_t segments_scratch_bytes(u64 n_reads, u64 seg_capacity);
 u64 segments_capacity(u64 n_reads, u64 total_bases, u32 t_max);
-hipError_t launch_segments_build(const u64* offsets, u64 n_reads, u32 k, u32 t_max, u64 seg_capacity, u64 end_of_bases, void* scratch,
-                                 const u64** starts_out, const u64** ends_out, unsigned long long* too_long, hipStream_t stream);
+hipError_t launch_segments_build(const u64* offsets, u64 n_reads, u32 k, u32 t_max, u64 seg_capacity, void* scratch,
+                                 const u64** starts_out, const u64** ends_out, const u64** total_out, unsigned long long* too_long,
+                                 hipStream_t stream);
 hipError_t launch_scan_bitsliced_long(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary* out,
                                       unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
@@ -467,9 +468,9 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
         if (!handled && reads->d_offsets && reads->read_len > 256 && k >= 13 && k <= 31 &&
             (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
             // Long ragged reads (a length bound above the frames: PacBio / ONT reads, contigs), round 4: cut into overlapping
-            // segments on the device (kmx_segments.hip) and scanned by the ragged bit-sliced kernel as reads of their own.  The
-            // one host round trip of this path: the first and the last offset (the segment arrays are sized from the number of
-            // bases).  No scratch -> the lane-per-read kernel below.
+            // segments on the device (kmx_segments.hip) and scanned by the ragged bit-sliced kernel as reads of their own.  Two
+            // host round trips: the first and the last offset (the segment arrays are sized from the number of bases), then the
+            // number of segments.  No scratch -> the lane-per-read kernel below.
             KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, reads->d_offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
             KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned + 1, reads->d_offsets + reads->n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
             KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -480,11 +481,17 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
                 void* scratch = big_scratch(ctx, kmx::segments_scratch_bytes(reads->n_reads, cap));
                 if (scratch) {
                     ctx->fx_valid = false;   // (the work buffer is overwritten: the fastx chunk prefixes in it are gone)
-                    const uint64_t *starts = nullptr, *ends = nullptr;
-                    KMX_HIP(ctx, kmx::launch_segments_build(reads->d_offsets, reads->n_reads, k, t_max, cap, o_last, scratch, &starts, &ends,
+                    const uint64_t *starts = nullptr, *ends = nullptr, *d_total = nullptr;
+                    KMX_HIP(ctx, kmx::launch_segments_build(reads->d_offsets, reads->n_reads, k, t_max, cap, scratch, &starts, &ends, &d_total,
                                                             ctx->d_scratch + 8, ctx->stream));
-                    if (int st = prepare_dirty_flags(ctx, cap, k)) return st;
-                    KMX_HIP(ctx, kmx::launch_scan_bitsliced_ragged(reads->d_bases, starts, cap, t_max + k - 1u, k, want_fold, d_out,
+                    // (the second and last round trip: how many segments there are -- the bound above is up to one per read too high)
+                    KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+                    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    const uint64_t n_seg = ctx->h_pinned[0];
+                    if (n_seg == 0) return KMX_OK;   // no read holds a window
+                    if (n_seg > cap) return fail_hip(ctx, hipErrorUnknown, "segment count above its bound");
+                    if (int st = prepare_dirty_flags(ctx, n_seg, k)) return st;
+                    KMX_HIP(ctx, kmx::launch_scan_bitsliced_ragged(reads->d_bases, starts, n_seg, t_max + k - 1u, k, want_fold, d_out,
                                                                    ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled, want_sumfw, ends));
                 }
             }

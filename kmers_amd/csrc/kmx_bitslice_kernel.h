@@ -113,10 +113,13 @@ constexpr int bs_acc_blocks(int K) { return (K + 30) / 16 + 1; }
 // Waves per SIMD a variant is compiled for.  With 16 (bs_acc_blocks(K) - 1) accumulators and the prefetch rows of a tile in
 // registers the kernels need 100..168 registers: three waves (measured round 4: a 32-accumulator form at four waves was 3 %
 // slower than the 64-accumulator one at three -- profiles/r04_mfma_variants.txt; the short frames that fit 128 registers run
-// at four).  The ragged variants on the 16-word frame and at 5 windows per lane (176..248 registers) run at two: at three they
-// spill up to 68 bytes and lose 1..3 %; so do the two-word k on the 13- and 16-word frames (200+ bytes of spills at three).
+// at four).  The ragged variants (176..248 registers) and the two-word k on the 13- and 16-word frames run at two.  The ragged
+// 10-word frame at three waves spills 8..68 bytes and measured 4..10 % faster -- and one build of it returned a wrong
+// sum_canon on 1.2e6 segments of 1000-base reads (tests/test_gpu_round4.py::test_long_uniform_reads_at_size) while a build
+// that differed by the order of two conjuncts passed: a spill-dependent miscompare not understood yet, so no ragged variant
+// is compiled into spills.
 template <int K, int NW, int WPL, bool PACKED, bool RAGGED> constexpr int bs_waves() {
-    return ((RAGGED && (NW > 10 || WPL > 4)) || (K > 32 && NW > 10)) ? 2 : 3;
+    return (RAGGED || (K > 32 && NW > 10)) ? 2 : 3;
 }
 // tiles between two folds of the fp32 accumulators into the 64-bit class sums: a power of two, far below the 2^24 / (8 window
 // blocks x 64 reads) the sums stay exact integers for, and small enough that the full-size runs (~500 tiles per wave) exercise
@@ -411,7 +414,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     auto issue_loads_ragged = [&](const TileMeta& m, int row0 = 0, int row1 = 64) {
         // unconditional (a tile outside the frame reads 16 bytes of the queue block instead, and rolls per lane): loads under a
         // branch make hipcc wait with vmcnt(0) where phase A would count them down
-        const uint8_t* __restrict__ tb = m.fits ? bases + m.base : reinterpret_cast<const uint8_t*>(queue);
+        // (the stand-in source: a quiet line of the queue block, NOT the ticket heads -- reads of a line that thousands of atomics
+        // hit at the same time took ~2.6 us apiece, 26 us per tile that does not fit)
+        const uint8_t* __restrict__ tb = m.fits ? bases + m.base : reinterpret_cast<const uint8_t*>(queue + 544);
         const u32 lo = m.fits ? (m.n_ch - 1u) * 16u : 0u;
         u32 l16 = lane16;                       // (opaque copy: see issue_loads)
         asm volatile("" : "+v"(l16));
@@ -482,7 +487,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // share it, the heads drifted apart, and with them the addresses in flight -- the HBM stream is measurably better when the
     // tiles being read lie close together (+1..2 %; tools/stream_patterns.hip).  Until the first head is seen exhausted: from
     // then on the heads are swept once, in order, as before.
-    bool rot = true;
+    bool rot = !RAGGED;   // (the ragged variants measured 10 % SLOWER with it, same box, same day: profiles/r04_rotation_ragged.txt)
     auto dequeue = [&]() -> u64 {
         while (heads_left != 0u) {
             unsigned long long v = 0;

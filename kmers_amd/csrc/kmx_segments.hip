@@ -7,9 +7,9 @@
 // (scan_bitsliced_kernel<.., RAGGED>: `offsets` = starts, `ends` = ends).  A window depends on its own k bases only, so the
 // summaries are the reads' (canonical_kmer_iterator.rs:42-70 per read; the sums and the xor fold are over windows).
 //
-// Three small kernels, no host round trip between them: per-block segment counts; an exclusive scan of the block counts (one
-// block); the fill (block-local scan + the block's base).  The arrays are sized from an upper bound S_max >= S (the host knows
-// the total number of bases); the entries past the last segment are empty segments at the end of the buffer.
+// Three small kernels: per-block segment counts; an exclusive scan of the block counts (one block); the fill (block-local scan +
+// the block's base, the block's threads writing its run of the arrays together).  The arrays are sized from an upper bound
+// S_max >= S (the host knows the total number of bases); the host reads S back and scans exactly S segments.
 #include "kmx_device.h"
 
 namespace kmx {
@@ -73,25 +73,33 @@ __global__ void __launch_bounds__(1024) seg_scan_blocks_kernel(u64* __restrict__
     if (threadIdx.x == 0) *total = carry_s;
 }
 
+// The block's 1024 reads own a contiguous run of the output, [block_base, block_base + block total).  The threads fill it
+// TOGETHER, one segment per thread and step (coalesced 8-byte stores): which read a segment belongs to is a binary search over
+// the block's per-read first-segment indices in LDS.  (One thread writing all segments of "its" reads took 0.5 ms for 2e5 reads
+// of 30 kbp: ~230 scattered stores per read, in series.)  A block whose reads are long has hundreds of thousands of segments to
+// write: gridDim.y blocks share the run (each repeats the cheap block-local scan and fills its slice).
 __global__ void __launch_bounds__(SEG_THREADS) seg_fill_kernel(const u64* __restrict__ offsets, u64 n_reads, u32 k, u32 t_max,
                                                               const u64* __restrict__ block_base, u64* __restrict__ starts,
                                                               u64* __restrict__ ends) {
     __shared__ u64 wave_tot[SEG_THREADS / 64];
+    __shared__ u32 first[SEG_PER_BLOCK + 1];     // first segment of read i of the block, relative to the block's base
+    __shared__ u64 r_o0[SEG_PER_BLOCK];
+    __shared__ u32 r_len[SEG_PER_BLOCK];
     const u64 r0 = ((u64)blockIdx.x * SEG_THREADS + threadIdx.x) * SEG_PER_THREAD;
     u32 c[SEG_PER_THREAD];
-    u64 o0[SEG_PER_THREAD], len[SEG_PER_THREAD];
     u64 mine = 0;
 #pragma unroll
     for (u32 i = 0; i < SEG_PER_THREAD; ++i) {
         const u64 r = r0 + i;
+        u64 o0 = 0, len = 0;
         c[i] = 0;
-        o0[i] = 0;
-        len[i] = 0;
         if (r < n_reads) {
-            o0[i] = offsets[r];
-            len[i] = offsets[r + 1u] - o0[i];
-            c[i] = seg_count(len[i], k, t_max);
+            o0 = offsets[r];
+            len = offsets[r + 1u] - o0;
+            c[i] = seg_count(len, k, t_max);
         }
+        r_o0[threadIdx.x * SEG_PER_THREAD + i] = o0;
+        r_len[threadIdx.x * SEG_PER_THREAD + i] = c[i] ? (u32)len : 0u;
         mine += c[i];
     }
     u64 x = mine;   // inclusive scan over the block's threads
@@ -102,30 +110,33 @@ __global__ void __launch_bounds__(SEG_THREADS) seg_fill_kernel(const u64* __rest
     }
     if ((threadIdx.x & 63u) == 63u) wave_tot[threadIdx.x >> 6] = x;
     __syncthreads();
-    u64 at = block_base[blockIdx.x] + x - mine;
+    u64 at = x - mine;
     for (u32 w = 0; w < (threadIdx.x >> 6); ++w) at += wave_tot[w];
 #pragma unroll
     for (u32 i = 0; i < SEG_PER_THREAD; ++i) {
-        if (c[i] == 0u) continue;
-        const u32 w = (u32)len[i] - k + 1u;
-        const u32 t = (w + c[i] - 1u) / c[i];          // windows per segment, balanced; the last segment takes what is left
-        const u64 read_end = o0[i] + len[i];
-        for (u32 j = 0; j < c[i]; ++j) {
-            const u64 s = o0[i] + (u64)j * t;
-            const u64 e = s + t + (k - 1u);
-            starts[at + j] = s;
-            ends[at + j] = e < read_end ? e : read_end;
-        }
+        first[threadIdx.x * SEG_PER_THREAD + i] = (u32)at;     // (a block holds fewer than 2^32 segments: 1024 reads of < 2^31 bases)
         at += c[i];
     }
-}
-
-// the entries between the last segment and the array's capacity: empty segments at the end of the buffer
-__global__ void seg_pad_kernel(const u64* __restrict__ total, u64 capacity, u64 end_of_bases, u64* __restrict__ starts, u64* __restrict__ ends) {
-    const u64 first = *total;
-    for (u64 i = first + (u64)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += (u64)gridDim.x * blockDim.x) {
-        starts[i] = end_of_bases;
-        ends[i] = end_of_bases;
+    const u32 block_total = (u32)(wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3]);
+    if (threadIdx.x == 0) first[SEG_PER_BLOCK] = block_total;
+    __syncthreads();
+    const u64 base = block_base[blockIdx.x];
+    const u32 slice = (block_total + gridDim.y - 1u) / gridDim.y;
+    const u32 s_end = slice * (blockIdx.y + 1u) < block_total ? slice * (blockIdx.y + 1u) : block_total;
+    for (u32 s = slice * blockIdx.y + threadIdx.x; s < s_end; s += SEG_THREADS) {
+        // the last read i with first[i] <= s (reads without a segment share their successor's index and are skipped over)
+        u32 lo = 0, hi = SEG_PER_BLOCK;
+        while (hi - lo > 1u) {
+            const u32 mid = (lo + hi) >> 1;
+            if (first[mid] <= s) lo = mid; else hi = mid;
+        }
+        const u32 j = s - first[lo];
+        const u32 len = r_len[lo], w = len - k + 1u;
+        const u32 cnt = first[lo + 1u] - first[lo];
+        const u32 t = (w + cnt - 1u) / cnt;          // windows per segment, balanced; the last segment takes what is left
+        const u64 o0 = r_o0[lo], st = o0 + (u64)j * t, e = st + t + (k - 1u), read_end = o0 + len;
+        starts[base + s] = st;
+        ends[base + s] = e < read_end ? e : read_end;
     }
 }
 
@@ -140,9 +151,11 @@ size_t segments_scratch_bytes(u64 n_reads, u64 seg_capacity) {
 // S_max for reads of `total_bases` bases in all: read r has at most len_r / t_max + 1 segments
 u64 segments_capacity(u64 n_reads, u64 total_bases, u32 t_max) { return ((total_bases / t_max + n_reads + 63u) & ~63ull) + 64u; }
 
-// Builds starts[] / ends[] (seg_capacity entries each, inside `scratch`) on `stream`.  `end_of_bases` = offsets[n_reads].
-hipError_t launch_segments_build(const u64* offsets, u64 n_reads, u32 k, u32 t_max, u64 seg_capacity, u64 end_of_bases, void* scratch,
-                                 const u64** starts_out, const u64** ends_out, unsigned long long* too_long, hipStream_t stream) {
+// Builds starts[] / ends[] (room for seg_capacity entries each, inside `scratch`) on `stream`; *total_out (device) = the number of
+// segments written.
+hipError_t launch_segments_build(const u64* offsets, u64 n_reads, u32 k, u32 t_max, u64 seg_capacity, void* scratch,
+                                 const u64** starts_out, const u64** ends_out, const u64** total_out, unsigned long long* too_long,
+                                 hipStream_t stream) {
     const u64 n_blocks = (n_reads + SEG_PER_BLOCK - 1u) / SEG_PER_BLOCK;
     if (n_blocks == 0 || n_blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     u64* starts = static_cast<u64*>(scratch);
@@ -151,10 +164,13 @@ hipError_t launch_segments_build(const u64* offsets, u64 n_reads, u32 k, u32 t_m
     u64* total = block_sums + n_blocks;
     hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)n_blocks), dim3(SEG_THREADS), 0, stream, offsets, n_reads, k, t_max, block_sums, too_long);
     hipLaunchKernelGGL(seg_scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, block_sums, n_blocks, total);
-    hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)n_blocks), dim3(SEG_THREADS), 0, stream, offsets, n_reads, k, t_max, block_sums, starts, ends);
-    hipLaunchKernelGGL(seg_pad_kernel, dim3(64), dim3(256), 0, stream, total, seg_capacity, end_of_bases, starts, ends);
+    // (slices of ~4096 segments: by the bound, the average block of 1024 reads holds seg_capacity / n_blocks of them)
+    u64 splits = seg_capacity / n_blocks / 4096u;
+    splits = splits < 1u ? 1u : splits > 64u ? 64u : splits;
+    hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)n_blocks, (unsigned)splits), dim3(SEG_THREADS), 0, stream, offsets, n_reads, k, t_max, block_sums, starts, ends);
     *starts_out = starts;
     *ends_out = ends;
+    *total_out = total;
     return hipGetLastError();
 }
 

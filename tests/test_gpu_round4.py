@@ -255,3 +255,44 @@ def test_reduce_long_ragged_reads(ctx, orc, k, case):
     o2 = orc.canonical_reduce(host, n_reads - cut, 0, k, hasher_k=k, offsets=offsets[cut:])
     g2 = ctx.canonical_reduce(dev, n_reads - cut, 100_000_000, k, _lib.HASH_LEX, k, 0, offsets=d_off[cut:])
     _same(g2, o2)
+
+
+@pytest.mark.parametrize("L,n", [(1000, 150_000), (300, 400_000)])
+def test_long_uniform_reads_at_size(ctx, orc, L, n):
+    """uniform reads longer than a frame, enough of them that every wave scans several tiles of segments: a three-wave build of the
+    ragged kernel (68 bytes of spills) returned a wrong sum_canon here -- n_valid and xor_hash right -- while every smaller
+    test passed (round 4; the ragged variants are compiled without spills since)"""
+    from kmers_amd import _lib
+
+    k = 31
+    bases = ctx.gen_reads(n * L, first_byte=L)
+    host = bases.cpu().numpy()
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+    for hasher in (_lib.HASH_NONE, _lib.HASH_LEX):
+        g = ctx.canonical_reduce(bases, n, L, k, hasher, k if hasher else 0, 0)
+        _same(g, o, hasher != _lib.HASH_NONE)
+    # the same bytes as ragged reads of 2 L / L bases behind an offsets array with a bound above 256 (segments built on the device)
+    lens = np.where(np.arange(n // 2) % 2 == 0, 2 * L, 0) + np.where(np.arange(n // 2) % 2 == 1, 2 * L, 0)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    o2 = orc.canonical_reduce(host, len(lens), 0, k, hasher_k=k, offsets=offsets)
+    g2 = ctx.canonical_reduce(bases, len(lens), 1 << 16, k, _lib.HASH_LEX, k, 0, offsets=ctx.to_device(offsets))
+    _same(g2, o2)
+
+
+@pytest.mark.parametrize("k,L,n", [(63, 150, 1_500_000), (50, 150, 1_500_000), (64, 120, 1_500_000), (31, 256, 900_000), (21, 220, 1_000_000), (18, 250, 900_000)])
+def test_variants_with_spills_at_size(ctx, orc, k, L, n):
+    """the instantiations hipcc compiles with a few spilled registers (the two-word k from 50 up at three waves per SIMD, the
+    16-word frame), at a size where every wave scans many tiles, against the oracle (see test_long_uniform_reads_at_size)"""
+    from kmers_amd import _lib
+
+    bases = ctx.gen_reads(n * L, first_byte=7 * k)
+    host = bases.cpu().numpy()
+    if k <= 31:
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        _same(g, o)
+        assert g.sum_fw == o.sum_fw
+    else:
+        o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+        g = ctx.canonical_reduce2(bases, n, L, k, with_hash=True)
+        assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)

@@ -43,19 +43,21 @@ def test_bitsliced_kernels_stay_out_of_scratch(kernels):
         # (round 4: the 16-word frame at 8 windows per lane -- reads of 256 bases -- keeps 72 bytes of spills at three waves per
         # SIMD, measured 4 % faster than two waves without any)
         assert int(d["ScratchSize [bytes/lane]"]) <= 80, (name, d["ScratchSize [bytes/lane]"])
+        if re.search(r"ELb0ELb1EEEv", name):   # the ragged variants: no spills at all (round 4: a spill-dependent wrong sum at size)
+            assert int(d["ScratchSize [bytes/lane]"]) == 0, (name, d["ScratchSize [bytes/lane]"])
     assert seen >= 100   # every k of the three families, every frame
 
 
 def test_headline_kernel_occupancy(kernels):
     """k = 31, 150 bp (10-word frame, 4 windows per lane): 3 waves per SIMD since pass 2 runs on the matrix pipe (64 fp32
     accumulators, the first and the last block pair sharing one block; four waves of a 32-accumulator form measured slower);
-    the ragged variant 3 (2 at five windows per lane), two-word k = 63: 3"""
+    the ragged variants 2 (never compiled into spills: see bs_waves), two-word k = 63: 3"""
     def occ(pattern):
         hits = [d for n, d in kernels.items() if re.search(pattern, n)]
         assert len(hits) == 1, (pattern, len(hits))
         return int(hits[0]["Occupancy [waves/SIMD]"])
     assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0EEEv") == 3
-    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb1EEEv") == 3
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb1EEEv") == 2
     assert occ(r"scan_bitsliced_kernelILi31ELi10ELi5ELb0ELb1EEEv") == 2
     assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb0EEEv") == 3
 
