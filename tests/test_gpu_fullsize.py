@@ -318,3 +318,38 @@ def test_full_size_identical_reads_through_the_accumulator_folds(ctx, orc, k, tw
         assert (g.xor_lo, g.xor_hi) == ((o.xor_lo, o.xor_hi) if n % 2 else (0, 0))
     del bases
     torch.cuda.empty_cache()
+
+
+def test_full_size_long_ragged_reads(ctx, orc):
+    """6 G bases of 1 000..20 000-base reads behind an offsets array, length bound above 256: the segment path of round 4
+    (kmx_segments.hip).  Exact window count, shard linearity over three cuts of the batch, an oracle-checked prefix, and the
+    same summary from the per-read path on a slice."""
+    from kmers_amd import _lib
+
+    k = 31
+    rng = np.random.default_rng(77)
+    n = 570_000
+    lens = rng.integers(1000, 20001, n)
+    lens[rng.integers(0, n, 500)] = rng.integers(0, 40, 500)     # a few empty / shorter-than-k reads between them
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total = int(offsets[-1])
+    bases = ctx.gen_reads(total)
+    d_off = ctx.to_device(offsets)
+    whole = ctx.canonical_reduce(bases, n, 1 << 20, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=d_off)
+    assert whole.n_valid == int(np.maximum(lens - k + 1, 0).sum())
+    cuts = [0, n // 3 + 1, n // 2 + 77, n]
+    acc = dict(n=0, s=0, x=0, f=0)
+    for a, b in zip(cuts, cuts[1:]):
+        part = ctx.canonical_reduce(bases, b - a, 1 << 20, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=d_off[a:b + 1])
+        acc["n"] += part.n_valid
+        acc["s"] = (acc["s"] + part.sum_canon) & M64
+        acc["x"] ^= part.xor_hash
+        acc["f"] = (acc["f"] + part.sum_fw) & M64
+    assert (acc["n"], acc["s"], acc["x"], acc["f"]) == (whole.n_valid, whole.sum_canon, whole.xor_hash, whole.sum_fw)
+    n_chk = 15_000
+    host = bases[: int(offsets[n_chk])].cpu().numpy()
+    o = orc.canonical_reduce(host, n_chk, 0, k, hasher_k=k, offsets=offsets[: n_chk + 1])
+    g = ctx.canonical_reduce(bases, n_chk, 1 << 20, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=d_off[: n_chk + 1])
+    assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
+    p = ctx.canonical_reduce(bases, n_chk, 0, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=d_off[: n_chk + 1])   # no bound: the per-read path
+    assert (p.n_valid, p.sum_canon, p.xor_hash, p.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
