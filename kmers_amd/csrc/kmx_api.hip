@@ -30,6 +30,7 @@ hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+u64 bitsliced_segments_per_read(u32 L, u32 k);
 hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 L_hint, u32 k, bool want_hash,
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
                                         bool want_sumfw = false, const u64* ends = nullptr /* the reads' ends: nullptr = offsets + 1 */);
@@ -455,7 +456,8 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
             }
         }
         if (!reads->d_offsets) {
-            if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
+            // (reads longer than a frame are scanned as segments: a mask word per 64 of THOSE)
+            if (int st = prepare_dirty_flags(ctx, reads->n_reads * kmx::bitsliced_segments_per_read(reads->read_len, k), k)) return st;
             KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, want_fold, want_sumfw,
                                                     d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         }
@@ -548,7 +550,7 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
     if (!reads->d_offsets) {
         bool handled = false;
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 8, ctx->stream));   // queue heads + the "a tile was flagged" word
-        if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
+        if (int st = prepare_dirty_flags(ctx, reads->n_reads * kmx::bitsliced_segments_per_read(reads->read_len, k), k)) return st;
         KMX_HIP(ctx, kmx::launch_scan_bitsliced2(reads->d_bases, reads->n_reads, reads->read_len, k, with_hash != 0, d_out,
                                                  ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;

@@ -9,6 +9,7 @@ KMX_BS_DEFINE_K(31, true)
 // `packed`: a SeqVector (16-byte aligned words).  ASCII reads may start anywhere: a base that is not 16-byte aligned costs
 // a tile one more chunk, which the frames hold except for their very longest reads (L = 160 / 256)
 static bool bs_domain(const void* p, u64 n_reads, u32 L, u32 k, bool packed) {
+    if (L > 256 && !packed) return (reinterpret_cast<uintptr_t>(p) & 15u) == 0u && n_reads * (u64)L < (1ull << 62);   // (segments of long reads: launch_bs_seg)
     if (L < k || L > 256) return false;
     if (reinterpret_cast<uintptr_t>(p) & 15u) {
         if (packed || L == 160 || L == 256) return false;
@@ -79,7 +80,7 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
-    if (L < k || L > 256 || ((reinterpret_cast<uintptr_t>(bases) & 15u) && (L == 160 || L == 256))) return hipSuccess;
+    if (L < k || ((reinterpret_cast<uintptr_t>(bases) & 15u) && (L == 160 || L >= 256))) return hipSuccess;
     if (n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
 #define KMX_BS2_CASE(K) \
     case K:             \
@@ -117,5 +118,9 @@ hipError_t launch_scan_bitsliced_long(const uint8_t* bases, u64 n_reads, u32 L, 
             return hipSuccess;
     }
 }
+
+// segments a uniform read of L bases is cut into by the bit-sliced scan (1: none, it fits a frame): what the caller sizes the
+// dirty-read masks from
+u64 bitsliced_segments_per_read(u32 L, u32 k) { return (L > 256u && k >= 13u && k <= 64u && k != 32u) ? bs_seg_plan(L, k).J : 1u; }
 
 }  // namespace kmx

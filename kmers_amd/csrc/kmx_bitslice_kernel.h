@@ -125,12 +125,24 @@ template <int K, int NW, int WPL, bool PACKED, bool RAGGED> constexpr int bs_wav
 // blocks x 64 reads) the sums stay exact integers for, and small enough that the full-size runs (~500 tiles per wave) exercise
 // the fold (~1.5 instructions per tile)
 constexpr unsigned BS_FOLD_TILES = 256;
-template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
+// SEG (round 4): uniform reads too long for a frame (L > 256) as overlapping SEGMENTS on the UNIFORM kernel.  A read of
+// seg.L bases = Wr windows is cut into seg.J segments; the first seg.J1 hold T windows, the others T - 1 (J1 T + (J - J1)(T - 1)
+// = Wr: every window belongs to exactly one segment), segment j starts at base pos(j) = j T - max(0, j - J1) of its read.  A
+// "read" of the kernel is a segment: L = T + K - 1 bases are loaded for each; a SHORT segment's last window (the next segment's
+// first) is masked out of m, and the one thing that still counts it -- the closed form over the plane totals -- is corrected
+// by the totals of the short segments' last K planes (TOTS).  No offsets, no validity planes, no extra transposes: the
+// uniform kernel's instruction count, three waves per SIMD, every k from 13 to 64.
+struct BsSeg {
+    u32 L, J, J1, magic;   // magic = floor(2^32 / J) + 1: n / J = umulhi(n, magic) for the n < J + 64 < 128 it is used for (J < 64)
+    u64 magic64;           // floor(2^64 / J) + 1: g / J = umul64hi(g, magic64), exact while g J < 2^64 (a 64-bit division per tile cost ~150 instructions)
+};
+template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, bool SEG = false>
 __global__ void __launch_bounds__(256, (bs_waves<K, NW, WPL, PACKED, RAGGED>()))
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead,
-                      const u64* __restrict__ ends) {
+                      const u64* __restrict__ ends, const BsSeg seg) {
+    static_assert(!SEG || (!PACKED && !RAGGED && NW == 10), "segments of long uniform reads: ASCII, the 10-word frame");
     // `ends` (RAGGED with offsets): read r = bases[offsets[r], ends[r]) -- offsets + 1 for reads stored back to back, an array of
     // its own for the overlapping SEGMENTS a batch of long ragged reads was cut into (kmx_segments.hip, round 4).
     // `lead` (uniform ASCII input whose first byte is not 16-byte aligned): `bases` is the aligned address below it and
@@ -164,12 +176,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 lane = threadIdx.x & 63u;
     const u32 half = lane >> 5, p = lane & 31u;
     const u32 wib = threadIdx.x >> 6;
-    const u32 chunks = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);   // 16-byte chunks a tile may span (+1 for an unaligned start)
+    const u32 chunks = 4u * L + ((RAGGED || SEG || lead != 0u) ? 1u : 0u);   // 16-byte chunks a tile may span (+1 for an unaligned start)
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
     u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
     if (ldsw < 64u * WPL) ldsw = 64u * WPL;            // (it holds the mask words of pass 2 afterwards)
     constexpr u32 CSA_DW = 4u * ((K + 1) / 2);         // 2 * NT 64-bit sums of the counter classes
-    u32* P = lds + wib * (ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW);
+    constexpr u32 TOTS_DW = SEG ? 64u * NW : 0u;       // SEG: per-plane totals of the SHORT segments (as TOT, [group][lane])
+    u32* P = lds + wib * (ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW + TOTS_DW);
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
     const u64 n_full = n_reads >> 6;
@@ -282,6 +295,48 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
     u64* const CSA = reinterpret_cast<u64*>(P + ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u));
     for (u32 i = lane; i < 2u * NT; i += 64u) CSA[i] = 0ull;
+    // ---- SEG: where the 64 segments of a tile lie.  Wave-uniform: the tile's first byte (aligned down to 16), its bytes from
+    // there, the alignment lead, the index j0 of its first segment within that segment's read; per lane: the segment's first
+    // byte relative to the tile's, and whether it is a short one.
+    u32* const TOTS = reinterpret_cast<u32*>(CSA) + CSA_DW;
+    struct SegTile { u64 base = 0; u32 nbytes = 0, lead = 0, j0 = 0; };
+    SegTile cur_g, nx_g;
+    u32 seg_rel = 0;            // this lane's segment of the CURRENT tile: first byte - the tile's first byte
+    u64 seg_short = 0;          // the current tile's short segments (bit = lane = segment)
+    u32 n_short = 0;            // short segments (not blanked) in this wave's scanned tiles: one window less each
+    auto seg_pos = [&](u32 j) -> u32 { return j * W - (j > seg.J1 ? j - seg.J1 : 0u); };
+    auto seg_div = [&](u32 n, u32& q, u32& r) {      // n < J + 64
+        q = seg.J >= 64u ? (n >= seg.J ? 1u : 0u) : __umulhi(n, seg.magic);
+        r = n - q * seg.J;
+    };
+    auto seg_geom = [&](u64 t, SegTile& g) {
+        const u64 g0 = t * 64u, i0 = __umul64hi(g0, seg.magic64);
+        const u32 j0 = (u32)(g0 - i0 * seg.J);
+        const u64 first = i0 * (u64)seg.L + seg_pos(j0);
+        u32 di, j1;
+        seg_div(j0 + 63u, di, j1);
+        const u64 last_end = (i0 + di) * (u64)seg.L + seg_pos(j1) + (W - (j1 >= seg.J1 ? 1u : 0u)) + (u32)(K - 1);
+        g.base = first & ~15ull;
+        g.lead = (u32)(first & 15u);
+        // whole 16-byte chunks: the bytes behind the tile's last segment are the next tile's (real bases, not the zeros of an
+        // out-of-range load, which phase A would take for invalid bytes and blank the tile's last segment for) -- except at
+        // the very end of the batch, where the range stops with the last read
+        const u64 all_end = (n_reads / seg.J) * (u64)seg.L;
+        u64 span_end = (last_end + 15u) & ~15ull;
+        span_end = span_end < all_end ? span_end : all_end;
+        g.nbytes = (u32)(span_end - g.base);
+        g.j0 = j0;
+    };
+    auto seg_lane = [&](const SegTile& g) {          // seg_rel / seg_short of the tile that becomes current
+        u32 di, j;
+        seg_div(g.j0 + lane, di, j);
+        seg_rel = di * seg.L + seg_pos(j) - seg_pos(g.j0);    // (mod 2^32: the true difference is below 64 L)
+        seg_short = __ballot(j >= seg.J1);
+    };
+    if constexpr (SEG) {
+#pragma unroll
+        for (int g = 0; g < NW; ++g) TOTS[64u * g + lane] = 0;
+    }
     // acc[q][j] of lane (half, p) is G[o][beta] for o = (j & 3) + 8 (j >> 2) + 4 half (mod 32), plane 32 q + p relative to the
     // window block: base o_blk + 16 q + p / 2, bit p & 1.  The diagonal t = beta - o in [0, K) is base t of the window; t and
     // K-1-t share a counter class.
@@ -363,6 +418,28 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 fb.x0 ^= lex_hash(canon, (u32)K);
                 fb.fw += fw;
             });
+        } else if constexpr (SEG && K <= 32) {
+            const u64 i = read / seg.J;
+            const u32 j = (u32)(read - i * seg.J);
+            roll_read(bases + i * (u64)seg.L + seg_pos(j), L - (j >= seg.J1 ? 1u : 0u), (u32)K, [&](u32, u64 fw, u64 rc) {
+                const u64 canon = fw < rc ? fw : rc;
+                fb.n += 1;
+                fb.s0 += canon;
+                fb.x0 ^= lex_hash(canon, (u32)K);
+                fb.fw += fw;
+            });
+        } else if constexpr (SEG) {
+            const u64 i = read / seg.J;
+            const u32 j = (u32)(read - i * seg.J);
+            roll_read2(bases + i * (u64)seg.L + seg_pos(j), L - (j >= seg.J1 ? 1u : 0u), (u32)K, [&](u32, U128 fw, U128 rc) {
+                const U128 c = lt128(fw, rc) ? fw : rc;
+                const U128 h = lex_hash128(c, (u32)K);
+                fb.n += 1;
+                fb.s0 += c.lo;
+                fb.s1 += c.hi;
+                fb.x0 ^= h.lo;
+                fb.x1 ^= h.hi;
+            });
         } else if constexpr (K <= 32) {
             roll_read(s, L, (u32)K, [&](u32, u64 fw, u64 rc) {
                 const u64 canon = fw < rc ? fw : rc;
@@ -435,8 +512,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // rows -- 5 of 10, 7 of 13, 8 of 16 --, 3 of the 7 (5) rows of the short frames
     constexpr int LATE = PACKED ? 0 : NW == 10 ? 5 : NW < 10 ? (K > 32 ? 0 : 3) : NW == 13 ? 7 : 8;
     u64 tile = ~0ull, next_tile = ~0ull;
+    bool seg_ld_next = false;         // SEG: issue_loads is asked for the next tile (nx_g), not for the current one (cur_g)
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
-        const uint8_t* __restrict__ tb = bases + tile * (PACKED ? 16u : 64u) * (u64)L;
+        const uint8_t* __restrict__ tb = SEG ? bases + (seg_ld_next ? nx_g.base : cur_g.base) : bases + tile * (PACKED ? 16u : 64u) * (u64)L;
         // The per-row offsets are derived afresh from an opaque copy of the lane offset: left to itself hipcc hoists all
         // NLD of them out of the tile loop as zero-extended 64-bit values (24 registers at NLD = 10, and a 64-bit add per
         // row per tile); recomputed they are one 32-bit op each and the loads take the SGPR-base + VGPR-offset form
@@ -447,7 +525,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             // (the tile index is wave-uniform, but only readfirstlane tells hipcc so: a descriptor it takes for lane-dependent is
             // fed to every load through a waterfall loop)
             uint8_t* const tbu = reinterpret_cast<uint8_t*>(uniform_u64(reinterpret_cast<u64>(tb)));
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tbu, 0, (int)__builtin_amdgcn_readfirstlane(chunks * 16u), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tbu, 0, (int)__builtin_amdgcn_readfirstlane(SEG ? (seg_ld_next ? nx_g.nbytes : cur_g.nbytes) : chunks * 16u), 0x00020000);
 #pragma unroll
             for (int it = 0; it < NLD; ++it) {
                 if (it < row0 || it >= row1) continue;
@@ -526,6 +604,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     auto prefetch = [&](u64 t, u64 fallback_t, int row0 = 0, int row1 = 64) {   // clamped => unconditional, one basic block, pinned by sched barriers
         const u64 nxt = t < n_full ? t : fallback_t;
+        if constexpr (SEG) seg_ld_next = t < n_full;
         __builtin_amdgcn_sched_barrier(0);
         issue_loads(nxt, row0, row1);
         __builtin_amdgcn_sched_barrier(0);
@@ -594,7 +673,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             return false;
         } else {
-            if (chunks >= 64u * (NW - 1)) {
+            if (SEG) {     // the tile's own chunk count
+                const u32 n_ch = (cur_g.nbytes + 15u) >> 4;
+#pragma unroll
+                for (int it = 0; it < NW; ++it) {
+                    const int left = (int)n_ch - 64 * it;
+                    if ((int)lane < left) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
+                }
+            } else if (chunks >= 64u * (NW - 1)) {
                 // wave-uniform: only the last row of chunks is partial (L = 150: 600 = 9*64 + 24)
 #pragma unroll
                 for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
@@ -620,6 +706,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         u32 F[NXT];
         if constexpr (RAGGED) {
             posF = cur_m.rel + 16u * PAD;
+            qF = posF >> 4;
+            aF = 2u * (posF & 15u);
+        }
+        if constexpr (SEG) {
+            posF = seg_rel + cur_g.lead + 16u * PAD;
             qF = posF >> 4;
             aF = 2u * (posF & 15u);
         }
@@ -794,6 +885,18 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
                 for (int g = 0; g < NW; ++g) atomicAdd(tot_l + 64 * g, Y[g]);
             }
+            if constexpr (SEG) {
+                // the planes of bases W-1 .. W+K-2 (the last window) restricted to the short segments: what the closed form takes back out
+                const u32 sh_half = half ? (u32)(seg_short >> 32) : (u32)seg_short;
+                if (seg_short != 0ull) {
+                    u32* const tots_l = TOTS + lane;
+#pragma unroll
+                    for (int g = 0; g < NW; ++g) {
+                        if (16u * g + 15u < W - 1u) continue;     // (wave-uniform)
+                        atomicAdd(tots_l + 64 * g, (u32)__builtin_popcount(F[g] & sh_half));
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < NE; ++e) atomicAdd(&QT[e * 64 + lane], Y[NW + e]);               // ragged: read-end planes, totals only
 #undef KMX_HRUN_BEGIN
@@ -890,6 +993,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     for (int w = 0; w < WPL; ++w) m[w] &= vm;
                 }
             }
+            if constexpr (SEG) {
+                if (seg_short != 0ull) {      // (wave-uniform)
+                    const u32 keep = ~(set ? (u32)(seg_short >> 32) : (u32)seg_short);
+                    const u32 ws = W - 1u - o;                 // which of the lane's windows is window W-1 (none: >= WPL)
+#pragma unroll
+                    for (int w = 0; w < WPL; ++w) m[w] = (u32)w == ws ? m[w] & keep : m[w];
+                }
+            }
 #pragma unroll
             for (int w = 0; w < WPL; ++w) pc_acc(mcnt, m[w]);   // (a tile that is not scanned: lt == 0, nothing is added)
             if constexpr (LATE > 0) {   // the rest of the next tile's rows: the registers of pass 1's plane window are free now
@@ -965,6 +1076,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #undef KMX_PLANE
 #undef KMX_PLANE_AT
         if (run) n_bs_tiles += 1;
+        if constexpr (SEG) {
+            if (run) n_short += (u32)__builtin_popcountll(seg_short & valid_reads);
+        }
         if (run && (n_bs_tiles & (BS_FOLD_TILES - 1u)) == 0u) fold_acc();   // (wave-uniform, rare: keeps every fp32 accumulator an exact integer)
     };
 
@@ -980,9 +1094,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
         if (next_tile < n_full) meta_issue(next_tile);
     } else {
+        if constexpr (SEG) {
+            if (tile < n_full) seg_geom(tile, cur_g);
+            if (next_tile < n_full) seg_geom(next_tile, nx_g);
+        }
         if (tile < n_full) issue_loads(tile);
     }
     while (tile < n_full) {
+        if constexpr (SEG) seg_lane(cur_g);
 #ifdef KMX_BS_TIMING
         t_last = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1011,6 +1130,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             lds_fence();
             u32 rd_off = lane * L + lead, rd_len = L;    // the read's bytes, relative to the tile's aligned start
             if constexpr (RAGGED) { rd_off = cur_m.rel; rd_len = cur_m.len; }
+            if constexpr (SEG) { rd_off = seg_rel + cur_g.lead; rd_len = L - (u32)((seg_short >> lane) & 1ull); }
             // a read is blanked if any chunk it touches is bad (a chunk shared by two reads blanks both: they are rolled exactly anyway)
             const u32 c0 = rd_off >> 4, c1 = rd_len ? (rd_off + rd_len - 1u) >> 4 : c0;
             const u32 q0 = c0 >> 6, b0 = c0 & 63u;
@@ -1051,7 +1171,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             // every path, the wait is free: the wave has just used all of them.
             if constexpr (LATE > 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             if constexpr (INLINE) {
-                if (bad_tile && blank_dirty_reads(chunks)) bad_tile = false;
+                if (bad_tile && blank_dirty_reads(SEG ? (cur_g.nbytes + 15u) >> 4 : chunks)) bad_tile = false;
             }
             prefetch(next_tile, tile, 0, NLD - LATE);
         }
@@ -1074,6 +1194,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         if constexpr (RAGGED) {
             cur_m = nx_m;
             if (next_tile < n_full) meta_issue(next_tile);
+        }
+        if constexpr (SEG) {
+            cur_g = nx_g;
+            if (next_tile < n_full) seg_geom(next_tile, nx_g);
         }
     }
 #ifdef KMX_BS_TIMING
@@ -1103,7 +1227,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u64 bs_n = 0, bs_s0 = 0, bs_s1 = 0, bs_x0 = 0, bs_x1 = 0, bs_fw = 0;
     if (n_bs_tiles != 0u) {
         // k-mers handled bit-sliced by this wave
-        const u64 nk = RAGGED ? wave_sum(NVR[lane]) : ((u64)n_bs_tiles * 64u - n_blanked) * (u64)W;
+        const u64 nk = RAGGED ? wave_sum(NVR[lane]) : ((u64)n_bs_tiles * 64u - n_blanked) * (u64)W - n_short;   // (SEG: a short segment holds one window less)
         bs_n = nk;
         u64 fwall = 0;
         u32 tot[NW];
@@ -1117,6 +1241,15 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 fwall += (u64)pcq * (wf << (qidx & 1u));
             }
             tot[g] = pcq + __shfl_xor(pcq, 32, WAVE);      // lanes p and p+32 hold the same plane of the two sets
+            if constexpr (SEG) {
+                // the short segments' last window (W-1) does not exist: base i of it sat at exponent i - (W-1) of the forward word
+                const u32 pcs = TOTS[64u * g + lane], i = qidx >> 1;
+                if constexpr (K <= 32) {
+                    if (i >= W - 1u && i <= L - 1u) fwall -= (u64)pcs * ((1ull << (2u * (i - (W - 1u)))) << (qidx & 1u));
+                }
+                const u32 both = pcs + __shfl_xor(pcs, 32, WAVE);
+                if (half == 0) (PL + PLANES)[32u * g + p] = both;     // (the set-1 plane area is free by now)
+            }
         }
         if constexpr (K <= 32) bs_fw = wave_sum(fwall);
         u32 mcnt_c;
@@ -1151,6 +1284,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 for (u32 i = (u32)K - 1u - t; i + 2u <= (u32)K; ++i) tq -= QE[2u * i + bb];
             } else {
                 for (u32 i = t2; i <= L - 1u - t; ++i) tq += PL[2u * i + bb];
+                if constexpr (SEG) tq -= (PL + PLANES)[2u * (W - 1u + t2) + bb];   // window W-1 of the short segments
             }
             const u64 cnt = cc + (nk - mc) - tq;
             const u32 sh = 2u * (t & 31u) + bb;
@@ -1197,10 +1331,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 // iterator semantics (roll_read).  Every mask goes back to zero: the caller never clears the array.
 // Arguments as scan_bitsliced_kernel's (RAGGED with offsets == nullptr: segments of long uniform reads, lead = seg_T,
 // want_sumfw = seg_L).
-template <int K, bool RAGGED>
+template <int K, bool RAGGED, bool SEG = false>
 __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash,
                                                            u32 want_sumfw, void* __restrict__ out, unsigned long long* __restrict__ queue,
-                                                           const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends) {
+                                                           const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends,
+                                                           const BsSeg seg) {
     u64* const masks = reinterpret_cast<u64*>(queue[515]);
     if (masks == nullptr || queue[512] == 0) return;   // queue[512]: "a tile was marked" (zeroed by the caller with the heads)
     __shared__ u64 aside_all[4][64];
@@ -1225,6 +1360,12 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
             const u64 read = aside[slot];
             const uint8_t* sp = bases + lead + read * (u64)L;
             u32 len = L;
+            if constexpr (SEG) {     // segment `read` of a long uniform read (scan_bitsliced_kernel<.., SEG>)
+                const u64 i = read / seg.J;
+                const u32 j = (u32)(read - i * seg.J), w = L - (u32)K + 1u;
+                sp = bases + i * (u64)seg.L + (j * w - (j > seg.J1 ? j - seg.J1 : 0u));
+                len = L - (j >= seg.J1 ? 1u : 0u);
+            }
             if constexpr (RAGGED) {
                 u64 o0, o1;
                 if (seg_mode) {
@@ -1331,28 +1472,33 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
 
 // ------------------------------------------------------------------ launcher
 
-template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false>
+template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, bool SEG = false>
 static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
                             unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets = nullptr,
                             u32 seg_T = 0 /* RAGGED, offsets == nullptr: segments of long uniform reads, see the kernel */,
-                            const u64* ends = nullptr /* RAGGED with offsets: the reads' ends (nullptr: offsets + 1) */) {
+                            const u64* ends = nullptr /* RAGGED with offsets: the reads' ends (nullptr: offsets + 1) */,
+                            BsSeg seg = BsSeg{0, 0, 0, 0, 0} /* SEG: n_reads counts segments, L = the segment frame */) {
     if (offsets != nullptr && ends == nullptr) ends = offsets + 1;
-    auto kern = scan_bitsliced_kernel<K, NW, WPL, PACKED, RAGGED>;
+    auto kern = scan_bitsliced_kernel<K, NW, WPL, PACKED, RAGGED, SEG>;
     // uniform ASCII reads from a base that is not 16-byte aligned: the kernel streams from the aligned address below it
     u32 lead = 0;
     if constexpr (RAGGED) lead = seg_T;
-    if constexpr (!PACKED && !RAGGED) {
+    if constexpr (!PACKED && !RAGGED && !SEG) {
         lead = (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
         bases -= lead;
         if (lead != 0u && 4u * L + 1u > 64u * (u32)NW) return hipErrorInvalidValue;   // (callers check: the extra chunk must fit the frame)
     }
-    const u32 chunks = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);
+    if constexpr (SEG) {   // (a tile is addressed from the buffer's first byte: its own 16-byte alignment is the kernel's business)
+        if ((reinterpret_cast<uintptr_t>(bases) & 15u) != 0u || 4u * L + 1u > 64u * (u32)NW) return hipErrorInvalidValue;
+    }
+    const u32 chunks = 4u * L + ((RAGGED || SEG || lead != 0u) ? 1u : 0u);
     u32 ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
     if (ldsw < 64u * (u32)WPL) ldsw = 64u * (u32)WPL;
     constexpr u32 NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;
     constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
     constexpr u32 CSA_DW = 4u * ((K + 1) / 2);
-    const size_t lds_bytes = (size_t)(ldsw + 4u * (u32)bs_plane_dwords(NW) + (RAGGED ? 2u * (32u * NV + 8u) : 0u) + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW) * 4u * 4u;
+    constexpr u32 TOTS_DW = SEG ? 64u * NW : 0u;
+    const size_t lds_bytes = (size_t)(ldsw + 4u * (u32)bs_plane_dwords(NW) + (RAGGED ? 2u * (32u * NV + 8u) : 0u) + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW + TOTS_DW) * 4u * 4u;
     // blocks per CU, cached per host thread and device (one thread per context / GPU is the ABI's model: a plain static
     // would be shared, and written, by all of them)
     static thread_local int bpc = 0, bpc_dev = -1;
@@ -1374,16 +1520,36 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     const u64 need = (n_tiles + 3u) / 4u;
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets, lead, ends);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
     if constexpr (!PACKED) {
         // the reads the main pass blanked out (none on clean input: the waves return at once)
         u64 grid1 = (u64)n_cu * 4u;
         const u64 need1 = ((n_reads >> 6) + 255u) / 256u;   // a wave takes 64 masks at a time
         if (grid1 > need1) grid1 = need1;
-        hipLaunchKernelGGL((roll_flagged_kernel<K, RAGGED>), dim3((unsigned)(grid1 ? grid1 : 1)), dim3(256), 0, stream, bases, n_reads, L, want_hash,
-                           want_sumfw, out, queue, offsets, lead, ends);
+        hipLaunchKernelGGL((roll_flagged_kernel<K, RAGGED, SEG>), dim3((unsigned)(grid1 ? grid1 : 1)), dim3(256), 0, stream, bases, n_reads, L, want_hash,
+                           want_sumfw, out, queue, offsets, lead, ends, seg);
     }
     return hipGetLastError();
+}
+
+// Uniform reads longer than a frame (L > 256), any k from 13 to 64: how they are cut (see BsSeg).  T <= min(128, 160 - k) windows
+// per segment (the 10-word frame holds 159 bases + the alignment lead), as few segments as that allows, all of T or T - 1 windows.
+struct BsSegPlan { u32 J, J1, T; };
+static inline BsSegPlan bs_seg_plan(u32 L, u32 k) {
+    const u32 wr = L - k + 1u, t_max = 160u - k < 128u ? 160u - k : 128u;
+    const u32 J = (wr + t_max - 1u) / t_max, T = (wr + J - 1u) / J;
+    return BsSegPlan{J, J - (J * T - wr), T};
+}
+template <int K>
+static hipError_t launch_bs_seg(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
+                                unsigned long long* queue, int n_cu, hipStream_t stream) {
+    const BsSegPlan pl = bs_seg_plan(L, (u32)K);
+    if (pl.T <= 64u || pl.T > 128u || n_reads > (1ull << 40) / pl.J) return hipErrorInvalidValue;
+    const BsSeg seg{L, pl.J, pl.J1, pl.J < 64u ? (u32)(0x100000000ull / pl.J) + 1u : 0u, ~0ull / pl.J + 1ull};   // (J >= 2: floor((2^64 - 1) / J) = floor(2^64 / J) unless J is a power of two, where the + 1 lands on 2^64 / J + 1 as well)
+    const u64 n_seg = n_reads * pl.J;
+    const u32 Lf = pl.T + (u32)K - 1u;
+    if (pl.T <= 96u) return launch_bs<K, 10, 3, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, 0, nullptr, seg);
+    return launch_bs<K, 10, 4, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, 0, nullptr, seg);
 }
 
 // One entry point per k (the instantiations are spread over several translation units so that they compile in
@@ -1394,6 +1560,7 @@ static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
                                 unsigned long long* queue, int n_cu, hipStream_t stream) {
     const u32 W = L - (u32)K + 1u;
     if constexpr (!PACKED) {
+        if (L > 256u) return launch_bs_seg<K>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
         // up to 112 bp (the 100 / 101 / 75 / 76 / 50 / 36 bp of older runs): the 7-word frame -- 7 instead of 10 transposes per
         // half-wave, 28 instead of 40 prefetch registers, two thirds of the plane area (a read's extra chunk from an unaligned base must fit too)
         const u32 mis = (reinterpret_cast<uintptr_t>(bases) & 15u) ? 1u : 0u;
@@ -1443,6 +1610,7 @@ template <int K>
 static hipError_t launch_bs2_any(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, void* out, unsigned long long* queue,
                                  int n_cu, hipStream_t stream) {
     const u32 W = L - (u32)K + 1u;
+    if (L > 256u) return launch_bs_seg<K>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);
     if (L > 160) {
         const u32 mis = (reinterpret_cast<uintptr_t>(bases) & 15u) ? 1u : 0u;
         if (4u * L + mis <= 64u * 13u) return launch_bs<K, 13, 6>(bases, n_reads, L, want_hash, 0, out, queue, n_cu, stream);

@@ -296,3 +296,55 @@ def test_variants_with_spills_at_size(ctx, orc, k, L, n):
         o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
         g = ctx.canonical_reduce2(bases, n, L, k, with_hash=True)
         assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+
+# ------------------------------------------------------------------ uniform reads above 256 bases: segments on the uniform kernel
+
+@pytest.mark.parametrize("k", [13, 21, 30, 31])
+@pytest.mark.parametrize("L,n", [(257, 64 * 9 + 5), (287, 64 * 4), (300, 64 * 6 + 1), (383, 200), (1000, 64 * 3 + 1), (1021, 130), (5003, 150), (20000, 70), (100_003, 9)])
+def test_long_uniform_reads_as_segments(ctx, orc, k, L, n):
+    """round 4: a read of L > 256 bases is cut into J segments of T or T - 1 windows (bs_seg_plan) that the UNIFORM kernel scans
+    (a short segment's last window masked, the closed form corrected by the short segments' plane totals); dirty bytes, the
+    hash fold, sum_fw, tiles that end inside a read, a final partial tile of segments"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(k * 1000 + L)
+    host = _dirty(rng, n * L, 0.0003)
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+    dev = ctx.to_device(host)
+    for _ in range(2):
+        g = ctx.canonical_reduce(dev, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        _same(g, o)
+        assert g.sum_fw == o.sum_fw
+    g = ctx.canonical_reduce(dev, n, L, k, _lib.HASH_IDENTITY, 0, 0)
+    assert (g.n_valid, g.sum_canon) == (o.n_valid, o.sum_canon)
+
+
+@pytest.mark.parametrize("k", [33, 47, 48, 63, 64])
+@pytest.mark.parametrize("L,n", [(257, 64 * 5 + 3), (300, 64 * 6 + 1), (1000, 64 * 3 + 1), (5003, 90), (20000, 40)])
+def test_long_uniform_reads_as_segments_two_word(ctx, orc, k, L, n):
+    rng = np.random.default_rng(k * 1000 + L)
+    host = _dirty(rng, n * L, 0.0003)
+    o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+    dev = ctx.to_device(host)
+    for _ in range(2):
+        g = ctx.canonical_reduce2(dev, n, L, k, with_hash=True)
+        assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+
+@pytest.mark.parametrize("k,L,n", [(31, 1000, 150_000), (31, 300, 400_000), (63, 1000, 100_000), (21, 777, 150_000)])
+def test_long_uniform_segments_at_size(ctx, orc, k, L, n):
+    """the same at sizes where every wave scans many tiles of segments (the accumulators and the short-segment totals carry over)"""
+    from kmers_amd import _lib
+
+    bases = ctx.gen_reads(n * L, first_byte=3 * L)
+    host = bases.cpu().numpy()
+    if k <= 31:
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        _same(g, o)
+        assert g.sum_fw == o.sum_fw
+    else:
+        o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+        g = ctx.canonical_reduce2(bases, n, L, k, with_hash=True)
+        assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
