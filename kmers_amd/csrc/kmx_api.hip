@@ -40,8 +40,6 @@ u64 segments_capacity(u64 n_reads, u64 total_bases, u32 t_max);
 hipError_t launch_segments_build(const u64* offsets, u64 n_reads, u32 k, u32 t_max, u64 seg_capacity, void* scratch,
                                  const u64** starts_out, const u64** ends_out, const u64** total_out, unsigned long long* too_long,
                                  hipStream_t stream);
-hipError_t launch_scan_bitsliced_long(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary* out,
-                                      unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 // kmx_fastx.hip
@@ -460,12 +458,6 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
             if (int st = prepare_dirty_flags(ctx, reads->n_reads * kmx::bitsliced_segments_per_read(reads->read_len, k), k)) return st;
             KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, want_fold, want_sumfw,
                                                     d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
-        }
-        if (!handled && !reads->d_offsets && reads->read_len > 256 && !want_sumfw) {   // long uniform reads: overlapping 160-base segments on the ragged kernel
-            const uint64_t n_seg = reads->n_reads * (((uint64_t)reads->read_len - k + (161u - k)) / (161u - k));
-            if (int st = prepare_dirty_flags(ctx, n_seg, k)) return st;
-            KMX_HIP(ctx, kmx::launch_scan_bitsliced_long(reads->d_bases, reads->n_reads, reads->read_len, k, want_fold, d_out,
-                                                         ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         }
         if (!handled && reads->d_offsets && reads->read_len > 256 && k >= 13 && k <= 31 &&
             (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {

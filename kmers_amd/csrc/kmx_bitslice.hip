@@ -55,8 +55,7 @@ hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 
 KMX_BS2_DEFINE_K(63)
 
 // Ragged reads (offsets array): `L_hint` = upper bound of the read lengths if the caller knows one (0 = unknown -> the
-// 160-base frame; tiles holding a longer read roll per lane).  `want_sumfw` rides in the argument that carries seg_L for the
-// segments of long uniform reads (offsets == nullptr there).
+// 160-base frame; tiles holding a longer read roll per lane).
 hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 L_hint, u32 k, bool want_hash,
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
                                         bool want_sumfw, const u64* ends) {
@@ -68,7 +67,7 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
 #define KMX_BSR_CASE(K) \
     case K:             \
         *handled = true; \
-        return launch_bs_ragged_k##K(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, 0, want_sumfw ? 1u : 0u, ends);
+        return launch_bs_ragged_k##K(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, want_sumfw ? 1u : 0u, ends);
     switch (k) {
         KMX_BSR_FOR_EACH_K(KMX_BSR_CASE)
         default:
@@ -88,32 +87,6 @@ hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 
         return launch_bs2_k##K(bases, n_reads, L, want_hash, out, queue, n_cu, stream);
     switch (k) {
         KMX_BS2_FOR_EACH_K(KMX_BS2_CASE)
-        default:
-            return hipSuccess;
-    }
-}
-
-// Uniform reads too long for a frame (L > 256: long reads, contigs): each read is cut into overlapping segments of
-// T = 161 - k windows (160 bases) that the ragged kernel scans as reads of their own -- neighbouring segments share
-// their k - 1 bases in LDS, HBM is still read once.  k in 13..31, 16-byte aligned base, no sum_fw (as for ragged reads).
-hipError_t launch_scan_bitsliced_long(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary* out,
-                                      unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
-    *handled = false;
-    if (L <= 256 || k < 13 || k > 31 || (reinterpret_cast<uintptr_t>(bases) & 15u)) return hipSuccess;
-    // as few segments as fit the 160-base frame, all of (nearly) the same size: windows per segment T = ceil(W / J) -- a
-    // 300-base read is three segments of 90 windows (3 windows per lane), not 130 + 130 + 10 (4 per lane, the third tile idle)
-    const u32 Tmax = 161u - k, W = L - k + 1u;
-    const u32 J0 = (W + Tmax - 1u) / Tmax;
-    const u32 T = (W + J0 - 1u) / J0, Lf = T + k - 1u;
-    const u64 J = ((u64)W + T - 1u) / T;            // segments per read (as the kernel derives it from T)
-    if (n_reads > (1ull << 40) / J || n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
-    const u64 n_seg = n_reads * J;
-#define KMX_BSL_CASE(K) \
-    case K:             \
-        *handled = true; \
-        return launch_bs_ragged_k##K(bases, nullptr, n_seg, Lf, want_hash, out, queue, n_cu, stream, T, L, nullptr);
-    switch (k) {
-        KMX_BSR_FOR_EACH_K(KMX_BSL_CASE)
         default:
             return hipSuccess;
     }

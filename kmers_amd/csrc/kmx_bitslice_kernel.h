@@ -118,8 +118,9 @@ constexpr int bs_acc_blocks(int K) { return (K + 30) / 16 + 1; }
 // sum_canon on 1.2e6 segments of 1000-base reads (tests/test_gpu_round4.py::test_long_uniform_reads_at_size) while a build
 // that differed by the order of two conjuncts passed: a spill-dependent miscompare not understood yet, so no ragged variant
 // is compiled into spills.
-template <int K, int NW, int WPL, bool PACKED, bool RAGGED> constexpr int bs_waves() {
-    return (RAGGED || (K > 32 && NW > 10)) ? 2 : 3;
+// (SEG with two-word k: the segment bookkeeping on top of the two-word frame spilled 32..80 bytes at three waves -- same rule.)
+template <int K, int NW, int WPL, bool PACKED, bool RAGGED, bool SEG = false> constexpr int bs_waves() {
+    return (RAGGED || (K > 32 && (NW > 10 || SEG))) ? 2 : 3;
 }
 // tiles between two folds of the fp32 accumulators into the 64-bit class sums: a power of two, far below the 2^24 / (8 window
 // blocks x 64 reads) the sums stay exact integers for, and small enough that the full-size runs (~500 tiles per wave) exercise
@@ -137,7 +138,7 @@ struct BsSeg {
     u64 magic64;           // floor(2^64 / J) + 1: g / J = umul64hi(g, magic64), exact while g J < 2^64 (a 64-bit division per tile cost ~150 instructions)
 };
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, bool SEG = false>
-__global__ void __launch_bounds__(256, (bs_waves<K, NW, WPL, PACKED, RAGGED>()))
+__global__ void __launch_bounds__(256, (bs_waves<K, NW, WPL, PACKED, RAGGED, SEG>()))
 scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw,
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead,
@@ -228,42 +229,16 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         NVR[lane] = 0;
         if (lane < 16u) VAL[(lane >> 3) * VS + 32u * NV + (lane & 7u)] = 0;   // the zero words (never written again)
     }
-    // RAGGED with offsets == nullptr: "reads" are the overlapping SEGMENTS of uniform reads too long for a frame (L > 256):
-    // read i of `seg_L` bases is cut into J segments of seg_T windows each (the last one shorter), segment j = bases
-    // [j*seg_T, j*seg_T + seg_T + K - 1) of the read -- neighbours share K - 1 bases in LDS, nothing is read twice from HBM,
-    // and every window of the read belongs to exactly one segment.  The two parameters ride in arguments this variant does
-    // not use otherwise (lead = seg_T, want_sumfw = seg_L); n_reads counts segments.
-    const bool seg_mode = RAGGED && offsets == nullptr;
-    const u32 seg_T = lead, seg_L = want_sumfw;
-    const u32 seg_J = seg_mode ? (seg_L - (u32)K + seg_T) / seg_T : 1u;      // ceil((seg_L - K + 1) / seg_T)
-    // (reads behind an offsets array: the argument is what its name says; uniform reads: as given)
-    const bool sumfw_on = RAGGED ? (!seg_mode && want_sumfw != 0u) : (want_sumfw != 0u);
-    auto seg_bounds = [&](u64 g, u64& o0, u64& o1) {
-        const u64 i = g / seg_J;
-        const u32 j = (u32)(g - i * seg_J);
-        o0 = i * (u64)seg_L + (u64)j * seg_T;
-        const u64 e = o0 + seg_T + (u32)(K - 1), re = (i + 1u) * (u64)seg_L;
-        o1 = e < re ? e : re;
-    };
-    const u64 total_bytes = !RAGGED ? 0 : seg_mode ? (n_reads / seg_J) * (u64)seg_L : ends[n_reads - 1u];
+    const bool sumfw_on = want_sumfw != 0u;
+    const u64 total_bytes = RAGGED ? ends[n_reads - 1u] : 0;
     // ragged: per-tile geometry of the current and of the next tile (rel/len per lane, the rest wave-uniform)
     struct TileMeta { u32 rel = 0, len = 0, n_ch = 0; u64 base = 0; bool fits = true; };
     TileMeta cur_m, nx_m;
     // the two offsets of a lane are requested one iteration before anything looks at them (meta_issue / meta_finish)
     u64 raw_o0 = 0, raw_o1 = 0;
     auto meta_issue = [&](u64 t) {
-        if (seg_mode) {
-            // the tile's first segment once (wave-uniform 64-bit division), the lane's own by a 32-bit one
-            const u64 g0 = t * 64u, i0 = g0 / seg_J;
-            const u32 jj = (u32)(g0 - i0 * seg_J) + lane, di = jj / seg_J, j = jj - di * seg_J;
-            const u64 i = i0 + di;
-            raw_o0 = i * (u64)seg_L + (u64)j * seg_T;
-            const u64 e = raw_o0 + seg_T + (u32)(K - 1), re = (i + 1u) * (u64)seg_L;
-            raw_o1 = e < re ? e : re;
-        } else {
-            raw_o0 = offsets[t * 64u + lane];
-            raw_o1 = ends[t * 64u + lane];
-        }
+        raw_o0 = offsets[t * 64u + lane];
+        raw_o1 = ends[t * 64u + lane];
     };
     auto meta_finish = [&](TileMeta& m) {
         const u64 o0 = raw_o0, o1 = raw_o1;
@@ -380,7 +355,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
                 atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)r0);
                 if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)h0);
-                if (sumfw_on) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);   // (segments of long reads: no sum_fw; the argument carries seg_L)
+                if (sumfw_on) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
             } else {
                 kmx_summary2* o = static_cast<kmx_summary2*>(out);
                 atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
@@ -398,9 +373,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     auto fallback_read_acc = [&](u64 read, FbAcc& fb) {
         const uint8_t* s = bases + lead + read * (u64)L;
         if constexpr (RAGGED) {
-            u64 o0, o1;
-            if (seg_mode) seg_bounds(read, o0, o1);
-            else { o0 = offsets[read]; o1 = ends[read]; }
+            const u64 o0 = offsets[read], o1 = ends[read];
             if (read_too_long(o1 - o0, queue + KMX_TOOLONG_FROM_QUEUE)) return;   // (not scanned; kmx_ctx_synchronize reports it)
             roll_read(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
                 const u64 canon = fw < rc ? fw : rc;
@@ -1329,8 +1302,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 // which scanned the tile without them.  A lane takes the mask of one tile, the wave gathers the reads 64 at a time (one
 // ballot + one v_mbcnt per round: no list in memory, no atomics) and rolls them, one lane per read, with the reference's
 // iterator semantics (roll_read).  Every mask goes back to zero: the caller never clears the array.
-// Arguments as scan_bitsliced_kernel's (RAGGED with offsets == nullptr: segments of long uniform reads, lead = seg_T,
-// want_sumfw = seg_L).
+// Arguments as scan_bitsliced_kernel's.
 template <int K, bool RAGGED, bool SEG = false>
 __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash,
                                                            u32 want_sumfw, void* __restrict__ out, unsigned long long* __restrict__ queue,
@@ -1342,9 +1314,6 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
     const u32 lane = threadIdx.x & 63u;
     u64* const aside = aside_all[threadIdx.x >> 6];
     const u64 n_full = n_reads >> 6;
-    const bool seg_mode = RAGGED && offsets == nullptr;
-    const u32 seg_T = lead, seg_L = want_sumfw;
-    const u32 seg_J = seg_mode ? (seg_L - (u32)K + seg_T) / seg_T : 1u;
     u64 a_n = 0, a_s0 = 0, a_s1 = 0, a_x0 = 0, a_x1 = 0, a_fw = 0;
     u32 n_aside = 0;
     auto roll = [&]() {
@@ -1367,17 +1336,7 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
                 len = L - (j >= seg.J1 ? 1u : 0u);
             }
             if constexpr (RAGGED) {
-                u64 o0, o1;
-                if (seg_mode) {
-                    const u64 i = read / seg_J;
-                    const u32 j = (u32)(read - i * seg_J);
-                    o0 = i * (u64)seg_L + (u64)j * seg_T;
-                    const u64 e = o0 + seg_T + (u32)(K - 1), re = (i + 1u) * (u64)seg_L;
-                    o1 = e < re ? e : re;
-                } else {
-                    o0 = offsets[read];
-                    o1 = ends[read];
-                }
+                const u64 o0 = offsets[read], o1 = ends[read];
                 sp = bases + o0;
                 len = (u32)(o1 - o0);
             }
@@ -1456,7 +1415,7 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
             atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
             atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)s0);
             if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)x0);
-            if (RAGGED ? (!seg_mode && want_sumfw != 0u) : (want_sumfw != 0u)) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
+            if (want_sumfw != 0u) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
         } else {
             kmx_summary2* o = static_cast<kmx_summary2*>(out);
             atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
@@ -1475,14 +1434,12 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
 template <int K, int NW, int WPL, bool PACKED = false, bool RAGGED = false, bool SEG = false>
 static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
                             unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets = nullptr,
-                            u32 seg_T = 0 /* RAGGED, offsets == nullptr: segments of long uniform reads, see the kernel */,
-                            const u64* ends = nullptr /* RAGGED with offsets: the reads' ends (nullptr: offsets + 1) */,
+                            const u64* ends = nullptr /* RAGGED: the reads' ends (nullptr: offsets + 1) */,
                             BsSeg seg = BsSeg{0, 0, 0, 0, 0} /* SEG: n_reads counts segments, L = the segment frame */) {
     if (offsets != nullptr && ends == nullptr) ends = offsets + 1;
     auto kern = scan_bitsliced_kernel<K, NW, WPL, PACKED, RAGGED, SEG>;
     // uniform ASCII reads from a base that is not 16-byte aligned: the kernel streams from the aligned address below it
     u32 lead = 0;
-    if constexpr (RAGGED) lead = seg_T;
     if constexpr (!PACKED && !RAGGED && !SEG) {
         lead = (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
         bases -= lead;
@@ -1548,8 +1505,8 @@ static hipError_t launch_bs_seg(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
     const BsSeg seg{L, pl.J, pl.J1, pl.J < 64u ? (u32)(0x100000000ull / pl.J) + 1u : 0u, ~0ull / pl.J + 1ull};   // (J >= 2: floor((2^64 - 1) / J) = floor(2^64 / J) unless J is a power of two, where the + 1 lands on 2^64 / J + 1 as well)
     const u64 n_seg = n_reads * pl.J;
     const u32 Lf = pl.T + (u32)K - 1u;
-    if (pl.T <= 96u) return launch_bs<K, 10, 3, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, 0, nullptr, seg);
-    return launch_bs<K, 10, 4, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, 0, nullptr, seg);
+    if (pl.T <= 96u) return launch_bs<K, 10, 3, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
+    return launch_bs<K, 10, 4, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
 }
 
 // One entry point per k (the instantiations are spread over several translation units so that they compile in
@@ -1633,32 +1590,31 @@ static hipError_t launch_bs2_any(const uint8_t* bases, u64 n_reads, u32 L, u32 w
     X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) X(64)
 
 // ragged reads: Lf = the frame (longest read a tile may hold; a tile with a longer read rolls per lane)
-// offsets == nullptr: segments of uniform reads of seg_L bases, seg_T windows each (n_reads = segments, Lf = seg_T + K - 1)
 template <int K>
 static hipError_t launch_bs_ragged_any(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out,
-                                       unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L, const u64* ends) {
+                                       unsigned long long* queue, int n_cu, hipStream_t stream, u32 want_sumfw, const u64* ends) {
     const u32 W = Lf - (u32)K + 1u;
     if (Lf > 160) {
-        if (W <= 160u) return launch_bs<K, 16, 5, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
-        if (W <= 192u) return launch_bs<K, 16, 6, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
-        if (W <= 224u) return launch_bs<K, 16, 7, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
-        return launch_bs<K, 16, 8, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
+        if (W <= 160u) return launch_bs<K, 16, 5, false, true>(bases, n_reads, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, ends);
+        if (W <= 192u) return launch_bs<K, 16, 6, false, true>(bases, n_reads, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, ends);
+        if (W <= 224u) return launch_bs<K, 16, 7, false, true>(bases, n_reads, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, ends);
+        return launch_bs<K, 16, 8, false, true>(bases, n_reads, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, ends);
     }
     if (Lf <= 111u && Lf >= (u32)K) {   // short reads (a tile of 64 spans at most 448 chunks): the 7-word frame
-        if (W <= 96u) return launch_bs<K, 7, 3, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
-        return launch_bs<K, 7, 4, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
+        if (W <= 96u) return launch_bs<K, 7, 3, false, true>(bases, n_reads, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, ends);
+        return launch_bs<K, 7, 4, false, true>(bases, n_reads, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, ends);
     }
-    if (W <= 96u) return launch_bs<K, 10, 3, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
-    if (W <= 128u) return launch_bs<K, 10, 4, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
-    return launch_bs<K, 10, 5, false, true>(bases, n_reads, Lf, want_hash, seg_L, out, queue, n_cu, stream, offsets, seg_T, ends);
+    if (W <= 96u) return launch_bs<K, 10, 3, false, true>(bases, n_reads, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, ends);
+    if (W <= 128u) return launch_bs<K, 10, 4, false, true>(bases, n_reads, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, ends);
+    return launch_bs<K, 10, 5, false, true>(bases, n_reads, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, ends);
 }
 #define KMX_BSR_DECLARE_K(K) \
     hipError_t launch_bs_ragged_k##K(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out, \
-                                     unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L, const u64* ends);
+                                     unsigned long long* queue, int n_cu, hipStream_t stream, u32 want_sumfw, const u64* ends);
 #define KMX_BSR_DEFINE_K(K)                                                                                                  \
     hipError_t launch_bs_ragged_k##K(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out, \
-                                     unsigned long long* queue, int n_cu, hipStream_t stream, u32 seg_T, u32 seg_L, const u64* ends) { \
-        return launch_bs_ragged_any<K>(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, seg_T, seg_L, ends);  \
+                                     unsigned long long* queue, int n_cu, hipStream_t stream, u32 want_sumfw, const u64* ends) { \
+        return launch_bs_ragged_any<K>(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, want_sumfw, ends);  \
     }
 // k with a bit-sliced kernel for ragged reads: 13..31, like the uniform kernel
 #define KMX_BSR_FOR_EACH_K(X) \

@@ -43,7 +43,9 @@ def test_bitsliced_kernels_stay_out_of_scratch(kernels):
         # (round 4: the 16-word frame at 8 windows per lane -- reads of 256 bases -- keeps 72 bytes of spills at three waves per
         # SIMD, measured 4 % faster than two waves without any)
         assert int(d["ScratchSize [bytes/lane]"]) <= 80, (name, d["ScratchSize [bytes/lane]"])
-        if re.search(r"ELb0ELb1EEEv", name):   # the ragged variants: no spills at all (round 4: a spill-dependent wrong sum at size)
+        # the ragged variants and the segment variants (long uniform reads): no spills at all (round 4: a spill-dependent wrong
+        # sum at size).  Template flags: PACKED, RAGGED, SEG.
+        if re.search(r"ELb0ELb1ELb0EEEv|ELb0ELb0ELb1EEEv", name):
             assert int(d["ScratchSize [bytes/lane]"]) == 0, (name, d["ScratchSize [bytes/lane]"])
     assert seen >= 100   # every k of the three families, every frame
 
@@ -56,10 +58,12 @@ def test_headline_kernel_occupancy(kernels):
         hits = [d for n, d in kernels.items() if re.search(pattern, n)]
         assert len(hits) == 1, (pattern, len(hits))
         return int(hits[0]["Occupancy [waves/SIMD]"])
-    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0EEEv") == 3
-    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb1EEEv") == 2
-    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi5ELb0ELb1EEEv") == 2
-    assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb0EEEv") == 3
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0ELb0EEEv") == 3
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb1ELb0EEEv") == 2
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi5ELb0ELb1ELb0EEEv") == 2
+    assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb0ELb0EEEv") == 3
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0ELb1EEEv") == 3   # segments of long uniform reads
+    assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb0ELb1EEEv") == 2
 
 
 def test_scan_and_histogram_kernels_do_not_call(kernels):
