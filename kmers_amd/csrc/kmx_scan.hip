@@ -147,7 +147,12 @@ struct SinkWindowsT {
         NWL = reinterpret_cast<u32*>(WOL + 64);
         nwr = W_;
         out1 = line_aligned(p_) ? (p_.fw ? p_.fw : p_.rc ? p_.rc : p_.canon) : nullptr;
+        want_fw = p_.fw != nullptr;
+        want_rc = !want_fw && p_.rc != nullptr;
     }
+    // line-aligned mode: the one array's word of a window -- two wave-uniform masks decide, no branch per window
+    bool want_fw, want_rc;
+    __device__ __forceinline__ u64 pick(bool lt, u64 fw, u64 rc) const { return ((lt || want_fw) && !want_rc) ? fw : rc; }
     __device__ __forceinline__ void store(u64 slot, u64 fw, u64 rc) {
         const bool lt = fw < rc;
         if (p.fw) p.fw[slot] = fw;
@@ -166,8 +171,8 @@ struct SinkWindowsT {
     }
     __device__ __forceinline__ void fast(u32 o, u64 fw, u64 rc) {
         const bool lt = fw < rc;
-        if (out1) {
-            Tfw[lane * RPITCH + (o & 31u)] = p.fw ? fw : p.rc ? rc : (lt ? fw : rc);
+        if constexpr (ALIGNED) {
+            Tfw[lane * RPITCH + (o & 31u)] = pick(lt, fw, rc);
             return;
         }
         const u32 s = o & 15u, at = lane * PITCH + s;
@@ -181,24 +186,55 @@ struct SinkWindowsT {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (out1) {
+        if constexpr (ALIGNED) {
+            // 16 lanes per read and line, four reads per step.  The tile's first read is a multiple of 64, so read*W mod 16 comes
+            // from the read's index in the tile, and every address is a 32-bit offset from a wave-uniform base.  The loop is
+            // bound by the LDS round trip of each step (two waves per SIMD): the ring read of step i + 1 is issued before
+            // the store of step i.
             const bool last = o0 + cnt == W;      // the last pass also writes what is left of each read (< 32 windows)
+            const u32 g = lane >> 4, s = lane & 15u, Wm = W & 15u;
+            uint8_t* const gbase = reinterpret_cast<uint8_t*>(out1 + read0 * W);
             for (u32 sub = 0; sub < (last ? 2u : 1u); ++sub) {
-#pragma unroll KMX_WIN_UNROLL_A
-                for (u32 it = 0; it < 16u; ++it) {
-                    const u32 idx = it * 64u + lane, r = idx >> 4, s = idx & 15u;
-                    const u64 read = read0 + r;
-                    const u32 a = ((u32)(read & 15u) * (W & 15u)) & 15u;   // read*W mod 16
+                auto prep = [&](u32 it, u32& at, u32& goff) -> bool {
+                    const u32 r = 4u * it + g;
+                    const u32 a = (r * Wm) & 15u;          // read*W mod 16
                     const u32 lo = o0 > a ? o0 - a : 0u;
-                    const u32 hi = last ? W : o0 + 16u - a;
+                    u32 hi = last ? W : o0 + 16u - a;
+                    if (merge) {
+                        // the line that read r shares with read r - 1 (its head: windows [0, 16 - a)) and the one it shares with
+                        // read r + 1 (its tail: the last (a + W) mod 16 windows) are written whole by heads_done(); the two at the
+                        // ends of the tile are shared with other tiles and go out in pieces here
+                        if (o0 == 0u && a != 0u && r != 0u) hi = 0u;
+                        if (last && r != 63u) hi = W - ((a + Wm) & 15u);
+                    }
                     const u32 o = lo + 16u * sub + s;
+                    at = r * RPITCH + (o & 31u);
+                    goff = (r * W + o) * 8u;
+                    return o < hi;
+                };
+                // (merged: a read's part of the last pass is one line or none -- only the tile's last read, whose tail goes out
+                // in pieces, has windows left for the second round)
+                const u32 it_first = (merge && sub == 1u) ? 15u : 0u;
+                u32 at0, go0;
+                bool c0 = prep(it_first, at0, go0);
+                u64 v0 = Tfw[at0];
+#pragma unroll KMX_WIN_UNROLL_A
+                for (u32 it = it_first; it < 16u; ++it) {
+                    u32 at1 = 0, go1 = 0;
+                    bool c1 = false;
+                    u64 v1 = 0;
+                    c1 = prep((it + 1u) & 15u, at1, go1);    // (the 17th: loaded, never stored)
+                    v1 = Tfw[at1];
+                    // (every store of this loop, the pieces at the ends of a tile too, carries the nt hint: nt only on the whole lines
+                    // measured like no nt at all, 4.93 against 4.14-4.30 ms)
 #if KMX_WIN_NT
-                    // (every store of this loop, the half lines at the ends of a read too: nt only on the whole lines measured like no nt at all,
-                    // 4.93 against 4.14-4.30 ms -- the half lines, 64 contiguous bytes from 8 lanes, are what stays open in the L2 otherwise)
-                    if (o < hi) __builtin_nontemporal_store(Tfw[r * RPITCH + (o & 31u)], &out1[read * W + o]);
+                    if (c0) __builtin_nontemporal_store(v0, reinterpret_cast<u64*>(gbase + go0));
 #else
-                    if (o < hi) out1[read * W + o] = Tfw[r * RPITCH + (o & 31u)];
+                    if (c0) *reinterpret_cast<u64*>(gbase + go0) = v0;
 #endif
+                    c0 = c1;
+                    v0 = v1;
+                    go0 = go1;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -249,6 +285,60 @@ struct SinkWindowsT {
             base = read * W;
         }
         next = 0;
+#ifndef KMX_WIN_MERGE
+#define KMX_WIN_MERGE 1
+#endif
+        merge = KMX_WIN_MERGE && ALIGNED && W >= 32u;
+    }
+    // ---- line-aligned mode: the output line two neighbouring reads of a tile share.  Written in two pieces (the tail of read
+    // r - 1 in the tile's last pass, the head of read r in its first), 16-byte multiples at W = 130, such a line costs ~3.4x a
+    // whole one: 3.5 TB/s at W = 110 / 130 / 138 against 4.7 at W = 120 (pieces of 64 bytes) and W = 128 (none).  So the kernel
+    // hands the first 16 windows of every read over once more after the last block (kRedoHead: ~10 instructions per window,
+    // this sink waits for its stores) -- staged in the ring slots next to the tail's, (W + o) mod 32 -- and the lines go out whole.
+    static constexpr bool kRedoHead = ALIGNED;
+#ifndef KMX_WIN_PREFETCH
+#define KMX_WIN_PREFETCH 1
+#endif
+    static constexpr bool kPrefetch = ALIGNED && KMX_WIN_PREFETCH != 0;   // (the staged variant is laid out for three waves: fifty more registers spill)
+    bool merge;
+    __device__ __forceinline__ bool wants_heads() const { return merge; }
+    __device__ __forceinline__ void head(u32 o, u64 fw, u64 rc) {
+        Tfw[lane * RPITCH + ((W + o) & 31u)] = pick(fw < rc, fw, rc);
+    }
+    __device__ __forceinline__ void heads_done(u64 read0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const u32 g = lane >> 4, s = lane & 15u, Wm = W & 15u;
+        uint8_t* const gbase = reinterpret_cast<uint8_t*>(out1 + read0 * W);
+        auto prep = [&](u32 it, u32& at, u32& goff) -> bool {
+            const u32 r = 4u * it + g + 1u;
+            const u32 a = (r * Wm) & 15u;
+            // slot s of the line: below a the tail of read r - 1 (window W - a + s), from a on the head of read r (window s - a)
+            at = s < a ? (r - 1u) * RPITCH + ((W - a + s) & 31u) : r * RPITCH + ((W + s - a) & 31u);
+            goff = (r * W - a + s) * 8u;
+            return r < 64u && a != 0u;
+        };
+        u32 at0, go0;
+        bool c0 = prep(0u, at0, go0);
+        u64 v0 = Tfw[at0];
+#pragma unroll KMX_WIN_UNROLL_A
+        for (u32 it = 0; it < 16u; ++it) {
+            u32 at1 = 0, go1 = 0;
+            bool c1 = false;
+            u64 v1 = 0;
+            if (it + 1u < 16u) {
+                c1 = prep(it + 1u, at1, go1);
+                v1 = c1 ? Tfw[at1] : 0;      // (r = 64: past the ring)
+            }
+            if (c0) __builtin_nontemporal_store(v0, reinterpret_cast<u64*>(gbase + go0));
+            c0 = c1;
+            v0 = v1;
+            go0 = go1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // A tile rolled per lane (an invalid byte in it) is staged and written back like a fast one -- skipped windows stay the
     // zeros the slots are pre-filled with -- instead of 8-byte stores 1 KB apart: tile_slow_* are the hooks of that path
@@ -259,7 +349,7 @@ struct SinkWindowsT {
 #pragma unroll 4
         for (u32 sI = 0; sI < 16u; ++sI) {
             const u32 o = o0 + sI;
-            if (out1) Tfw[lane * RPITCH + (o & 31u)] = 0;
+            if constexpr (ALIGNED) Tfw[lane * RPITCH + (o & 31u)] = 0;
             else {
                 const u32 at = lane * PITCH + (o & 15u);
                 if (p.fw) Tfw[at] = 0;
@@ -271,6 +361,7 @@ struct SinkWindowsT {
     }
     __device__ __forceinline__ void tile_slow_begin(u64 read) {
         begin_read(read);
+        merge = false;           // (a rolled tile writes its pieces where they fall)
         slow_read0 = read - lane;
         prefill(0);
     }
@@ -286,6 +377,114 @@ struct SinkWindowsT {
     __device__ __forceinline__ void end_read() { zero_to(nwr); }
     __device__ __forceinline__ void tile_fast_done(u32) {}
     __device__ __forceinline__ void finish(const WindowsParams&) {}
+};
+
+// The flags array alone (uniform reads, W >= 16): one byte per window, VALID | FW_CANONICAL -- two BITS per window.  A lane
+// keeps the "fw < rc" bit of every window of its read in registers (three instructions per window), the tile's bits meet in
+// LDS (64 x 8 dwords per mask) and go out as the tile's 64 W contiguous bytes, 16 per lane and store: which read a chunk of
+// 16 bytes belongs to is one multiply-high, its bits one funnel shift (two when the chunk straddles two reads), a nibble
+// becomes four flag bytes by one multiply.  A rolled tile (an invalid byte in it) sets its bits in LDS as the windows come and
+// is written the same way.  Beside one launch of the line-aligned kernel per u64 array this replaces the staged transposed
+// store of all four arrays where W is not a multiple of 16 (16-byte runs of the flags, 128-byte runs straddling two lines of
+// the words: 2.1 TB/s at W = 130).
+struct FlagsParams {
+    uint8_t* flags;
+    u32 magic;       // floor(2^32 / W) + 1: b / W = umulhi(b, magic) for b < 2^16
+};
+struct SinkFlags {
+    static constexpr u32 NB = 8, BP = 9;        // mask dwords per read (W <= 256); LDS pitch (the ninth stays zero)
+    static constexpr u32 kLdsDwordsPerWave = 0;
+    static constexpr bool kRagged = false;
+    static constexpr int kWaves = 3;            // (four: 40-60 bytes of spills)
+    static u32 block_lds_dwords(const FlagsParams&) { return 4u * 2u * 64u * BP; }
+    FlagsParams p;
+    u32* VB;      // [64][BP] valid bits of the tile's reads
+    u32* LB;      // [64][BP] fw < rc
+    u32 lb[NB];
+    u64 base;
+    u32 W, next, lane;
+    __device__ SinkFlags(const FlagsParams& p_, u32, u32 W_, u32*, u32 lane_, u32* block_lds, u32 tid) : p(p_), base(0), W(W_), next(0), lane(lane_) {
+        VB = block_lds + (tid >> 6) * (2u * 64u * BP);
+        LB = VB + 64u * BP;
+        VB[lane * BP + NB] = 0;
+        LB[lane * BP + NB] = 0;
+#pragma unroll
+        for (u32 j = 0; j < NB; ++j) lb[j] = 0;
+    }
+    __device__ __forceinline__ void fast(u32 o, u64 fw, u64 rc) {
+        const u32 bit = (fw < rc ? 1u : 0u) << (o & 31u);
+        // (o is a constant in the unrolled blocks -- one OR; the read's last, partial block comes with a run-time o: no indexed
+        // register array, eight selects)
+#pragma unroll
+        for (u32 j = 0; j < NB; ++j) lb[j] |= (o >> 5) == j ? bit : 0u;
+    }
+    __device__ __forceinline__ void block_done(u64, u32, u32) {}
+    // the tile's masks are in LDS: 4 W chunks of 16 flag bytes
+    __device__ __forceinline__ void write_tile(u64 read0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        typedef u32 v4u __attribute__((ext_vector_type(4)));
+        v4u* const out = reinterpret_cast<v4u*>(p.flags + read0 * W);
+        auto take16 = [&](const u32* M, u32 r0, u32 o0, u32 n0) -> u32 {
+            const u32 j = o0 >> 5;
+            u32 x = alignbit(M[r0 * BP + j + 1u], M[r0 * BP + j], o0 & 31u);
+            if (n0 < 16u) x = (x & ((1u << n0) - 1u)) | (M[(r0 + 1u) * BP] << n0);   // the chunk runs into the next read
+            return x & 0xFFFFu;
+        };
+        for (u32 c = lane; c < 4u * W; c += 64u) {
+            const u32 b = 16u * c, r0 = __umulhi(b, p.magic), o0 = b - r0 * W, n0 = W - o0;
+            const u32 v = take16(VB, r0, o0, n0), l = take16(LB, r0, o0, n0) & v;
+            auto bytes = [&](u32 sh) -> u32 {      // four windows -> four flag bytes
+                const u32 vn = (v >> sh) & 15u, ln = (l >> sh) & 15u;
+                return ((vn * 0x00204081u) & 0x01010101u) * KMX_WIN_VALID | ((ln * 0x00204081u) & 0x01010101u) * KMX_WIN_FW_CANONICAL;
+            };
+            __builtin_nontemporal_store(v4u{bytes(0), bytes(4), bytes(8), bytes(12)}, &out[c]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ void tile_fast_done(u32) {
+#pragma unroll
+        for (u32 j = 0; j < NB; ++j) {
+            const u32 lo = 32u * j;
+            VB[lane * BP + j] = W >= lo + 32u ? ~0u : W > lo ? (1u << (W - lo)) - 1u : 0u;    // every window of the read is valid
+            LB[lane * BP + j] = lb[j];
+            lb[j] = 0;
+        }
+        write_tile(tile_read0);
+    }
+    u64 tile_read0;
+    __device__ __forceinline__ void begin_read(u64 read) {
+        base = read * W;
+        next = 0;
+        tile_read0 = read - lane;
+    }
+    __device__ __forceinline__ void tile_slow_begin(u64 read) {
+        begin_read(read);
+#pragma unroll
+        for (u32 j = 0; j < NB; ++j) {
+            VB[lane * BP + j] = 0;
+            LB[lane * BP + j] = 0;
+        }
+    }
+    __device__ __forceinline__ void tile_slow_emit(u32 pos, u64 fw, u64 rc) {     // (a lane's own row: no atomics)
+        VB[lane * BP + (pos >> 5)] |= 1u << (pos & 31u);
+        if (fw < rc) LB[lane * BP + (pos >> 5)] |= 1u << (pos & 31u);
+    }
+    __device__ __forceinline__ void slow_block(u32) {}
+    __device__ __forceinline__ void tile_slow_end() { write_tile(tile_read0); }
+    // the final partial tile: byte stores, window by window
+    __device__ __forceinline__ void slow(u32 pos, u64 fw, u64 rc) {
+        for (; next < pos; ++next) p.flags[base + next] = 0;
+        p.flags[base + pos] = (uint8_t)(KMX_WIN_VALID | (fw < rc ? KMX_WIN_FW_CANONICAL : 0u));
+        next = pos + 1u;
+    }
+    __device__ __forceinline__ void end_read() {
+        for (; next < W; ++next) p.flags[base + next] = 0;
+    }
+    __device__ __forceinline__ void finish(const FlagsParams&) {}
 };
 
 // Each returns hipSuccess and sets *handled=false when (L,k) is outside the fast kernel's domain.
@@ -305,7 +504,33 @@ hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 
     *handled = scan_domain(bases, n_reads, L, k);
     if (!*handled) return hipSuccess;
     const WindowsParams p{fw, rc, canon, flags, nullptr};
-    if (SinkWindowsT<true>::wants_aligned(p, L - k + 1u)) return dispatch<SinkWindowsT<true>>(bases, n_reads, L, k, p, queue, n_cu, stream);
+    const u32 W = L - k + 1u;
+    if (SinkWindowsT<true>::wants_aligned(p, W)) return dispatch<SinkWindowsT<true>>(bases, n_reads, L, k, p, queue, n_cu, stream);
+    // several arrays, W not a multiple of 16 (the staged store's 128-byte runs would straddle two lines each): one pass of the
+    // line-aligned kernel per u64 array, one of the flags kernel -- the reads are a seventh of what one array takes to write
+    if ((W & 15u) != 0u && W >= 32u && (!flags || (reinterpret_cast<uintptr_t>(flags) & 15u) == 0u)) {
+        bool first = true;
+        auto again = [&]() -> hipError_t {      // (every pass owns the tile queue from zeroed heads)
+            if (first) {
+                first = false;
+                return hipSuccess;
+            }
+            return hipMemsetAsync(queue, 0, 32 * 128, stream);
+        };
+        u64* const arr[3] = {fw, rc, canon};
+        for (int a = 0; a < 3; ++a) {
+            if (!arr[a]) continue;
+            if (hipError_t e = again()) return e;
+            const WindowsParams one{a == 0 ? fw : nullptr, a == 1 ? rc : nullptr, a == 2 ? canon : nullptr, nullptr, nullptr};
+            if (hipError_t e = dispatch<SinkWindowsT<true>>(bases, n_reads, L, k, one, queue, n_cu, stream)) return e;
+        }
+        if (flags) {
+            if (hipError_t e = again()) return e;
+            const FlagsParams fp{flags, (u32)(0x100000000ull / W) + 1u};
+            if (hipError_t e = dispatch<SinkFlags>(bases, n_reads, L, k, fp, queue, n_cu, stream)) return e;
+        }
+        return hipSuccess;
+    }
     return dispatch<SinkWindowsT<false>>(bases, n_reads, L, k, p, queue, n_cu, stream);
 }
 

@@ -41,6 +41,19 @@ template <typename S> struct SinkBlockAlign<S, decltype((void)S::kBlockLdsAlign)
 // a sink may ask for complemented windows (fw ^ mask, rc ^ mask) from the kernel's fast path (static constexpr bool kComplement)
 template <typename S, typename = void> struct SinkComplement { static constexpr bool value = false; };
 template <typename S> struct SinkComplement<S, decltype((void)S::kComplement)> { static constexpr bool value = S::kComplement; };
+// a sink may ask for the first 16 windows of every read once more after the last block (static constexpr bool kRedoHead;
+// wants_heads(), head(o, fw, rc), heads_done(read0)): the materialise sink writes the output line that two neighbouring reads
+// share in one piece then
+template <typename S, typename = void> struct SinkRedoHead { static constexpr bool value = false; };
+template <typename S> struct SinkRedoHead<S, decltype((void)S::kRedoHead)> { static constexpr bool value = S::kRedoHead; };
+// a sink that stores to global memory in bulk may ask for the NEXT tile's bytes early (static constexpr bool kPrefetch).  On
+// gfx9 loads and stores share one in-order counter: a tile's loads, issued behind the 150 stores of the tile before, return
+// when the last of those has been acknowledged -- every tile began with a drain of the wave's store queue (materialise, one
+// array: 2.04 ms per 1e7 reads against 1.73 with the loads taken out).  With kPrefetch the loads of tile t + 1 are issued once
+// tile t has built its F / G words -- behind the stores of tile t - 1 only, which have had a whole load-and-encode phase to
+// drain -- and are encoded into ten registers right after the first window block, before that block's stores.
+template <typename S, typename = void> struct SinkPrefetch { static constexpr bool value = false; };
+template <typename S> struct SinkPrefetch<S, decltype((void)S::kPrefetch)> { static constexpr bool value = S::kPrefetch; };
 template <typename S, int NW> constexpr int sink_waves() { return NW <= 10 ? SinkWaves<S>::value : KMX_SCAN_WAVES; }   // (the 16-word frame would spill 1 KB)
 template <int NW, int V, int DW, typename Sink, typename Params, bool RAGGED = false>
 __global__ void __launch_bounds__(256, (sink_waves<Sink, NW>()))
@@ -126,6 +139,32 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         return ~0ull;
     };
     u64 next_tile = dequeue();
+    constexpr bool PF = SinkPrefetch<Sink>::value && !RAGGED;
+    [[maybe_unused]] u32 E[NW];          // PF: the next tile, encoded (chunk it * 64 + lane)
+    [[maybe_unused]] u32 bad_pf = 0;
+    [[maybe_unused]] uint4 wpf[NW];
+    auto pf_issue = [&](u64 t) {
+        const uint4* __restrict__ nb = reinterpret_cast<const uint4*>(bases + t * 64u * (u64)L);
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            const u32 c = it * 64u + lane;
+            if (c < chunks_u) wpf[it] = nb[c];
+        }
+    };
+    auto pf_take = [&]() {
+        bad_pf = 0;
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            const u32 c = it * 64u + lane;
+            if (c < chunks_u) E[it] = encode16(wpf[it], bad_pf);
+        }
+    };
+    if constexpr (PF) {
+        if (next_tile < n_full) {
+            pf_issue(next_tile);
+            pf_take();
+        }
+    }
     // ragged: this lane's [start, end) of the NEXT tile, fetched one tile ahead so that the tile's byte loads never wait
     // behind a dependent offsets load
     u64 nx_off = 0, nx_end = 0;
@@ -174,6 +213,16 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
                 continue;
             }
         }
+        u32 bad = 0;
+        if constexpr (PF) {
+            // ---- 1 + 2. the tile came in while the tile before was being written out
+            bad = bad_pf;
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const u32 c = it * 64u + lane;
+                if (c < chunks) P[1u + c] = E[it];
+            }
+        } else {
         // ---- 1. stream the tile: all loads in flight before the first use
         uint4 w[NW];
         if (tile_fits) {
@@ -184,13 +233,13 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
             }
         }
         // ---- 2. pack + validate, stage packed words in LDS
-        u32 bad = 0;
         if (tile_fits) {
 #pragma unroll
             for (int it = 0; it < NW; ++it) {
                 const u32 c = it * 64u + lane;
                 if (c < chunks) P[1u + c] = encode16(w[it], bad);
             }
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -204,6 +253,12 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
             roll_read_stepped(RAGGED ? bases + my_off : bases + lead + read * (u64)L, RAGGED ? my_len : L, roll_max, k,
                               [&](u32 pos, u64 fw, u64 rc) { sink.tile_slow_emit(pos, fw, rc); }, [&](u32 wb) { sink.slow_block(wb); });
             sink.tile_slow_end();
+            if constexpr (PF) {
+                if (next_tile < n_full) {
+                    pf_issue(next_tile);
+                    pf_take();
+                }
+            }
             continue;
         }
 
@@ -228,6 +283,9 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
 
         // ---- 4. windows: o = 16*i + s;  fw from F[i..i+2] >> 2s;  rc from G[M..M+2] >> (30-2s), M = NW-V-i
         sink.begin_read(read);
+        if constexpr (PF) {
+            if (next_tile < n_full) pf_issue(next_tile);
+        }
 #pragma unroll
         for (int i = 0; i <= NW - V; ++i) {
             const int M = NW - V - i;
@@ -264,10 +322,36 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
                 for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, RAGGED && !KMX_SCAN_DEV_NOGUARD, RAGGED ? -1 : s);
                 }
 #endif
+                if constexpr (PF) {
+                    if (i == 0 && next_tile < n_full) pf_take();    // (before the block's stores: nothing younger than the loads to wait for)
+                }
                 sink.block_done(tile * 64u, 16u * i, 16u);
             } else if ((u32)i == imax) {
                 for (u32 s = 0; s <= smax; ++s) window(16u * i + s, F[i], F[i + 1], F[i + 2], G[M], G[M + 1], G[M + 2], 2u * s, 30u - 2u * s);
+                if constexpr (PF) {
+                    if (i == 0 && next_tile < n_full) pf_take();
+                }
                 sink.block_done(tile * 64u, 16u * i, smax + 1u);
+            }
+        }
+        if constexpr (SinkRedoHead<Sink>::value && !RAGGED) {
+            if (sink.wants_heads()) {
+                constexpr int M0 = NW - V;
+                u32 f0 = F[0], f1 = F[1], f2 = F[2], g0 = G[M0], g1 = G[M0 + 1], g2 = G[M0 + 2];
+                asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(g0), "+v"(g1), "+v"(g2));
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    u64 fw, rc;
+                    if (DW == 2) {
+                        fw = ((u64)(alignbit(f2, f1, 2 * s) & mhi) << 32) | alignbit(f1, f0, 2 * s);
+                        rc = ((u64)(alignbit(g2, g1, 30 - 2 * s) & mhi) << 32) | alignbit(g1, g0, 30 - 2 * s);
+                    } else {
+                        fw = (u64)(alignbit(f1, f0, 2 * s) & mlo);
+                        rc = (u64)(alignbit(g1, g0, 30 - 2 * s) & mlo);
+                    }
+                    sink.head((u32)s, fw, rc);
+                }
+                sink.heads_done(tile * 64u);
             }
         }
         sink.tile_fast_done(nwin);

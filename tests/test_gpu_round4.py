@@ -348,3 +348,33 @@ def test_long_uniform_segments_at_size(ctx, orc, k, L, n):
         o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
         g = ctx.canonical_reduce2(bases, n, L, k, with_hash=True)
         assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+
+# ---------------------------------------------------------------- materialise: the output line two reads share
+
+@pytest.mark.parametrize("p_bad", [0.0, 0.001])
+@pytest.mark.parametrize("L,k", [(52, 21), (53, 21), (61, 31), (67, 21), (100, 21), (129, 21), (140, 31), (150, 21), (151, 21), (155, 21),
+                                 (158, 21), (160, 21), (160, 31), (150, 5), (45, 13), (51, 21)])
+def test_windows_single_array_shared_lines(ctx, orc, L, k, p_bad):
+    """one u64 array of uniform reads whose window count is not a multiple of 16: the output line that two neighbouring reads
+    of a tile share is written once, whole -- the head of the second read is rebuilt after the tile's last block
+    (kmx_scan.hip: heads_done).  Every residue of W mod 16, W around 32 (below it the pieces go out where they fall), tiles
+    with and without an invalid byte, a partial last tile; canonical_kmer_iterator.rs:42-70 per read."""
+    rng = np.random.default_rng(L * 1000 + k)
+    n = 64 * 7 + 29
+    host = _dirty(rng, n * L, p_bad)
+    bases = ctx.to_device(host)
+    fw, rc, canon, flags = orc.canonical_windows(host, n, L, k)
+    for name, exp in (("canon", canon), ("fw", fw), ("rc", rc)):
+        got = ctx.canonical_windows(bases, n, L, k, want=(name,))[name].cpu().numpy().view(np.uint64)
+        assert (got == exp).all(), (name, int((got != exp).sum()), np.flatnonzero(got != exp)[:8])
+    # several arrays: one pass of the same kernel per array of words, the flags from their own kernel (two bits per window in
+    # registers, the tile's bytes written 16 per lane)
+    for want in (("fw", "rc", "canon", "flags"), ("canon", "flags"), ("flags",), ("fw", "canon")):
+        got = ctx.canonical_windows(bases, n, L, k, want=want)
+        for name, exp in (("canon", canon), ("fw", fw), ("rc", rc)):
+            if name in want:
+                assert (got[name].cpu().numpy().view(np.uint64) == exp).all(), (want, name)
+        if "flags" in want:
+            gf = got["flags"].cpu().numpy()
+            assert (gf == flags).all(), (want, int((gf != flags).sum()), np.flatnonzero(gf != flags)[:8])
