@@ -106,6 +106,10 @@ struct SinkWindowsT {
     // store latency is all this sink waits for: occupancy over registers (the line-aligned variant spills at 168 registers
     // and its 17 KB ring per wave caps a CU at two blocks anyway)
     static constexpr int kWaves = ALIGNED ? 2 : KMX_WIN_WAVES;
+    // (the 16-word frame: two waves as well -- without the prefetch it needs 230 registers -- and, with the packed tile
+    // living in the ring, two blocks per CU up to 256 bases: 2.5 -> 4.5 TB/s)
+    static constexpr int kWavesBig = ALIGNED ? 2 : KMX_SCAN_WAVES;
+    static constexpr bool kAliasPacked = ALIGNED;
     static constexpr u32 kLdsDwordsPerWave = 0;
     // One u64 array and no flags (the usual call: the canonical words): write-back in units of whole, 128-byte ALIGNED
     // lines of the output.  The lines of read r are shifted by a = r*W mod 16 slots against its windows, so the windows

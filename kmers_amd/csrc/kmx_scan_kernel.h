@@ -54,7 +54,15 @@ template <typename S> struct SinkRedoHead<S, decltype((void)S::kRedoHead)> { sta
 // drain -- and are encoded into ten registers right after the first window block, before that block's stores.
 template <typename S, typename = void> struct SinkPrefetch { static constexpr bool value = false; };
 template <typename S> struct SinkPrefetch<S, decltype((void)S::kPrefetch)> { static constexpr bool value = S::kPrefetch; };
-template <typename S, int NW> constexpr int sink_waves() { return NW <= 10 ? SinkWaves<S>::value : KMX_SCAN_WAVES; }   // (the 16-word frame would spill 1 KB)
+// ... and for the 16-word frame (static constexpr int kWavesBig; without it: no cap -- most sinks would spill 1 KB there)
+template <typename S, typename = void> struct SinkWavesBig { static constexpr int value = KMX_SCAN_WAVES; };
+template <typename S> struct SinkWavesBig<S, decltype((void)S::kWavesBig)> { static constexpr int value = S::kWavesBig; };
+// a sink whose block-level LDS is one region per wave, empty between two tiles (static constexpr bool kAliasPacked;
+// wave_dwords(params) >= the packed tile), lends it to the tile's packed words: they are dead once the lanes hold their F / G
+// words, and a wave's LDS operations complete in order
+template <typename S, typename = void> struct SinkAliasPacked { static constexpr bool value = false; };
+template <typename S> struct SinkAliasPacked<S, decltype((void)S::kAliasPacked)> { static constexpr bool value = S::kAliasPacked; };
+template <typename S, int NW> constexpr int sink_waves() { return NW <= 10 ? SinkWaves<S>::value : SinkWavesBig<S>::value; }
 template <int NW, int V, int DW, typename Sink, typename Params, bool RAGGED = false>
 __global__ void __launch_bounds__(256, (sink_waves<Sink, NW>()))
 scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, Params params,
@@ -66,7 +74,10 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     const u32 wib = threadIdx.x >> 6;
     const u32 chunks_u = RAGGED ? 64u * NW : 4u * L + (lead != 0u ? 1u : 0u);  // 16-byte chunks per 64-read tile (ragged: the most a tile may span)
     const u32 ldsw = (chunks_u + 1u + 6u + 3u) & ~3u; // front pad 1, tail pad >= 6
-    u32* P = lds + wib * (ldsw + Sink::kLdsDwordsPerWave);
+    constexpr bool ALIAS = SinkAliasPacked<Sink>::value;
+    u32* P;
+    if constexpr (ALIAS) P = lds + wib * Sink::wave_dwords(params);
+    else P = lds + wib * (ldsw + Sink::kLdsDwordsPerWave);
 
     const u64 n_full = n_reads >> 6;
     const u64 wave_id = (u64)blockIdx.x * 4u + wib;
@@ -88,7 +99,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     u32 chunks = chunks_u;
 
     constexpr u32 BAL = SinkBlockAlign<Sink>::value;
-    Sink sink(params, k, nwin, P + ldsw, lane, lds + (4u * (ldsw + Sink::kLdsDwordsPerWave) + BAL - 1u) / BAL * BAL, threadIdx.x);
+    Sink sink(params, k, nwin, P + ldsw, lane, ALIAS ? lds : lds + (4u * (ldsw + Sink::kLdsDwordsPerWave) + BAL - 1u) / BAL * BAL, threadIdx.x);
 
     [[maybe_unused]] u32 nwin_min = nwin;   // ragged: the shortest read of the tile (blocks of windows below it need no per-lane mask)
     // `slot`: position of the window inside a fully unrolled block of 16 (a compile-time value there), -1 elsewhere; a
@@ -139,7 +150,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         return ~0ull;
     };
     u64 next_tile = dequeue();
-    constexpr bool PF = SinkPrefetch<Sink>::value && !RAGGED;
+    constexpr bool PF = SinkPrefetch<Sink>::value && !RAGGED && NW <= 10;   // (the 16-word frame: 80 more registers do not fit two waves)
     [[maybe_unused]] u32 E[NW];          // PF: the next tile, encoded (chunk it * 64 + lane)
     [[maybe_unused]] u32 bad_pf = 0;
     [[maybe_unused]] uint4 wpf[NW];
@@ -394,7 +405,11 @@ static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Pa
     const u32 chunks = RAGGED ? 64u * NW : 4u * L + (lead != 0u ? 1u : 0u);
     const u32 ldsw = (chunks + 1u + 6u + 3u) & ~3u;
     constexpr u32 BAL = SinkBlockAlign<Sink>::value;
-    const size_t lds_bytes = (size_t)((4u * (ldsw + Sink::kLdsDwordsPerWave) + BAL - 1u) / BAL * BAL) * 4u + (size_t)Sink::block_lds_dwords(params) * 4u;
+    size_t lds_bytes = (size_t)((4u * (ldsw + Sink::kLdsDwordsPerWave) + BAL - 1u) / BAL * BAL) * 4u + (size_t)Sink::block_lds_dwords(params) * 4u;
+    if constexpr (SinkAliasPacked<Sink>::value) {
+        if (Sink::block_lds_dwords(params) < 4u * ldsw) return hipErrorInvalidValue;
+        lds_bytes = (size_t)Sink::block_lds_dwords(params) * 4u;
+    }
     // blocks per CU, cached per host thread and device (the ABI's model is one thread per context / GPU: a plain static
     // would be written by all of them at once, and the function attribute below is a per-device setting)
     static thread_local int bpc = 0, bpc_dev = -1;
