@@ -36,7 +36,7 @@ for k in 13 17 21 25 27 29 31 33 41 47 51 55 63; do python3 bench.py --no-cpu-ba
 for spec in "36 400000000" "50 300000000" "62 240000000" "75 200000000" "100 150000000" "112 130000000" "125 120000000" "150 100000000" "161 93000000" "170 88000000" "200 75000000" "208 72000000" "216 69000000" "224 66000000" "250 60000000" "256 58000000" "300 50000000" "1000 15000000" "10000 1500000"; do set -- $spec
   python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len $1 --reads-per-gpu $2 2>/dev/null | python3 tools/bench_line.py "L=$1"; done > $out/len_sweep.txt
 # two-word k on the long frames (round 4), and the settle-steps cross-check of the headline (30 = the default, 0 beside it)
-for spec in "63 200 75000000" "63 250 60000000" "47 208 72000000" "33 250 60000000"; do set -- $spec
+for spec in "63 200 75000000" "63 250 60000000" "47 208 72000000" "33 250 60000000" "63 300 50000000" "63 1000 15000000" "41 1000 15000000" "33 10000 1500000"; do set -- $spec
   python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 -k $1 --read-len $2 --reads-per-gpu $3 2>/dev/null | python3 tools/bench_line.py "k=$1 L=$2"; done > $out/k2_long.txt
 for st in 30 0 30 0; do python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --sustain-steps 1000 --settle-steps $st 2>/dev/null | python3 tools/bench_line.py "[settle $st]"; done > $out/settle.txt
 python3 tools/bench_windows2.py > $out/windows2_bench.txt 2>/dev/null
@@ -44,6 +44,7 @@ python3 tools/bench_ragged.py 100000000 31 > $out/ragged_bench.txt 2>/dev/null
 python3 tools/bench_ragged.py 100000000 21 >> $out/ragged_bench.txt 2>/dev/null
 HIST=20 python3 tools/bench_dirty.py > $out/dirty_bench.txt 2>/dev/null
 python3 tools/bench_windows.py > $out/windows_bench.txt 2>/dev/null
+for L in 100 140 150 158 166 200 250 256; do echo "[1e7 reads of $L bases]"; python3 tools/bench_windows.py 10000000 $L 2>/dev/null | grep "^k="; done > $out/windows_len.txt
 python3 tools/bench_hist.py 100000000 12,16,20,22,23,24,26,28 > $out/hist_bench.txt 2>/dev/null
 python3 tools/bench_minimizers.py > $out/minimizers_bench.txt 2>/dev/null
 python3 tools/bench_fastx.py > $out/fastx_bench.txt 2>/dev/null
