@@ -78,7 +78,7 @@ typedef struct {
  * window) and raise a sticky flag on the context, the next kmx_ctx_synchronize returns KMX_E_ARG with the text in
  * kmx_last_error and clears the flag; kmx_reads_length_range returns KMX_E_ARG for such a batch right away.  Cut such
  * records into overlapping pieces first (k - 1 bases of overlap, or hand the bytes over as uniform reads: reads longer
- * than 256 bases are scanned in 160-base segments).  Uniform reads may start at any byte address; ragged reads need a
+ * than 256 bases are scanned as overlapping segments by the tiled kernel, every k from 13 to 64).  Uniform reads may start at any byte address; ragged reads need a
  * 16-byte-aligned d_bases for the tiled kernels (any address is served, by the per-read kernel). */
 
 /* Result of a streaming reduce pass (device-resident, 32 bytes).
