@@ -118,7 +118,10 @@ constexpr int bs_acc_blocks(int K) { return (K + 30) / 16 + 1; }
 // sum_canon on 1.2e6 segments of 1000-base reads (tests/test_gpu_round4.py::test_long_uniform_reads_at_size) while a build
 // that differed by the order of two conjuncts passed: a spill-dependent miscompare not understood yet, so no ragged variant
 // is compiled into spills.
-// (SEG with two-word k: the segment bookkeeping on top of the two-word frame spilled 32..80 bytes at three waves -- same rule.)
+// (SEG with two-word k: the segment bookkeeping on top of the two-word frame spilled 32..80 bytes at three waves -- same rule.
+// SEG in the 13-word frame, k >= 18: 16 bytes at three waves, which measured 13 % faster than two waves without any (1 000-base
+// reads 0.62 against 0.55 of the roofline) -- kept, and held against the oracle at size by
+// tests/test_gpu_round4.py::test_long_uniform_segments_at_size.)
 template <int K, int NW, int WPL, bool PACKED, bool RAGGED, bool SEG = false> constexpr int bs_waves() {
     return (RAGGED || (K > 32 && (NW > 10 || SEG))) ? 2 : 3;
 }
@@ -143,7 +146,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead,
                       const u64* __restrict__ ends, const BsSeg seg) {
-    static_assert(!SEG || (!PACKED && !RAGGED && NW == 10), "segments of long uniform reads: ASCII, the 10-word frame");
+    static_assert(!SEG || (!PACKED && !RAGGED && (NW == 10 || NW == 13)), "segments of long uniform reads: ASCII, the 10- and the 13-word frame");
     // `ends` (RAGGED with offsets): read r = bases[offsets[r], ends[r]) -- offsets + 1 for reads stored back to back, an array of
     // its own for the overlapping SEGMENTS a batch of long ragged reads was cut into (kmx_segments.hip, round 4).
     // `lead` (uniform ASCII input whose first byte is not 16-byte aligned): `bases` is the aligned address below it and
@@ -182,7 +185,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
     if (ldsw < 64u * WPL) ldsw = 64u * WPL;            // (it holds the mask words of pass 2 afterwards)
     constexpr u32 CSA_DW = 4u * ((K + 1) / 2);         // 2 * NT 64-bit sums of the counter classes
-    constexpr u32 TOTS_DW = SEG ? 64u * NW : 0u;       // SEG: per-plane totals of the SHORT segments (as TOT, [group][lane])
+    // SEG: per-plane totals of the SHORT segments (as TOT, [group][lane]) -- of the groups that hold the last window's K bases
+    // only, the first of them (W - 1) >> 4: the whole frame's worth cost the 13-word frame its third block per CU
+    constexpr u32 TOTS_G = (K - 1) / 16 + 2;
+    constexpr u32 TOTS_DW = SEG ? 64u * TOTS_G : 0u;
     u32* P = lds + wib * (ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW + TOTS_DW);
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
@@ -310,7 +316,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     if constexpr (SEG) {
 #pragma unroll
-        for (int g = 0; g < NW; ++g) TOTS[64u * g + lane] = 0;
+        for (u32 g = 0; g < TOTS_G; ++g) TOTS[64u * g + lane] = 0;
     }
     // acc[q][j] of lane (half, p) is G[o][beta] for o = (j & 3) + 8 (j >> 2) + 4 half (mod 32), plane 32 q + p relative to the
     // window block: base o_blk + 16 q + p / 2, bit p & 1.  The diagonal t = beta - o in [0, K) is base t of the window; t and
@@ -865,8 +871,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     u32* const tots_l = TOTS + lane;
 #pragma unroll
                     for (int g = 0; g < NW; ++g) {
-                        if (16u * g + 15u < W - 1u) continue;     // (wave-uniform)
-                        atomicAdd(tots_l + 64 * g, (u32)__builtin_popcount(F[g] & sh_half));
+                        const u32 gs = (u32)g - ((W - 1u) >> 4);  // (wave-uniform: 16 g + 15 >= W - 1 from the first one on)
+                        if (gs >= TOTS_G) continue;
+                        atomicAdd(tots_l + 64u * gs, (u32)__builtin_popcount(F[g] & sh_half));
                     }
                 }
             }
@@ -1216,7 +1223,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             tot[g] = pcq + __shfl_xor(pcq, 32, WAVE);      // lanes p and p+32 hold the same plane of the two sets
             if constexpr (SEG) {
                 // the short segments' last window (W-1) does not exist: base i of it sat at exponent i - (W-1) of the forward word
-                const u32 pcs = TOTS[64u * g + lane], i = qidx >> 1;
+                const u32 gs = (u32)g - ((W - 1u) >> 4), i = qidx >> 1;
+                const u32 pcs = gs < TOTS_G ? TOTS[64u * gs + lane] : 0u;
                 if constexpr (K <= 32) {
                     if (i >= W - 1u && i <= L - 1u) fwall -= (u64)pcs * ((1ull << (2u * (i - (W - 1u)))) << (qidx & 1u));
                 }
@@ -1454,7 +1462,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     constexpr u32 NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;
     constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
     constexpr u32 CSA_DW = 4u * ((K + 1) / 2);
-    constexpr u32 TOTS_DW = SEG ? 64u * NW : 0u;
+    constexpr u32 TOTS_DW = SEG ? 64u * ((K - 1) / 16 + 2) : 0u;
     const size_t lds_bytes = (size_t)(ldsw + 4u * (u32)bs_plane_dwords(NW) + (RAGGED ? 2u * (32u * NV + 8u) : 0u) + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW + TOTS_DW) * 4u * 4u;
     // blocks per CU, cached per host thread and device (one thread per context / GPU is the ABI's model: a plain static
     // would be shared, and written, by all of them)
@@ -1489,22 +1497,32 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     return hipGetLastError();
 }
 
-// Uniform reads longer than a frame (L > 256), any k from 13 to 64: how they are cut (see BsSeg).  T <= min(128, 160 - k) windows
-// per segment (the 10-word frame holds 159 bases + the alignment lead), as few segments as that allows, all of T or T - 1 windows.
-struct BsSegPlan { u32 J, J1, T; };
+// Uniform reads longer than a frame (L > 256), any k from 13 to 64: how they are cut (see BsSeg).  As few segments as the
+// largest frame allows, all of T or T - 1 windows.  Single-word k: the 13-word frame (207 bases + the alignment lead, six
+// windows per lane: T <= min(192, 208 - k)) -- k - 1 of every T + k - 1 bases are scanned twice, 30 of 158 in the 10-word frame
+// and 30 of 207 here (1 000-base reads 0.59 -> 0.64 of the roofline) -- unless the segments that come out fit the 10-word frame
+// (reads of 257..~450 bases).  Two-word k: the 10-word frame (T <= min(128, 160 - k); in the 13-word frame at two waves the
+// longer segments gain what the frame loses).
+struct BsSegPlan { u32 J, J1, T, NW; };
 static inline BsSegPlan bs_seg_plan(u32 L, u32 k) {
-    const u32 wr = L - k + 1u, t_max = 160u - k < 128u ? 160u - k : 128u;
+    const u32 wr = L - k + 1u;
+    const u32 t10 = 160u - k < 128u ? 160u - k : 128u, t13 = 208u - k < 192u ? 208u - k : 192u;
+    const u32 t_max = k <= 31u ? t13 : t10;
     const u32 J = (wr + t_max - 1u) / t_max, T = (wr + J - 1u) / J;
-    return BsSegPlan{J, J - (J * T - wr), T};
+    return BsSegPlan{J, J - (J * T - wr), T, (T <= t10) ? 10u : 13u};
 }
 template <int K>
 static hipError_t launch_bs_seg(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
                                 unsigned long long* queue, int n_cu, hipStream_t stream) {
     const BsSegPlan pl = bs_seg_plan(L, (u32)K);
-    if (pl.T <= 64u || pl.T > 128u || n_reads > (1ull << 40) / pl.J) return hipErrorInvalidValue;
+    if (pl.T <= 64u || pl.T > 192u || n_reads > (1ull << 40) / pl.J) return hipErrorInvalidValue;
     const BsSeg seg{L, pl.J, pl.J1, pl.J < 64u ? (u32)(0x100000000ull / pl.J) + 1u : 0u, ~0ull / pl.J + 1ull};   // (J >= 2: floor((2^64 - 1) / J) = floor(2^64 / J) unless J is a power of two, where the + 1 lands on 2^64 / J + 1 as well)
     const u64 n_seg = n_reads * pl.J;
     const u32 Lf = pl.T + (u32)K - 1u;
+    if constexpr (K <= 31) {
+        if (pl.NW == 13u) return launch_bs<K, 13, 6, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
+    }
+    if (pl.NW != 10u) return hipErrorInvalidValue;
     if (pl.T <= 96u) return launch_bs<K, 10, 3, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
     return launch_bs<K, 10, 4, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
 }

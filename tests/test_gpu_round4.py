@@ -301,7 +301,7 @@ def test_variants_with_spills_at_size(ctx, orc, k, L, n):
 # ------------------------------------------------------------------ uniform reads above 256 bases: segments on the uniform kernel
 
 @pytest.mark.parametrize("k", [13, 21, 30, 31])
-@pytest.mark.parametrize("L,n", [(257, 64 * 9 + 5), (287, 64 * 4), (300, 64 * 6 + 1), (383, 200), (1000, 64 * 3 + 1), (1021, 130), (5003, 150), (20000, 70), (100_003, 9)])
+@pytest.mark.parametrize("L,n", [(257, 64 * 9 + 5), (270, 64 * 3 + 7), (287, 64 * 4), (300, 64 * 6 + 1), (383, 200), (400, 64 * 5 + 2), (450, 64 * 2 + 9), (1000, 64 * 3 + 1), (1021, 130), (5003, 150), (20000, 70), (100_003, 9)])
 def test_long_uniform_reads_as_segments(ctx, orc, k, L, n):
     """round 4: a read of L > 256 bases is cut into J segments of T or T - 1 windows (bs_seg_plan) that the UNIFORM kernel scans
     (a short segment's last window masked, the closed form corrected by the short segments' plane totals); dirty bytes, the
@@ -332,7 +332,7 @@ def test_long_uniform_reads_as_segments_two_word(ctx, orc, k, L, n):
         assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
 
 
-@pytest.mark.parametrize("k,L,n", [(31, 1000, 150_000), (31, 300, 400_000), (63, 1000, 100_000), (21, 777, 150_000)])
+@pytest.mark.parametrize("k,L,n", [(31, 1000, 150_000), (31, 300, 400_000), (31, 400, 300_000), (63, 1000, 100_000), (21, 777, 150_000), (13, 10_000, 15_000)])
 def test_long_uniform_segments_at_size(ctx, orc, k, L, n):
     """the same at sizes where every wave scans many tiles of segments (the accumulators and the short-segment totals carry over)"""
     from kmers_amd import _lib
