@@ -68,7 +68,8 @@ hipError_t launch_windows_generic(const kmx_reads* r, const u64* win_off, u32 k,
                                   uint8_t* flags, int n_cu, hipStream_t st, unsigned long long* too_long);
 hipError_t launch_histogram_generic(const kmx_reads* r, u32 k, u32 hasher, u32 hk, u32 log2_buckets, u64* counts,
                                     int n_cu, hipStream_t st, unsigned long long* too_long);
-hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_summary2* out, int n_cu, hipStream_t st, unsigned long long* too_long);
+hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_summary2* out, int n_cu, hipStream_t st, unsigned long long* too_long,
+                                  const u32* gate);
 hipError_t launch_windows2_tiled(const kmx_reads* r, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu, hipStream_t st,
                                  bool* handled);
 hipError_t launch_windows2_generic(const kmx_reads* r, const u64* win_off, u32 k, u64* fw, u64* rc, u64* canon,
@@ -541,13 +542,31 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
     if (reads->n_reads == 0) return KMX_OK;
     if (!reads->d_offsets) {
         bool handled = false;
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 8, ctx->stream));   // queue heads + the "a tile was flagged" word
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 16, ctx->stream));   // queue heads + the "a tile was flagged" word + the uniform / ragged gate
         if (int st = prepare_dirty_flags(ctx, reads->n_reads * kmx::bitsliced_segments_per_read(reads->read_len, k), k)) return st;
         KMX_HIP(ctx, kmx::launch_scan_bitsliced2(reads->d_bases, reads->n_reads, reads->read_len, k, with_hash != 0, d_out,
                                                  ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
     }
-    KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8));
+    // Reads behind an offsets array with a length bound the tiled two-word kernel takes (what kmx_fastx_parse hands over): most
+    // FASTQ is untrimmed -- every read exactly L bases.  Decided on the device, as kmx_canonical_reduce does: a small kernel
+    // checks offsets[i] == i*L, the uniform scan and the lane-per-read kernel are both launched behind its verdict, one runs.
+    const uint32_t Lh = reads->read_len;
+    if (reads->d_offsets && Lh >= k && Lh <= 256 && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
+        uint32_t* gate = reinterpret_cast<uint32_t*>(ctx->d_scratch + 16 + 513);
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 16, ctx->stream));
+        KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 1, 1, ctx->stream));
+        KMX_HIP(ctx, kmx::launch_offsets_uniform_gate(reads->d_offsets, reads->n_reads, Lh, gate, ctx->n_cu, ctx->stream));
+        if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
+        bool h_u = false;
+        KMX_HIP(ctx, kmx::launch_scan_bitsliced2(reads->d_bases, reads->n_reads, Lh, k, with_hash != 0, d_out, ctx->d_scratch + 16,
+                                                 ctx->n_cu, ctx->stream, &h_u));
+        // (not launched: the verdict must not keep the lane-per-read kernel from running)
+        KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8, h_u ? gate : nullptr));
+        KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));   // never left armed
+        return KMX_OK;
+    }
+    KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8, nullptr));
     return KMX_OK;
 }
 

@@ -159,9 +159,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     constexpr u32 VS = RAGGED ? 32u * NV + 8u : 0u;             // validity planes of one set + 8 always-zero words (a lane's windows past the frame, idle lanes)
     constexpr int NXT = NW + NE;                                 // 32x32 transposes per half-wave and tile
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    // Gate (queue[513], zero unless kmx_canonical_reduce is deciding on the device whether reads behind an offsets array are
-    // in fact uniform -- offsets_uniform_gate_kernel): 1 = only the uniform kernels run, 2 = only the ragged ones.
-    if constexpr (!PACKED && K <= 32) {
+    // Gate (queue[513], zero unless kmx_canonical_reduce / kmx_canonical_reduce2 is deciding on the device whether reads behind
+    // an offsets array are in fact uniform -- offsets_uniform_gate_kernel): 1 = only the uniform kernels run, 2 = only the ragged
+    // ones (two-word k: the lane-per-read kernel).
+    if constexpr (!PACKED) {
         const u32 gate = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513]);
         if (gate == (RAGGED ? 1u : 2u)) return;
     }

@@ -103,7 +103,10 @@ histogram_generic_kernel(ReadsView rv, u32 k, u32 hasher, u32 hk, u32 log2_bucke
 
 // ---------------------------------------------------------------- [u64;2] k-mers (U128, roll_read2: kmx_device.h)
 __global__ void __launch_bounds__(256)
-reduce2_generic_kernel(ReadsView rv, u32 k, u32 with_hash, kmx_summary2* __restrict__ out) {
+reduce2_generic_kernel(ReadsView rv, u32 k, u32 with_hash, kmx_summary2* __restrict__ out, const u32* __restrict__ gate) {
+    // (gate: kmx_canonical_reduce2 deciding on the device whether the reads behind an offsets array are uniform; 1 = they are,
+    // and the tiled uniform kernel launched beside this one scans them)
+    if (gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) return;
     u64 n = 0, slo = 0, shi = 0, xlo = 0, xhi = 0;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < rv.n_reads; r += stride) {
@@ -467,10 +470,11 @@ hipError_t launch_histogram_generic(const kmx_reads* r, u32 k, u32 hasher, u32 h
     return hipGetLastError();
 }
 
-hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_summary2* out, int n_cu, hipStream_t st, unsigned long long* too_long) {
+hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_summary2* out, int n_cu, hipStream_t st, unsigned long long* too_long,
+                                  const u32* gate) {
     ReadsView rv{r->d_bases, r->n_reads, r->read_len, r->d_offsets, too_long};
     hipLaunchKernelGGL(reduce2_generic_kernel, dim3(grid_for(r->n_reads, n_cu)), dim3(256), 0, st, rv, k, with_hash,
-                       out);
+                       out, gate);
     return hipGetLastError();
 }
 

@@ -378,3 +378,32 @@ def test_windows_single_array_shared_lines(ctx, orc, L, k, p_bad):
         if "flags" in want:
             gf = got["flags"].cpu().numpy()
             assert (gf == flags).all(), (want, int((gf != flags).sum()), np.flatnonzero(gf != flags)[:8])
+
+
+# ---------------------------------------------------------------- two-word k behind an offsets array: uniform or not, decided on the device
+
+@pytest.mark.parametrize("k", [33, 47, 63, 64])
+@pytest.mark.parametrize("case", ["uniform", "one_trimmed", "last_trimmed", "no_bound"])
+def test_reduce2_offsets_picks_the_uniform_kernel_on_the_device(ctx, orc, k, case):
+    """kmx_canonical_reduce2 on reads behind an offsets array with a length bound (what kmx_fastx_parse hands over): a small
+    kernel checks offsets[i] == i * L, the tiled uniform kernel and the lane-per-read kernel are launched behind its verdict and
+    exactly one of them counts (kmer.rs:21-28,67-69 per read either way).  Twice in a row: the gate is never left armed."""
+    rng = np.random.default_rng(k * 7 + len(case))
+    L, n = 150, 64 * 11 + 23
+    lens = np.full(n, L)
+    if case == "one_trimmed":
+        lens[n // 3] = 97
+    if case == "last_trimmed":
+        lens[-1] = 149
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]), 0.0004)
+    o = orc.canonical_reduce2(host, n, 0, k, with_hash=True, offsets=offsets)
+    dev, d_off = ctx.to_device(host), ctx.to_device(offsets)
+    hint = 0 if case == "no_bound" else L
+    for _ in range(2):
+        g = ctx.canonical_reduce2(dev, n, hint, k, with_hash=True, offsets=d_off)
+        assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+    # and a plain uniform call right after (the gate word is shared with it)
+    if case == "uniform":
+        u = ctx.canonical_reduce2(dev, n, L, k, with_hash=True)
+        assert (u.n_valid, u.sum_lo, u.sum_hi, u.xor_lo, u.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
