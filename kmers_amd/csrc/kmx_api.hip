@@ -31,6 +31,9 @@ hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 u64 bitsliced_segments_per_read(u32 L, u32 k);
+hipError_t launch_scan_bitsliced2_ragged(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 L_hint, u32 k, bool want_hash,
+                                         kmx_summary2* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
+                                         const u64* ends = nullptr);
 hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 L_hint, u32 k, bool want_hash,
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
                                         bool want_sumfw = false, const u64* ends = nullptr /* the reads' ends: nullptr = offsets + 1 */);
@@ -548,22 +551,28 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
                                                  ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
     }
-    // Reads behind an offsets array with a length bound the tiled two-word kernel takes (what kmx_fastx_parse hands over): most
-    // FASTQ is untrimmed -- every read exactly L bases.  Decided on the device, as kmx_canonical_reduce does: a small kernel
-    // checks offsets[i] == i*L, the uniform scan and the lane-per-read kernel are both launched behind its verdict, one runs.
+    // Reads behind an offsets array (what kmx_fastx_parse hands over), 16-byte aligned base: the tiled kernels.  With a length bound
+    // the uniform two-word kernel takes, "is every read exactly that long" (untrimmed FASTQ) is decided on the device as
+    // kmx_canonical_reduce does it: a small kernel checks offsets[i] == i*L, the uniform scan and the ragged one (bound <= 160
+    // or none: the 10-word frame; else the lane-per-read kernel) are both launched behind its verdict, exactly one counts.
     const uint32_t Lh = reads->read_len;
-    if (reads->d_offsets && Lh >= k && Lh <= 256 && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
+    if (reads->d_offsets && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
         uint32_t* gate = reinterpret_cast<uint32_t*>(ctx->d_scratch + 16 + 513);
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 16, ctx->stream));
-        KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 1, 1, ctx->stream));
-        KMX_HIP(ctx, kmx::launch_offsets_uniform_gate(reads->d_offsets, reads->n_reads, Lh, gate, ctx->n_cu, ctx->stream));
         if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
-        bool h_u = false;
-        KMX_HIP(ctx, kmx::launch_scan_bitsliced2(reads->d_bases, reads->n_reads, Lh, k, with_hash != 0, d_out, ctx->d_scratch + 16,
-                                                 ctx->n_cu, ctx->stream, &h_u));
-        // (not launched: the verdict must not keep the lane-per-read kernel from running)
-        KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8, h_u ? gate : nullptr));
-        KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));   // never left armed
+        bool h_u = false, h_r = false;
+        if (Lh >= k && Lh <= 256) {
+            KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 1, 1, ctx->stream));
+            KMX_HIP(ctx, kmx::launch_offsets_uniform_gate(reads->d_offsets, reads->n_reads, Lh, gate, ctx->n_cu, ctx->stream));
+            KMX_HIP(ctx, kmx::launch_scan_bitsliced2(reads->d_bases, reads->n_reads, Lh, k, with_hash != 0, d_out, ctx->d_scratch + 16,
+                                                     ctx->n_cu, ctx->stream, &h_u));
+            // (not launched: the verdict must not keep the other kernel from running)
+            if (!h_u) KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));
+        }
+        KMX_HIP(ctx, kmx::launch_scan_bitsliced2_ragged(reads->d_bases, reads->d_offsets, reads->n_reads, Lh, k, with_hash != 0, d_out,
+                                                        ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &h_r));
+        if (!h_r) KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8, h_u ? gate : nullptr));
+        if (h_u) KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));   // never left armed
         return KMX_OK;
     }
     KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8, nullptr));

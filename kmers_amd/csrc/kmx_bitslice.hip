@@ -75,6 +75,26 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
     }
 }
 
+// Ragged reads, two-word k (round 4): the 10-word frame only -- a length bound above 160 leaves the call to the lane-per-read kernel
+hipError_t launch_scan_bitsliced2_ragged(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 L_hint, u32 k, bool want_hash,
+                                         kmx_summary2* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
+                                         const u64* ends) {
+    *handled = false;
+    if (!offsets || (reinterpret_cast<uintptr_t>(bases) & 15u) || L_hint > 160) return hipSuccess;
+    u32 Lf = L_hint ? L_hint : 160u;
+    if (Lf < k + 15u) Lf = k + 15u;       // keep at least 16 windows in the frame
+    if (Lf > 160u) return hipSuccess;
+#define KMX_BSR2_CASE(K) \
+    case K:              \
+        *handled = true; \
+        return launch_bs2_ragged_k##K(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, ends);
+    switch (k) {
+        KMX_BS2_FOR_EACH_K(KMX_BSR2_CASE)
+        default:
+            return hipSuccess;
+    }
+}
+
 // [u64;2] k-mers: every k from 33 to 64 is instantiated (k = 63 is BASELINE configs[2])
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {

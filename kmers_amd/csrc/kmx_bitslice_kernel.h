@@ -152,7 +152,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // `lead` (uniform ASCII input whose first byte is not 16-byte aligned): `bases` is the aligned address below it and
     // read r starts at byte lead + r*L.  A tile then spans one more chunk (its first holds the tail of the tile before
     // it), exactly like a ragged tile streamed from its aligned start; 0 for every other input.
-    static_assert(!RAGGED || (!PACKED && K <= 32), "ragged input: ASCII, single-word k-mers");
+    static_assert(!RAGGED || !PACKED, "ragged input: ASCII");
     static_assert(WPL <= 8, "the zero words behind the validity planes cover a lane's windows");
     constexpr int NE = RAGGED ? (K - 1 + 15) / 16 : 0;            // dwords holding the last K-1 bases of a read
     constexpr int NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;  // validity words per read (one bit per window of the frame)
@@ -382,13 +382,25 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         if constexpr (RAGGED) {
             const u64 o0 = offsets[read], o1 = ends[read];
             if (read_too_long(o1 - o0, queue + KMX_TOOLONG_FROM_QUEUE)) return;   // (not scanned; kmx_ctx_synchronize reports it)
-            roll_read(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
-                const u64 canon = fw < rc ? fw : rc;
-                fb.n += 1;
-                fb.s0 += canon;
-                fb.x0 ^= lex_hash(canon, (u32)K);
-                fb.fw += fw;
-            });
+            if constexpr (K <= 32) {
+                roll_read(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
+                    const u64 canon = fw < rc ? fw : rc;
+                    fb.n += 1;
+                    fb.s0 += canon;
+                    fb.x0 ^= lex_hash(canon, (u32)K);
+                    fb.fw += fw;
+                });
+            } else {
+                roll_read2(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, U128 fw, U128 rc) {
+                    const U128 c = lt128(fw, rc) ? fw : rc;
+                    const U128 h = lex_hash128(c, (u32)K);
+                    fb.n += 1;
+                    fb.s0 += c.lo;
+                    fb.s1 += c.hi;
+                    fb.x0 ^= h.lo;
+                    fb.x1 ^= h.hi;
+                });
+            }
         } else if constexpr (PACKED) {
             static_assert(!PACKED || K <= 32, "packed input: single-word k-mers");
             roll_read_packed(reinterpret_cast<const u64*>(bases), read * (u64)L, L, (u32)K, [&](u32, u64 fw, u64 rc) {
@@ -1638,6 +1650,16 @@ static hipError_t launch_bs_ragged_any(const uint8_t* bases, const u64* offsets,
 // k with a bit-sliced kernel for ragged reads: 13..31, like the uniform kernel
 #define KMX_BSR_FOR_EACH_K(X) \
     X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+// ... and two-word k (33..64; round 4): ONE instantiation each, the 10-word frame at four windows per lane -- a two-word k leaves
+// at most 128 windows in 160 bases; the window blocks past W are skipped at run time
+#define KMX_BSR2_DECLARE_K(K) \
+    hipError_t launch_bs2_ragged_k##K(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out, \
+                                      unsigned long long* queue, int n_cu, hipStream_t stream, const u64* ends);
+#define KMX_BSR2_DEFINE_K(K)                                                                                                  \
+    hipError_t launch_bs2_ragged_k##K(const uint8_t* bases, const u64* offsets, u64 n_reads, u32 Lf, u32 want_hash, void* out, \
+                                      unsigned long long* queue, int n_cu, hipStream_t stream, const u64* ends) {              \
+        return launch_bs<K, 10, 4, false, true>(bases, n_reads, Lf, want_hash, 0, out, queue, n_cu, stream, offsets, ends);    \
+    }
 
 #define KMX_BS_DECLARE_K(K) \
     hipError_t launch_bs_k##K(const uint8_t* bases, u64 n_reads, u32 L, bool packed, u32 want_hash, u32 want_sumfw, void* out, \
@@ -1658,5 +1680,6 @@ static hipError_t launch_bs_ragged_any(const uint8_t* bases, const u64* offsets,
 KMX_BS_FOR_EACH_K(KMX_BS_DECLARE_K)
 KMX_BS2_FOR_EACH_K(KMX_BS2_DECLARE_K)
 KMX_BSR_FOR_EACH_K(KMX_BSR_DECLARE_K)
+KMX_BS2_FOR_EACH_K(KMX_BSR2_DECLARE_K)
 
 }  // namespace kmx

@@ -407,3 +407,47 @@ def test_reduce2_offsets_picks_the_uniform_kernel_on_the_device(ctx, orc, k, cas
     if case == "uniform":
         u = ctx.canonical_reduce2(dev, n, L, k, with_hash=True)
         assert (u.n_valid, u.sum_lo, u.sum_hi, u.xor_lo, u.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+
+# ---------------------------------------------------------------- two-word k on truly ragged reads: the ragged bit-sliced kernel
+
+@pytest.mark.parametrize("k", [33, 40, 47, 48, 49, 50, 56, 63, 64])
+@pytest.mark.parametrize("case", ["trimmed", "mix_100_160", "no_bound_some_long", "short_and_empty", "bound_above_frame"])
+def test_reduce2_ragged_reads_tiled(ctx, orc, k, case):
+    """kmx_canonical_reduce2 on reads of unequal length behind an offsets array: the ragged bit-sliced kernel (validity planes,
+    read-end planes, the closed form over two words) in the 10-word frame -- a bound of at most 160 bases or none; tiles holding
+    a longer read roll per lane, a bound above the frame leaves the call to the lane-per-read kernel.  Dirty bytes, reads
+    shorter than k, empty reads, a partial last tile (kmer.rs:21-28,67-69 per read)."""
+    rng = np.random.default_rng(k * 13 + len(case))
+    n = 64 * 9 + 31
+    if case == "trimmed":
+        lens, hint = np.where(rng.random(n) < 0.05, rng.integers(36, 150, n), 150), 150
+    elif case == "mix_100_160":
+        lens, hint = rng.integers(100, 161, n), 160
+    elif case == "no_bound_some_long":
+        lens, hint = np.where(rng.random(n) < 0.02, rng.integers(161, 400, n), rng.integers(60, 161, n)), 0
+    elif case == "short_and_empty":
+        lens, hint = rng.integers(0, 2 * k, n), 2 * k
+    else:
+        lens, hint = rng.integers(100, 251, n), 250
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]), 0.0005)
+    o = orc.canonical_reduce2(host, n, 0, k, with_hash=True, offsets=offsets)
+    dev, d_off = ctx.to_device(host), ctx.to_device(offsets)
+    for with_hash in (True, False, True):
+        g = ctx.canonical_reduce2(dev, n, hint, k, with_hash=with_hash, offsets=d_off)
+        assert (g.n_valid, g.sum_lo, g.sum_hi) == (o.n_valid, o.sum_lo, o.sum_hi), (case, k)
+        assert (g.xor_lo, g.xor_hi) == ((o.xor_lo, o.xor_hi) if with_hash else (0, 0))
+
+
+@pytest.mark.parametrize("k,n", [(63, 400_000), (33, 400_000), (50, 300_000)])
+def test_reduce2_ragged_reads_at_size(ctx, orc, k, n):
+    """the same where every wave scans many tiles (the accumulators fold, the per-wave sums carry over)"""
+    rng = np.random.default_rng(k)
+    lens = np.where(rng.random(n) < 0.02, rng.integers(36, 150, n), 150)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    bases = ctx.gen_reads(int(offsets[-1]), first_byte=7)
+    host = bases.cpu().numpy()
+    o = orc.canonical_reduce2(host, n, 0, k, with_hash=True, offsets=offsets)
+    g = ctx.canonical_reduce2(bases, n, 150, k, with_hash=True, offsets=ctx.to_device(offsets))
+    assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)

@@ -48,7 +48,7 @@ for name in ("bench_default", "bench_under_trace", "bench_sustained3000", "bench
 for a, b in (("trace/t_kernel_stats.csv", "kernel_stats.csv"), ("trace_k21/t_kernel_stats.csv", "kernel_stats_k21.csv"),
              ("trace_k63/t_kernel_stats.csv", "kernel_stats_k63.csv"), ("trace_hash/t_kernel_stats.csv", "kernel_stats_hash.csv"),
              ("trace_hist20/t_kernel_stats.csv", "kernel_stats_hist20.csv"), ("pmc_summary.txt", "pmc_summary.txt"),
-             ("k_sweep.txt", "k_sweep.txt"), ("len_sweep.txt", "len_sweep.txt"), ("ragged_bench.txt", "ragged_bench.txt"),
+             ("k_sweep.txt", "k_sweep.txt"), ("len_sweep.txt", "len_sweep.txt"), ("ragged_bench.txt", "ragged_bench.txt"), ("ragged2_bench.txt", "ragged2_bench.txt"),
              ("dirty_bench.txt", "dirty_bench.txt"), ("windows_bench.txt", "windows_bench.txt"), ("windows_len.txt", "windows_len.txt"), ("hist_bench.txt", "hist_bench.txt"),
              ("minimizers_bench.txt", "minimizers_bench.txt"), ("windows2_bench.txt", "windows2_bench.txt"), ("k2_long.txt", "k2_long.txt"), ("settle.txt", "settle.txt"), ("fastx_bench.txt", "fastx_bench.txt"), ("fastq_pipeline.txt", "fastq_pipeline.txt"), ("step_times_cold.txt", "step_times_cold.txt")):
     copy(a, b)

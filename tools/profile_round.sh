@@ -42,6 +42,7 @@ for st in 30 0 30 0; do python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
 python3 tools/bench_windows2.py > $out/windows2_bench.txt 2>/dev/null
 python3 tools/bench_ragged.py 100000000 31 > $out/ragged_bench.txt 2>/dev/null
 python3 tools/bench_ragged.py 100000000 21 >> $out/ragged_bench.txt 2>/dev/null
+python3 tools/bench_ragged2.py 100000000 > $out/ragged2_bench.txt 2>/dev/null
 HIST=20 python3 tools/bench_dirty.py > $out/dirty_bench.txt 2>/dev/null
 python3 tools/bench_windows.py > $out/windows_bench.txt 2>/dev/null
 for L in 100 140 150 158 166 200 250 256; do echo "[1e7 reads of $L bases]"; python3 tools/bench_windows.py 10000000 $L 2>/dev/null | grep "^k="; done > $out/windows_len.txt
