@@ -406,6 +406,31 @@ int kmx_memset(kmx_ctx* ctx, void* d_dst, int value, size_t nbytes) {
 
 /* ------------------------------------------------------------ hot path ---- */
 
+// Long ragged reads (round 4): the reads of a batch behind an offsets array cut into overlapping segments of at most t_max windows
+// on the device (kmx_segments.hip), in the context's work buffer.  Two host round trips: the first and the last offset (the
+// arrays are sized from the number of bases), then the number of segments.  0: *starts / *ends / *n_seg are set (n_seg may be 0);
+// -1: no scratch (the caller falls back); > 0: a status to return.
+static int long_ragged_segments(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t t_max, const uint64_t** starts, const uint64_t** ends,
+                                uint64_t* n_seg) {
+    KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, reads->d_offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned + 1, reads->d_offsets + reads->n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t o_first = ctx->h_pinned[0], o_last = ctx->h_pinned[1];
+    if (!(o_last >= o_first && o_last - o_first < (1ull << 62))) return -1;
+    const uint64_t cap = kmx::segments_capacity(reads->n_reads, o_last - o_first, t_max);
+    void* scratch = big_scratch(ctx, kmx::segments_scratch_bytes(reads->n_reads, cap));
+    if (!scratch) return -1;
+    ctx->fx_valid = false;   // (the work buffer is overwritten: the fastx chunk prefixes in it are gone)
+    const uint64_t* d_total = nullptr;
+    KMX_HIP(ctx, kmx::launch_segments_build(reads->d_offsets, reads->n_reads, k, t_max, cap, scratch, starts, ends, &d_total, ctx->d_scratch + 8, ctx->stream));
+    // (the second and last round trip: how many segments there are -- the bound above is up to one per read too high)
+    KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_seg = ctx->h_pinned[0];
+    if (*n_seg > cap) return fail_hip(ctx, hipErrorUnknown, "segment count above its bound");
+    return 0;
+}
+
 int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
                          uint32_t flags, kmx_summary* d_out) {
     if (!ctx || !reads_ok(reads) || !d_out) return KMX_E_ARG;
@@ -469,29 +494,16 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
             // segments on the device (kmx_segments.hip) and scanned by the ragged bit-sliced kernel as reads of their own.  Two
             // host round trips: the first and the last offset (the segment arrays are sized from the number of bases), then the
             // number of segments.  No scratch -> the lane-per-read kernel below.
-            KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, reads->d_offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
-            KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned + 1, reads->d_offsets + reads->n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
-            KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            const uint64_t o_first = ctx->h_pinned[0], o_last = ctx->h_pinned[1];
             const uint32_t t_max = 161u - k < 128u ? 161u - k : 128u;      // windows per segment: at most 4 per lane (the three-wave variant)
-            if (o_last >= o_first && o_last - o_first < (1ull << 62)) {
-                const uint64_t cap = kmx::segments_capacity(reads->n_reads, o_last - o_first, t_max);
-                void* scratch = big_scratch(ctx, kmx::segments_scratch_bytes(reads->n_reads, cap));
-                if (scratch) {
-                    ctx->fx_valid = false;   // (the work buffer is overwritten: the fastx chunk prefixes in it are gone)
-                    const uint64_t *starts = nullptr, *ends = nullptr, *d_total = nullptr;
-                    KMX_HIP(ctx, kmx::launch_segments_build(reads->d_offsets, reads->n_reads, k, t_max, cap, scratch, &starts, &ends, &d_total,
-                                                            ctx->d_scratch + 8, ctx->stream));
-                    // (the second and last round trip: how many segments there are -- the bound above is up to one per read too high)
-                    KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
-                    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                    const uint64_t n_seg = ctx->h_pinned[0];
-                    if (n_seg == 0) return KMX_OK;   // no read holds a window
-                    if (n_seg > cap) return fail_hip(ctx, hipErrorUnknown, "segment count above its bound");
-                    if (int st = prepare_dirty_flags(ctx, n_seg, k)) return st;
-                    KMX_HIP(ctx, kmx::launch_scan_bitsliced_ragged(reads->d_bases, starts, n_seg, t_max + k - 1u, k, want_fold, d_out,
-                                                                   ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled, want_sumfw, ends));
-                }
+            const uint64_t *starts = nullptr, *ends = nullptr;
+            uint64_t n_seg = 0;
+            const int st = long_ragged_segments(ctx, reads, k, t_max, &starts, &ends, &n_seg);
+            if (st > 0) return st;
+            if (st == 0) {
+                if (n_seg == 0) return KMX_OK;   // no read holds a window
+                if (int st2 = prepare_dirty_flags(ctx, n_seg, k)) return st2;
+                KMX_HIP(ctx, kmx::launch_scan_bitsliced_ragged(reads->d_bases, starts, n_seg, t_max + k - 1u, k, want_fold, d_out,
+                                                               ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled, want_sumfw, ends));
             }
         }
         if (!handled && reads->d_offsets) {   // ragged reads on the bit-sliced kernel (read_len = optional length bound)
@@ -569,8 +581,23 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
             // (not launched: the verdict must not keep the other kernel from running)
             if (!h_u) KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));
         }
-        KMX_HIP(ctx, kmx::launch_scan_bitsliced2_ragged(reads->d_bases, reads->d_offsets, reads->n_reads, Lh, k, with_hash != 0, d_out,
-                                                        ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &h_r));
+        if (Lh > 256) {
+            // long ragged reads (a bound above the frames: PacBio / ONT lengths, contigs): segments cut on the device, as kmx_canonical_reduce does
+            const uint32_t t_max = 161u - k;      // (<= 128 windows for every two-word k: the 10-word frame)
+            const uint64_t *starts = nullptr, *ends = nullptr;
+            uint64_t n_seg = 0;
+            const int st = long_ragged_segments(ctx, reads, k, t_max, &starts, &ends, &n_seg);
+            if (st > 0) return st;
+            if (st == 0) {
+                if (n_seg == 0) return KMX_OK;
+                if (int st2 = prepare_dirty_flags(ctx, n_seg, k)) return st2;
+                KMX_HIP(ctx, kmx::launch_scan_bitsliced2_ragged(reads->d_bases, starts, n_seg, t_max + k - 1u, k, with_hash != 0, d_out,
+                                                                ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &h_r, ends));
+            }
+        } else {
+            KMX_HIP(ctx, kmx::launch_scan_bitsliced2_ragged(reads->d_bases, reads->d_offsets, reads->n_reads, Lh, k, with_hash != 0, d_out,
+                                                            ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &h_r));
+        }
         if (!h_r) KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8, h_u ? gate : nullptr));
         if (h_u) KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));   // never left armed
         return KMX_OK;

@@ -451,3 +451,33 @@ def test_reduce2_ragged_reads_at_size(ctx, orc, k, n):
     o = orc.canonical_reduce2(host, n, 0, k, with_hash=True, offsets=offsets)
     g = ctx.canonical_reduce2(bases, n, 150, k, with_hash=True, offsets=ctx.to_device(offsets))
     assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+
+@pytest.mark.parametrize("k", [33, 48, 63, 64])
+@pytest.mark.parametrize("case", ["long", "mixed", "few_huge", "with_empty"])
+def test_reduce2_long_ragged_reads(ctx, orc, k, case):
+    """two-word k, a length bound above 256: segments of at most 161 - k windows cut on the device, scanned by the two-word ragged
+    bit-sliced kernel (kmer.rs:21-28,67-69 per read)"""
+    rng = np.random.default_rng(k * 37 + len(case))
+    if case == "long":
+        lens = rng.integers(300, 5000, 600)
+    elif case == "mixed":
+        lens = np.where(rng.random(2500) < 0.3, rng.integers(257, 3000, 2500), rng.integers(0, 257, 2500))
+    elif case == "few_huge":
+        lens = np.array([250_000, 17, 131_313, k, k - 1, 90_001])
+    else:
+        lens = rng.integers(200, 2000, 800)
+        lens[rng.integers(0, 800, 60)] = 0
+        lens[rng.integers(0, 800, 60)] = k - 1
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n_reads = len(lens)
+    host = _dirty(rng, int(offsets[-1]), 0.0002)
+    o = orc.canonical_reduce2(host, n_reads, 0, k, with_hash=True, offsets=offsets)
+    dev, d_off = ctx.to_device(host), ctx.to_device(offsets)
+    for bound in (1 << 20, 300):
+        g = ctx.canonical_reduce2(dev, n_reads, bound, k, with_hash=True, offsets=d_off)
+        assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi), (case, k, bound)
+    cut = n_reads // 3
+    o2 = orc.canonical_reduce2(host, n_reads - cut, 0, k, with_hash=True, offsets=offsets[cut:])
+    g2 = ctx.canonical_reduce2(dev, n_reads - cut, 100_000_000, k, with_hash=True, offsets=d_off[cut:])
+    assert (g2.n_valid, g2.sum_lo, g2.sum_hi, g2.xor_lo, g2.xor_hi) == (o2.n_valid, o2.sum_lo, o2.sum_hi, o2.xor_lo, o2.xor_hi)

@@ -20,13 +20,17 @@ for name, lo, hi in (("300..1000", 300, 1000), ("1000..20000", 1000, 20000), ("1
     d_off = ctx.to_device(offsets)
     exp = int(np.maximum(lens - k + 1, 0).sum())
     for label, hint, reps in (("segments (bound 2^20)", 1 << 20, 5), ("per-read path (no bound)", 0, 1)):
-        out = ctx.canonical_reduce(bases, n, hint, k, offsets=d_off)
+        if k > 32:     # two-word k: kmx_canonical_reduce2 (it synchronises; the time includes the summary's way back)
+            call = lambda: ctx.canonical_reduce2(bases, n, hint, k, with_hash=False, offsets=d_off)
+        else:
+            call = lambda: ctx.canonical_reduce_async(bases, n, hint, k, 0, 0, 0, d_off)
+        out = ctx.canonical_reduce2(bases, n, hint, k, offsets=d_off) if k > 32 else ctx.canonical_reduce(bases, n, hint, k, offsets=d_off)
         if reps > 1:
-            warm(lambda: ctx.canonical_reduce(bases, n, hint, k, offsets=d_off), at_least=3)
+            warm(call, at_least=3)
         ts = []
         for _ in range(reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); ctx.canonical_reduce_async(bases, n, hint, k, 0, 0, 0, d_off); b.record(); torch.cuda.synchronize()
+            a.record(); call(); b.record(); torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
         ms = sorted(ts)[len(ts) // 2]
         print(f"lengths {name:14s} {n:9d} reads  {label:26s} {ms:9.3f} ms  {tb/ms/1e6:7.0f} GB/s = {tb/ms/1e6/8000:.3f} of 8 TB/s   n_valid {'ok' if out.n_valid == exp else 'WRONG'}")
