@@ -75,6 +75,8 @@ hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_
                                   const u32* gate);
 hipError_t launch_windows2_tiled(const kmx_reads* r, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu, hipStream_t st,
                                  bool* handled);
+hipError_t launch_windows2_tiled_ragged(const kmx_reads* r, const u64* win_offsets, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu,
+                                        hipStream_t st, bool* handled, unsigned long long* too_long);
 hipError_t launch_windows2_generic(const kmx_reads* r, const u64* win_off, u32 k, u64* fw, u64* rc, u64* canon,
                                    uint8_t* flags, int n_cu, hipStream_t st, unsigned long long* too_long);
 // kmx_elem.hip
@@ -616,6 +618,9 @@ int kmx_canonical_windows2(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t*
     bool handled = false;   // uniform reads of up to 256 bases in the dense layout (slot r*W + p): the tiled kernel (kmx_generic.hip)
     if (!reads->d_offsets && !d_win_offsets)   // (a caller's win_offsets for uniform reads are honoured by the lane-per-read kernel, as kmx_canonical_windows does)
         KMX_HIP(ctx, kmx::launch_windows2_tiled(reads, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled));
+    if (!handled && reads->d_offsets && d_win_offsets)   // ragged reads (round 4): tiled too; read_len = optional length bound
+        KMX_HIP(ctx, kmx::launch_windows2_tiled_ragged(reads, d_win_offsets, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled,
+                                                       ctx->d_scratch + 8));
     if (handled) return KMX_OK;
     KMX_HIP(ctx, kmx::launch_windows2_generic(reads, d_win_offsets, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, ctx->d_scratch + 8));
     return KMX_OK;

@@ -185,20 +185,29 @@ __device__ __forceinline__ void windows2_one_read(const uint8_t* s, u32 len, u32
 // STAGE (one word array asked for -- the usual call): the 16 bytes of a window go to a lane-major staging block in LDS, and
 // after every 8 windows the wave writes them back transposed -- 8 lanes cover one read's 128 contiguous bytes, a store
 // instruction covers 8 such runs -- instead of 64 separate 16-byte pieces 16*W bytes apart (2.1 -> see DESIGN 4.4 TB/s).
-template <int NW, bool STAGE>
+// RAGGED (round 4): reads behind an offsets array, output slots from win_offsets.  A tile is still 64 consecutive reads = one
+// contiguous byte span, streamed from its 16-byte aligned start; a lane carries its own start, window count and first slot, the
+// write-back takes every read's line boundaries from its own first slot.  A tile whose span or longest read leaves the frame
+// (L = the caller's length bound, at most 16 NW), or that would load past the end of the buffer, takes the per-read path.
+template <int NW, bool STAGE, bool RAGGED = false>
 __global__ void __launch_bounds__(256)
-windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, Win2Out out, u32 lead) {
+windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, Win2Out out, u32 lead,
+                      const u64* __restrict__ offsets, const u64* __restrict__ win_offsets, unsigned long long* __restrict__ too_long) {
     // `lead`: `bases` is the 16-byte aligned address at or below the first read, which starts `lead` bytes in
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const u32 lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
-    const u32 chunks = 4u * L + (lead != 0u ? 1u : 0u);      // 16-byte chunks of a 64-read tile
-    const u32 ldsw = (chunks + 1u + (u32)NW + 8u + 3u) & ~3u;   // front pad 1, tail pad: the last read's frame (and 6 dwords more) may lie past the tile
+    const u32 chunks_cap = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);      // 16-byte chunks of a 64-read tile (ragged: the most a tile may span)
+    u32 chunks = chunks_cap;
+    const u32 ldsw = (chunks_cap + 1u + (u32)NW + 8u + 3u) & ~3u;   // front pad 1, tail pad: the last read's frame (and 6 dwords more) may lie past the tile
     constexpr u32 SPITCH = 68u;                               // dwords per lane of the staging ring: 16 windows x 4 + 4 (bank spread)
     constexpr u32 STG = STAGE ? 64u * SPITCH : 0u;
     u32* const P = lds + wib * (ldsw + STG);
     u32* const S = P + ldsw;                                  // [64 lanes][SPITCH]
     const u64 n_full = n_reads >> 6;
-    const u32 W = L - k + 1u, omax = L - k;
+    const u32 W = L - k + 1u;
+    u32 omax = L - k;              // the last window of the tile's longest read (ragged: per tile)
+    u32 nwin = W;                  // windows of this lane's read
+    const u64 total_bytes = RAGGED ? offsets[n_reads] : 0;
     // the one array of a STAGE launch, and which words it takes
     u64* const one = out.fw ? out.fw : out.rc ? out.rc : out.canon;
     const u32 which = out.fw ? 0u : out.rc ? 1u : 2u;
@@ -208,8 +217,8 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 m2 = kb >= 96u ? ~0u : ((1u << (kb - 64u)) - 1u);
     const u32 m3 = kb >= 128u ? ~0u : (kb > 96u ? ((1u << (kb - 96u)) - 1u) : 0u);
     // this lane's read inside the packed tile: LDS dword 1 + c holds bases [16c, 16c + 16) of the tile
-    const u32 posF = lane * L + lead + 16u;
-    const u32 qF = posF >> 4, aF = 2u * (posF & 15u);
+    u32 posF = lane * L + lead + 16u;
+    u32 qF = posF >> 4, aF = 2u * (posF & 15u);
     // reverse complement of the read's 16*NW-base frame: Gfull[j] = revgroups(~F[NW-1-j]); the rc word of window o starts at base
     // NF - k - o of it.  H = Gfull moved down by e = (NF - k) & 15 bases: window 16 i + s then starts at bit 2 (16 - s) of
     // H[Q - i - 1] (s > 0) or is H[Q - i ..] itself (s = 0), Q = (NF - k) >> 4.
@@ -228,6 +237,31 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     for (u64 t = wave0; t < n_full; t += waves) {
         // ---- A. the tile's chunks: 16 bytes per lane and row, packed + validated into the LDS slice
         const uint8_t* __restrict__ tb = bases + t * 64u * (u64)L;
+        u64 my_off = 0;
+        u32 my_len = L;
+        u64 slot0 = (t * 64u + lane) * (u64)W;
+        bool fits = true;
+        if constexpr (RAGGED) {
+            const u64 o0 = offsets[t * 64u + lane], o1 = offsets[t * 64u + lane + 1u];
+            my_off = o0;
+            my_len = read_too_long(o1 - o0, too_long) ? 0u : (u32)(o1 - o0);    // (not materialised; kmx_ctx_synchronize reports it)
+            slot0 = win_offsets[t * 64u + lane];
+            const u32 t0l = __builtin_amdgcn_readfirstlane((u32)o0), t0h = __builtin_amdgcn_readfirstlane((u32)(o0 >> 32));
+            const u32 t1l = __builtin_amdgcn_readlane((u32)o1, 63), t1h = __builtin_amdgcn_readlane((u32)(o1 >> 32), 63);
+            const u64 t0 = ((u64)t0h << 32) | t0l, t1 = ((u64)t1h << 32) | t1l;
+            const u64 base_al = t0 & ~15ull, n_ch = (t1 - base_al + 15u) >> 4;
+            const u32 max_len = wave_max_u32(my_len);
+            fits = n_ch <= (u64)chunks_cap && max_len <= 16u * (u32)NW && max_len <= L && base_al + 16u * n_ch <= total_bytes && !__any(o1 - o0 > 0x7FFFFFFFull);
+            chunks = fits ? (u32)n_ch : 0u;
+            tb = bases + base_al;
+            posF = (u32)(o0 - base_al) + 16u;
+            qF = posF >> 4;
+            aF = 2u * (posF & 15u);
+            nwin = my_len >= k ? my_len - k + 1u : 0u;
+            const u32 nw_max = wave_max_u32(nwin);
+            if (nw_max == 0u) continue;     // no read of the tile holds a window
+            omax = nw_max - 1u;
+        }
         u32 bad = 0;
 #pragma unroll
         for (int it = 0; it < NW + 1; ++it) {
@@ -243,9 +277,8 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const u64 read = t * 64u + lane;
-        const u64 slot0 = read * (u64)W;
-        if (__any(chunk_has_invalid(bad))) {   // (wave-uniform) exact iterator semantics, one lane per read
-            windows2_one_read(bases + lead + read * (u64)L, L, k, slot0, out);
+        if (!fits || __any(chunk_has_invalid(bad))) {   // (wave-uniform) exact iterator semantics, one lane per read
+            windows2_one_read(RAGGED ? bases + my_off : bases + lead + read * (u64)L, my_len, k, slot0, out);
         } else {
             // rolling windows: f[j] = F[i + j], h[j] = H[Q - i - 1 + j], j = 0..4
             u32 f[5], h[5];
@@ -284,20 +317,22 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     const u64 rhi = ((u64)r3 << 32) | r2, rlo = ((u64)r1 << 32) | r0;
                     const bool lt = fhi < rhi || (fhi == rhi && flo < rlo);
                     const u64 j = 2u * (slot0 + o);
+                    const bool act = !RAGGED || o < nwin;      // (ragged: a shorter read's lane idles through the longest read's windows)
                     if constexpr (STAGE) {
                         // ring slot = the window's ABSOLUTE output slot mod 16: a 128-byte line of the output array is one
                         // aligned half of the ring, whatever W is
                         const bool takef = which == 0u || (which == 2u && lt);
-                        *reinterpret_cast<uint4*>(S + lane * SPITCH + 4u * ((a_own + (u32)s) & 15u)) =
-                            takef ? make_uint4(a0, a1, a2, a3) : make_uint4(r0, r1, r2, r3);
-                    } else {
+                        if (act)
+                            *reinterpret_cast<uint4*>(S + lane * SPITCH + 4u * ((a_own + (u32)s) & 15u)) =
+                                takef ? make_uint4(a0, a1, a2, a3) : make_uint4(r0, r1, r2, r3);
+                    } else if (act) {
                         if (out.fw) *reinterpret_cast<uint4*>(out.fw + j) = make_uint4(a0, a1, a2, a3);
                         if (out.rc) *reinterpret_cast<uint4*>(out.rc + j) = make_uint4(r0, r1, r2, r3);
                         if (out.canon) *reinterpret_cast<uint4*>(out.canon + j) = lt ? make_uint4(a0, a1, a2, a3) : make_uint4(r0, r1, r2, r3);
                     }
-                    if (out.flags) fl4 |= (KMX_WIN_VALID | (lt ? KMX_WIN_FW_CANONICAL : 0u)) << (8u * ((u32)s & 3u));
+                    if (out.flags && act) fl4 |= (KMX_WIN_VALID | (lt ? KMX_WIN_FW_CANONICAL : 0u)) << (8u * ((u32)s & 3u));
                     // four flags per store (one byte each: the slots of a read are contiguous; the address need not be aligned)
-                    if (((u32)s & 3u) == 3u || o == omax) {
+                    if (act && (((u32)s & 3u) == 3u || o + 1u == nwin)) {
                         if (out.flags) {
                             uint8_t* const fp = out.flags + slot0 + (o & ~3u);
                             const u32 nfl = (o & 3u) + 1u;
@@ -326,11 +361,16 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
                             for (u32 rr = 0; rr < 8u; ++rr) {
                                 const u32 rl = rr * 8u + (lane >> 3);           // read (lane) of the tile this lane serves now
-                                const u64 s0 = (t * 64u + rl) * (u64)W;         // its first slot
+                                u64 s0 = (t * 64u + rl) * (u64)W;               // its first slot
+                                u32 nw_rl = W;                                  // ... and its windows
+                                if constexpr (RAGGED) {
+                                    s0 = ((u64)(u32)__shfl((int)(u32)(slot0 >> 32), (int)rl, WAVE) << 32) | (u32)__shfl((int)(u32)slot0, (int)rl, WAVE);
+                                    nw_rl = (u32)__shfl((int)nwin, (int)rl, WAVE);
+                                }
                                 const u32 a = (u32)s0 & 7u;
                                 auto upto = [&](int oo) -> u32 {               // windows of read rl written once the flush at window oo is done
                                     if (oo < 0) return 0u;
-                                    if ((u32)oo == omax) return W;
+                                    if ((u32)oo + 1u >= nw_rl) return nw_rl;
                                     const int w = (int)(((a + (u32)oo + 1u) & ~7u)) - (int)a;
                                     return w > 0 ? (u32)w : 0u;
                                 };
@@ -373,14 +413,20 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 rem = (u32)(n_reads & 63u);
     if (rem != 0u && wave0 == 0 && lane < rem) {
         const u64 read = n_full * 64u + lane;
-        windows2_one_read(bases + lead + read * (u64)L, L, k, read * (u64)W, out);
+        if constexpr (RAGGED) {
+            const u64 o0 = offsets[read], o1 = offsets[read + 1u];
+            if (!read_too_long(o1 - o0, too_long)) windows2_one_read(bases + o0, (u32)(o1 - o0), k, win_offsets[read], out);
+        } else {
+            windows2_one_read(bases + lead + read * (u64)L, L, k, read * (u64)W, out);
+        }
     }
 }
 
-template <int NW>
-static hipError_t launch_windows2_tiled_nw(const uint8_t* bases, u64 n_reads, u32 L, u32 k, const Win2Out& out, int n_cu, hipStream_t st) {
-    const u32 lead = (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
-    const u32 chunks = 4u * L + (lead != 0u ? 1u : 0u);
+template <int NW, bool RAGGED = false>
+static hipError_t launch_windows2_tiled_nw(const uint8_t* bases, u64 n_reads, u32 L, u32 k, const Win2Out& out, int n_cu, hipStream_t st,
+                                           const u64* offsets = nullptr, const u64* win_offsets = nullptr, unsigned long long* too_long = nullptr) {
+    const u32 lead = RAGGED ? 0u : (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
+    const u32 chunks = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);
     const u32 ldsw = (chunks + 1u + (u32)NW + 8u + 3u) & ~3u;
     const size_t lds_bytes = (size_t)(ldsw + 64u * 68u) * 4u * 4u;
     u64 grid = (u64)n_cu * 4u;
@@ -396,12 +442,12 @@ static hipError_t launch_windows2_tiled_nw(const uint8_t* bases, u64 n_reads, u3
         if (!arr[a]) continue;
         Win2Out o1{nullptr, nullptr, nullptr, first ? out.flags : nullptr};
         (a == 0 ? o1.fw : a == 1 ? o1.rc : o1.canon) = arr[a];
-        hipLaunchKernelGGL((windows2_tiled_kernel<NW, true>), dim3((unsigned)grid), dim3(256), lds_bytes, st, bases - lead, n_reads, L, k, o1, lead);
+        hipLaunchKernelGGL((windows2_tiled_kernel<NW, true, RAGGED>), dim3((unsigned)grid), dim3(256), lds_bytes, st, bases - lead, n_reads, L, k, o1, lead, offsets, win_offsets, too_long);
         first = false;
     }
     if (first) {   // flags only
         const size_t lds0 = (size_t)ldsw * 4u * 4u;
-        hipLaunchKernelGGL((windows2_tiled_kernel<NW, false>), dim3((unsigned)grid), dim3(256), lds0, st, bases - lead, n_reads, L, k, out, lead);
+        hipLaunchKernelGGL((windows2_tiled_kernel<NW, false, RAGGED>), dim3((unsigned)grid), dim3(256), lds0, st, bases - lead, n_reads, L, k, out, lead, offsets, win_offsets, too_long);
     }
     return hipGetLastError();
 }
@@ -421,6 +467,22 @@ hipError_t launch_windows2_tiled(const kmx_reads* r, u32 k, u64* fw, u64* rc, u6
     const Win2Out out{fw, rc, canon, flags};
     if (L <= 160) return launch_windows2_tiled_nw<10>(r->d_bases, r->n_reads, L, k, out, n_cu, st);
     return launch_windows2_tiled_nw<16>(r->d_bases, r->n_reads, L, k, out, n_cu, st);
+}
+
+// ragged reads (offsets + win_offsets), k in 33..64, 16-byte aligned bases; read_len = optional length bound (0: unknown -> the
+// 256-base frame); tiles with a longer read take the per-read path inside the kernel
+hipError_t launch_windows2_tiled_ragged(const kmx_reads* r, const u64* win_offsets, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu,
+                                        hipStream_t st, bool* handled, unsigned long long* too_long) {
+    *handled = false;
+    if (!r->d_offsets || !win_offsets || k < 33 || k > 64 || r->n_reads < 64u || r->read_len > 256) return hipSuccess;
+    if (reinterpret_cast<uintptr_t>(r->d_bases) & 15u) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(fw) | reinterpret_cast<uintptr_t>(rc) | reinterpret_cast<uintptr_t>(canon)) & 15u) return hipSuccess;
+    u32 L = r->read_len ? r->read_len : 256u;
+    if (L < k + 15u) L = k + 15u;
+    *handled = true;
+    const Win2Out out{fw, rc, canon, flags};
+    if (L <= 160) return launch_windows2_tiled_nw<10, true>(r->d_bases, r->n_reads, L, k, out, n_cu, st, r->d_offsets, win_offsets, too_long);
+    return launch_windows2_tiled_nw<16, true>(r->d_bases, r->n_reads, L, k, out, n_cu, st, r->d_offsets, win_offsets, too_long);
 }
 
 __global__ void __launch_bounds__(256)

@@ -481,3 +481,58 @@ def test_reduce2_long_ragged_reads(ctx, orc, k, case):
     o2 = orc.canonical_reduce2(host, n_reads - cut, 0, k, with_hash=True, offsets=offsets[cut:])
     g2 = ctx.canonical_reduce2(dev, n_reads - cut, 100_000_000, k, with_hash=True, offsets=d_off[cut:])
     assert (g2.n_valid, g2.sum_lo, g2.sum_hi, g2.xor_lo, g2.xor_hi) == (o2.n_valid, o2.sum_lo, o2.sum_hi, o2.xor_lo, o2.xor_hi)
+
+
+# ---------------------------------------------------------------- two-word materialise of ragged reads: tiled
+
+@pytest.mark.parametrize("k", [33, 47, 63, 64])
+@pytest.mark.parametrize("case", ["trimmed_150", "mix_100_160", "mix_to_250", "no_bound_some_long", "short_and_empty", "gaps"])
+def test_windows2_ragged_reads_tiled(ctx, orc, k, case):
+    """kmx_canonical_windows2 on reads behind an offsets array: the tiled kernel with a per-lane start, window count and first
+    output slot (kmx_generic.hip: windows2_tiled_kernel<.., RAGGED>); a tile with a read above the bound, or an invalid byte,
+    takes the per-read path inside it.  Every array alone (the staged whole-line write-back), all of them, flags alone;
+    `gaps`: a caller's win_offsets that leave room between the reads -- what lies there stays untouched."""
+    import torch
+    from kmers_amd.api import _ptr
+
+    rng = np.random.default_rng(k * 17 + len(case))
+    n = 64 * 7 + 19
+    gap = 0
+    if case == "trimmed_150":
+        lens, hint = np.where(rng.random(n) < 0.05, rng.integers(36, 150, n), 150), 150
+    elif case == "mix_100_160":
+        lens, hint = rng.integers(100, 161, n), 160
+    elif case == "mix_to_250":
+        lens, hint = rng.integers(80, 251, n), 250
+    elif case == "no_bound_some_long":
+        lens, hint = np.where(rng.random(n) < 0.02, rng.integers(257, 600, n), rng.integers(60, 257, n)), 0
+    elif case == "short_and_empty":
+        lens, hint = rng.integers(0, 2 * k, n), 2 * k
+    else:
+        lens, hint, gap = rng.integers(100, 151, n), 150, 3
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    nw = np.maximum(lens - k + 1, 0)
+    wo = np.concatenate([[0], np.cumsum(nw + gap)]).astype(np.uint64)
+    total = int(wo[-1])
+    host = _dirty(rng, int(offsets[-1]), 0.0003)
+    fw, rc, canon, flags = orc.canonical_windows2(host, n, 0, k, offsets=offsets)       # dense, read after read
+    dense_at = np.concatenate([[0], np.cumsum(nw)])
+    keep = np.concatenate([np.arange(wo[i], wo[i] + nw[i], dtype=np.int64) for i in range(n)]) if total else np.zeros(0, np.int64)
+    dev, d_off, d_wo = ctx.to_device(host), ctx.to_device(offsets), ctx.to_device(wo)
+    r = ctx._reads(dev, n, hint, d_off)
+    exp = {"fw": fw, "rc": rc, "canon": canon}
+    for want in (("canon",), ("fw",), ("rc",), ("fw", "rc", "canon", "flags"), ("flags",)):
+        outs = {nm: torch.full((2 * total,), -1, dtype=torch.int64, device=dev.device) for nm in ("fw", "rc", "canon") if nm in want}
+        fl = torch.full((total,), 0x7F, dtype=torch.uint8, device=dev.device) if "flags" in want else None
+        ctx._ck(ctx.lib.kmx_canonical_windows2(ctx._h, C.byref(r), _ptr(d_wo), k, _ptr(outs.get("fw")), _ptr(outs.get("rc")), _ptr(outs.get("canon")), _ptr(fl)))
+        ctx.synchronize()
+        for nm, t in outs.items():
+            got = t.cpu().numpy().view(np.uint64).reshape(total, 2)
+            assert (got[keep] == exp[nm].reshape(-1, 2)).all(), (case, k, want, nm, int((got[keep] != exp[nm].reshape(-1, 2)).any(axis=1).sum()))
+            if gap:
+                mask = np.ones(total, bool); mask[keep] = False
+                assert (t.cpu().numpy().reshape(total, 2)[mask] == -1).all(), "the gaps are the caller's"
+        if fl is not None:
+            gf = fl.cpu().numpy()
+            assert (gf[keep] == flags).all(), (case, k, want)
+    assert dense_at[-1] == len(flags)

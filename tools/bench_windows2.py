@@ -33,3 +33,18 @@ for k in (33, 47, 63, 64):
     ms_a = t(lambda: ctx._ck(ctx.lib.kmx_canonical_windows2(ctx._h, C.byref(r), None, k, _ptr(fw), _ptr(rc), _ptr(canon), _ptr(fl))))
     print(f"k={k}: fw+rc+canon+flags {ms_a:8.3f} ms = {49*tot/ms_a/1e6:6.0f} GB/s written")
     del canon, fw, rc, fl
+# ragged reads (offsets + win_offsets; round 4: the tiled kernel with per-lane geometry)
+import numpy as np
+k = 63
+for name, lens, hint in (("all 150, bound 150", np.full(n, 150), 150), ("2 % trimmed to 70..149, bound 150", np.where(np.random.default_rng(1).random(n) < 0.02, np.random.default_rng(2).integers(70, 150, n), 150), 150),
+                         ("100..160 mix, bound 160", np.random.default_rng(3).integers(100, 161, n), 160)):
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    wo = np.concatenate([[0], np.cumsum(np.maximum(lens - k + 1, 0))]).astype(np.uint64)
+    rb = ctx.gen_reads(int(off[-1]))
+    d_off, d_wo = ctx.to_device(off), ctx.to_device(wo)
+    tot = int(wo[-1])
+    canon = ctx.empty(2 * tot, torch.int64)
+    rr = ctx._reads(rb, n, hint, d_off)
+    ms = t(lambda: ctx._ck(ctx.lib.kmx_canonical_windows2(ctx._h, C.byref(rr), _ptr(d_wo), k, None, None, _ptr(canon), None)))
+    print(f"k={k} ragged {name}: canon only {ms:8.3f} ms = {16*tot/ms/1e6:6.0f} GB/s written, {tot/ms/1e6:6.1f} G k-mers/s")
+    del rb, canon, d_off, d_wo

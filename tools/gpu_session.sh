@@ -1,5 +1,4 @@
 # scratch: the command list of the current gpurun call (tools/README.md); the round's profile set is tools/profile_round.sh
-O=$GRAFT_REPO_ROOT/gpurun_out/r6y; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r7a; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt
-python3 tools/bench_long_ragged.py 6e9 63 2>/dev/null | tee $O/long_ragged2.txt
