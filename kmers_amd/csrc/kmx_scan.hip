@@ -85,8 +85,12 @@ struct WindowsParams {
 // Fast path: the 16 windows of a block are staged through LDS (lane-major, pitch 17) and written back transposed,
 // so every store instruction covers 128-byte contiguous runs (16 windows of one read) instead of 64 scattered
 // 8-byte words at a stride of W*8 bytes.
-template <bool ALIGNED>
+// RG (round 4): the line-aligned ring for RAGGED reads too (one array asked for): a read's line shift comes from its first output
+// slot (win_offsets[r] mod 16) instead of r*W, its window count from the offsets; a read's last pass writes what is left of
+// it.  No shared-line merge, no prefetch of the next tile (the tile's geometry is not known that early).
+template <bool ALIGNED, bool RG = false>
 struct SinkWindowsT {
+    static_assert(!RG || ALIGNED, "the ragged ring is a mode of the line-aligned sink");
     static constexpr u32 PITCH = 17;                        // u64 per lane row (16 + 1 pad: conflict-free both ways)
     static constexpr u32 PLANE = 64u * PITCH * 2u;          // dwords of one staged u64 array of a wave
     // staging sized by what the caller asked for (with all three u64 planes a block holds 108 KB = one block per CU and one
@@ -126,7 +130,7 @@ struct SinkWindowsT {
         return ((p.fw ? 1u : 0u) + (p.rc ? 1u : 0u) + (p.canon ? 1u : 0u)) == 1u && !p.flags && (W & 15u) != 0u;
     }
     static __host__ __device__ u32 wave_dwords(const WindowsParams& p) {
-        if (line_aligned(p)) return 64u * RPITCH * 2u;
+        if (line_aligned(p)) return 64u * RPITCH * 2u + (RG ? 64u * 3u : 0u);   // (RG: first slot and window count of the tile's 64 reads, behind the ring)
         return ((p.fw ? 1u : 0u) + (p.rc ? 1u : 0u) + (p.canon ? 1u : 0u)) * PLANE + (p.flags ? 64u * 16u / 4u : 0u) +
                (p.win_offsets ? 64u * 3u : 0u);   // ragged: first slot and window count of the tile's 64 reads
     }
@@ -139,7 +143,7 @@ struct SinkWindowsT {
     u32* NWL;               // ragged: [64] their window counts
     u64 base;      // slot of window 0 of the current read
     u32 W, nwr, next, lane; // W: windows per read (uniform layout); nwr: windows of this lane's read
-    static constexpr bool kRagged = !ALIGNED;   // (the line-aligned write-back assumes one window count per read)
+    static constexpr bool kRagged = !ALIGNED || RG;
     __device__ SinkWindowsT(const WindowsParams& p_, u32, u32 W_, u32*, u32 lane_, u32* block_lds, u32 tid)
         : p(p_), base(0), W(W_), next(0), lane(lane_) {
         u32* mine = block_lds + (tid >> 6) * wave_dwords(p_);
@@ -148,6 +152,7 @@ struct SinkWindowsT {
         Tcn = Trc + (p_.rc ? PLANE / 2u : 0u);
         TF = reinterpret_cast<uint8_t*>(Tcn + (p_.canon ? PLANE / 2u : 0u));
         WOL = reinterpret_cast<u64*>(TF + (p_.flags ? 64u * 16u : 0u));
+        if constexpr (RG) WOL = Tfw + 64u * RPITCH;
         NWL = reinterpret_cast<u32*>(WOL + 64);
         nwr = W_;
         out1 = line_aligned(p_) ? (p_.fw ? p_.fw : p_.rc ? p_.rc : p_.canon) : nullptr;
@@ -195,12 +200,25 @@ struct SinkWindowsT {
             // from the read's index in the tile, and every address is a 32-bit offset from a wave-uniform base.  The loop is
             // bound by the LDS round trip of each step (two waves per SIMD): the ring read of step i + 1 is issued before
             // the store of step i.
-            const bool last = o0 + cnt == W;      // the last pass also writes what is left of each read (< 32 windows)
+            bool last = o0 + cnt == W;      // the last pass also writes what is left of each read (< 32 windows)
+            if constexpr (RG) last = __any(nwr > o0 && nwr <= o0 + cnt);    // (ragged: some read of the tile ends in this pass)
             const u32 g = lane >> 4, s = lane & 15u, Wm = W & 15u;
-            uint8_t* const gbase = reinterpret_cast<uint8_t*>(out1 + read0 * W);
+            uint8_t* const gbase = reinterpret_cast<uint8_t*>(RG ? out1 + WOL[0] : out1 + read0 * W);
             for (u32 sub = 0; sub < (last ? 2u : 1u); ++sub) {
                 auto prep = [&](u32 it, u32& at, u32& goff) -> bool {
                     const u32 r = 4u * it + g;
+                    if constexpr (RG) {
+                        // the read's own line shift and window count; its slots relative to the tile's first (win_offsets are the
+                        // exclusive prefix sums of the window counts: 64 reads of at most 256 windows)
+                        const u64 s0 = WOL[r];
+                        const u32 Wr = NWL[r], a = (u32)s0 & 15u;
+                        const u32 lo = o0 > a ? o0 - a : 0u;
+                        const u32 hi = o0 + cnt >= Wr ? Wr : o0 + 16u - a;
+                        const u32 o = lo + 16u * sub + s;
+                        at = r * RPITCH + (o & 31u);
+                        goff = ((u32)(s0 - WOL[0]) + o) * 8u;
+                        return o < hi;
+                    }
                     const u32 a = (r * Wm) & 15u;          // read*W mod 16
                     const u32 lo = o0 > a ? o0 - a : 0u;
                     u32 hi = last ? W : o0 + 16u - a;
@@ -284,7 +302,7 @@ struct SinkWindowsT {
         if (p.win_offsets) {
             base = p.win_offsets[read];
             nwr = (u32)(p.win_offsets[read + 1u] - base);
-            if (!ALIGNED) { WOL[lane] = base; NWL[lane] = nwr; }   // for the transposed write-back (block_done starts with a wave barrier)
+            if (!ALIGNED || RG) { WOL[lane] = base; NWL[lane] = nwr; }   // for the transposed write-back (block_done starts with a wave barrier)
         } else {
             base = read * W;
         }
@@ -292,7 +310,7 @@ struct SinkWindowsT {
 #ifndef KMX_WIN_MERGE
 #define KMX_WIN_MERGE 1
 #endif
-        merge = KMX_WIN_MERGE && ALIGNED && W >= 32u;
+        merge = KMX_WIN_MERGE && ALIGNED && !RG && W >= 32u;
     }
     // ---- line-aligned mode: the output line two neighbouring reads of a tile share.  Written in two pieces (the tail of read
     // r - 1 in the tile's last pass, the head of read r in its first), 16-byte multiples at W = 130, such a line costs ~3.4x a
@@ -545,6 +563,8 @@ hipError_t launch_windows_ragged(const uint8_t* bases, const u64* offsets, const
     *handled = offsets && win_offsets && scan_domain_ragged(bases, L, k);
     if (!*handled) return hipSuccess;
     const WindowsParams p{fw, rc, canon, flags, win_offsets};
+    // one u64 array, no flags (the usual call: the canonical words): whole lines through the ring, each read shifted by its own first slot
+    if (((fw ? 1 : 0) + (rc ? 1 : 0) + (canon ? 1 : 0)) == 1 && !flags) return dispatch<SinkWindowsT<true, true>, WindowsParams, NoPre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
     return dispatch<SinkWindowsT<false>>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
 }
 

@@ -449,7 +449,7 @@ static bool scan_domain_ragged(const uint8_t* bases, u32 L, u32 k) {
 }
 
 // offsets != nullptr: ragged reads; L is then only an upper bound of the read lengths (0 = unknown) that selects the frame
-template <typename SinkT, typename Params, typename Pre = NoPre>
+template <typename SinkT, typename Params, typename Pre = NoPre, bool ONLY_RAGGED = false>
 static hipError_t dispatch(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Params p, unsigned long long* queue,
                            int n_cu, hipStream_t stream, Pre pre = Pre(), const u64* offsets = nullptr) {
     const bool big = L > 160 || (offsets && L == 0);
@@ -467,6 +467,8 @@ static hipError_t dispatch(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Para
         if (big) return launch_one<16, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
         return launch_one<10, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
     }
+    if constexpr (ONLY_RAGGED) return hipErrorInvalidValue;   // (a sink instantiated for reads behind an offsets array only)
+    else {
     if (k <= 16) {
         if (big) return launch_one<16, 1, 1, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
         return launch_one<10, 1, 1, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
@@ -477,6 +479,7 @@ static hipError_t dispatch(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Para
     }
     if (big) return launch_one<16, 2, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
     return launch_one<10, 2, 2, SinkT, Params, Pre>(bases, n_reads, L, k, p, queue, n_cu, stream, pre);
+    }
 }
 
 }  // namespace kmx

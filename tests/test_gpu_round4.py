@@ -536,3 +536,33 @@ def test_windows2_ragged_reads_tiled(ctx, orc, k, case):
             gf = fl.cpu().numpy()
             assert (gf[keep] == flags).all(), (case, k, want)
     assert dense_at[-1] == len(flags)
+
+
+# ---------------------------------------------------------------- single-word materialise of ragged reads, one array: whole lines
+
+@pytest.mark.parametrize("k", [13, 21, 31])
+@pytest.mark.parametrize("case", ["trimmed_150", "mix_100_160", "mix_to_250", "no_bound_some_long", "short_and_empty"])
+def test_windows_ragged_single_array_ring(ctx, orc, k, case):
+    """kmx_canonical_windows on reads behind an offsets array, ONE u64 array and no flags: the line-aligned ring with each read's
+    line shift taken from its own first output slot and its window count from the offsets (SinkWindowsT<true, true>); a read's
+    last pass writes what is left of it.  Tiles with an invalid byte or a read above the bound roll per lane through the same
+    ring (canonical_kmer_iterator.rs:42-70 per read)."""
+    rng = np.random.default_rng(k * 19 + len(case))
+    n = 64 * 8 + 37
+    if case == "trimmed_150":
+        lens, hint = np.where(rng.random(n) < 0.05, rng.integers(36, 150, n), 150), 150
+    elif case == "mix_100_160":
+        lens, hint = rng.integers(100, 161, n), 160
+    elif case == "mix_to_250":
+        lens, hint = rng.integers(80, 251, n), 250
+    elif case == "no_bound_some_long":
+        lens, hint = np.where(rng.random(n) < 0.02, rng.integers(257, 600, n), rng.integers(60, 257, n)), 0
+    else:
+        lens, hint = rng.integers(0, 3 * k, n), 3 * k
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = _dirty(rng, int(offsets[-1]), 0.0003)
+    fw, rc, canon, flags = orc.canonical_windows(host, n, 0, k, offsets=offsets)
+    dev, d_off = ctx.to_device(host), ctx.to_device(offsets)
+    for name, exp in (("canon", canon), ("fw", fw), ("rc", rc)):
+        got = ctx.canonical_windows(dev, n, hint, k, offsets=d_off, host_offsets=offsets, want=(name,))[name].cpu().numpy().view(np.uint64)
+        assert (got == exp).all(), (case, k, name, int((got != exp).sum()), np.flatnonzero(got != exp)[:8])
