@@ -648,6 +648,7 @@ def worker(args, traffic_raw=None, traffic_err=None):
             if td is not None:
                 traffic, traffic_detail = td["bytes_per_step"], td
         bs_kernel = (13 <= k <= 31 or 33 <= k <= 64) and L <= 256
+        seg_kernel = (13 <= k <= 31 or 33 <= k <= 64) and L > 256 and not args.packed
         if hist_mode:
             kernel_name = "kmx::scan_uniform_kernel<SinkHist*> (partition pass + per-partition tables)"
         elif bs_kernel:
@@ -655,6 +656,13 @@ def worker(args, traffic_raw=None, traffic_err=None):
             frame = 10 if (k > 32 or args.packed) and L <= 160 else 16 if args.packed else (13 if L <= 208 else 16) if k > 32 else \
                 next(nw for nw, lmax in ((5, 80), (7, 112), (8, 128), (10, 160), (13, 208), (16, 256)) if L <= lmax)
             kernel_name = "kmx::scan_bitsliced_kernel<%d,%d,*>" % (k, frame)
+        elif seg_kernel:
+            # reads above 256 bases: equal overlapping segments on the uniform kernel (bs_seg_plan in kmx_bitslice_kernel.h)
+            wr, t10 = L - k + 1, min(128, 160 - k)
+            t_max = min(192, 208 - k) if k <= 31 else t10
+            n_seg = -(-wr // t_max)
+            t_seg = -(-wr // n_seg)
+            kernel_name = "kmx::scan_bitsliced_kernel<%d,%d,*,SEG> (%d segments of %d windows per read)" % (k, 10 if t_seg <= t10 else 13, n_seg, t_seg)
         else:
             kernel_name = "kmx::scan_uniform_kernel" if k <= 31 else "kmx::reduce2_generic_kernel"
         cfg_names = {"1": "BASELINE configs[1]", "2": "BASELINE configs[2]", "3": "BASELINE configs[3]", "4": "BASELINE configs[4]"}
