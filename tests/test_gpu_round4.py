@@ -566,3 +566,21 @@ def test_windows_ragged_single_array_ring(ctx, orc, k, case):
     for name, exp in (("canon", canon), ("fw", fw), ("rc", rc)):
         got = ctx.canonical_windows(dev, n, hint, k, offsets=d_off, host_offsets=offsets, want=(name,))[name].cpu().numpy().view(np.uint64)
         assert (got == exp).all(), (case, k, name, int((got != exp).sum()), np.flatnonzero(got != exp)[:8])
+
+
+@pytest.mark.parametrize("lead", [1, 5, 8, 15])
+@pytest.mark.parametrize("L,k", [(150, 21), (150, 31), (100, 13), (200, 31), (250, 27)])
+def test_windows_uniform_from_a_misaligned_base(ctx, orc, lead, L, k):
+    """kmx_canonical_windows on uniform reads whose first byte is not 16-byte aligned: the line-aligned kernel streams from the
+    aligned address below (a tile spans one more chunk; the next tile's prefetch starts there too), one array and all four"""
+    rng = np.random.default_rng(lead * 1000 + L + k)
+    n = 64 * 6 + 11
+    host_all = _dirty(rng, n * L + 32, 0.0004)
+    dev_all = ctx.to_device(host_all)
+    host, dev = host_all[lead:lead + n * L], dev_all[lead:lead + n * L]
+    fw, rc, canon, flags = orc.canonical_windows(host, n, L, k)
+    got = ctx.canonical_windows(dev, n, L, k, want=("canon",))["canon"].cpu().numpy().view(np.uint64)
+    assert (got == canon).all()
+    outs = ctx.canonical_windows(dev, n, L, k)
+    assert (outs["fw"].cpu().numpy().view(np.uint64) == fw).all() and (outs["rc"].cpu().numpy().view(np.uint64) == rc).all()
+    assert (outs["canon"].cpu().numpy().view(np.uint64) == canon).all() and (outs["flags"].cpu().numpy() == flags).all()
