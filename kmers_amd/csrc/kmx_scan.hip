@@ -25,6 +25,7 @@
 //   A tile that contains any invalid byte (or the final partial tile) takes the reference-shaped
 //   per-lane rolling path instead (roll_read) -- bit-exact with the iterator's skip semantics.
 //   Tiles come from the same interleaved dynamic queue as the bit-sliced kernel.
+#include <type_traits>
 #include "kmx_scan_kernel.h"
 
 namespace kmx {
@@ -200,23 +201,24 @@ struct SinkWindowsT {
             // from the read's index in the tile, and every address is a 32-bit offset from a wave-uniform base.  The loop is
             // bound by the LDS round trip of each step (two waves per SIMD): the ring read of step i + 1 is issued before
             // the store of step i.
+            typedef typename std::conditional<RG, u64, u32>::type goff_t;     // byte offset of a slot from the tile's first
             bool last = o0 + cnt == W;      // the last pass also writes what is left of each read (< 32 windows)
             if constexpr (RG) last = __any(nwr > o0 && nwr <= o0 + cnt);    // (ragged: some read of the tile ends in this pass)
             const u32 g = lane >> 4, s = lane & 15u, Wm = W & 15u;
             uint8_t* const gbase = reinterpret_cast<uint8_t*>(RG ? out1 + WOL[0] : out1 + read0 * W);
             for (u32 sub = 0; sub < (last ? 2u : 1u); ++sub) {
-                auto prep = [&](u32 it, u32& at, u32& goff) -> bool {
+                auto prep = [&](u32 it, u32& at, goff_t& goff) -> bool {
                     const u32 r = 4u * it + g;
                     if constexpr (RG) {
-                        // the read's own line shift and window count; its slots relative to the tile's first (win_offsets are the
-                        // exclusive prefix sums of the window counts: 64 reads of at most 256 windows)
+                        // the read's own line shift and window count; its slots relative to the tile's first, in 64 bits (a rolled
+                        // tile may hold reads of any length)
                         const u64 s0 = WOL[r];
                         const u32 Wr = NWL[r], a = (u32)s0 & 15u;
                         const u32 lo = o0 > a ? o0 - a : 0u;
                         const u32 hi = o0 + cnt >= Wr ? Wr : o0 + 16u - a;
                         const u32 o = lo + 16u * sub + s;
                         at = r * RPITCH + (o & 31u);
-                        goff = ((u32)(s0 - WOL[0]) + o) * 8u;
+                        goff = (s0 - WOL[0] + o) * 8u;
                         return o < hi;
                     }
                     const u32 a = (r * Wm) & 15u;          // read*W mod 16
@@ -237,12 +239,14 @@ struct SinkWindowsT {
                 // (merged: a read's part of the last pass is one line or none -- only the tile's last read, whose tail goes out
                 // in pieces, has windows left for the second round)
                 const u32 it_first = (merge && sub == 1u) ? 15u : 0u;
-                u32 at0, go0;
+                u32 at0;
+                goff_t go0;
                 bool c0 = prep(it_first, at0, go0);
                 u64 v0 = Tfw[at0];
 #pragma unroll KMX_WIN_UNROLL_A
                 for (u32 it = it_first; it < 16u; ++it) {
-                    u32 at1 = 0, go1 = 0;
+                    u32 at1 = 0;
+                    goff_t go1 = 0;
                     bool c1 = false;
                     u64 v1 = 0;
                     c1 = prep((it + 1u) & 15u, at1, go1);    // (the 17th: loaded, never stored)

@@ -541,7 +541,7 @@ def test_windows2_ragged_reads_tiled(ctx, orc, k, case):
 # ---------------------------------------------------------------- single-word materialise of ragged reads, one array: whole lines
 
 @pytest.mark.parametrize("k", [13, 21, 31])
-@pytest.mark.parametrize("case", ["trimmed_150", "mix_100_160", "mix_to_250", "no_bound_some_long", "short_and_empty"])
+@pytest.mark.parametrize("case", ["trimmed_150", "mix_100_160", "mix_to_250", "no_bound_some_long", "short_and_empty", "one_huge"])
 def test_windows_ragged_single_array_ring(ctx, orc, k, case):
     """kmx_canonical_windows on reads behind an offsets array, ONE u64 array and no flags: the line-aligned ring with each read's
     line shift taken from its own first output slot and its window count from the offsets (SinkWindowsT<true, true>); a read's
@@ -557,6 +557,9 @@ def test_windows_ragged_single_array_ring(ctx, orc, k, case):
         lens, hint = rng.integers(80, 251, n), 250
     elif case == "no_bound_some_long":
         lens, hint = np.where(rng.random(n) < 0.02, rng.integers(257, 600, n), rng.integers(60, 257, n)), 0
+    elif case == "one_huge":      # (a rolled tile whose slots span far more than a frame's worth)
+        lens, hint = rng.integers(100, 151, n), 150
+        lens[70] = 70_000
     else:
         lens, hint = rng.integers(0, 3 * k, n), 3 * k
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
