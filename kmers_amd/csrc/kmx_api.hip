@@ -24,7 +24,10 @@ hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 
                                   uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 hipError_t launch_windows_ragged(const uint8_t* bases, const u64* offsets, const u64* win_offsets, u64 n_reads, u32 L, u32 k,
                                  u64* fw, u64* rc, u64* canon, uint8_t* flags, unsigned long long* queue, int n_cu,
-                                 hipStream_t stream, bool* handled);
+                                 hipStream_t stream, bool* handled, const u64* ends = nullptr /* the reads' ends: nullptr = offsets + 1 */);
+size_t uniform_segments_scratch_bytes(u64 n_seg);
+hipError_t launch_uniform_segments_plan(u64 n_reads, u32 L, u32 k, u32 T, void* scratch, const u64** starts, const u64** ends, const u64** wins, u64* n_seg_out,
+                                        hipStream_t stream);
 // kmx_bitslice.hip
 hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
@@ -539,6 +542,26 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
         KMX_HIP(ctx, kmx::launch_windows_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, d_fw, d_rc, d_canon,
                                                  d_flags, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
+        // Uniform reads longer than a frame (round 4): every read as segments of at most 257 - k windows, each a read of its own for the ragged
+        // materialise kernels (its start, its end, its first output slot: three arrays in the work buffer, 24 bytes per segment against
+        // the ~1.8 KB a segment writes).  16-byte aligned base; no scratch -> the lane-per-read kernel below.
+        const uint32_t L = reads->read_len;
+        if (L > 256 && k <= 31 && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u && reads->n_reads < (1ull << 40) && (uint64_t)L * reads->n_reads < (1ull << 62)) {
+            // (as few segments as the 16-word frame allows, all of the same size but the last)
+            const uint32_t W = L - k + 1u, J = (W + (257u - k) - 1u) / (257u - k), T = (W + J - 1u) / J;
+            const uint64_t n_seg_host = reads->n_reads * J;
+            void* scratch = big_scratch(ctx, kmx::uniform_segments_scratch_bytes(n_seg_host));
+            if (scratch) {
+                ctx->fx_valid = false;   // (the work buffer is overwritten: the fastx chunk prefixes in it are gone)
+                const uint64_t *starts = nullptr, *ends = nullptr, *wins = nullptr;
+                uint64_t n_seg = 0;
+                KMX_HIP(ctx, kmx::launch_uniform_segments_plan(reads->n_reads, L, k, T, scratch, &starts, &ends, &wins, &n_seg, ctx->stream));
+                KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+                KMX_HIP(ctx, kmx::launch_windows_ragged(reads->d_bases, starts, wins, n_seg, 256u, k, d_fw, d_rc, d_canon, d_flags, ctx->d_scratch + 16, ctx->n_cu,
+                                                        ctx->stream, &handled, ends));
+                if (handled) return KMX_OK;
+            }
+        }
     }
     if (reads->d_offsets && d_win_offsets) {     // ragged reads: the tiled word-domain kernel (read_len = optional length bound)
         bool handled = false;

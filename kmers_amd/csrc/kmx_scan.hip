@@ -563,13 +563,13 @@ hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 
 // ragged reads: win_offsets[r] = slot of window 0 of read r (n_reads+1 entries); L = optional bound of the read lengths
 hipError_t launch_windows_ragged(const uint8_t* bases, const u64* offsets, const u64* win_offsets, u64 n_reads, u32 L, u32 k,
                                  u64* fw, u64* rc, u64* canon, uint8_t* flags, unsigned long long* queue, int n_cu,
-                                 hipStream_t stream, bool* handled) {
+                                 hipStream_t stream, bool* handled, const u64* ends) {
     *handled = offsets && win_offsets && scan_domain_ragged(bases, L, k);
     if (!*handled) return hipSuccess;
     const WindowsParams p{fw, rc, canon, flags, win_offsets};
     // one u64 array, no flags (the usual call: the canonical words): whole lines through the ring, each read shifted by its own first slot
-    if (((fw ? 1 : 0) + (rc ? 1 : 0) + (canon ? 1 : 0)) == 1 && !flags) return dispatch<SinkWindowsT<true, true>, WindowsParams, NoPre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
-    return dispatch<SinkWindowsT<false>>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
+    if (((fw ? 1 : 0) + (rc ? 1 : 0) + (canon ? 1 : 0)) == 1 && !flags) return dispatch<SinkWindowsT<true, true>, WindowsParams, NoPre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets, ends);
+    return dispatch<SinkWindowsT<false>>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets, ends);
 }
 
 }  // namespace kmx

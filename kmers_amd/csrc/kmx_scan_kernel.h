@@ -66,7 +66,10 @@ template <typename S, int NW> constexpr int sink_waves() { return NW <= 10 ? Sin
 template <int NW, int V, int DW, typename Sink, typename Params, bool RAGGED = false>
 __global__ void __launch_bounds__(256, (sink_waves<Sink, NW>()))
 scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, Params params,
-                    unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead) {
+                    unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends_arg) {
+    // RAGGED: read r = bases[offsets[r], ends[r]); ends_arg == nullptr: the reads lie back to back (ends = offsets + 1).  A
+    // separate ends array serves reads that OVERLAP in memory: the segments a long read is cut into (materialise, round 4).
+    [[maybe_unused]] const u64* __restrict__ const ends = RAGGED ? (ends_arg ? ends_arg : offsets + 1) : nullptr;
     // `lead` (uniform reads whose first byte is not 16-byte aligned): `bases` is the aligned address below it, read r
     // starts at byte lead + r*L and a tile spans one more chunk (as a ragged tile streamed from its aligned start does)
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -81,7 +84,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
 
     const u64 n_full = n_reads >> 6;
     const u64 wave_id = (u64)blockIdx.x * 4u + wib;
-    const u64 total_bytes = RAGGED ? offsets[n_reads] : 0;
+    const u64 total_bytes = RAGGED ? ends[n_reads - 1u] : 0;
 
     // per-lane alignment of this lane's read inside the packed tile (LDS index 1+c holds bases [16c,16c+16))
     u32 posF = lane * L + lead + 16u;
@@ -181,7 +184,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     u64 nx_off = 0, nx_end = 0;
     if (RAGGED && next_tile < n_full) {
         nx_off = offsets[next_tile * 64u + lane];
-        nx_end = offsets[next_tile * 64u + lane + 1u];
+        nx_end = ends[next_tile * 64u + lane];
     }
     for (u64 tile = next_tile; tile < n_full; tile = next_tile) {
         next_tile = dequeue();
@@ -200,7 +203,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
             const u64 t0 = ((u64)t0h << 32) | t0l, t1 = ((u64)t1h << 32) | t1l;
             if (next_tile < n_full) {
                 nx_off = offsets[next_tile * 64u + lane];
-                nx_end = offsets[next_tile * 64u + lane + 1u];
+                nx_end = ends[next_tile * 64u + lane];
             }
             const u64 base_al = t0 & ~15ull;
             const u64 n_ch = (t1 - base_al + 15u) >> 4;
@@ -374,7 +377,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         const u64 read = n_full * 64u + lane;
         sink.begin_read(read);
         if constexpr (RAGGED) {
-            const u64 o0 = offsets[read], len64 = offsets[read + 1u] - o0;
+            const u64 o0 = offsets[read], len64 = ends[read] - o0;
             if (!read_too_long(len64, queue + KMX_TOOLONG_FROM_QUEUE))
                 roll_read(bases + o0, (u32)len64, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
         } else {
@@ -394,7 +397,8 @@ struct NoPre {
 };
 template <int NW, int V, int DW, typename Sink, typename Params, typename Pre = NoPre, bool RAGGED = false>
 static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Params& params,
-                             unsigned long long* queue, int n_cu, hipStream_t stream, Pre pre = Pre(), const u64* offsets = nullptr) {
+                             unsigned long long* queue, int n_cu, hipStream_t stream, Pre pre = Pre(), const u64* offsets = nullptr,
+                             const u64* ends = nullptr) {
     auto kern = scan_uniform_kernel<NW, V, DW, Sink, Params, RAGGED>;
     u32 lead = 0;   // uniform reads from a base that is not 16-byte aligned: streamed from the aligned address below it
     if constexpr (!RAGGED) {
@@ -434,7 +438,7 @@ static hipError_t launch_one(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Pa
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
     if (!pre(grid)) return hipErrorOutOfMemory;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, params, queue, offsets, lead);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, k, params, queue, offsets, lead, ends);
     return hipGetLastError();
 }
 
@@ -451,21 +455,21 @@ static bool scan_domain_ragged(const uint8_t* bases, u32 L, u32 k) {
 // offsets != nullptr: ragged reads; L is then only an upper bound of the read lengths (0 = unknown) that selects the frame
 template <typename SinkT, typename Params, typename Pre = NoPre, bool ONLY_RAGGED = false>
 static hipError_t dispatch(const uint8_t* bases, u64 n_reads, u32 L, u32 k, Params p, unsigned long long* queue,
-                           int n_cu, hipStream_t stream, Pre pre = Pre(), const u64* offsets = nullptr) {
+                           int n_cu, hipStream_t stream, Pre pre = Pre(), const u64* offsets = nullptr, const u64* ends = nullptr) {
     const bool big = L > 160 || (offsets && L == 0);
     if constexpr (!SinkT::kRagged) {
         if (offsets) return hipErrorInvalidValue;
     } else if (offsets) {
         if (k <= 16) {
-            if (big) return launch_one<16, 1, 1, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
-            return launch_one<10, 1, 1, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+            if (big) return launch_one<16, 1, 1, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets, ends);
+            return launch_one<10, 1, 1, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets, ends);
         }
         if (k == 17) {   // the one k whose rc window sits at the V = 1 register index while the k-mer needs two dwords
-            if (big) return launch_one<16, 1, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
-            return launch_one<10, 1, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+            if (big) return launch_one<16, 1, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets, ends);
+            return launch_one<10, 1, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets, ends);
         }
-        if (big) return launch_one<16, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
-        return launch_one<10, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets);
+        if (big) return launch_one<16, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets, ends);
+        return launch_one<10, 2, 2, SinkT, Params, Pre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, pre, offsets, ends);
     }
     if constexpr (ONLY_RAGGED) return hipErrorInvalidValue;   // (a sink instantiated for reads behind an offsets array only)
     else {

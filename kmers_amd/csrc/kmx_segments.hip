@@ -174,4 +174,38 @@ hipError_t launch_segments_build(const u64* offsets, u64 n_reads, u32 k, u32 t_m
     return hipGetLastError();
 }
 
+// ---- uniform reads longer than a frame, materialise (round 4): read r of L bases (W = L - k + 1 windows) as J = ceil(W / T) segments
+// of T windows (the last one what is left), each a "read" of its own for the ragged materialise kernels: segment g = r J + j
+// starts at byte r L + j T, ends k - 1 bases behind its last window's start, and its windows go to the output slots
+// r W + j T ... -- consecutive segments, consecutive slots: `wins` is the exclusive prefix sum the kernels expect.
+__global__ void __launch_bounds__(256) seg_plan_uniform_kernel(u64 n_seg, u32 L, u32 k, u32 T, u32 J, u64* __restrict__ starts, u64* __restrict__ ends,
+                                                               u64* __restrict__ wins) {
+    const u64 g = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u32 W = L - k + 1u;
+    if (g < n_seg) {
+        const u64 r = g / J;
+        const u32 j = (u32)(g - r * J);
+        const u32 nw = W - j * T < T ? W - j * T : T;
+        starts[g] = r * (u64)L + (u64)j * T;
+        ends[g] = r * (u64)L + (u64)j * T + nw + (k - 1u);
+        wins[g] = r * (u64)W + (u64)j * T;
+    }
+    if (g == n_seg) wins[g] = (n_seg / J) * (u64)W;
+}
+
+size_t uniform_segments_scratch_bytes(u64 n_seg) { return (size_t)(3u * n_seg + 8u) * 8u; }
+
+hipError_t launch_uniform_segments_plan(u64 n_reads, u32 L, u32 k, u32 T, void* scratch, const u64** starts, const u64** ends, const u64** wins, u64* n_seg_out,
+                                        hipStream_t stream) {
+    const u32 W = L - k + 1u, J = (W + T - 1u) / T;
+    const u64 n_seg = n_reads * J;
+    u64* a = static_cast<u64*>(scratch);
+    hipLaunchKernelGGL(seg_plan_uniform_kernel, dim3((unsigned)((n_seg + 256u) / 256u)), dim3(256), 0, stream, n_seg, L, k, T, J, a, a + n_seg, a + 2u * n_seg);
+    *starts = a;
+    *ends = a + n_seg;
+    *wins = a + 2u * n_seg;
+    *n_seg_out = n_seg;
+    return hipGetLastError();
+}
+
 }  // namespace kmx

@@ -587,3 +587,24 @@ def test_windows_uniform_from_a_misaligned_base(ctx, orc, lead, L, k):
     outs = ctx.canonical_windows(dev, n, L, k)
     assert (outs["fw"].cpu().numpy().view(np.uint64) == fw).all() and (outs["rc"].cpu().numpy().view(np.uint64) == rc).all()
     assert (outs["canon"].cpu().numpy().view(np.uint64) == canon).all() and (outs["flags"].cpu().numpy() == flags).all()
+
+
+# ---------------------------------------------------------------- materialise of uniform reads above 256 bases: segments
+
+@pytest.mark.parametrize("k", [13, 21, 31])
+@pytest.mark.parametrize("L,n", [(257, 64 * 3 + 5), (300, 200), (483, 70), (1000, 64 + 9), (5003, 21), (40_000, 3)])
+def test_windows_long_uniform_reads_as_segments(ctx, orc, k, L, n):
+    """kmx_canonical_windows on uniform reads longer than a frame (round 4): every read as segments of 257 - k windows -- a start,
+    an end and a first output slot each, planned on the device -- that the ragged materialise kernels take as reads of their
+    own (they overlap by k - 1 bases in memory; their windows are consecutive in the output).  One array (the ring) and all
+    four (the staged write-back); dirty bytes; canonical_kmer_iterator.rs:42-70 per read."""
+    rng = np.random.default_rng(k * 23 + L)
+    host = _dirty(rng, n * L, 0.0002)
+    dev = ctx.to_device(host)
+    fw, rc, canon, flags = orc.canonical_windows(host, n, L, k)
+    for name, exp in (("canon", canon), ("fw", fw)):
+        got = ctx.canonical_windows(dev, n, L, k, want=(name,))[name].cpu().numpy().view(np.uint64)
+        assert (got == exp).all(), (name, int((got != exp).sum()), np.flatnonzero(got != exp)[:8])
+    outs = ctx.canonical_windows(dev, n, L, k)
+    assert (outs["fw"].cpu().numpy().view(np.uint64) == fw).all() and (outs["rc"].cpu().numpy().view(np.uint64) == rc).all()
+    assert (outs["canon"].cpu().numpy().view(np.uint64) == canon).all() and (outs["flags"].cpu().numpy() == flags).all()
