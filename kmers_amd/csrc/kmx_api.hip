@@ -79,7 +79,7 @@ hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_
 hipError_t launch_windows2_tiled(const kmx_reads* r, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu, hipStream_t st,
                                  bool* handled);
 hipError_t launch_windows2_tiled_ragged(const kmx_reads* r, const u64* win_offsets, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu,
-                                        hipStream_t st, bool* handled, unsigned long long* too_long);
+                                        hipStream_t st, bool* handled, unsigned long long* too_long, const u64* ends = nullptr);
 hipError_t launch_windows2_generic(const kmx_reads* r, const u64* win_off, u32 k, u64* fw, u64* rc, u64* canon,
                                    uint8_t* flags, int n_cu, hipStream_t st, unsigned long long* too_long);
 // kmx_elem.hip
@@ -641,6 +641,23 @@ int kmx_canonical_windows2(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t*
     bool handled = false;   // uniform reads of up to 256 bases in the dense layout (slot r*W + p): the tiled kernel (kmx_generic.hip)
     if (!reads->d_offsets && !d_win_offsets)   // (a caller's win_offsets for uniform reads are honoured by the lane-per-read kernel, as kmx_canonical_windows does)
         KMX_HIP(ctx, kmx::launch_windows2_tiled(reads, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled));
+    if (!handled && !reads->d_offsets && !d_win_offsets && reads->read_len > 256 && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u &&
+        reads->n_reads < (1ull << 40) && (uint64_t)reads->read_len * reads->n_reads < (1ull << 62)) {
+        // uniform reads longer than a frame (round 4): planned as segments on the device, as kmx_canonical_windows does
+        const uint32_t L = reads->read_len, W = L - k + 1u, J = (W + (257u - k) - 1u) / (257u - k), T = (W + J - 1u) / J;
+        void* scratch = big_scratch(ctx, kmx::uniform_segments_scratch_bytes(reads->n_reads * J));
+        if (scratch) {
+            ctx->fx_valid = false;
+            const uint64_t *starts = nullptr, *ends = nullptr, *wins = nullptr;
+            uint64_t n_seg = 0;
+            KMX_HIP(ctx, kmx::launch_uniform_segments_plan(reads->n_reads, L, k, T, scratch, &starts, &ends, &wins, &n_seg, ctx->stream));
+            kmx_reads segs = *reads;
+            segs.d_offsets = starts;
+            segs.n_reads = n_seg;
+            segs.read_len = 256u;
+            KMX_HIP(ctx, kmx::launch_windows2_tiled_ragged(&segs, wins, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled, ctx->d_scratch + 8, ends));
+        }
+    }
     if (!handled && reads->d_offsets && d_win_offsets)   // ragged reads (round 4): tiled too; read_len = optional length bound
         KMX_HIP(ctx, kmx::launch_windows2_tiled_ragged(reads, d_win_offsets, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled,
                                                        ctx->d_scratch + 8));

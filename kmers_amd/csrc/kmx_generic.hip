@@ -192,8 +192,12 @@ __device__ __forceinline__ void windows2_one_read(const uint8_t* s, u32 len, u32
 template <int NW, bool STAGE, bool RAGGED = false>
 __global__ void __launch_bounds__(256)
 windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, Win2Out out, u32 lead,
-                      const u64* __restrict__ offsets, const u64* __restrict__ win_offsets, unsigned long long* __restrict__ too_long) {
+                      const u64* __restrict__ offsets, const u64* __restrict__ win_offsets, unsigned long long* __restrict__ too_long,
+                      const u64* __restrict__ ends_arg) {
     // `lead`: `bases` is the 16-byte aligned address at or below the first read, which starts `lead` bytes in
+    // RAGGED: read r = bases[offsets[r], ends[r]); ends_arg == nullptr: back to back (ends = offsets + 1); a separate array serves
+    // reads that overlap in memory -- the segments a long uniform read is planned as (kmx_segments.hip)
+    [[maybe_unused]] const u64* __restrict__ const ends = RAGGED ? (ends_arg ? ends_arg : offsets + 1) : nullptr;
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const u32 lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     const u32 chunks_cap = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);      // 16-byte chunks of a 64-read tile (ragged: the most a tile may span)
@@ -207,7 +211,7 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 W = L - k + 1u;
     u32 omax = L - k;              // the last window of the tile's longest read (ragged: per tile)
     u32 nwin = W;                  // windows of this lane's read
-    const u64 total_bytes = RAGGED ? offsets[n_reads] : 0;
+    const u64 total_bytes = RAGGED ? ends[n_reads - 1u] : 0;
     // the one array of a STAGE launch, and which words it takes
     u64* const one = out.fw ? out.fw : out.rc ? out.rc : out.canon;
     const u32 which = out.fw ? 0u : out.rc ? 1u : 2u;
@@ -242,7 +246,7 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         u64 slot0 = (t * 64u + lane) * (u64)W;
         bool fits = true;
         if constexpr (RAGGED) {
-            const u64 o0 = offsets[t * 64u + lane], o1 = offsets[t * 64u + lane + 1u];
+            const u64 o0 = offsets[t * 64u + lane], o1 = ends[t * 64u + lane];
             my_off = o0;
             my_len = read_too_long(o1 - o0, too_long) ? 0u : (u32)(o1 - o0);    // (not materialised; kmx_ctx_synchronize reports it)
             slot0 = win_offsets[t * 64u + lane];
@@ -414,7 +418,7 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     if (rem != 0u && wave0 == 0 && lane < rem) {
         const u64 read = n_full * 64u + lane;
         if constexpr (RAGGED) {
-            const u64 o0 = offsets[read], o1 = offsets[read + 1u];
+            const u64 o0 = offsets[read], o1 = ends[read];
             if (!read_too_long(o1 - o0, too_long)) windows2_one_read(bases + o0, (u32)(o1 - o0), k, win_offsets[read], out);
         } else {
             windows2_one_read(bases + lead + read * (u64)L, L, k, read * (u64)W, out);
@@ -424,7 +428,8 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 
 template <int NW, bool RAGGED = false>
 static hipError_t launch_windows2_tiled_nw(const uint8_t* bases, u64 n_reads, u32 L, u32 k, const Win2Out& out, int n_cu, hipStream_t st,
-                                           const u64* offsets = nullptr, const u64* win_offsets = nullptr, unsigned long long* too_long = nullptr) {
+                                           const u64* offsets = nullptr, const u64* win_offsets = nullptr, unsigned long long* too_long = nullptr,
+                                           const u64* ends = nullptr) {
     const u32 lead = RAGGED ? 0u : (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
     const u32 chunks = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);
     const u32 ldsw = (chunks + 1u + (u32)NW + 8u + 3u) & ~3u;
@@ -442,12 +447,12 @@ static hipError_t launch_windows2_tiled_nw(const uint8_t* bases, u64 n_reads, u3
         if (!arr[a]) continue;
         Win2Out o1{nullptr, nullptr, nullptr, first ? out.flags : nullptr};
         (a == 0 ? o1.fw : a == 1 ? o1.rc : o1.canon) = arr[a];
-        hipLaunchKernelGGL((windows2_tiled_kernel<NW, true, RAGGED>), dim3((unsigned)grid), dim3(256), lds_bytes, st, bases - lead, n_reads, L, k, o1, lead, offsets, win_offsets, too_long);
+        hipLaunchKernelGGL((windows2_tiled_kernel<NW, true, RAGGED>), dim3((unsigned)grid), dim3(256), lds_bytes, st, bases - lead, n_reads, L, k, o1, lead, offsets, win_offsets, too_long, ends);
         first = false;
     }
     if (first) {   // flags only
         const size_t lds0 = (size_t)ldsw * 4u * 4u;
-        hipLaunchKernelGGL((windows2_tiled_kernel<NW, false, RAGGED>), dim3((unsigned)grid), dim3(256), lds0, st, bases - lead, n_reads, L, k, out, lead, offsets, win_offsets, too_long);
+        hipLaunchKernelGGL((windows2_tiled_kernel<NW, false, RAGGED>), dim3((unsigned)grid), dim3(256), lds0, st, bases - lead, n_reads, L, k, out, lead, offsets, win_offsets, too_long, ends);
     }
     return hipGetLastError();
 }
@@ -472,7 +477,7 @@ hipError_t launch_windows2_tiled(const kmx_reads* r, u32 k, u64* fw, u64* rc, u6
 // ragged reads (offsets + win_offsets), k in 33..64, 16-byte aligned bases; read_len = optional length bound (0: unknown -> the
 // 256-base frame); tiles with a longer read take the per-read path inside the kernel
 hipError_t launch_windows2_tiled_ragged(const kmx_reads* r, const u64* win_offsets, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu,
-                                        hipStream_t st, bool* handled, unsigned long long* too_long) {
+                                        hipStream_t st, bool* handled, unsigned long long* too_long, const u64* ends) {
     *handled = false;
     if (!r->d_offsets || !win_offsets || k < 33 || k > 64 || r->n_reads < 64u || r->read_len > 256) return hipSuccess;
     if (reinterpret_cast<uintptr_t>(r->d_bases) & 15u) return hipSuccess;
@@ -481,8 +486,8 @@ hipError_t launch_windows2_tiled_ragged(const kmx_reads* r, const u64* win_offse
     if (L < k + 15u) L = k + 15u;
     *handled = true;
     const Win2Out out{fw, rc, canon, flags};
-    if (L <= 160) return launch_windows2_tiled_nw<10, true>(r->d_bases, r->n_reads, L, k, out, n_cu, st, r->d_offsets, win_offsets, too_long);
-    return launch_windows2_tiled_nw<16, true>(r->d_bases, r->n_reads, L, k, out, n_cu, st, r->d_offsets, win_offsets, too_long);
+    if (L <= 160) return launch_windows2_tiled_nw<10, true>(r->d_bases, r->n_reads, L, k, out, n_cu, st, r->d_offsets, win_offsets, too_long, ends);
+    return launch_windows2_tiled_nw<16, true>(r->d_bases, r->n_reads, L, k, out, n_cu, st, r->d_offsets, win_offsets, too_long, ends);
 }
 
 __global__ void __launch_bounds__(256)

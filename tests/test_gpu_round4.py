@@ -608,3 +608,18 @@ def test_windows_long_uniform_reads_as_segments(ctx, orc, k, L, n):
     outs = ctx.canonical_windows(dev, n, L, k)
     assert (outs["fw"].cpu().numpy().view(np.uint64) == fw).all() and (outs["rc"].cpu().numpy().view(np.uint64) == rc).all()
     assert (outs["canon"].cpu().numpy().view(np.uint64) == canon).all() and (outs["flags"].cpu().numpy() == flags).all()
+
+
+@pytest.mark.parametrize("k", [33, 47, 64])
+@pytest.mark.parametrize("L,n", [(257, 64 * 2 + 5), (300, 150), (1000, 64 + 9), (5003, 21), (40_000, 3)])
+def test_windows2_long_uniform_reads_as_segments(ctx, orc, k, L, n):
+    """kmx_canonical_windows2 on uniform reads longer than a frame: the same device-side plan (segments with a start, an end and a
+    first output slot) through windows2_tiled_kernel<.., RAGGED> with its separate ends array; kmer.rs:21-28,67-69 per read"""
+    rng = np.random.default_rng(k * 29 + L)
+    host = _dirty(rng, n * L, 0.0002)
+    dev = ctx.to_device(host)
+    fw, rc, canon, flags = orc.canonical_windows2(host, n, L, k)
+    outs = ctx.canonical_windows2(dev, n, L, k)
+    for name, exp in (("fw", fw), ("rc", rc), ("canon", canon)):
+        assert (outs[name].cpu().numpy().view(np.uint64).reshape(-1, 2) == exp.reshape(-1, 2)).all(), (name, k, L)
+    assert (outs["flags"].cpu().numpy() == flags).all()
