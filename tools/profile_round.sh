@@ -46,6 +46,7 @@ python3 tools/bench_ragged2.py 100000000 > $out/ragged2_bench.txt 2>/dev/null
 HIST=20 python3 tools/bench_dirty.py > $out/dirty_bench.txt 2>/dev/null
 python3 tools/bench_windows.py > $out/windows_bench.txt 2>/dev/null
 for L in 100 140 150 158 166 200 250 256; do echo "[1e7 reads of $L bases]"; python3 tools/bench_windows.py 10000000 $L 2>/dev/null | grep "^k="; done > $out/windows_len.txt
+for spec in "5000000 300" "1500000 1000" "150000 10000"; do set -- $spec; echo "[$1 reads of $2 bases: planned as segments on the device]"; python3 tools/bench_windows.py $1 $2 2>/dev/null | grep "^k="; done >> $out/windows_len.txt
 python3 tools/bench_hist.py 100000000 12,16,20,22,23,24,26,28 > $out/hist_bench.txt 2>/dev/null
 python3 tools/bench_minimizers.py > $out/minimizers_bench.txt 2>/dev/null
 python3 tools/bench_fastx.py > $out/fastx_bench.txt 2>/dev/null
