@@ -1,5 +1,6 @@
 """Randomised parity sweep over the arguments that select kernels (k, read length / length bound, layout, dirt, hasher,
-base alignment): kmx_canonical_reduce / kmx_canonical_reduce2 / kmx_histogram against the oracle.  Fixed seeds; every case
+base alignment): kmx_canonical_reduce / kmx_canonical_reduce2 / kmx_histogram / kmx_canonical_windows / kmx_canonical_windows2
+against the oracle.  Fixed seeds; every case
 is small enough for the oracle, together they walk the frames (7 / 10 / 16 words, segments), the windows-per-lane
 variants, the blanking of dirty reads and the fallbacks of each."""
 import os
@@ -79,11 +80,24 @@ def test_reduce2_and_histogram_random_configuration(ctx, orc, seed):
     p_bad = float(rng.choice([0.0, 0.001, 0.02]))
     if seed % 2 == 0:
         k = int(rng.integers(33, 65))
-        L = max(k, int(rng.choice([64, 100, 112, 150, 160, 161, 250])))
-        host = _bytes(rng, n * L, p_bad, False)
         wh = bool(rng.integers(0, 2))
-        o = orc.canonical_reduce2(host, n, L, k, with_hash=wh)
-        g = ctx.canonical_reduce2(ctx.to_device(host), n, L, k, with_hash=wh)
+        if seed % 4 == 0:
+            L = max(k, int(rng.choice([64, 100, 112, 150, 160, 161, 250, 257, 300, 1000])))
+            if L > 256:
+                n = min(n, 64 * 5 + 9)
+            host = _bytes(rng, n * L, p_bad, False)
+            o = orc.canonical_reduce2(host, n, L, k, with_hash=wh)
+            g = ctx.canonical_reduce2(ctx.to_device(host), n, L, k, with_hash=wh)
+        else:      # behind an offsets array: uniform in fact (the device-side gate), ragged (the two-word ragged kernel), any bound
+            top = int(rng.choice([70, 100, 150, 160, 250]))
+            lens = np.full(n, top) if rng.integers(0, 3) == 0 else rng.integers(0, top + 1, size=n)
+            if rng.integers(0, 3) == 0:
+                lens[rng.integers(0, n)] = top + int(rng.integers(1, 400))      # one read past the bound
+            L = int(rng.choice([0, top, max(top, 160), 100_000]))
+            offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+            host = _bytes(rng, int(offsets[-1]) + 16, p_bad, False)[: int(offsets[-1])]
+            o = orc.canonical_reduce2(host, n, 0, k, with_hash=wh, offsets=offsets)
+            g = ctx.canonical_reduce2(ctx.to_device(host), n, L, k, with_hash=wh, offsets=ctx.to_device(offsets))
         assert tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_), (k, L, n)
     else:
         k = int(rng.choice([9, 15, 21, 31]))
@@ -113,7 +127,9 @@ def test_windows_random_configuration(ctx, orc, seed):
     p_bad = float(rng.choice([0.0, 0.0, 0.003, 0.05]))
     want = [("canon",), ("fw",), ("rc", "flags"), ("fw", "rc", "canon", "flags")][int(rng.integers(0, 4))]
     if rng.integers(0, 2):
-        L = max(k, int(rng.choice([k, 40, 100, 128, 150, 158, 160, 200, 256, 300])))
+        L = max(k, int(rng.choice([k, 40, 100, 128, 150, 158, 160, 200, 256, 300, 500, 1000])))
+        if L > 300:
+            n = min(n, 65)
         host = _bytes(rng, n * L, p_bad, bool(rng.integers(0, 2)))
         o = orc.canonical_windows(host, n, L, k)
         g = ctx.canonical_windows(ctx.to_device(host), n, L, k, want=want)
@@ -129,6 +145,33 @@ def test_windows_random_configuration(ctx, orc, seed):
         got = g[name].cpu().numpy()
         got = got.view(np.uint64) if name != "flags" else got
         assert np.array_equal(got, ref[name]), (name, k, n, p_bad)
+
+
+@pytest.mark.parametrize("seed", range(max(40, N_FUZZ // 3)))
+def test_windows2_random_configuration(ctx, orc, seed):
+    """kmx_canonical_windows2 (two-word materialise: tiled uniform, tiled ragged, long reads as segments, the per-read fallbacks)"""
+    rng = np.random.default_rng(15000 + seed)
+    k = int(rng.integers(33, 65))
+    n = int(rng.choice([1, 64, 65, 64 * 5 + 7]))
+    p_bad = float(rng.choice([0.0, 0.0, 0.002, 0.03]))
+    if rng.integers(0, 2):
+        L = max(k, int(rng.choice([k, 100, 150, 160, 161, 250, 256, 257, 300, 700])))
+        if L > 300:
+            n = min(n, 65)
+        host = _bytes(rng, n * L, p_bad, False)
+        o = orc.canonical_windows2(host, n, L, k)
+        g = ctx.canonical_windows2(ctx.to_device(host), n, L, k)
+    else:
+        lens = rng.integers(0, int(rng.choice([100, 160, 300])) + 1, size=n)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        host = _bytes(rng, int(offsets[-1]) + 16, p_bad, False)[: int(offsets[-1])]
+        o = orc.canonical_windows2(host, n, 0, k, offsets=offsets)
+        d_host = ctx.to_device(host) if len(host) else ctx.to_device(np.zeros(16, np.uint8))
+        g = ctx.canonical_windows2(d_host, n, int(rng.choice([0, 160, 256])), k, offsets=ctx.to_device(offsets), host_offsets=offsets)
+    ref = dict(zip(("fw", "rc", "canon", "flags"), o))
+    for name in ("fw", "rc", "canon"):
+        assert np.array_equal(g[name].cpu().numpy().view(np.uint64).reshape(-1, 2), ref[name].reshape(-1, 2)), (name, k, n, p_bad)
+    assert np.array_equal(g["flags"].cpu().numpy(), ref["flags"]), (k, n, p_bad)
 
 
 @pytest.mark.parametrize("seed", range(max(40, N_FUZZ // 3)))
