@@ -1,4 +1,4 @@
 # scratch: the command list of the current gpurun call (tools/README.md); the round's profile set is tools/profile_round.sh
-O=$GRAFT_REPO_ROOT/gpurun_out/r7k; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r7l; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-KMX_FUZZ_N=3000 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu > $O/fuzz.txt 2>&1; tail -12 $O/fuzz.txt
+KMX_FUZZ_N=12000 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu > $O/fuzz.txt 2>&1; tail -2 $O/fuzz.txt
