@@ -590,13 +590,25 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
     }
     // Reads behind an offsets array (what kmx_fastx_parse hands over), 16-byte aligned base: the tiled kernels.  With a length bound
     // the uniform two-word kernel takes, "is every read exactly that long" (untrimmed FASTQ) is decided on the device as
-    // kmx_canonical_reduce does it: a small kernel checks offsets[i] == i*L, the uniform scan and the ragged one (bound <= 160
-    // or none: the 10-word frame; else the lane-per-read kernel) are both launched behind its verdict, exactly one counts.
+    // kmx_canonical_reduce does it: a small kernel checks offsets[i] == i*L, the uniform scan and the ragged one (the 10-word frame:
+    // the reads themselves with a bound of at most 160 or none, segments of them above) are both launched behind its verdict, exactly one counts.
     const uint32_t Lh = reads->read_len;
     if (reads->d_offsets && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
         uint32_t* gate = reinterpret_cast<uint32_t*>(ctx->d_scratch + 16 + 513);
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 16, ctx->stream));
-        if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
+        // A bound above the 10-word frame (161...: 250-base reads, long reads): the ragged kernel scans SEGMENTS of at most 161 - k
+        // windows, cut on the device as kmx_canonical_reduce does for long reads (two host round trips) -- first of all, so that the
+        // masks of the dirty reads are sized once for whichever kernel will run.
+        const uint64_t *starts = nullptr, *ends = nullptr;
+        uint64_t n_seg = 0;
+        bool segmented = false;
+        if (Lh > 160) {
+            const int st = long_ragged_segments(ctx, reads, k, 161u - k, &starts, &ends, &n_seg);
+            if (st > 0) return st;
+            segmented = st == 0;
+            if (segmented && n_seg == 0) return KMX_OK;      // no read holds a window
+        }
+        if (int st = prepare_dirty_flags(ctx, segmented && n_seg > reads->n_reads ? n_seg : reads->n_reads, k)) return st;
         bool h_u = false, h_r = false;
         if (Lh >= k && Lh <= 256) {
             KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 1, 1, ctx->stream));
@@ -606,23 +618,12 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
             // (not launched: the verdict must not keep the other kernel from running)
             if (!h_u) KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));
         }
-        if (Lh > 256) {
-            // long ragged reads (a bound above the frames: PacBio / ONT lengths, contigs): segments cut on the device, as kmx_canonical_reduce does
-            const uint32_t t_max = 161u - k;      // (<= 128 windows for every two-word k: the 10-word frame)
-            const uint64_t *starts = nullptr, *ends = nullptr;
-            uint64_t n_seg = 0;
-            const int st = long_ragged_segments(ctx, reads, k, t_max, &starts, &ends, &n_seg);
-            if (st > 0) return st;
-            if (st == 0) {
-                if (n_seg == 0) return KMX_OK;
-                if (int st2 = prepare_dirty_flags(ctx, n_seg, k)) return st2;
-                KMX_HIP(ctx, kmx::launch_scan_bitsliced2_ragged(reads->d_bases, starts, n_seg, t_max + k - 1u, k, with_hash != 0, d_out,
-                                                                ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &h_r, ends));
-            }
-        } else {
+        if (segmented)
+            KMX_HIP(ctx, kmx::launch_scan_bitsliced2_ragged(reads->d_bases, starts, n_seg, 160u, k, with_hash != 0, d_out, ctx->d_scratch + 16, ctx->n_cu,
+                                                            ctx->stream, &h_r, ends));
+        else if (Lh <= 160)
             KMX_HIP(ctx, kmx::launch_scan_bitsliced2_ragged(reads->d_bases, reads->d_offsets, reads->n_reads, Lh, k, with_hash != 0, d_out,
                                                             ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &h_r));
-        }
         if (!h_r) KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8, h_u ? gate : nullptr));
         if (h_u) KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));   // never left armed
         return KMX_OK;

@@ -383,18 +383,19 @@ def test_windows_single_array_shared_lines(ctx, orc, L, k, p_bad):
 # ---------------------------------------------------------------- two-word k behind an offsets array: uniform or not, decided on the device
 
 @pytest.mark.parametrize("k", [33, 47, 63, 64])
+@pytest.mark.parametrize("L", [150, 250])
 @pytest.mark.parametrize("case", ["uniform", "one_trimmed", "last_trimmed", "no_bound"])
-def test_reduce2_offsets_picks_the_uniform_kernel_on_the_device(ctx, orc, k, case):
+def test_reduce2_offsets_picks_the_uniform_kernel_on_the_device(ctx, orc, k, case, L):
     """kmx_canonical_reduce2 on reads behind an offsets array with a length bound (what kmx_fastx_parse hands over): a small
     kernel checks offsets[i] == i * L, the tiled uniform kernel and the lane-per-read kernel are launched behind its verdict and
     exactly one of them counts (kmer.rs:21-28,67-69 per read either way).  Twice in a row: the gate is never left armed."""
-    rng = np.random.default_rng(k * 7 + len(case))
-    L, n = 150, 64 * 11 + 23
+    rng = np.random.default_rng(k * 7 + len(case) + L)
+    n = 64 * 11 + 23
     lens = np.full(n, L)
     if case == "one_trimmed":
         lens[n // 3] = 97
     if case == "last_trimmed":
-        lens[-1] = 149
+        lens[-1] = L - 1
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     host = _dirty(rng, int(offsets[-1]), 0.0004)
     o = orc.canonical_reduce2(host, n, 0, k, with_hash=True, offsets=offsets)
