@@ -568,7 +568,29 @@ hipError_t launch_windows_ragged(const uint8_t* bases, const u64* offsets, const
     if (!*handled) return hipSuccess;
     const WindowsParams p{fw, rc, canon, flags, win_offsets};
     // one u64 array, no flags (the usual call: the canonical words): whole lines through the ring, each read shifted by its own first slot
-    if (((fw ? 1 : 0) + (rc ? 1 : 0) + (canon ? 1 : 0)) == 1 && !flags) return dispatch<SinkWindowsT<true, true>, WindowsParams, NoPre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets, ends);
+    const int n_arr = (fw ? 1 : 0) + (rc ? 1 : 0) + (canon ? 1 : 0);
+    if (n_arr == 1 && !flags) return dispatch<SinkWindowsT<true, true>, WindowsParams, NoPre, true>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets, ends);
+    // several arrays: one pass of the ring per array of words, the flags through the staged write-back alone (all four arrays of 2e7
+    // trimmed 150-base reads 23.9 -> 20.6 ms, of 1.5e6 x 1 000 bases 16.4 -> 12.6 ms)
+    if (n_arr >= 2) {
+        bool first = true;
+        u64* const arr[3] = {fw, rc, canon};
+        for (int a = 0; a < 3; ++a) {
+            if (!arr[a]) continue;
+            if (!first) {
+                if (hipError_t e = hipMemsetAsync(queue, 0, 32 * 128, stream)) return e;
+            }
+            first = false;
+            const WindowsParams one{a == 0 ? fw : nullptr, a == 1 ? rc : nullptr, a == 2 ? canon : nullptr, nullptr, win_offsets};
+            if (hipError_t e = dispatch<SinkWindowsT<true, true>, WindowsParams, NoPre, true>(bases, n_reads, L, k, one, queue, n_cu, stream, NoPre(), offsets, ends)) return e;
+        }
+        if (flags) {
+            if (hipError_t e = hipMemsetAsync(queue, 0, 32 * 128, stream)) return e;
+            const WindowsParams fo{nullptr, nullptr, nullptr, flags, win_offsets};
+            if (hipError_t e = dispatch<SinkWindowsT<false>>(bases, n_reads, L, k, fo, queue, n_cu, stream, NoPre(), offsets, ends)) return e;
+        }
+        return hipSuccess;
+    }
     return dispatch<SinkWindowsT<false>>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets, ends);
 }
 

@@ -1,30 +1,33 @@
 # scratch: the command list of the current gpurun call (tools/README.md); the round's profile set is tools/profile_round.sh
-O=$GRAFT_REPO_ROOT/gpurun_out/r7m; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r7n; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt
-python3 - <<'PY'
-import numpy as np, torch, sys, ctypes as C
+export KMX_LIB_VARIANT=wpa
+timeout 1200 python -m pytest tests -x -q -m gpu -k "windows" > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
+for v in default wpa; do
+  if [ "$v" == "default" ]; then unset KMX_LIB_VARIANT; else export KMX_LIB_VARIANT=$v; fi
+  echo "[$v]"; python3 tools/bench_windows.py 1500000 1000 2>/dev/null | grep "flags"
+  python3 - <<'PY'
+import sys, numpy as np, torch, ctypes as C
 sys.path.insert(0, 'tools')
 from _timing import warm
 from kmers_amd.api import Context, _ptr
 ctx = Context(0)
-n = 40_000_000
-rng = np.random.default_rng(1)
-def t(f):
-    warm(f); ts = []
+n, k = 20_000_000, 31
+lens = np.where(np.random.default_rng(1).random(n) < 0.02, np.random.default_rng(2).integers(36, 150, n), 150)
+off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+wo = np.concatenate([[0], np.cumsum(np.maximum(lens - k + 1, 0))]).astype(np.uint64)
+rb = ctx.gen_reads(int(off[-1])); d_off, d_wo = ctx.to_device(off), ctx.to_device(wo)
+tot = int(wo[-1])
+fw, rc, cn, fl = (ctx.empty(tot, torch.int64) for _ in range(3)) , None, None, None
+a = [ctx.empty(tot, torch.int64) for _ in range(3)]; f = ctx.empty(tot, torch.uint8)
+r = ctx._reads(rb, n, 150, d_off)
+def t(fn):
+    warm(fn); ts = []
     for _ in range(5):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); f(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+        x, y = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x.record(); fn(); y.record(); torch.cuda.synchronize(); ts.append(x.elapsed_time(y))
     return sorted(ts)[2]
-out = ctx.empty(5, torch.int64)
-for name, lens, hint in (("all 250, bound 250", np.full(n, 250), 250), ("2 % trimmed to 100..249, bound 250", np.where(rng.random(n) < 0.02, rng.integers(100, 250, n), 250), 250)):
-    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
-    total = int(offsets[-1])
-    bases = ctx.gen_reads(total)
-    d_off = ctx.to_device(offsets)
-    for k in (63, 33):
-        r = ctx._reads(bases, n, hint, d_off)
-        ms = t(lambda: ctx._ck(ctx.lib.kmx_canonical_reduce2(ctx._h, C.byref(r), k, 1, _ptr(out))))
-        print(f"k={k} 4e7 reads  {name:36s} {ms:8.3f} ms  {total / ms / 1e6:7.0f} GB/s = {total / ms / 8e9:.3f} of the roofline")
-    del bases, d_off
+ms = t(lambda: ctx._ck(ctx.lib.kmx_canonical_windows(ctx._h, C.byref(r), _ptr(d_wo), k, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(f))))
+print(f"ragged 2 % trimmed, 2e7 reads: fw+rc+canon+flags {ms:8.3f} ms = {25*tot/ms/1e6:6.0f} GB/s written")
 PY
+done | tee $O/wpa.txt
