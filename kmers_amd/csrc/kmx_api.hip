@@ -41,11 +41,11 @@ hipError_t launch_scan_bitsliced_ragged(const uint8_t* bases, const u64* offsets
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
                                         bool want_sumfw = false, const u64* ends = nullptr /* the reads' ends: nullptr = offsets + 1 */);
 // kmx_segments.hip
-size_t segments_scratch_bytes(u64 n_reads, u64 seg_capacity);
+size_t segments_scratch_bytes(u64 n_reads, u64 seg_capacity, bool with_wins = false);
 u64 segments_capacity(u64 n_reads, u64 total_bases, u32 t_max);
 hipError_t launch_segments_build(const u64* offsets, u64 n_reads, u32 k, u32 t_max, u64 seg_capacity, void* scratch,
                                  const u64** starts_out, const u64** ends_out, const u64** total_out, unsigned long long* too_long,
-                                 hipStream_t stream);
+                                 hipStream_t stream, const u64* win_offsets = nullptr, const u64** wins_out = nullptr);
 hipError_t launch_scan_bitsliced_packed(const uint64_t* words, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
                                         kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 // kmx_fastx.hip
@@ -416,23 +416,26 @@ int kmx_memset(kmx_ctx* ctx, void* d_dst, int value, size_t nbytes) {
 // arrays are sized from the number of bases), then the number of segments.  0: *starts / *ends / *n_seg are set (n_seg may be 0);
 // -1: no scratch (the caller falls back); > 0: a status to return.
 static int long_ragged_segments(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t t_max, const uint64_t** starts, const uint64_t** ends,
-                                uint64_t* n_seg) {
+                                uint64_t* n_seg, const uint64_t* win_offsets = nullptr, const uint64_t** wins = nullptr) {
     KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, reads->d_offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
     KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned + 1, reads->d_offsets + reads->n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
     KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t o_first = ctx->h_pinned[0], o_last = ctx->h_pinned[1];
     if (!(o_last >= o_first && o_last - o_first < (1ull << 62))) return -1;
     const uint64_t cap = kmx::segments_capacity(reads->n_reads, o_last - o_first, t_max);
-    void* scratch = big_scratch(ctx, kmx::segments_scratch_bytes(reads->n_reads, cap));
+    void* scratch = big_scratch(ctx, kmx::segments_scratch_bytes(reads->n_reads, cap, win_offsets != nullptr));
     if (!scratch) return -1;
     ctx->fx_valid = false;   // (the work buffer is overwritten: the fastx chunk prefixes in it are gone)
     const uint64_t* d_total = nullptr;
-    KMX_HIP(ctx, kmx::launch_segments_build(reads->d_offsets, reads->n_reads, k, t_max, cap, scratch, starts, ends, &d_total, ctx->d_scratch + 8, ctx->stream));
+    KMX_HIP(ctx, kmx::launch_segments_build(reads->d_offsets, reads->n_reads, k, t_max, cap, scratch, starts, ends, &d_total, ctx->d_scratch + 8, ctx->stream,
+                                            win_offsets, wins));
     // (the second and last round trip: how many segments there are -- the bound above is up to one per read too high)
     KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
     KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_seg = ctx->h_pinned[0];
     if (*n_seg > cap) return fail_hip(ctx, hipErrorUnknown, "segment count above its bound");
+    if (wins != nullptr && *wins != nullptr && *n_seg != 0)     // the slot behind the last segment's windows: the batch's total
+        KMX_HIP(ctx, hipMemcpyAsync(const_cast<uint64_t*>(*wins) + *n_seg, win_offsets + reads->n_reads, 8, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
 
@@ -563,6 +566,22 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
             }
         }
     }
+    if (reads->d_offsets && d_win_offsets && reads->read_len > 256 && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
+        // long ragged reads (a length bound above the frames), round 4: cut into segments of at most 257 - k windows on the device
+        // (kmx_segments.hip: a start, an end and a first output slot each; two host round trips), materialised as reads of their own
+        const uint64_t *starts = nullptr, *ends = nullptr, *wins = nullptr;
+        uint64_t n_seg = 0;
+        const int st = long_ragged_segments(ctx, reads, k, 257u - k, &starts, &ends, &n_seg, d_win_offsets, &wins);
+        if (st > 0) return st;
+        if (st == 0) {
+            if (n_seg == 0) return KMX_OK;      // no read holds a window
+            bool handled = false;
+            KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+            KMX_HIP(ctx, kmx::launch_windows_ragged(reads->d_bases, starts, wins, n_seg, 256u, k, d_fw, d_rc, d_canon, d_flags, ctx->d_scratch + 16, ctx->n_cu,
+                                                    ctx->stream, &handled, ends));
+            if (handled) return KMX_OK;
+        }
+    }
     if (reads->d_offsets && d_win_offsets) {     // ragged reads: the tiled word-domain kernel (read_len = optional length bound)
         bool handled = false;
         KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
@@ -652,6 +671,21 @@ int kmx_canonical_windows2(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t*
             const uint64_t *starts = nullptr, *ends = nullptr, *wins = nullptr;
             uint64_t n_seg = 0;
             KMX_HIP(ctx, kmx::launch_uniform_segments_plan(reads->n_reads, L, k, T, scratch, &starts, &ends, &wins, &n_seg, ctx->stream));
+            kmx_reads segs = *reads;
+            segs.d_offsets = starts;
+            segs.n_reads = n_seg;
+            segs.read_len = 256u;
+            KMX_HIP(ctx, kmx::launch_windows2_tiled_ragged(&segs, wins, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled, ctx->d_scratch + 8, ends));
+        }
+    }
+    if (!handled && reads->d_offsets && d_win_offsets && reads->read_len > 256 && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
+        // long ragged reads (a length bound above the frames): segments cut on the device, as kmx_canonical_windows does
+        const uint64_t *starts = nullptr, *ends = nullptr, *wins = nullptr;
+        uint64_t n_seg = 0;
+        const int st = long_ragged_segments(ctx, reads, k, 257u - k, &starts, &ends, &n_seg, d_win_offsets, &wins);
+        if (st > 0) return st;
+        if (st == 0) {
+            if (n_seg == 0) return KMX_OK;
             kmx_reads segs = *reads;
             segs.d_offsets = starts;
             segs.n_reads = n_seg;

@@ -78,12 +78,15 @@ __global__ void __launch_bounds__(1024) seg_scan_blocks_kernel(u64* __restrict__
 // the block's per-read first-segment indices in LDS.  (One thread writing all segments of "its" reads took 0.5 ms for 2e5 reads
 // of 30 kbp: ~230 scattered stores per read, in series.)  A block whose reads are long has hundreds of thousands of segments to
 // write: gridDim.y blocks share the run (each repeats the cheap block-local scan and fills its slice).
+// (materialise: `win_offsets` != nullptr -- the first output slot of every read -- and `wins` takes every SEGMENT's first slot, the
+// slot array the ragged materialise kernels expect: a read's segments write consecutive slots)
 __global__ void __launch_bounds__(SEG_THREADS) seg_fill_kernel(const u64* __restrict__ offsets, u64 n_reads, u32 k, u32 t_max,
                                                               const u64* __restrict__ block_base, u64* __restrict__ starts,
-                                                              u64* __restrict__ ends) {
+                                                              u64* __restrict__ ends, const u64* __restrict__ win_offsets, u64* __restrict__ wins) {
     __shared__ u64 wave_tot[SEG_THREADS / 64];
     __shared__ u32 first[SEG_PER_BLOCK + 1];     // first segment of read i of the block, relative to the block's base
     __shared__ u64 r_o0[SEG_PER_BLOCK];
+    __shared__ u64 r_w0[SEG_PER_BLOCK];
     __shared__ u32 r_len[SEG_PER_BLOCK];
     const u64 r0 = ((u64)blockIdx.x * SEG_THREADS + threadIdx.x) * SEG_PER_THREAD;
     u32 c[SEG_PER_THREAD];
@@ -99,6 +102,7 @@ __global__ void __launch_bounds__(SEG_THREADS) seg_fill_kernel(const u64* __rest
             c[i] = seg_count(len, k, t_max);
         }
         r_o0[threadIdx.x * SEG_PER_THREAD + i] = o0;
+        r_w0[threadIdx.x * SEG_PER_THREAD + i] = (win_offsets != nullptr && r < n_reads) ? win_offsets[r] : 0ull;
         r_len[threadIdx.x * SEG_PER_THREAD + i] = c[i] ? (u32)len : 0u;
         mine += c[i];
     }
@@ -137,15 +141,16 @@ __global__ void __launch_bounds__(SEG_THREADS) seg_fill_kernel(const u64* __rest
         const u64 o0 = r_o0[lo], st = o0 + (u64)j * t, e = st + t + (k - 1u), read_end = o0 + len;
         starts[base + s] = st;
         ends[base + s] = e < read_end ? e : read_end;
+        if (wins != nullptr) wins[base + s] = r_w0[lo] + (u64)j * t;
     }
 }
 
 }  // namespace
 
 // scratch the segment arrays of a batch need: two u64 per segment of the upper bound + the block counts + the total
-size_t segments_scratch_bytes(u64 n_reads, u64 seg_capacity) {
+size_t segments_scratch_bytes(u64 n_reads, u64 seg_capacity, bool with_wins) {
     const u64 n_blocks = (n_reads + SEG_PER_BLOCK - 1u) / SEG_PER_BLOCK;
-    return (size_t)(2u * seg_capacity + n_blocks + 8u) * 8u;
+    return (size_t)(2u * seg_capacity + n_blocks + 8u + (with_wins ? seg_capacity + 8u : 0u)) * 8u;
 }
 
 // S_max for reads of `total_bases` bases in all: read r has at most len_r / t_max + 1 segments
@@ -155,22 +160,24 @@ u64 segments_capacity(u64 n_reads, u64 total_bases, u32 t_max) { return ((total_
 // segments written.
 hipError_t launch_segments_build(const u64* offsets, u64 n_reads, u32 k, u32 t_max, u64 seg_capacity, void* scratch,
                                  const u64** starts_out, const u64** ends_out, const u64** total_out, unsigned long long* too_long,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, const u64* win_offsets, const u64** wins_out) {
     const u64 n_blocks = (n_reads + SEG_PER_BLOCK - 1u) / SEG_PER_BLOCK;
     if (n_blocks == 0 || n_blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     u64* starts = static_cast<u64*>(scratch);
     u64* ends = starts + seg_capacity;
     u64* block_sums = ends + seg_capacity;
     u64* total = block_sums + n_blocks;
+    u64* wins = win_offsets ? total + 8 : nullptr;      // (materialise: seg_capacity + 1 slots behind everything else)
     hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)n_blocks), dim3(SEG_THREADS), 0, stream, offsets, n_reads, k, t_max, block_sums, too_long);
     hipLaunchKernelGGL(seg_scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, block_sums, n_blocks, total);
     // (slices of ~4096 segments: by the bound, the average block of 1024 reads holds seg_capacity / n_blocks of them)
     u64 splits = seg_capacity / n_blocks / 4096u;
     splits = splits < 1u ? 1u : splits > 64u ? 64u : splits;
-    hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)n_blocks, (unsigned)splits), dim3(SEG_THREADS), 0, stream, offsets, n_reads, k, t_max, block_sums, starts, ends);
+    hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)n_blocks, (unsigned)splits), dim3(SEG_THREADS), 0, stream, offsets, n_reads, k, t_max, block_sums, starts, ends, win_offsets, wins);
     *starts_out = starts;
     *ends_out = ends;
     *total_out = total;
+    if (wins_out) *wins_out = wins;
     return hipGetLastError();
 }
 

@@ -624,3 +624,54 @@ def test_windows2_long_uniform_reads_as_segments(ctx, orc, k, L, n):
     for name, exp in (("fw", fw), ("rc", rc), ("canon", canon)):
         assert (outs[name].cpu().numpy().view(np.uint64).reshape(-1, 2) == exp.reshape(-1, 2)).all(), (name, k, L)
     assert (outs["flags"].cpu().numpy() == flags).all()
+
+
+@pytest.mark.parametrize("k", [13, 21, 31])
+@pytest.mark.parametrize("case", ["long", "mixed", "few_huge", "with_empty"])
+def test_windows_long_ragged_reads_as_segments(ctx, orc, k, case):
+    """kmx_canonical_windows on ragged reads with a length bound above 256: every read cut into segments on the device
+    (kmx_segments.hip: a start, an end and a first output slot per segment), materialised by the ragged kernels as reads of their
+    own; one array (the ring) and all four; an offsets array that does not start at 0"""
+    rng = np.random.default_rng(k * 41 + len(case))
+    if case == "long":
+        lens = rng.integers(300, 4000, 300)
+    elif case == "mixed":
+        lens = np.where(rng.random(1500) < 0.3, rng.integers(257, 2000, 1500), rng.integers(0, 257, 1500))
+    elif case == "few_huge":
+        lens = np.array([120_000, 17, 61_313, k, k - 1, 40_001])
+    else:
+        lens = rng.integers(200, 1500, 500)
+        lens[rng.integers(0, 500, 40)] = 0
+        lens[rng.integers(0, 500, 40)] = k - 1
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = len(lens)
+    host = _dirty(rng, int(offsets[-1]), 0.0002)
+    fw, rc, canon, flags = orc.canonical_windows(host, n, 0, k, offsets=offsets)
+    dev, d_off = ctx.to_device(host), ctx.to_device(offsets)
+    got = ctx.canonical_windows(dev, n, 1 << 20, k, offsets=d_off, host_offsets=offsets, want=("canon",))["canon"].cpu().numpy().view(np.uint64)
+    assert (got == canon).all(), (case, k, int((got != canon).sum()), np.flatnonzero(got != canon)[:8])
+    outs = ctx.canonical_windows(dev, n, 300, k, offsets=d_off, host_offsets=offsets)
+    assert (outs["fw"].cpu().numpy().view(np.uint64) == fw).all() and (outs["rc"].cpu().numpy().view(np.uint64) == rc).all()
+    assert (outs["canon"].cpu().numpy().view(np.uint64) == canon).all() and (outs["flags"].cpu().numpy() == flags).all()
+
+
+@pytest.mark.parametrize("k", [33, 64])
+@pytest.mark.parametrize("case", ["long", "mixed", "few_huge"])
+def test_windows2_long_ragged_reads_as_segments(ctx, orc, k, case):
+    """kmx_canonical_windows2 on ragged reads with a length bound above 256: the same device-side segments (start, end, first
+    output slot) through windows2_tiled_kernel<.., RAGGED>"""
+    rng = np.random.default_rng(k * 43 + len(case))
+    if case == "long":
+        lens = rng.integers(300, 3000, 200)
+    elif case == "mixed":
+        lens = np.where(rng.random(900) < 0.3, rng.integers(257, 1500, 900), rng.integers(0, 257, 900))
+    else:
+        lens = np.array([60_000, 17, 31_313, k, k - 1, 20_001])
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = len(lens)
+    host = _dirty(rng, int(offsets[-1]), 0.0002)
+    fw, rc, canon, flags = orc.canonical_windows2(host, n, 0, k, offsets=offsets)
+    outs = ctx.canonical_windows2(ctx.to_device(host), n, 1 << 20, k, offsets=ctx.to_device(offsets), host_offsets=offsets)
+    for name, exp in (("fw", fw), ("rc", rc), ("canon", canon)):
+        assert (outs[name].cpu().numpy().view(np.uint64).reshape(-1, 2) == exp.reshape(-1, 2)).all(), (name, k, case)
+    assert (outs["flags"].cpu().numpy() == flags).all()
