@@ -62,9 +62,11 @@ typedef struct kmx_ctx kmx_ctx;
  *   tiled kernels, and the tighter it is the fewer windows a lane carries (150 bp reads: 7 % faster at k = 31 with 150
  *   than with 160 or 0).  It is only a hint -- tiles with a longer read take the exact per-read path, and the
  *   histogram's work buffer, sized from it, overflows into exact (slow) global atomics.  A bound ABOVE 256 says "long reads"
- *   (PacBio / ONT reads, contigs): kmx_canonical_reduce (13 <= k <= 31, 16-byte aligned d_bases) then cuts every read into
- *   overlapping segments on the device and scans those (two host round trips: the batch's first and last offset, the number of
- *   segments; the segment arrays live in the context's work buffer); with 0 or a bound <= 256 a long read costs its tile the per-read path.
+ *   (PacBio / ONT reads, contigs): kmx_canonical_reduce (13 <= k <= 31), kmx_canonical_reduce2, kmx_canonical_windows and
+ *   kmx_canonical_windows2 (16-byte aligned d_bases) then cut every read into overlapping segments on the device and scan those (two
+ *   host round trips: the batch's first and last offset, the number of segments; the segment arrays live in the context's work
+ *   buffer); with 0 or a bound <= 256 a long read costs its tile the per-read path.  (kmx_canonical_reduce2 cuts ragged reads with
+ *   any bound above 160 this way: the two-word ragged kernel holds 160 bases.)
  * d_bases must be a device pointer whenever n_reads > 0, also when every read is empty (KMX_E_ARG otherwise). */
 typedef struct {
     const uint8_t *d_bases;
