@@ -621,7 +621,17 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
         const uint64_t *starts = nullptr, *ends = nullptr;
         uint64_t n_seg = 0;
         bool segmented = false;
-        if (Lh > 160) {
+        bool cut = Lh > 160;
+        if (cut && Lh <= 256) {
+            // (a bound the uniform kernel takes: if the batch holds exactly n_reads * bound bases it is, almost certainly, untrimmed --
+            // the gate below will say so for sure -- and the segments would be built for nothing: 16 bytes of offsets tell.  Should
+            // the gate disagree, the lane-per-read kernel counts.)
+            KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, reads->d_offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
+            KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned + 1, reads->d_offsets + reads->n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+            KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->h_pinned[0] == 0 && ctx->h_pinned[1] == reads->n_reads * (uint64_t)Lh) cut = false;
+        }
+        if (cut) {
             const int st = long_ragged_segments(ctx, reads, k, 161u - k, &starts, &ends, &n_seg);
             if (st > 0) return st;
             segmented = st == 0;

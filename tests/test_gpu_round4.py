@@ -675,3 +675,21 @@ def test_windows2_long_ragged_reads_as_segments(ctx, orc, k, case):
     for name, exp in (("fw", fw), ("rc", rc), ("canon", canon)):
         assert (outs[name].cpu().numpy().view(np.uint64).reshape(-1, 2) == exp.reshape(-1, 2)).all(), (name, k, case)
     assert (outs["flags"].cpu().numpy() == flags).all()
+
+
+@pytest.mark.parametrize("k", [33, 63])
+def test_reduce2_offsets_total_matches_the_bound_but_reads_differ(ctx, orc, k):
+    """kmx_canonical_reduce2, a bound of 161...256: a batch whose bases add up to n_reads * bound is taken for untrimmed and the
+    segments are not built -- here the total matches while two reads differ (one longer than the bound, one shorter): the
+    device-side gate says "not uniform" and the lane-per-read kernel counts.  Still the per-read result."""
+    rng = np.random.default_rng(k)
+    n, L = 64 * 6 + 3, 250
+    lens = np.full(n, L)
+    lens[10] += 7
+    lens[200] -= 7
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    assert int(offsets[-1]) == n * L
+    host = _dirty(rng, int(offsets[-1]), 0.0003)
+    o = orc.canonical_reduce2(host, n, 0, k, with_hash=True, offsets=offsets)
+    g = ctx.canonical_reduce2(ctx.to_device(host), n, L, k, with_hash=True, offsets=ctx.to_device(offsets))
+    assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
