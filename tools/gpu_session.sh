@@ -1,6 +1,4 @@
 # scratch: the command list of the current gpurun call (tools/README.md); the round's profile set is tools/profile_round.sh
-O=$GRAFT_REPO_ROOT/gpurun_out/r7t; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r7u; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
-python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | python3 tools/bench_line.py "driver command"
+bash tools/variants.sh default st50 st90 | tee $O/static.txt
