@@ -353,3 +353,50 @@ def test_full_size_long_ragged_reads(ctx, orc):
     assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
     p = ctx.canonical_reduce(bases, n_chk, 0, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=d_off[: n_chk + 1])   # no bound: the per-read path
     assert (p.n_valid, p.sum_canon, p.xor_hash, p.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
+
+
+@pytest.mark.parametrize("k", [63, 33])
+def test_full_size_two_word_k_behind_offsets(ctx, big, k):
+    """round 4, two-word k on the full 1e8 reads behind an offsets array, three ways that must agree with the uniform scan: bound
+    150 (the device-side gate picks the uniform kernel), bound 160 (the two-word ragged kernel scans them as ragged reads), bound
+    250 on the same bytes re-cut as 6e7 reads of 250 bases (segments of 161 - k windows) against the uniform scan of those"""
+    n = N_FULL
+    a = ctx.canonical_reduce2(big, n, L, k, with_hash=True)
+    off = ctx.to_device(np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    for bound in (150, 160):
+        r = ctx.canonical_reduce2(big, n, bound, k, with_hash=True, offsets=off)
+        assert tuple(getattr(r, f) for f, _ in r._fields_) == tuple(getattr(a, f) for f, _ in a._fields_), bound
+    del off
+    L2 = 250
+    n2 = n * L // L2
+    u = ctx.canonical_reduce2(big[: n2 * L2], n2, L2, k, with_hash=True)
+    assert u.n_valid == n2 * (L2 - k + 1)
+    lens = np.full(n2, L2, dtype=np.uint64)
+    lens[5] -= 3          # (one read shorter: the batch's total no longer says "untrimmed", the reads are cut into segments)
+    off2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    g = ctx.canonical_reduce2(big[: int(off2[-1])], n2, L2, k, with_hash=True, offsets=ctx.to_device(off2))
+    # the two batches differ in read 5 and in where every later read starts (3 bases earlier): only the counts are comparable
+    assert g.n_valid == n2 * (L2 - k + 1) - 3
+
+
+def test_full_size_materialised_words_add_up_to_the_scan(ctx, big):
+    """round 4: the canonical words that kmx_canonical_windows writes -- uniform 150-base reads (the line-aligned kernel), the same
+    bytes as reads of 1 000 bases (segments planned on the device), and as ragged reads behind offsets (the ragged ring) -- must
+    add up (mod 2^64) to the sum_canon of kmx_canonical_reduce over the same reads: two independent kernels, one checksum"""
+    import torch
+
+    k = 31
+    M = (1 << 64) - 1
+    for Lr, n, ragged in ((150, 20_000_000, False), (1000, 3_000_000, False), (150, 20_000_000, True)):
+        bases = big[: n * Lr]
+        s = ctx.canonical_reduce(bases, n, Lr, k)
+        if ragged:
+            off = np.arange(n + 1, dtype=np.uint64) * np.uint64(Lr)
+            w = ctx.canonical_windows(bases, n, 160, k, offsets=ctx.to_device(off), host_offsets=off, want=("canon",))["canon"]
+        else:
+            w = ctx.canonical_windows(bases, n, Lr, k, want=("canon",))["canon"]
+        assert w.numel() == s.n_valid
+        # (int64 wrapping sums: the same bits as the unsigned sum)
+        total = int(w.sum(dtype=torch.int64).item()) & M
+        assert total == s.sum_canon, (Lr, ragged)
+        del w
