@@ -39,6 +39,8 @@ print("per-wave lifetime ms (first 64 waves): min %.3f max %.3f" % (d[:,7].min()
 tiles = d[:, 5]
 names = ["A0 wait loads", "A encode+lds", "ticket take/issue", "B+C realign+transpose", "D pass 2", "", "", "", "D pass 1 + late rows"]
 print("tiles per wave", tiles.mean())
+q = np.percentile(tiles, [0, 10, 50, 90, 100])
+print("tiles per wave: min %d p10 %d median %d p90 %d max %d  (the ticket queue lets a wave that is served more often take more tiles)" % tuple(q))
 tot = 0
 for i, nme in enumerate(names):
     if not nme:
