@@ -571,8 +571,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
         return ~0ull;
     };
-    // The ticket for tile t+2 is requested at the end of iteration t and only looked at an iteration later: reading the
-    // atomic's return value right away (as dequeue() does) stalled every wave for a device-atomic round trip per tile.
+    // The ticket for tile t+2 is requested in iteration t right behind phase A -- after the wave has taken its rows and asked for
+    // the first rows of tile t+1 -- and looked at when the iteration ends: phases B-D later.  (Requested at the very end of the
+    // iteration, as rounds 2-4 had it, the atomic was the youngest operation in flight when phase A waited for its last rows,
+    // and loads and atomics complete in one order on gfx9: every tile waited for a fresh device atomic.  Reading the return
+    // value right away, as dequeue() does, costs the same round trip.)
     u32 pend = 0;            // (the low word: a head hands out fewer than 2^32 tickets -- launch_bs checks the tile count)
     u32 pend_qid = 0;
     auto ticket_issue = [&]() {
@@ -580,7 +583,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         if (heads_left != 0u && lane == 0) {
             unsigned long long one = 1ull;   // (made here: hoisted, the constant holds a register pair across the tile loop)
             asm volatile("" : "+v"(one));
-            pend = (u32)atomicAdd(queue + qid * 16u, one);
+            // The head's address goes through a VGPR the compiler cannot see through: with a wave-uniform address hipcc's atomic
+            // optimizer rewrites the add (a scan over the active lanes, ONE atomic, the result handed back to the lanes) and needs
+            // the returned value AT ONCE -- an `s_waitcnt vmcnt(0)` right behind the atomic: the device-atomic round trip and the
+            // rows of the next tile, every tile (~17 % of a wave's cycles sat there since round 3: profiles/r04_phase_timing*.txt).
+            u32 zero = 0;
+            asm volatile("" : "+v"(zero));
+            pend = (u32)atomicAdd(queue + qid * 16u + zero, one);
         }
         if (rot) qid = (qid + 1u) & (NQ - 1u);
     };
@@ -1078,7 +1087,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // Pipeline order 1: [A of tile t] [issue loads of tile t+1] [B,C,D of tile t]
     tile = uniform_u64(dequeue());
     next_tile = uniform_u64(dequeue());
-    ticket_issue();
     if constexpr (RAGGED) {
         if (tile < n_full) {
             meta_issue(tile);
@@ -1156,6 +1164,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 issue_loads_ragged(nx_m, 0, NLD - LATE);
             }
             __builtin_amdgcn_sched_barrier(0);
+            ticket_issue();
         } else {
             bad_tile = phase_A();
             // LATE > 0: the waits for the rows' loads sit under branches of phase A (lanes past the tile skip their chunk), so
@@ -1167,6 +1176,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 if (bad_tile && blank_dirty_reads(SEG ? (cur_g.nbytes + 15u) >> 4 : chunks)) bad_tile = false;
             }
             prefetch(next_tile, tile, 0, NLD - LATE);
+            ticket_issue();
         }
         lds_fence();
         KMX_T(1)
@@ -1181,8 +1191,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             KMX_T(4)
         }
         tile = next_tile;
-        next_tile = uniform_u64(ticket_take());     // requested one whole iteration ago (kept in scalar registers)
-        ticket_issue();
+        next_tile = uniform_u64(ticket_take());     // requested behind this iteration's phase A: phases B-D ago
         KMX_T(2)
         if constexpr (RAGGED) {
             cur_m = nx_m;
