@@ -1,4 +1,6 @@
 # scratch: the command list of the current gpurun call (tools/README.md); the round's profile set is tools/profile_round.sh
+O=$GRAFT_REPO_ROOT/gpurun_out/r8c; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-bash tools/profile_round.sh gpurun_out/r04d > gpurun_out/r04d.log 2>&1
-tail -3 gpurun_out/r04d.log
+timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt
+KMX_FUZZ_N=9000 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu > $O/fuzz.txt 2>&1; tail -1 $O/fuzz.txt
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
