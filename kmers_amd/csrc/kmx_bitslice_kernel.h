@@ -502,7 +502,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     // rows of the prefetch requested late (between the passes of phase D; their registers are free until then): half of a tile's
     // rows -- 5 of 10, 7 of 13, 8 of 16 --, 3 of the 7 (5) rows of the short frames
-    constexpr int LATE = PACKED ? 0 : NW == 10 ? 5 : NW < 10 ? (K > 32 ? 0 : 3) : NW == 13 ? 7 : 8;
+    // Rows of the next tile requested LATE (between pass 1 and pass 2 of phase D) instead of right behind phase A.  The 10-word
+    // frame at up to four windows per lane (k = 22..31 on 150-base reads): none -- since the ticket is no longer waited for at once
+    // (see ticket_issue) the whole tile requested early is +2 % (160-168 registers, no spills); at five windows per lane the
+    // same costs 8-16 bytes of spills and 7 %, and stays at five late rows.
+    constexpr int LATE = PACKED ? 0 : NW == 10 ? ((K > 32 || RAGGED || SEG || WPL > 4) ? 5 : 0) : NW < 10 ? (K > 32 ? 0 : 3) : NW == 13 ? 7 : 8;
     u64 tile = ~0ull, next_tile = ~0ull;
     bool seg_ld_next = false;         // SEG: issue_loads is asked for the next tile (nx_g), not for the current one (cur_g)
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
