@@ -1,8 +1,6 @@
 # scratch: the command list of the current gpurun call (tools/README.md); the round's profile set is tools/profile_round.sh
-O=$GRAFT_REPO_ROOT/gpurun_out/r8g; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r8i; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-for v in default ls0 default ls0; do
-  if [ "$v" == "default" ]; then unset KMX_LIB_VARIANT; else export KMX_LIB_VARIANT=$v; fi
-  for spec in "62 240000000" "75 200000000" "100 150000000" "112 130000000" "125 120000000" "161 93000000" "200 75000000" "224 66000000" "250 60000000" "256 58000000"; do set -- $spec
-    python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len $1 --reads-per-gpu $2 2>/dev/null | python3 tools/bench_line.py "[$v] L=$1"; done
-done | cut -c1-110 | tee $O/ls0.txt
+timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2>/dev/null; python3 tools/bench_line.py "driver command" < $O/bench_default.json
