@@ -1,6 +1,5 @@
 # scratch: the command list of the current gpurun call (tools/README.md); the round's profile set is tools/profile_round.sh
-O=$GRAFT_REPO_ROOT/gpurun_out/r8i; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r8k; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2>/dev/null; python3 tools/bench_line.py "driver command" < $O/bench_default.json
