@@ -10,10 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# KMX_LIB_VARIANT=<name> (development only): load kmers_amd/libkmx_<name>.so, a build of the same sources with extra -D
-# switches (kmers_amd/build.py); the default library is never overwritten by such builds
-_VARIANT = os.environ.get("KMX_LIB_VARIANT", "")
-LIB_PATH = os.path.join(_HERE, f"libkmx_{_VARIANT}.so" if _VARIANT else "libkmx.so")
+# The one library this package loads.  Nothing in the environment changes it: development builds (tools/dev_variant.py) are
+# selected by the tool or test that wants one (tools/devlib.py, `pytest --kmx-lib`), in code, before load().
+LIB_PATH = os.path.join(_HERE, "libkmx.so")
 COMM_ID_BYTES = 128
 
 # status codes (include/kmx.h)

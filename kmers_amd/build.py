@@ -3,10 +3,9 @@
 The .so is written next to this file (kmers_amd/libkmx.so): it is git-ignored but travels
 to the GPU box with the repo snapshot, so nothing is compiled there.
 
-Development variants (`-D` switches of the kernels) never touch the default library: they are built
-into their own object directory and `libkmx_<variant>.so`, selected at load time by the environment
-variable KMX_LIB_VARIANT (kmers_amd/_lib.py).  The default build records its flags in a stamp file, so
-a library left behind by different flags is rebuilt instead of being taken for current.
+Development builds (patched copies of the sources, extra -D switches) are made OUTSIDE this package by tools/dev_variant.py;
+nothing here, and nothing in kmers_amd/_lib.py, knows about them.  The build records its flags in a stamp file, so objects left
+behind by different flags are rebuilt instead of being taken for current.
 """
 from __future__ import annotations
 
@@ -39,10 +38,6 @@ def hipcc() -> str:
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found: libkmx is HIP-only (gfx950) and has no other build")
-
-
-def lib_path(variant: str | None = None) -> str:
-    return LIB if not variant else os.path.join(HERE, f"libkmx_{variant}.so")
 
 
 def _stale(target: str, deps: list[str]) -> bool:
@@ -89,14 +84,14 @@ def _split_usage(stderr: str) -> tuple[str, str]:
     return "\n".join(" | ".join(k) for k in kernels) + "\n", "\n".join(other)
 
 
-def _compile(src: str, obj_dir: str, force: bool, extra: list[str]) -> str:
-    obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+def _compile(src: str, force: bool) -> str:
+    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     if force or _stale(obj, [path] + _headers_of(src)):
         # -Rpass-analysis=kernel-resource-usage: registers / scratch / occupancy of every kernel, kept next to the object
         # (<src>.usage.txt; tests/test_kernel_resources.py reads them: a hot kernel that starts using scratch, or stops
         # inlining a lambda, shows there before it shows in a benchmark)
-        cmd = [hipcc(), *CXXFLAGS, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", obj]
+        cmd = [hipcc(), *CXXFLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -108,51 +103,28 @@ def _compile(src: str, obj_dir: str, force: bool, extra: list[str]) -> str:
     return obj
 
 
-def build(force: bool = False, extra: list[str] | None = None, variant: str | None = None, only: list[str] | None = None) -> str:
-    """Build the default library, or -- with `variant` -- a development variant compiled with the `extra` flags.
-    `only`: the sources the extra flags apply to (the other objects are shared with the default build)."""
-    extra = list(extra or [])
-    if extra and not variant:
-        raise ValueError("extra flags build a named variant (variant=...): the default libkmx.so is always the default build")
+def build(force: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    obj_dir = OBJ if not variant else os.path.join(CSRC, f"_obj_{variant}")
-    os.makedirs(obj_dir, exist_ok=True)
-    stamp = os.path.join(obj_dir, "flags.txt")
-    flags_now = " ".join(CXXFLAGS + extra)
+    stamp = os.path.join(OBJ, "flags.txt")
+    flags_now = " ".join(CXXFLAGS)
     try:
         with open(stamp) as f:
             if f.read() != flags_now:
                 force = True
     except OSError:
         force = True   # objects of unknown provenance (e.g. left by an older build script)
-    lib = lib_path(variant)
-
-    def one(s: str) -> str:
-        if variant and only is not None and s not in only:
-            return _compile(s, OBJ, False, [])
-        return _compile(s, obj_dir, force, extra)
-
     with ThreadPoolExecutor(max_workers=JOBS) as ex:
-        objs = list(ex.map(one, SOURCES))
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
     with open(stamp, "w") as f:
         f.write(flags_now)
-    if force or _stale(lib, objs):
-        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs,
-               "-Wl,-rpath,/opt/rocm/lib", "-ldl", f"-Wl,-soname,{os.path.basename(lib)}"]   # (RCCL: dlopen at the first kmx_comm_* call)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs,
+               "-Wl,-rpath,/opt/rocm/lib", "-ldl", f"-Wl,-soname,{os.path.basename(LIB)}"]   # (RCCL: dlopen at the first kmx_comm_* call)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return lib
+    return LIB
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if a != "--force"]
-    if args:   # python -m kmers_amd.build VARIANT [--only a.hip,b.hip] -DX=1 ...
-        only = None
-        if "--only" in args:
-            i = args.index("--only")
-            only = args[i + 1].split(",")
-            del args[i:i + 2]
-        print(build(force="--force" in sys.argv, extra=args[1:], variant=args[0], only=only))
-    else:
-        print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv))

@@ -463,14 +463,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
     };
 
-#ifdef KMX_BS_TIMING
-    const u64 k_c0 = __builtin_readcyclecounter(), k_w0 = wall_clock64();
-    u64 tph[6] = {0, 0, 0, 0, 0, 0};
-    u64 t_last = 0;
-#define KMX_T(i) { const u64 t_now = __builtin_readcyclecounter(); tph[i] += t_now - t_last; t_last = t_now; }
-#else
-#define KMX_T(i)
-#endif
     // software pipeline: the loads of tile t+1 are issued right after tile t has been packed, so they
     // are in flight during the realign / transpose / item phases of tile t (HBM latency ~4 us under load)
     constexpr int NLD = PACKED ? (NW + 3) / 4 : NW;   // 16-byte loads per lane and tile (packed: 16*L bytes per tile)
@@ -1019,7 +1011,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 }
             }
             if (!run) break;
-            KMX_T(5)
             asm volatile("" ::: "memory");
             {
                 // ---- pass 2 on the matrix pipe.  C[t][b] = sum_o sum_r m[o][r] & plane[o+t][b][r] is the sum along the diagonal
@@ -1107,11 +1098,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     }
     while (tile < n_full) {
         if constexpr (SEG) seg_lane(cur_g);
-#ifdef KMX_BS_TIMING
-        t_last = __builtin_readcyclecounter();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        KMX_T(0)
-#endif
         bool bad_tile;
         // INLINE: which reads hold the invalid bytes?  The tile is still in w[]: its chunks' verdicts again, one ballot per row
         // (the bitmap parks in the plane area, free until phase C), every lane looks up the chunks of its read, and the reads'
@@ -1183,20 +1169,16 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             ticket_issue();
         }
         lds_fence();
-        KMX_T(1)
         if (bad_tile) {   // not blanked in place: a ragged tile outside the frame (packed input has no such tiles, uniform ASCII reads never get here)
             if constexpr (RAGGED) fallback_read(tile * 64u + lane, true);
         }
         {
             const bool run = !bad_tile;
             if (run) phase_BC();
-            KMX_T(3)
             if (run || LATE > 0) phase_D(run);
-            KMX_T(4)
         }
         tile = next_tile;
         next_tile = uniform_u64(ticket_take());     // requested behind this iteration's phase A: phases B-D ago
-        KMX_T(2)
         if constexpr (RAGGED) {
             cur_m = nx_m;
             if (next_tile < n_full) meta_issue(next_tile);
@@ -1206,18 +1188,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             if (next_tile < n_full) seg_geom(next_tile, nx_g);
         }
     }
-#ifdef KMX_BS_TIMING
-    if (lane == 0 && wave_id < 4096) {
-        u64* dbg = reinterpret_cast<u64*>(out) + 8 + wave_id * 10;
-        for (int i = 0; i < 5; ++i) dbg[i] = tph[i];
-        dbg[8] = tph[5];
-        dbg[5] = n_bs_tiles;
-        dbg[6] = __builtin_readcyclecounter() - k_c0;   // shader cycles of this wave's whole run
-        dbg[7] = wall_clock64() - k_w0;                 // same interval in 100 MHz ticks
-        dbg[6] = (__builtin_readcyclecounter() - k_c0);
-        dbg[5] = ((u64)n_bs_tiles) | (k_w0 << 20);      // tiles in the low 20 bits, absolute start above
-    }
-#endif
 
     // ---- final partial tile: per-lane rolling
     const u32 rem = (u32)(n_reads & 63u);

@@ -25,12 +25,6 @@ __device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh) { return __built
 // in naive_impl (ACGT) codes, plus `bad`: OR of (byte ^ expected upper-case letter) over the 16
 // bytes -- the chunk is all-ACGTacgt  <=>  (bad & 0xDFDFDFDF) == 0  (exact, case-insensitive,
 // same accept set as encode_binary_u8, src/naive_impl/mod.rs:40-50).
-#ifndef KMX_BS_ABLATE
-#define KMX_BS_ABLATE 0
-#endif
-#ifndef KMX_ENC_CHAIN
-#define KMX_ENC_CHAIN 1
-#endif
 // a 32-bit constant materialised in a VGPR (pure, so it is hoisted out of loops and shared)
 template <u32 C>
 __device__ __forceinline__ u32 vgpr_const() {
@@ -40,10 +34,6 @@ __device__ __forceinline__ u32 vgpr_const() {
 }
 
 __device__ __forceinline__ u32 encode16(uint4 w, u32& bad) {
-#if (KMX_BS_ABLATE & 16)
-    bad |= 0u;
-    return w.x ^ w.y ^ w.z ^ w.w;   // dev ablation: no packing, no validation
-#endif
     // expected letter by internal code*2 as v_perm selector: 0->'A' 2->'C' 4->'T' 6->'G'
     constexpr u32 TBL_LO = 0x00430041u;  // bytes 0..3 : 'A', -, 'C', -
     constexpr u32 TBL_HI = 0x00470054u;  // bytes 4..7 : 'T', -, 'G', -
@@ -53,22 +43,16 @@ __device__ __forceinline__ u32 encode16(uint4 w, u32& bad) {
     const u32 x1 = w.y ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t1);
     const u32 x2 = w.z ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t2);
     const u32 x3 = w.w ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t3);
-#if !(KMX_BS_ABLATE & 8)
     bad = __builtin_amdgcn_bitop3_b32(bad, x0, x1, 0xFE);   // 3-input OR at full rate (v_or3_b32 is half rate)
     bad = __builtin_amdgcn_bitop3_b32(bad, x2, x3, 0xFE);
-#endif
     // v_dot4_u32_u8: sum of (2*code_i) * 4^i  = 2 * (4 bases packed in 8 bits)
     const u32 d0 = __builtin_amdgcn_udot4(t0, W4, 0u, false);
     const u32 d1 = __builtin_amdgcn_udot4(t1, W4, 0u, false);
     const u32 d2 = __builtin_amdgcn_udot4(t2, W4, 0u, false);
     const u32 d3 = __builtin_amdgcn_udot4(t3, W4, 0u, false);
-#if KMX_ENC_CHAIN
     u32 p = (d1 << 8) | d0;          // v_lshl_or_b32 chain: 2 half-rate ops instead of lshl, lshl, or3
     p = (d2 << 16) | p;
     p = (d3 << 23) | (p >> 1);
-#else
-    u32 p = ((d0 | (d1 << 8) | (d2 << 16)) >> 1) | (d3 << 23);
-#endif
     // internal (ACTG) -> naive_impl (ACGT) codes: p ^ ((p >> 1) & 0x55555555) as one v_bitop3_b32 whose
     // constant sits in a VGPR (an SGPR source would halve the issue rate)
     return __builtin_amdgcn_bitop3_b32(p >> 1, p, vgpr_const<0x55555555u>(), 0x6c);

@@ -28,15 +28,8 @@ namespace kmx {
 
 namespace {
 
-#ifndef KMX_FX_ABLATE
-#define KMX_FX_ABLATE 0   // dev: 1 = pass 3 without its byte stores (timing only)
-#endif
-#ifndef KMX_FX_STAGE_NT
-#define KMX_FX_STAGE_NT 1   // 1: the aligned 16-byte stores of the staged write-back carry the nt hint (whole lines from consecutive lanes: FASTA +3 %, FASTQ unchanged)
-#endif
-#ifndef KMX_FX_STAGE
-#define KMX_FX_STAGE 1   // pass 3 writes its bytes through an LDS image of the row's output (0: straight from the lanes)
-#endif
+// Pass 3 writes its bytes through an LDS image of the row's output; the aligned 16-byte stores of that write-back carry the nt hint
+// (whole lines from consecutive lanes: FASTA +3 %, FASTQ unchanged -- profiles/r03_fastx_staged_emit.txt).
 constexpr u32 FX_THREADS = 256;
 constexpr u32 FX_LANE = 64;                  // consecutive bytes a lane owns per step (four dwordx4 loads)
 constexpr u32 FX_ROW = FX_THREADS * FX_LANE; // bytes a block handles per step (16 KiB)
@@ -587,7 +580,6 @@ __device__ __forceinline__ void fastx_emit_rows(const uint8_t* __restrict__ text
         const u32 ikr = block_scan_add_dpp(kept | (recs << 16), tmp32, tkr);
         const u64 o = out_pos + ((ikr & 0xFFFFu) - kept);
         u64 r = rec + ((ikr >> 16) - recs);
-#if KMX_FX_STAGE
         {
             // The row's bytes go out through LDS: the lanes deposit their pieces where they will lie (same offset modulo 16 as in
             // memory), then the block writes whole 16-byte pieces, consecutive lanes consecutive addresses -- full lines instead of
@@ -595,26 +587,19 @@ __device__ __forceinline__ void fastx_emit_rows(const uint8_t* __restrict__ text
             uint8_t* const ob = stage + (row & 1u) * FX_OB;
             const u32 row_kept = tkr & 0xFFFFu;
             const u32 al = (u32)((reinterpret_cast<uintptr_t>(bases) + out_pos) & 15u);       // where the row's first byte sits in its 16-byte piece
-            if (ks && !(KMX_FX_ABLATE & 1)) emit_bytes(d, ks, ob + al + (u32)(o - out_pos));
+            if (ks) emit_bytes(d, ks, ob + al + (u32)(o - out_pos));
             __syncthreads();
             uint8_t* const g0 = bases + out_pos - al;                                          // 16-byte aligned
             const u32 end = al + row_kept;
-            for (u32 lo = 16u * threadIdx.x; lo < end && !(KMX_FX_ABLATE & 1); lo += 16u * FX_THREADS) {
+            for (u32 lo = 16u * threadIdx.x; lo < end; lo += 16u * FX_THREADS) {
                 if (lo >= al && lo + 16u <= end) {
-#if KMX_FX_STAGE_NT
                     { typedef u32 v4u __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(*reinterpret_cast<const v4u*>(ob + lo), reinterpret_cast<v4u*>(g0 + lo)); }
-#else
-                    *reinterpret_cast<uint4*>(g0 + lo) = *reinterpret_cast<const uint4*>(ob + lo);
-#endif
                 } else {                       // the first and the last piece of a row: shared with the rows around it, byte by byte
                     const u32 b0 = lo > al ? lo : al, b1 = lo + 16u < end ? lo + 16u : end;
                     for (u32 b = b0; b < b1; ++b) g0[b] = ob[b];
                 }
             }
         }
-#else
-        if (ks && !(KMX_FX_ABLATE & 1)) emit_bytes(d, ks, bases + o);
-#endif
         out_pos += tkr & 0xFFFFu;
         rec += tkr >> 16;
         while (rs) {      // the read that begins after newline q starts at the output position of the bytes kept so far
@@ -630,7 +615,7 @@ fastx_emit_kernel(const uint8_t* __restrict__ text, u64 n, const u64* __restrict
                   uint8_t* __restrict__ bases, u64* __restrict__ offsets) {
     __shared__ u32 tmp32[FX_THREADS / 64];
     __shared__ u32 wave_last[FX_THREADS / 64];
-    __shared__ __attribute__((aligned(16))) uint8_t stage[KMX_FX_STAGE ? 2 * FX_OB : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[2 * FX_OB];
     const u64 chunk = blockIdx.x;
     const u64 c0 = chunk * FX_CHUNK;
     const u64* pf = prefix + chunk * FX_PFX_WORDS;

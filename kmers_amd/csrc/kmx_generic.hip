@@ -5,9 +5,7 @@
 // correctness-first, these are not the roofline kernels.
 #include "kmx_device.h"
 
-#ifndef KMX_WIN2_NT
-#define KMX_WIN2_NT 1   // 1: the line-aligned stores of the tiled [u64;2] write-back carry the nt hint (k = 33 / 64: 5.5 -> 4.7 / 4.7 -> 4.0 ms per 2e7 reads, k = 47 / 63 +2 %: profiles/r03_nt_stores.txt)
-#endif
+// (the line-aligned stores of the tiled [u64;2] write-back carry the nt hint (k = 33 / 64: 5.5 -> 4.7 / 4.7 -> 4.0 ms per 2e7 reads, k = 47 / 63 +2 %: profiles/r03_nt_stores.txt)
 namespace kmx {
 
 struct ReadsView {
@@ -384,11 +382,7 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                                     const u32 w = wdone + base + piece;
                                     if (w < wnew) {
                                         const uint4 v = *reinterpret_cast<const uint4*>(S + rl * SPITCH + 4u * (((u32)s0 + w) & 15u));
-#if KMX_WIN2_NT
                                         { typedef u32 v4u __attribute__((ext_vector_type(4))); const v4u vv = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(vv, reinterpret_cast<v4u*>(one + 2u * (s0 + w))); }
-#else
-                                        *reinterpret_cast<uint4*>(one + 2u * (s0 + w)) = v;
-#endif
                                     }
                                 }
                             }

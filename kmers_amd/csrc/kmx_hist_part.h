@@ -4,9 +4,7 @@
 // entries: the first level of 2^23..2^28 buckets) -- two translation units so that the two sets of scan-kernel instantiations
 // compile in parallel (together they took 3.6 minutes, twice the rest of the library).
 #pragma once
-#ifndef KMX_HIST_ROW_NT
-#define KMX_HIST_ROW_NT 0   // 1: the 64-byte rows of pass 1 are written with the nt hint (measured: -0.2 ... +2 %, inside the noise; off)
-#endif
+// (the 64-byte rows of pass 1 are plain stores: with the nt hint they measured -0.2 ... +2 %, inside the noise)
 #include "kmx_scan_kernel.h"
 
 namespace kmx {
@@ -116,10 +114,7 @@ struct SinkHistPartT {
     // 47 % of their cycles.
     static constexpr bool kBatch16 = true;
     static constexpr int kWaves = 3;   // (LDS allows three blocks per CU: keep the registers inside 168)
-#ifndef KMX_HIST_BATCH
-#define KMX_HIST_BATCH 8
-#endif
-    static constexpr int NB = KMX_HIST_BATCH;   // windows whose slot requests are in flight together (divides 16)
+    static constexpr int NB = 8;   // windows whose slot requests are in flight together (divides 16)
     u32 pend[NB];   // the mixes of the windows collected so far
     // The returned word is {appended : 16 | written out : 16} with written out in {0, HALF} and appended < 2 ROW + 64 (flush_rows
     // keeps them small: no 16-bit wrap to mask), so "staged before me" is one sub-dword subtract, the ring byte offset
@@ -194,11 +189,7 @@ struct SinkHistPartT {
                 const u32 half = w & HALF;   // written-out count is a multiple of HALF: the row starts at ring entry 0 or HALF
                 const uint4 v = *reinterpret_cast<const uint4*>(ring + q * ROW + half + EPL * l4);
                 if (pos + HALF <= p.cap) {
-#if KMX_HIST_ROW_NT
-                    { typedef u32 v4u __attribute__((ext_vector_type(4))); const v4u vv = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(vv, reinterpret_cast<v4u*>(seg + (u64)q * p.cap + pos + EPL * l4)); }
-#else
                     *reinterpret_cast<uint4*>(seg + (u64)q * p.cap + pos + EPL * l4) = v;
-#endif
                 } else {   // segment full: the ids go to the global table
                     const u32 hi = q << lowbits, idm = (1u << lowbits) - 1u;
                     const u32 vv[4] = {v.x, v.y, v.z, v.w};

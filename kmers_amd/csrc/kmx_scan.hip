@@ -96,24 +96,15 @@ struct SinkWindowsT {
     static constexpr u32 PLANE = 64u * PITCH * 2u;          // dwords of one staged u64 array of a wave
     // staging sized by what the caller asked for (with all three u64 planes a block holds 108 KB = one block per CU and one
     // wave per SIMD; canonical words alone: 9 KB per wave, three blocks per CU)
-#ifndef KMX_WIN_WAVES
-#define KMX_WIN_WAVES 3
-#endif
-#ifndef KMX_WIN_NT
-#define KMX_WIN_NT 1   // 1: the stores of the line-aligned write-back, and of the staged one when W is a multiple of 8 (whole or half lines), carry the nt hint: canon-only k = 31 4.9 -> 4.3 ms per 2e7 reads (smaller pieces must NOT: the L2 merges those)
-#endif
-#ifndef KMX_WIN_UNROLL_A
-#define KMX_WIN_UNROLL_A 1   // unroll factor of the line-aligned write-back loop (4: 253-256 registers and up to 276 bytes of spills in the window loop; rolled: 182, none -- canon-only materialise at k = 31 5.4 -> 4.9 ms per 2e7 reads)
-#endif
-#ifndef KMX_WIN_UNROLL_S
-#define KMX_WIN_UNROLL_S 1   // ... of the staged (several arrays / flags) write-back loop (fw + rc + canon + flags: 18.3-19.0 -> 17.1 ms per 2e7 reads)
-#endif
+// (the stores of the line-aligned write-back, and of the staged one when W is a multiple of 8 (whole or half lines), carry the nt hint: canon-only k = 31 4.9 -> 4.3 ms per 2e7 reads (smaller pieces must NOT: the L2 merges those))
+// (the line-aligned write-back loop stays rolled (unrolled by 4: 253-256 registers and up to 276 bytes of spills in the window loop; rolled: 182, none -- canon-only materialise at k = 31 5.4 -> 4.9 ms per 2e7 reads))
+// (... and so does the staged (several arrays / flags) write-back loop (fw + rc + canon + flags: 18.3-19.0 -> 17.1 ms per 2e7 reads))
     // store latency is all this sink waits for: occupancy over registers (the line-aligned variant spills at 168 registers
     // and its 17 KB ring per wave caps a CU at two blocks anyway)
-    static constexpr int kWaves = ALIGNED ? 2 : KMX_WIN_WAVES;
+    static constexpr int kWaves = ALIGNED ? 2 : 3;
     // (the 16-word frame: two waves as well -- without the prefetch it needs 230 registers -- and, with the packed tile
     // living in the ring, two blocks per CU up to 256 bases: 2.5 -> 4.5 TB/s)
-    static constexpr int kWavesBig = ALIGNED ? 2 : KMX_SCAN_WAVES;
+    static constexpr int kWavesBig = ALIGNED ? 2 : 1;
     static constexpr bool kAliasPacked = ALIGNED;
     static constexpr u32 kLdsDwordsPerWave = 0;
     // One u64 array and no flags (the usual call: the canonical words): write-back in units of whole, 128-byte ALIGNED
@@ -243,7 +234,7 @@ struct SinkWindowsT {
                 goff_t go0;
                 bool c0 = prep(it_first, at0, go0);
                 u64 v0 = Tfw[at0];
-#pragma unroll KMX_WIN_UNROLL_A
+#pragma unroll 1
                 for (u32 it = it_first; it < 16u; ++it) {
                     u32 at1 = 0;
                     goff_t go1 = 0;
@@ -253,11 +244,7 @@ struct SinkWindowsT {
                     v1 = Tfw[at1];
                     // (every store of this loop, the pieces at the ends of a tile too, carries the nt hint: nt only on the whole lines
                     // measured like no nt at all, 4.93 against 4.14-4.30 ms)
-#if KMX_WIN_NT
                     if (c0) __builtin_nontemporal_store(v0, reinterpret_cast<u64*>(gbase + go0));
-#else
-                    if (c0) *reinterpret_cast<u64*>(gbase + go0) = v0;
-#endif
                     c0 = c1;
                     v0 = v1;
                     go0 = go1;
@@ -268,8 +255,8 @@ struct SinkWindowsT {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             return;
         }
-        if (KMX_WIN_NT && !p.win_offsets && (W & 7u) == 0u && cnt == 16u) {   // uniform reads, W a multiple of 8: every 16-window run is a whole line or two half lines (W = 120: 17.5 -> 15.7 ms for all four arrays; at W = 130, 16-byte aligned runs, nt costs 40 %)
-#pragma unroll KMX_WIN_UNROLL_S
+        if (!p.win_offsets && (W & 7u) == 0u && cnt == 16u) {   // uniform reads, W a multiple of 8: every 16-window run is a whole line or two half lines (W = 120: 17.5 -> 15.7 ms for all four arrays; at W = 130, 16-byte aligned runs, nt costs 40 %)
+#pragma unroll 1
             for (u32 it = 0; it < 16u; ++it) {
                 const u32 idx = it * 64u + lane, r = idx >> 4, sw = idx & 15u;
                 const u64 slot = (read0 + r) * W + o0 + sw;
@@ -280,7 +267,7 @@ struct SinkWindowsT {
                 if (p.flags) p.flags[slot] = TF[r * 16u + sw];
             }
         } else {
-#pragma unroll KMX_WIN_UNROLL_S
+#pragma unroll 1
         for (u32 it = 0; it < 16u; ++it) {
             const u32 idx = it * 64u + lane, r = idx >> 4, sw = idx & 15u;
             if (sw < cnt && (!p.win_offsets || o0 + sw < NWL[r])) {
@@ -311,10 +298,7 @@ struct SinkWindowsT {
             base = read * W;
         }
         next = 0;
-#ifndef KMX_WIN_MERGE
-#define KMX_WIN_MERGE 1
-#endif
-        merge = KMX_WIN_MERGE && ALIGNED && !RG && W >= 32u;
+        merge = ALIGNED && !RG && W >= 32u;
     }
     // ---- line-aligned mode: the output line two neighbouring reads of a tile share.  Written in two pieces (the tail of read
     // r - 1 in the tile's last pass, the head of read r in its first), 16-byte multiples at W = 130, such a line costs ~3.4x a
@@ -322,10 +306,7 @@ struct SinkWindowsT {
     // hands the first 16 windows of every read over once more after the last block (kRedoHead: ~10 instructions per window,
     // this sink waits for its stores) -- staged in the ring slots next to the tail's, (W + o) mod 32 -- and the lines go out whole.
     static constexpr bool kRedoHead = ALIGNED;
-#ifndef KMX_WIN_PREFETCH
-#define KMX_WIN_PREFETCH 1
-#endif
-    static constexpr bool kPrefetch = ALIGNED && KMX_WIN_PREFETCH != 0;   // (the staged variant is laid out for three waves: fifty more registers spill)
+    static constexpr bool kPrefetch = ALIGNED;   // (the staged variant is laid out for three waves: fifty more registers spill)
     bool merge;
     __device__ __forceinline__ bool wants_heads() const { return merge; }
     __device__ __forceinline__ void head(u32 o, u64 fw, u64 rc) {
@@ -348,7 +329,7 @@ struct SinkWindowsT {
         u32 at0, go0;
         bool c0 = prep(0u, at0, go0);
         u64 v0 = Tfw[at0];
-#pragma unroll KMX_WIN_UNROLL_A
+#pragma unroll 1
         for (u32 it = 0; it < 16u; ++it) {
             u32 at1 = 0, go1 = 0;
             bool c1 = false;

@@ -20,17 +20,10 @@ namespace kmx {
 // one contiguous byte span, streamed from its 16-byte-aligned start; lanes carry their own start and window count,
 // windows past a lane's read are masked.  A tile whose span or longest read does not fit the NW-word frame, or that
 // would load past the end of the buffer, takes the per-lane rolling path.
-#ifndef KMX_SCAN_RAGGED_2COPY
-#define KMX_SCAN_RAGGED_2COPY 0
-#endif
-#ifndef KMX_SCAN_DEV_NOGUARD
-#define KMX_SCAN_DEV_NOGUARD 0   // dev: drop the per-window length mask of the ragged kernel (wrong for unequal lengths; timing only)
-#endif
-#ifndef KMX_SCAN_WAVES
-#define KMX_SCAN_WAVES 1   // waves per SIMD the register allocation is sized for (hipcc otherwise spends up to 256 VGPRs on hoisting)
-#endif
+// SinkWaves / SinkWavesBig: waves per SIMD the register allocation of a sink is sized for (default 1: hipcc otherwise spends up to 256
+// VGPRs on hoisting)
 // a sink may ask for a register budget of its own (static constexpr int kWaves)
-template <typename S, typename = void> struct SinkWaves { static constexpr int value = KMX_SCAN_WAVES; };
+template <typename S, typename = void> struct SinkWaves { static constexpr int value = 1; };
 template <typename S> struct SinkWaves<S, decltype((void)S::kWaves)> { static constexpr int value = S::kWaves; };
 // a sink may take the 16 windows of an unrolled block together (static constexpr bool kBatch16 = true; fast_slot())
 template <typename S, typename = void> struct SinkBatch16 { static constexpr bool value = false; };
@@ -55,7 +48,7 @@ template <typename S> struct SinkRedoHead<S, decltype((void)S::kRedoHead)> { sta
 template <typename S, typename = void> struct SinkPrefetch { static constexpr bool value = false; };
 template <typename S> struct SinkPrefetch<S, decltype((void)S::kPrefetch)> { static constexpr bool value = S::kPrefetch; };
 // ... and for the 16-word frame (static constexpr int kWavesBig; without it: no cap -- most sinks would spill 1 KB there)
-template <typename S, typename = void> struct SinkWavesBig { static constexpr int value = KMX_SCAN_WAVES; };
+template <typename S, typename = void> struct SinkWavesBig { static constexpr int value = 1; };
 template <typename S> struct SinkWavesBig<S, decltype((void)S::kWavesBig)> { static constexpr int value = S::kWavesBig; };
 // a sink whose block-level LDS is one region per wave, empty between two tiles (static constexpr bool kAliasPacked;
 // wave_dwords(params) >= the packed tile), lends it to the tile's packed words: they are dead once the lanes hold their F / G
@@ -309,15 +302,6 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
                 // and keeps them all live -- 228-256 VGPRs, 1-2 waves per SIMD instead of 4.
                 u32 f0 = F[i], f1 = F[i + 1], f2 = F[i + 2], g0 = G[M], g1 = G[M + 1], g2 = G[M + 2];
                 asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(g0), "+v"(g1), "+v"(g2));
-#if KMX_SCAN_RAGGED_2COPY
-                if (!RAGGED || 16u * i + 16u <= nwin_min) {   // every lane owns all 16 windows: straight-line code
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, false);
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, true);
-                }
-#else
                 if constexpr (RAGGED && SinkBatch16<Sink>::value) {
                     // a sink that takes the windows of a block in batches (the partitioned histogram: its LDS round trips, paid
                     // once per batch instead of once per window, are what the ragged scan otherwise runs at): a second,
@@ -333,9 +317,8 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
                 // (a second, unmasked copy of the block for tiles of equal-length reads doubles the code past the
                 //  instruction cache and costs more than the per-window mask it saves)
 #pragma unroll
-                for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, RAGGED && !KMX_SCAN_DEV_NOGUARD, RAGGED ? -1 : s);
+                for (int s = 0; s < 16; ++s) window(16 * i + s, f0, f1, f2, g0, g1, g2, 2 * s, 30 - 2 * s, RAGGED, RAGGED ? -1 : s);
                 }
-#endif
                 if constexpr (PF) {
                     if (i == 0 && next_tile < n_full) pf_take();    // (before the block's stores: nothing younger than the loads to wait for)
                 }

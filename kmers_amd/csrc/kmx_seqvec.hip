@@ -14,9 +14,7 @@
 // CanonicalKmer::append_base, canonical_kmer.rs:90-94).
 #include "kmx_device.h"
 
-#ifndef KMX_MM_NT
-#define KMX_MM_NT 1   // 1: the per-window stores of the sliding-minimum kernel carry the nt hint (+2 ... +6 %: profiles/r03_nt_stores.txt)
-#endif
+// (the per-window stores of the sliding-minimum kernel carry the nt hint (+2 ... +6 %: profiles/r03_nt_stores.txt)
 namespace kmx {
 
 // the 2k-bit field at base position pos (RawVector::int(pos*2, k*2)), k in [1,32]; words past the end read as 0
@@ -278,13 +276,8 @@ seqvec_minimizers_slide_kernel(const u64* __restrict__ words, u64 n_reads, u32 L
             const u64 a = A[rr * NL + i], b = A[rr * NL + i + second];
             const u32 pos = (u32)((a < b ? a : b) & 0xFFu);
             const u64 slot = (r0 + rr) * (u64)W + i;
-#if KMX_MM_NT
             __builtin_nontemporal_store(lds_field(FW + rr * ND, 2u * pos, 2u * w), &out_word[slot]);
             __builtin_nontemporal_store(pos, &out_pos[slot]);
-#else
-            out_word[slot] = lds_field(FW + rr * ND, 2u * pos, 2u * w);
-            out_pos[slot] = pos;
-#endif
         }
         __syncthreads();
     }

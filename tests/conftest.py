@@ -8,8 +8,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    # development only: run the suite against a library built by tools/dev_variant.py instead of kmers_amd/libkmx.so
+    parser.addoption("--kmx-lib", action="store", default=None, help="path of a development build of libkmx.so")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    path = config.getoption("--kmx-lib")
+    if path:
+        from kmers_amd import _lib
+
+        _lib.LIB_PATH = os.path.abspath(path)
 
 
 @pytest.fixture(scope="session")

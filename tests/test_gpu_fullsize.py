@@ -1,6 +1,10 @@
-"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle cannot scan
-1.2e10 k-mers in seconds): exact window counts, shard linearity (checksum of checksums), an oracle-checked
-prefix, and exact accounting of injected invalid bytes."""
+"""Parity at BASELINE.json's full sizes.
+
+Two kinds of checks: (1) the WHOLE input against the multi-threaded CPU oracle (SURVEY 8(d) "Parity at scale": the device buffer
+is streamed to the host slab by slab, every usable core scans its share of a slab with the oracle -- ctypes releases the GIL --
+and the slab summaries are combined: wrapping add / xor / bucket-wise add), one GPU call against it; (2) size-independent
+properties: exact window counts, shard linearity (checksum of checksums), exact accounting of injected invalid bytes, the
+kernels against each other."""
 import os
 
 import numpy as np
@@ -25,6 +29,85 @@ def ctx():
 @pytest.fixture(scope="module")
 def big(ctx):
     return ctx.gen_reads(N_FULL * L)
+
+
+def _usable_cores():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def _oracle_over_device_buffer(buf, n_reads, read_len, per_part, combine, slab_reads=6_000_000):
+    """the oracle over ALL reads of a device buffer: D2H in slabs of `slab_reads` reads, each slab cut into one part per core,
+    `per_part(host_bytes, n)` on a thread per part, the results folded with `combine(acc, part)` (acc starts as None)"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    cores = _usable_cores()
+    acc = None
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        for lo in range(0, n_reads, slab_reads):
+            hi = min(n_reads, lo + slab_reads)
+            host = buf[lo * read_len:hi * read_len].cpu().numpy()
+            m = hi - lo
+            step = (m + cores - 1) // cores
+            cuts = [(a, min(m, a + step)) for a in range(0, m, step)]
+            for part in ex.map(lambda ab: per_part(host[ab[0] * read_len:ab[1] * read_len], ab[1] - ab[0]), cuts):
+                acc = part if acc is None else combine(acc, part)
+    return acc
+
+
+@pytest.mark.parametrize("k", [31, 21])
+def test_full_input_against_the_oracle(ctx, orc, big, k):
+    """BASELINE configs[1] / [2] (k = 31, 21) and the per-GPU work of configs[3] (k = 31 + the LexHasher word hash folded in):
+    ONE whole-buffer GPU call == the oracle over all 1e8 reads -- n_valid, the wrapping sum of the canonical words, the xor of
+    the Lex hashes and the sum of the forward words (canonical_kmer_iterator.rs:42-70, canonical_kmer.rs:113-119, hash.rs:60-71)"""
+    from kmers_amd import _lib
+
+    g = ctx.canonical_reduce(big, N_FULL, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+
+    def part(host, n):
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        return (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
+
+    def comb(a, b):
+        return (a[0] + b[0], (a[1] + b[1]) & M64, a[2] ^ b[2], (a[3] + b[3]) & M64)
+
+    o = _oracle_over_device_buffer(big, N_FULL, L, part, comb)
+    assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == o
+    # the headline call itself (no hash, no forward sum: what bench.py times) returns the same count and sum
+    h = ctx.canonical_reduce(big, N_FULL, L, k)
+    assert (h.n_valid, h.sum_canon) == o[:2]
+
+
+def test_full_input_two_word_k_against_the_oracle(ctx, orc, big):
+    """BASELINE configs[2], k = 63 ([u64;2] storage): one GPU call == the oracle over all 1e8 reads (low / high word sums and the
+    128-bit xor fold; the order and the hash of two-word k-mers are build-defined)"""
+    k = 63
+    g = ctx.canonical_reduce2(big, N_FULL, L, k, with_hash=True)
+
+    def part(host, n):
+        o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+        return (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+    def comb(a, b):
+        return (a[0] + b[0], (a[1] + b[1]) & M64, (a[2] + b[2]) & M64, a[3] ^ b[3], a[4] ^ b[4])
+
+    o = _oracle_over_device_buffer(big, N_FULL, L, part, comb)
+    assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == o
+
+
+def test_full_input_histogram_against_the_oracle(ctx, orc):
+    """BASELINE configs[4] at its own per-GPU size: 1.25e8 reads, k = 31, 2^20 buckets of the Lex hash -- every bucket of ONE GPU
+    call == the oracle's histogram of all reads"""
+    n = int(os.environ.get("KMX_TEST_HIST_READS", 125_000_000))
+    k, b = 31, 20
+    buf = ctx.gen_reads(n * L)
+    g = ctx.histogram(buf, n, L, k, 1, k, b).cpu().numpy().astype(np.uint64)
+    o = _oracle_over_device_buffer(buf, n, L, lambda host, m: orc.histogram(host, m, L, k, k, b).astype(np.uint64),
+                                   lambda a, c: a + c, slab_reads=8_000_000)
+    assert int(o.sum()) == n * (L - k + 1)
+    assert np.array_equal(g, o)
 
 
 @pytest.mark.parametrize("k", [31, 21])

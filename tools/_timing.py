@@ -4,6 +4,10 @@ inputs on the host) the first ten or so launches of any kernel run up to 40 % sl
 import time
 import torch
 
+import devlib
+
+devlib.from_env()   # KMX_DEV_LIB=NAME: a development build (tools/dev_variant.py) instead of kmers_amd/libkmx.so
+
 
 def warm(f, seconds=0.12, at_least=12):
     """call f until `seconds` of wall time and `at_least` calls have passed (the calls are queued asynchronously: synchronise)"""

@@ -1,6 +1,10 @@
-"""dev tool: build libkmx with -DKMX_BS_TIMING and print the per-phase cycle breakdown of the bit-sliced kernel"""
+"""dev tool: the per-phase cycle breakdown of the bit-sliced kernel, from a build with the instrumentation patch:
+    python tools/dev_variant.py bstiming --only kmx_bitslice.hip --patch tools/patches/bs_timing.patch
+    KMX_DEV_LIB=bstiming python tools/bs_timing.py [n_reads] [reps] [ragged]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import devlib
+devlib.from_env()
 import numpy as np, torch, ctypes as C
 from kmers_amd.api import Context
 from kmers_amd import _lib
