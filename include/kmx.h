@@ -66,7 +66,10 @@ typedef struct kmx_ctx kmx_ctx;
  *   kmx_canonical_windows2 (16-byte aligned d_bases) then cut every read into overlapping segments on the device and scan those (two
  *   host round trips: the batch's first and last offset, the number of segments; the segment arrays live in the context's work
  *   buffer); with 0 or a bound <= 256 a long read costs its tile the per-read path.  (kmx_canonical_reduce2 cuts ragged reads with
- *   any bound above 160 this way: the two-word ragged kernel holds 160 bases.)
+ *   any bound above 160 this way: the two-word ragged kernel holds 160 bases; with a bound of 161..256 it first reads the batch's
+ *   first and last offset back -- one host round trip -- and skips the cut when they say "untrimmed".)
+ *   EVERY call that takes one of these routes SYNCHRONISES the context's stream on the host (once or twice) and cannot be captured
+ *   in a HIP graph; all other scan calls only enqueue work.
  * d_bases must be a device pointer whenever n_reads > 0, also when every read is empty (KMX_E_ARG otherwise). */
 typedef struct {
     const uint8_t *d_bases;
@@ -109,7 +112,9 @@ void kmx_ctx_destroy(kmx_ctx *ctx);
 int kmx_ctx_synchronize(kmx_ctx *ctx);                         /* also reports what the asynchronous scans could not: KMX_E_ARG after a read of >= 2^31 bases was skipped */
 int kmx_ctx_device(const kmx_ctx *ctx);
 /* The context owns ONE grow-only device work buffer (bucket-id streams of kmx_histogram above 2^14 buckets, chunk prefixes of
- * kmx_fastx_parse); reads are processed in as many chunks as it takes.  Its size is chosen per call -- an eighth of the device
+ * kmx_fastx_parse, the segment arrays of reads longer than 256 bases: 16-24 bytes per segment of <= 226 windows); the histogram
+ * processes its reads in as many chunks as it takes, a batch of long reads whose segment arrays do not fit under a limit set
+ * here takes the per-read kernels instead (same results, a tenth of the rate).  Its size is chosen per call -- an eighth of the device
  * memory, at most half of what is free -- unless a limit is set here (bytes; 0 = automatic again).  A server that shares the
  * device caps it; a small limit forces the chunked paths. */
 int kmx_ctx_set_work_buffer_limit(kmx_ctx *ctx, size_t bytes);
@@ -160,7 +165,7 @@ int kmx_canonical_windows2(kmx_ctx *ctx, const kmx_reads *reads, const uint64_t 
  * GPUs, all-reduces it (RCCL ncclSum/uint64).
  * With 2^15..2^22 buckets the reads (uniform or ragged) go through a grow-only work buffer owned by the context (sized to
  * the call: 3 bytes per window, at most an eighth of the device memory -- 8 GiB if that is more -- and at most half of
- * what is free; KMX_HIST_SCRATCH_MB overrides): growing it synchronises the stream once. */
+ * what is free; kmx_ctx_set_work_buffer_limit overrides): growing it synchronises the stream once. */
 int kmx_histogram(kmx_ctx *ctx, const kmx_reads *reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
                   uint32_t log2_buckets, uint64_t *d_counts);
 

@@ -189,6 +189,13 @@ void* big_scratch(void* user, size_t bytes) {
     return q;
 }
 
+// The segment arrays of the long-read paths (16-24 bytes per segment): inside the cap of kmx_ctx_set_work_buffer_limit, or not at
+// all -- the call then takes the per-read kernels, as it does when the allocation fails.
+static void* capped_scratch(kmx_ctx* ctx, size_t bytes) {
+    if (ctx->big_limit != 0 && bytes > ctx->big_limit) return nullptr;
+    return big_scratch(ctx, bytes);
+}
+
 // an eighth of the device memory, at least 8 GiB (kmx_ctx_set_work_buffer_limit overrides), and at most half of what is free: fewer,
 // larger chunks of reads per call (configs[4], 1.25e8 reads: 6 chunks at 8 GiB 19.3 ms, 2 at 36 GiB 18.6 ms)
 // (`held`: the work buffer the context already owns -- it is not part of "free" any more, but it IS available: without adding
@@ -423,7 +430,7 @@ static int long_ragged_segments(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k
     const uint64_t o_first = ctx->h_pinned[0], o_last = ctx->h_pinned[1];
     if (!(o_last >= o_first && o_last - o_first < (1ull << 62))) return -1;
     const uint64_t cap = kmx::segments_capacity(reads->n_reads, o_last - o_first, t_max);
-    void* scratch = big_scratch(ctx, kmx::segments_scratch_bytes(reads->n_reads, cap, win_offsets != nullptr));
+    void* scratch = capped_scratch(ctx, kmx::segments_scratch_bytes(reads->n_reads, cap, win_offsets != nullptr));
     if (!scratch) return -1;
     ctx->fx_valid = false;   // (the work buffer is overwritten: the fastx chunk prefixes in it are gone)
     const uint64_t* d_total = nullptr;
@@ -549,11 +556,11 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
         // materialise kernels (its start, its end, its first output slot: three arrays in the work buffer, 24 bytes per segment against
         // the ~1.8 KB a segment writes).  16-byte aligned base; no scratch -> the lane-per-read kernel below.
         const uint32_t L = reads->read_len;
-        if (L > 256 && k <= 31 && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u && reads->n_reads < (1ull << 40) && (uint64_t)L * reads->n_reads < (1ull << 62)) {
+        if (L > 256 && k >= 2 && k <= 31 /* the tiled materialise kernel's domain: nothing is planned for a k it refuses */ && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u && reads->n_reads < (1ull << 40) && (uint64_t)L * reads->n_reads < (1ull << 62)) {
             // (as few segments as the 16-word frame allows, all of the same size but the last)
             const uint32_t W = L - k + 1u, J = (W + (257u - k) - 1u) / (257u - k), T = (W + J - 1u) / J;
             const uint64_t n_seg_host = reads->n_reads * J;
-            void* scratch = big_scratch(ctx, kmx::uniform_segments_scratch_bytes(n_seg_host));
+            void* scratch = capped_scratch(ctx, kmx::uniform_segments_scratch_bytes(n_seg_host));
             if (scratch) {
                 ctx->fx_valid = false;   // (the work buffer is overwritten: the fastx chunk prefixes in it are gone)
                 const uint64_t *starts = nullptr, *ends = nullptr, *wins = nullptr;
@@ -566,7 +573,7 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
             }
         }
     }
-    if (reads->d_offsets && d_win_offsets && reads->read_len > 256 && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
+    if (reads->d_offsets && d_win_offsets && reads->read_len > 256 && k >= 2 && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
         // long ragged reads (a length bound above the frames), round 4: cut into segments of at most 257 - k windows on the device
         // (kmx_segments.hip: a start, an end and a first output slot each; two host round trips), materialised as reads of their own
         const uint64_t *starts = nullptr, *ends = nullptr, *wins = nullptr;
@@ -675,7 +682,7 @@ int kmx_canonical_windows2(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t*
         reads->n_reads < (1ull << 40) && (uint64_t)reads->read_len * reads->n_reads < (1ull << 62)) {
         // uniform reads longer than a frame (round 4): planned as segments on the device, as kmx_canonical_windows does
         const uint32_t L = reads->read_len, W = L - k + 1u, J = (W + (257u - k) - 1u) / (257u - k), T = (W + J - 1u) / J;
-        void* scratch = big_scratch(ctx, kmx::uniform_segments_scratch_bytes(reads->n_reads * J));
+        void* scratch = capped_scratch(ctx, kmx::uniform_segments_scratch_bytes(reads->n_reads * J));
         if (scratch) {
             ctx->fx_valid = false;
             const uint64_t *starts = nullptr, *ends = nullptr, *wins = nullptr;

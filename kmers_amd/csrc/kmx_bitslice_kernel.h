@@ -1497,13 +1497,12 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
 // largest frame allows, all of T or T - 1 windows.  Single-word k: the 13-word frame (207 bases + the alignment lead, six
 // windows per lane: T <= min(192, 208 - k)) -- k - 1 of every T + k - 1 bases are scanned twice, 30 of 158 in the 10-word frame
 // and 30 of 207 here (1 000-base reads 0.59 -> 0.64 of the roofline) -- unless the segments that come out fit the 10-word frame
-// (reads of 257..~450 bases).  Two-word k: the 10-word frame (T <= min(128, 160 - k); in the 13-word frame at two waves the
-// longer segments gain what the frame loses).
+// (reads of 257..~450 bases).  Two-word k (round 5): the same choice -- the 13-word frame at two waves per SIMD.
 struct BsSegPlan { u32 J, J1, T, NW; };
 static inline BsSegPlan bs_seg_plan(u32 L, u32 k) {
     const u32 wr = L - k + 1u;
     const u32 t10 = 160u - k < 128u ? 160u - k : 128u, t13 = 208u - k < 192u ? 208u - k : 192u;
-    const u32 t_max = k <= 31u ? t13 : t10;
+    const u32 t_max = t13;   // (two-word k too, round 5: see launch_bs_seg)
     const u32 J = (wr + t_max - 1u) / t_max, T = (wr + J - 1u) / J;
     return BsSegPlan{J, J - (J * T - wr), T, (T <= t10) ? 10u : 13u};
 }
@@ -1517,6 +1516,12 @@ static hipError_t launch_bs_seg(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
     const u32 Lf = pl.T + (u32)K - 1u;
     if constexpr (K <= 31) {
         if (pl.NW == 13u) return launch_bs<K, 13, 6, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
+    } else {
+        // Two-word k in the 13-word frame as well (round 5): of a 10-word segment's <= 159 bases k - 1 = 32..63 are shared with the next
+        // one -- 97 windows per 159 bases loaded at k = 63 -- and the 13-word frame's 207 bases hold 145 (1.43 instead of 1.64 bytes
+        // loaded per byte of input).  ONE instantiation per k: T <= 208 - k windows need five windows per lane from k = 48 up, six below.
+        constexpr int WPL13 = (208 - K <= 160) ? 5 : 6;
+        if (pl.NW == 13u) return launch_bs<K, 13, WPL13, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
     }
     if (pl.NW != 10u) return hipErrorInvalidValue;
     if (pl.T <= 96u) return launch_bs<K, 10, 3, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);

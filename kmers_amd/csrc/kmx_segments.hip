@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(1024) seg_scan_blocks_kernel(u64* __restrict__
 // slot array the ragged materialise kernels expect: a read's segments write consecutive slots)
 __global__ void __launch_bounds__(SEG_THREADS) seg_fill_kernel(const u64* __restrict__ offsets, u64 n_reads, u32 k, u32 t_max,
                                                               const u64* __restrict__ block_base, u64* __restrict__ starts,
-                                                              u64* __restrict__ ends, const u64* __restrict__ win_offsets, u64* __restrict__ wins) {
+                                                              u64* __restrict__ ends, const u64* __restrict__ win_offsets, u64* __restrict__ wins,
+                                                              u64 seg_capacity) {
     __shared__ u64 wave_tot[SEG_THREADS / 64];
     __shared__ u32 first[SEG_PER_BLOCK + 1];     // first segment of read i of the block, relative to the block's base
     __shared__ u64 r_o0[SEG_PER_BLOCK];
@@ -139,6 +140,9 @@ __global__ void __launch_bounds__(SEG_THREADS) seg_fill_kernel(const u64* __rest
         const u32 cnt = first[lo + 1u] - first[lo];
         const u32 t = (w + cnt - 1u) / cnt;          // windows per segment, balanced; the last segment takes what is left
         const u64 o0 = r_o0[lo], st = o0 + (u64)j * t, e = st + t + (k - 1u), read_end = o0 + len;
+        // (offsets that do not increase give lengths whose segments outnumber the bound the arrays were sized from: nothing is
+        // written past them, and the host, which compares the total with the bound before it scans, fails the call)
+        if (base + s >= seg_capacity) continue;
         starts[base + s] = st;
         ends[base + s] = e < read_end ? e : read_end;
         if (wins != nullptr) wins[base + s] = r_w0[lo] + (u64)j * t;
@@ -173,7 +177,7 @@ hipError_t launch_segments_build(const u64* offsets, u64 n_reads, u32 k, u32 t_m
     // (slices of ~4096 segments: by the bound, the average block of 1024 reads holds seg_capacity / n_blocks of them)
     u64 splits = seg_capacity / n_blocks / 4096u;
     splits = splits < 1u ? 1u : splits > 64u ? 64u : splits;
-    hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)n_blocks, (unsigned)splits), dim3(SEG_THREADS), 0, stream, offsets, n_reads, k, t_max, block_sums, starts, ends, win_offsets, wins);
+    hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)n_blocks, (unsigned)splits), dim3(SEG_THREADS), 0, stream, offsets, n_reads, k, t_max, block_sums, starts, ends, win_offsets, wins, seg_capacity);
     *starts_out = starts;
     *ends_out = ends;
     *total_out = total;

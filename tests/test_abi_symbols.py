@@ -88,4 +88,14 @@ def test_no_development_knobs_in_the_product():
             continue
         for fn in fns:
             if fn.endswith((".hip", ".h")):
-                assert "getenv" not in open(os.path.join(dp, fn)).read(), fn
+                txt = open(os.path.join(dp, fn)).read()
+                assert "getenv" not in txt, fn
+                # (round 5) no compile-time switches either: the sources have ONE reading -- a conditional on a KMX_ macro (other than
+                # an include guard, of which there is none: #pragma once) is an experiment left behind; development builds are
+                # patched copies made by tools/dev_variant.py
+                for ln in txt.splitlines():
+                    assert not re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b.*\bKMX_", ln), (fn, ln)
+    # ... and the loader takes nothing from the environment: the library it loads is kmers_amd/libkmx.so
+    for py in ("_lib.py", "api.py", "dist.py", "__init__.py"):
+        txt = open(os.path.join(ROOT, "kmers_amd", py)).read()
+        assert "os.environ" not in txt and "getenv" not in txt, py

@@ -1,0 +1,171 @@
+"""Round-5 GPU parity tests (through the C ABI, bit-exact against the CPU oracle).
+
+  * every RAGGED instantiation of the bit-sliced scan -- each frame (7 / 10 / 16 words) at each number of windows per lane it is
+    launched with, single- and two-word k -- AT SIZE: enough reads that every wave scans several tiles, so state a wave carries
+    from tile to tile (plane totals, read-end totals, the fp32 accumulators, the ticket pipeline) is exercised, with trimmed
+    reads, reads shorter than k, and a sprinkle of invalid bytes.  Round 4 lost a build of the three-wave ragged 10-word frame
+    that returned a wrong sum_canon only at such sizes (DESIGN "The round-4 miscompare"); ADVICE r4 asked for an at-size oracle
+    check of every ragged frame / windows-per-lane combination, not only of the ones that happened to fail.
+  * the segment paths honour kmx_ctx_set_work_buffer_limit, malformed offsets cannot push the segment fill past its
+    arrays.
+Reference semantics at stake: CanonicalKmerIterator::find_next, canonical_kmer_iterator.rs:42-70; canonical_kmer.rs:113-119."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from kmers_amd.api import Context
+
+    c = Context()
+    yield c
+    c.close()
+
+
+def _ragged_batch(ctx, n, lo, hi, frac_full, seed, p_bad=0.0, frac_short=0.0, k=31):
+    """n reads: a fraction `frac_full` of `hi` bases, the others uniform in [lo, hi], a fraction `frac_short` shorter than k; bases
+    from the device generator, a byte in `p_bad` of the reads replaced by 'N'"""
+    rng = np.random.default_rng(seed)
+    lens = np.where(rng.random(n) < frac_full, hi, rng.integers(lo, hi + 1, n)).astype(np.int64)
+    if frac_short:
+        short = rng.random(n) < frac_short
+        lens[short] = rng.integers(0, k, int(short.sum()))
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total = int(offsets[-1])
+    bases = ctx.gen_reads(total, first_byte=seed)
+    host = bases.cpu().numpy().copy()
+    if p_bad:
+        reads = np.nonzero((rng.random(n) < p_bad) & (lens > 0))[0]
+        pos = offsets[reads].astype(np.int64) + (rng.random(len(reads)) * lens[reads]).astype(np.int64)
+        host[pos] = ord("N")
+        bases = ctx.to_device(host)
+    return bases, host, offsets
+
+
+# (k, bound handed to the call, shortest read, longest read): the frame and the windows per lane follow from the bound
+# (launch_bs_ragged_any): 7-word frame <= 111 bases (3 / 4 windows per lane), 10-word frame <= 160 (3 / 4 / 5), 16-word <= 256 (5..8)
+RAGGED_SHAPES = [
+    (31, 100, 36, 100), (13, 100, 30, 100), (21, 111, 40, 111), (13, 111, 20, 111),                # 7 words: W <= 96 / <= 128
+    (31, 126, 50, 126), (31, 150, 36, 150), (31, 158, 100, 158), (21, 150, 36, 150), (13, 160, 100, 160), (29, 157, 60, 157),   # 10 words: 3 / 4 / 5
+    (31, 190, 100, 190), (31, 222, 150, 222), (31, 250, 100, 250), (21, 256, 200, 256), (13, 200, 150, 200), (17, 240, 100, 240),  # 16 words: 5..8
+    (31, 0, 100, 160),                                                                              # no bound: the 16-word frame
+]
+
+
+@pytest.mark.parametrize("k,bound,lo,hi", RAGGED_SHAPES)
+def test_ragged_frames_at_size(ctx, orc, k, bound, lo, hi):
+    from kmers_amd import _lib
+
+    n = 1_200_000 if hi <= 160 else 800_000
+    bases, host, offsets = _ragged_batch(ctx, n, lo, hi, 0.9, seed=1000 * k + hi, p_bad=0.0005, frac_short=0.001, k=k)
+    o = orc.canonical_reduce(host, n, 0, k, hasher_k=k, offsets=offsets)
+    d_off = ctx.to_device(offsets)
+    for flags in (0, _lib.REDUCE_SUM_FW):
+        g = ctx.canonical_reduce(bases, n, bound, k, _lib.HASH_LEX, k, flags, offsets=d_off)
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+        if flags:
+            assert g.sum_fw == o.sum_fw
+    # ... and a second call gives the same (the masks of the blanked reads are back to zero, nothing is left in the queue block)
+    g2 = ctx.canonical_reduce(bases, n, bound, k, _lib.HASH_LEX, k, 0, offsets=d_off)
+    assert (g2.n_valid, g2.sum_canon, g2.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+
+
+@pytest.mark.parametrize("k,bound,lo,hi", [(33, 150, 60, 150), (47, 150, 100, 150), (63, 150, 80, 150), (64, 160, 100, 160), (50, 120, 70, 120), (40, 0, 100, 160)])
+def test_ragged_two_word_frames_at_size(ctx, orc, k, bound, lo, hi):
+    n = 1_000_000
+    bases, host, offsets = _ragged_batch(ctx, n, lo, hi, 0.9, seed=77 * k + hi, p_bad=0.0005, frac_short=0.001, k=k)
+    o = orc.canonical_reduce2(host, n, 0, k, with_hash=True, offsets=offsets)
+    g = ctx.canonical_reduce2(bases, n, bound, k, with_hash=True, offsets=ctx.to_device(offsets))
+    assert tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
+
+
+@pytest.mark.parametrize("k,lo,hi,n", [(31, 300, 3000, 120_000), (21, 257, 1000, 300_000), (13, 1000, 20_000, 20_000), (31, 1000, 1000, 150_000)])
+def test_long_ragged_reads_at_size(ctx, orc, k, lo, hi, n):
+    """reads longer than a frame behind an offsets array (a bound above 256): segments cut on the device, scanned by the ragged
+    10-word frame through a separate ends array -- 1e6+ segments, every wave several tiles of them"""
+    from kmers_amd import _lib
+
+    bases, host, offsets = _ragged_batch(ctx, n, lo, hi, 0.3, seed=5 * k + hi, p_bad=0.001, frac_short=0.002, k=k)
+    o = orc.canonical_reduce(host, n, 0, k, hasher_k=k, offsets=offsets)
+    g = ctx.canonical_reduce(bases, n, 1 << 20, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=ctx.to_device(offsets))
+    assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
+
+
+# ------------------------------------------------------------------ ADVICE r4
+
+def test_segment_paths_honour_the_work_buffer_limit(orc):
+    """a cap smaller than the segment arrays of a batch of long reads: the call takes the per-read kernels (same result), and the
+    work buffer does not grow past the cap"""
+    import ctypes as C
+
+    from kmers_amd import _lib
+    from kmers_amd.api import Context
+
+    c = Context()
+    try:
+        k, n = 31, 3000
+        rng = np.random.default_rng(9)
+        lens = rng.integers(400, 5000, n).astype(np.int64)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        bases = c.gen_reads(int(offsets[-1]))
+        host = bases.cpu().numpy()
+        o = orc.canonical_reduce(host, n, 0, k, hasher_k=k, offsets=offsets)
+        d_off = c.to_device(offsets)
+        assert c.lib.kmx_ctx_set_work_buffer_limit(c._h, 4096) == 0
+        g = c.canonical_reduce(bases, n, 1 << 16, k, _lib.HASH_LEX, k, 0, offsets=d_off)
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+        held, allocs = C.c_size_t(), C.c_uint64()
+        assert c.lib.kmx_ctx_work_buffer_info(c._h, C.byref(held), C.byref(allocs)) == 0
+        assert held.value <= 4096
+        outs = c.canonical_windows(bases, n, 1 << 16, k, offsets=d_off, host_offsets=offsets, want=("canon",))
+        _, _, canon, _ = orc.canonical_windows(host, n, 0, k, offsets=offsets)
+        assert (outs["canon"].cpu().numpy().view(np.uint64) == canon).all()
+        assert c.lib.kmx_ctx_work_buffer_info(c._h, C.byref(held), C.byref(allocs)) == 0
+        assert held.value <= 4096
+        # without the cap the same calls take the segment path and agree
+        assert c.lib.kmx_ctx_set_work_buffer_limit(c._h, 0) == 0
+        g2 = c.canonical_reduce(bases, n, 1 << 16, k, _lib.HASH_LEX, k, 0, offsets=d_off)
+        assert (g2.n_valid, g2.sum_canon, g2.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+        assert c.lib.kmx_ctx_work_buffer_info(c._h, C.byref(held), C.byref(allocs)) == 0
+        assert held.value > 4096
+    finally:
+        c.close()
+
+
+def test_segment_fill_stays_inside_its_arrays_on_malformed_offsets():
+    """offsets that go backwards give per-read lengths that add up to far more than offsets[n] - offsets[0], the number the segment
+    arrays are sized from: the call must fail (or skip) without writing past them -- the context stays usable and a correct call
+    afterwards is exact (before: the fill kernel wrote every counted segment and the host compared the count with the bound later)"""
+    from kmers_amd import _lib
+    from kmers_amd._lib import KmxError
+    from kmers_amd.api import Context
+    from oracle import oracle as orc
+
+    c = Context()
+    try:
+        k, n = 31, 4096
+        L = 3000
+        bases = c.gen_reads(n * L)
+        good = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+        bad = good.copy()
+        # a saw-tooth: every other offset jumps back to the start, so read lengths of ~n L / 2 bases each are claimed
+        bad[1:-1:2] = 0
+        try:
+            c.canonical_reduce(bases, n, 1 << 20, k, _lib.HASH_NONE, 0, 0, offsets=c.to_device(bad))
+        except KmxError:
+            pass
+        try:
+            c.synchronize()
+        except KmxError:
+            pass
+        host = bases.cpu().numpy()
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        g = c.canonical_reduce(bases, n, 1 << 20, k, _lib.HASH_LEX, k, 0, offsets=c.to_device(good))
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+    finally:
+        c.close()

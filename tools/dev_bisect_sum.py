@@ -29,8 +29,9 @@ L = int(args.get("L", 1000))
 n = int(args.get("n", 150000))
 k = int(args.get("k", 31))
 mode = args.get("mode", "uniform")
+fb = int(args.get("fb", L))   # first byte of the synthetic stream (bench.py: 0)
 ctx = Context(0)
-bases = ctx.gen_reads(n * L, first_byte=L)
+bases = ctx.gen_reads(n * L, first_byte=fb)
 host = bases.cpu().numpy()
 
 
@@ -90,7 +91,7 @@ def show(tag, g, o):
 
 
 gs, o = run(0, n, reps=4)
-print(f"# L={L} n={n} k={k} mode={mode}; 4 calls: {'identical' if len(set(gs)) == 1 else 'DIFFER between calls: ' + str(gs)}")
+print(f"# L={L} n={n} k={k} mode={mode} fb={fb}; 4 calls: {'identical' if len(set(gs)) == 1 else 'DIFFER between calls: ' + str(gs)}")
 ok = show("whole", gs[0], o)
 if ok and len(set(gs)) == 1:
     print("nothing to bisect")

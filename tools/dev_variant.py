@@ -79,16 +79,14 @@ def main(argv: list[str]) -> str:
         if hits == 0:
             raise SystemExit(f"substitution matched nothing: {pat!r}")
         print(f"  sub {pat!r}: {hits} site(s)")
-    objs = []
-    for s in kb.SOURCES:
+    def one(s: str) -> str:
         if s not in only:
-            objs.append(os.path.join(kb.OBJ, os.path.splitext(s)[0] + ".o"))
-            continue
+            return os.path.join(kb.OBJ, os.path.splitext(s)[0] + ".o")
         obj = os.path.join(vdir, os.path.splitext(s)[0] + ".o")
         cmd = [kb.hipcc(), *kb.CXXFLAGS, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(csrc, s), "-o", obj]
         if keep_asm:
             cmd += ["-save-temps=obj"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=vdir)
         if r.returncode != 0:
             raise SystemExit(f"hipcc failed for {s}:\n{r.stderr}")
         usage, other = kb._split_usage(r.stderr)
@@ -96,7 +94,11 @@ def main(argv: list[str]) -> str:
             f.write(usage)
         if other.strip():
             sys.stderr.write(other + "\n")
-        objs.append(obj)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=kb.JOBS) as ex:
+        objs = list(ex.map(one, kb.SOURCES))
     lib = os.path.join(vdir, "libkmx.so")
     cmd = [kb.hipcc(), "-shared", "-fPIC", f"--offload-arch={kb.ARCH}", "-o", lib, *objs, "-Wl,-rpath,/opt/rocm/lib", "-ldl", "-Wl,-soname,libkmx.so"]
     subprocess.run(cmd, check=True)

@@ -23,10 +23,10 @@ python3 tools/pmc_summary.py $out > $out/pmc_summary.txt 2>&1
 # un-profiled lines: the driver's command (with in-run traffic + CPU baseline), the other configs, the sustained run
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --sustain-steps 3000 > $out/bench_sustained3000.json 2> /dev/null
-python3 bench.py --config 2 -k 21 --no-traffic > $out/bench_k21.json 2> /dev/null
-python3 bench.py --config 2 -k 63 --no-traffic > $out/bench_k63.json 2> /dev/null
-python3 bench.py --config 3 --no-traffic > $out/bench_hash.json 2> /dev/null
-python3 bench.py --config 4 --no-traffic --no-cpu-baseline --steps 5 --warmup 2 --sustain-steps 20 > $out/bench_hist20.json 2> /dev/null
+python3 bench.py --config 2 -k 21 --no-cpu-baseline > $out/bench_k21.json 2> /dev/null
+python3 bench.py --config 2 -k 63 --no-cpu-baseline > $out/bench_k63.json 2> /dev/null
+python3 bench.py --config 3 --no-cpu-baseline > $out/bench_hash.json 2> /dev/null
+python3 bench.py --config 4 --no-cpu-baseline --steps 5 --warmup 2 --sustain-steps 20 > $out/bench_hist20.json 2> /dev/null
 python3 bench.py --config 4 --dist-single --no-cpu-baseline --steps 5 --warmup 2 --sustain-steps 0 > $out/bench_hist20_rccl1.json 2> /dev/null
 # the N > 1 control flow on this one-GPU box (both ranks on cuda:0, gloo; stated in the line): what an 8-GPU line will carry
 KMX_BENCH_TEST_SHARED_GPU=1 python3 bench.py --gpus 2 --reads-per-gpu 20000000 --steps 5 --warmup 2 --sustain-steps 0 --no-traffic --cpu-baseline-seconds 8 > $out/bench_2ranks_shared_gpu.json 2> /dev/null
