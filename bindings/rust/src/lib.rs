@@ -322,7 +322,7 @@ pub struct HipSeqVector<'c> {
 }
 
 impl<'c> HipSeqVector<'c> {
-    /// `SeqVector::from(&[u8])` (seq_vector.rs:346-358); panics on a non-ACGTacgt byte like `Kmer::from` does
+    /// `SeqVector::from(&[u8])` (seq_vector.rs:230-242); panics on a non-ACGTacgt byte like `Kmer::from` does
     pub fn from_bytes(ctx: &'c HipContext, bytes: &[u8]) -> Result<Self, KmxError> {
         let d_words = ctx.alloc(8 * ((bytes.len() + 31) / 32).max(1) + 16)?;
         ctx.ck(unsafe { kmx_memset(ctx.0, d_words.as_mut_ptr(), 0, d_words.len()) })?;
@@ -339,7 +339,7 @@ impl<'c> HipSeqVector<'c> {
     pub fn is_empty(&self) -> bool {
         self.len == 0
     }
-    /// `SeqVector::get_kmer_u64(pos, k)` (seq_vector.rs:217-220) for many positions
+    /// `SeqVector::get_kmer_u64(pos, k)` (seq_vector.rs:96-99) for many positions
     pub fn get_kmers(&self, pos: &[u64], k: u8) -> Result<Vec<u64>, KmxError> {
         let bytes = unsafe { std::slice::from_raw_parts(pos.as_ptr() as *const u8, 8 * pos.len()) };
         let d_pos = self.ctx.upload(bytes)?;
@@ -347,14 +347,14 @@ impl<'c> HipSeqVector<'c> {
         self.ctx.ck(unsafe { kmx_seqvec_get_kmers(self.ctx.0, self.d_words.as_ptr(), self.len as u64, d_pos.as_ptr(), pos.len() as u64, k as u32, d_out.as_mut_ptr()) })?;
         d_out.download(pos.len())
     }
-    /// `iter_kmers(k)` (seq_vector.rs:56-63, 236-243): the forward words of every window, in order
+    /// `iter_kmers(k)` (seq_vector.rs:64-71, 117-124): the forward words of every window, in order
     pub fn iter_kmers(&self, k: u8) -> Result<Vec<u64>, KmxError> {
         let cnt = (self.len + 1).saturating_sub(k as usize);
         let d_out = self.ctx.alloc(8 * cnt.max(1))?;
         self.ctx.ck(unsafe { kmx_seqvec_iter_kmers(self.ctx.0, self.d_words.as_ptr(), self.len as u64, 0, self.len as u64, k as u32, d_out.as_mut_ptr()) })?;
         d_out.download(cnt)
     }
-    /// `String::from(&SeqVector)` (seq_vector.rs:272-284)
+    /// `String::from(&SeqVector)` (seq_vector.rs:171-182)
     pub fn to_string(&self) -> Result<String, KmxError> {
         let d_b = self.ctx.alloc(self.len.max(1))?;
         self.ctx.ck(unsafe { kmx_seqvec_to_bytes(self.ctx.0, self.d_words.as_ptr(), self.len as u64, d_b.as_mut_ptr()) })?;

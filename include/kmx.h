@@ -253,22 +253,22 @@ int kmx_encoding_decode_p(kmx_ctx *ctx, const void *d_in, uint64_t n, uint8_t en
 /* ----------------------------------------------------------------------------------------------------------------
  * SeqVector -- the reference's 2-bit packed sequence container (src/naive_impl/seq_vector.rs).
  * Layout: base i at flat bits [2i, 2i+1] of a little-endian u64 word array, codes A0 C1 G2 T3 (it is built from
- * Kmer::from of 32-base chunks, seq_vector.rs:346-358); a vector of n bases owns ceil(n/32) words, bits past 2n are 0.
+ * Kmer::from of 32-base chunks, seq_vector.rs:230-242); a vector of n bases owns ceil(n/32) words, bits past 2n are 0.
  * The caller owns `d_words`; reads stored back to back are slices [r*L, (r+1)*L) of one vector (SeqVector::slice).
  * -------------------------------------------------------------------------------------------------------------- */
-/* SeqVector::push_chars (seq_vector.rs:241-262) / From<&[u8]> (:346-358, n_bases_before = 0): append `n` ASCII bases
+/* SeqVector::push_chars (seq_vector.rs:141-161) / From<&[u8]> (:230-242, n_bases_before = 0): append `n` ASCII bases
  * to a vector that holds `n_bases_before`.  Strict like Kmer::from (kmer.rs:234-251 panics on a bad base):
  * KMX_E_INVALID_BASE with *h_first_bad = index into d_bytes of the first offending byte (the words are then
  * unspecified).  d_words must have room for ceil((n_bases_before + n)/32) words. */
 int kmx_seqvec_push_chars(kmx_ctx *ctx, uint64_t *d_words, uint64_t n_bases_before, const uint8_t *d_bytes, uint64_t n,
                           uint64_t *h_first_bad);
-/* String::from(&SeqVector) (seq_vector.rs:272-284): n upper-case letters */
+/* String::from(&SeqVector) (seq_vector.rs:171-182): n upper-case letters */
 int kmx_seqvec_to_bytes(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_bases, uint8_t *d_bytes);
-/* SeqVector::get_kmer_u64(pos, k) (seq_vector.rs:217-220; get_base = k 1) for n positions; k in [1,32].
+/* SeqVector::get_kmer_u64(pos, k) (seq_vector.rs:96-99; get_base = k 1) for n positions; k in [1,32].
  * A position whose k-mer does not lie inside the vector (the reference asserts pos < len) gives KMX_E_ARG. */
 int kmx_seqvec_get_kmers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_bases, const uint64_t *d_pos, uint64_t n,
                          uint32_t k, uint64_t *d_out);
-/* SeqVectorSlice::iter_kmers(k) (seq_vector.rs:56-63, 236-243) over the slice [start, end): end-start-k+1 forward
+/* SeqVectorSlice::iter_kmers(k) (seq_vector.rs:64-71, 117-124) over the slice [start, end): end-start-k+1 forward
  * words (not canonicalised), in order. */
 int kmx_seqvec_iter_kmers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_bases, uint64_t start, uint64_t end,
                           uint32_t k, uint64_t *d_out);
@@ -285,7 +285,7 @@ int kmx_seqvec_canonical_reduce(kmx_ctx *ctx, const uint64_t *d_words, uint64_t 
  * sub-word of `width` bases and its offset.  1 <= width <= k <= 32. */
 int kmx_minimizer_words(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n, uint32_t k, uint32_t width, uint32_t hasher,
                         uint32_t hasher_k, uint64_t *d_mmer, uint32_t *d_offset);
-/* SeqVectorSlice::iter_minimizers(k, w, hasher) (seq_vector.rs:65-72; SeqVecMinimizerIter, minimizers.rs:39-141) for
+/* SeqVectorSlice::iter_minimizers(k, w, hasher) (seq_vector.rs:73-80; SeqVecMinimizerIter, minimizers.rs:39-141) for
  * every read slice [r*read_len, (r+1)*read_len) of a SeqVector: MappedMinimizer{word, pos} per k-mer, slot
  * r*(read_len-k+1) + i, pos relative to the slice.  read_len >= k (the iterator asserts it), 1 <= w <= k, w <= 32. */
 int kmx_seqvec_minimizers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_reads, uint32_t read_len, uint32_t k,

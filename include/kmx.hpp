@@ -408,7 +408,7 @@ class SeqVector {
     explicit SeqVector(const std::string& s, Context& ctx = Context::instance()) : ctx_(&ctx) { push_chars(s); }                 // From<&String>, :323-329
     size_t len() const { return n_; }              // :208-210
     bool is_empty() const { return n_ == 0; }      // :212-214
-    void push_chars(const std::string& bytes) {    // :241-262 (panics on a non-ACGTacgt byte like Kmer::from)
+    void push_chars(const std::string& bytes) {    // :141-161 (panics on a non-ACGTacgt byte like Kmer::from)
         if (bytes.empty()) return;
         reserve(n_ + bytes.size());
         DeviceBuffer<uint8_t> d(*ctx_, reinterpret_cast<const uint8_t*>(bytes.data()), bytes.size());
@@ -418,7 +418,7 @@ class SeqVector {
         ctx_->check(st, "SeqVector::push_chars");
         n_ += bytes.size();
     }
-    uint64_t get_kmer_u64(size_t pos, size_t k) const {   // :217-220 (assert!(pos < len))
+    uint64_t get_kmer_u64(size_t pos, size_t k) const {   // :96-99 (assert!(pos < len))
         DeviceBuffer<uint64_t> p(*ctx_, 1), o(*ctx_, 1);
         const uint64_t pp = pos;
         p.upload(&pp, 1);
@@ -429,7 +429,7 @@ class SeqVector {
     }
     Kmer get_kmer(size_t pos, size_t k) const { return Kmer::from_u64(get_kmer_u64(pos, k), static_cast<uint8_t>(k)); }   // :212-215
     uint64_t get_base(size_t pos) const { return get_kmer_u64(pos, 1); }                                                 // :222-224
-    std::vector<uint64_t> iter_kmers(size_t k, size_t start = 0, size_t end = SIZE_MAX) const {   // :236-243 (+ slice, :226-234)
+    std::vector<uint64_t> iter_kmers(size_t k, size_t start = 0, size_t end = SIZE_MAX) const {   // :117-124 (+ slice, :226-234)
         if (end == SIZE_MAX) end = n_;
         const size_t cnt = end - start >= k ? end - start - k + 1 : 0;
         if (cnt == 0) return {};
@@ -437,7 +437,7 @@ class SeqVector {
         ctx_->check(kmx_seqvec_iter_kmers(ctx_->get(), words_->data(), n_, start, end, static_cast<uint32_t>(k), o.data()), "SeqVector::iter_kmers");
         return o.download();
     }
-    std::string to_string() const {   // String::from(&SeqVector), :272-284
+    std::string to_string() const {   // String::from(&SeqVector), :171-182
         if (n_ == 0) return {};
         DeviceBuffer<uint8_t> o(*ctx_, n_);
         ctx_->check(kmx_seqvec_to_bytes(ctx_->get(), words_->data(), n_, o.data()), "SeqVector::to_string");
@@ -457,7 +457,7 @@ class SeqVector {
         uint64_t as_u64() const { return word; }
         bool operator==(const MappedMinimizer& o) const { return word == o.word && pos == o.pos; }
     };
-    // iter_minimizers(k, w, LexHasherState::new(lex_hasher_k)) collected (seq_vector.rs:245-252; minimizers.rs:39-141)
+    // iter_minimizers(k, w, LexHasherState::new(lex_hasher_k)) collected (seq_vector.rs:126-133; minimizers.rs:39-141)
     std::vector<MappedMinimizer> iter_minimizers(size_t k, size_t w, size_t lex_hasher_k) const {
         if (n_ < k) throw Panic(KMX_E_ARG, "SeqVecMinimizerIter::new: assertion failed: sv.len() >= k");
         const size_t cnt = n_ - k + 1;

@@ -261,14 +261,14 @@ class Context:
     # ---- SeqVector (src/naive_impl/seq_vector.rs): 2-bit packed sequences on the device
     @_on_ctx_stream
     def seqvec_from_bytes(self, data: torch.Tensor, n: int | None = None) -> torch.Tensor:
-        """SeqVector::from(&[u8]) (seq_vector.rs:346-358): ceil(n/32) u64 words (as int64 tensor), base i at bits [2i,2i+1]"""
+        """SeqVector::from(&[u8]) (seq_vector.rs:230-242): ceil(n/32) u64 words (as int64 tensor), base i at bits [2i,2i+1]"""
         n = data.numel() if n is None else n
         words = torch.zeros((n + 31) // 32 + 2, dtype=torch.int64, device=self.device)[: (n + 31) // 32]
         return self.seqvec_push_chars(words, 0, data, n)
 
     @_on_ctx_stream
     def seqvec_push_chars(self, words: torch.Tensor, n_before: int, data: torch.Tensor, n: int | None = None) -> torch.Tensor:
-        """SeqVector::push_chars (seq_vector.rs:241-262): append n ASCII bases after the n_before already stored"""
+        """SeqVector::push_chars (seq_vector.rs:141-161): append n ASCII bases after the n_before already stored"""
         n = data.numel() if n is None else n
         bad = C.c_uint64()
         st = self.lib.kmx_seqvec_push_chars(self._h, _ptr(words) if words.numel() else None, n_before, _ptr(data) if n else None, n, C.byref(bad))

@@ -55,6 +55,20 @@ __device__ __forceinline__ u64 uniform_u64(u64 v) {
     return ((u64)hi << 32) | lo;
 }
 
+// the lane id, rematerialised where it is wanted (two VALU instructions that nothing can hoist): at a cold use site of a long kernel
+// the alternative is a register held -- or spilled and reloaded behind an s_waitcnt vmcnt(0), with the next tile's rows in flight -- across the tile loop
+__device__ __forceinline__ u32 lane_now() {
+    u32 r;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(r));
+    return r;
+}
+
+// the word of a wave-uniform 64-bit mask that belongs to this lane's half-wave (lanes 0..31: the low word).  hipcc turns
+// `half ? (u32)(x >> 32) : (u32)x` into a 64-bit shift by a VGPR holding 32 * half -- one more value kept across the tile loop, and in the
+// variants that run at their register limit the one that gets spilled: its reload sat in the middle of every tile behind an
+// s_waitcnt vmcnt(0), i.e. behind the next tile's rows (round 5; the 13-word segment variant had three of them per tile)
+__device__ __forceinline__ u32 half_word(u64 x) { return (u32)(x >> (lane_now() & 32u)); }
+
 // one step of the fw<rc ripple: lt' = (~a & ~q) | ((a ^ q) & lt) as a single v_bitop3_b32
 // (truth table with S0=lt=0xF0, S1=a=0xCC, S2=q=0xAA: 0x11 | (0x66 & 0xF0) = 0x71)
 __device__ __forceinline__ u32 ripple(u32 lt, u32 a, u32 q) { return __builtin_amdgcn_bitop3_b32(lt, a, q, 0x71); }
@@ -113,17 +127,24 @@ constexpr int bs_acc_blocks(int K) { return (K + 30) / 16 + 1; }
 // Waves per SIMD a variant is compiled for.  With 16 (bs_acc_blocks(K) - 1) accumulators and the prefetch rows of a tile in
 // registers the kernels need 100..168 registers: three waves (measured round 4: a 32-accumulator form at four waves was 3 %
 // slower than the 64-accumulator one at three -- profiles/r04_mfma_variants.txt; the short frames that fit 128 registers run
-// at four).  The ragged variants (176..248 registers) and the two-word k on the 13- and 16-word frames run at two.  The ragged
-// 10-word frame at three waves spills 8..68 bytes and measured 4..10 % faster -- and one build of it returned a wrong
-// sum_canon on 1.2e6 segments of 1000-base reads (tests/test_gpu_round4.py::test_long_uniform_reads_at_size) while a build
-// that differed by the order of two conjuncts passed: a spill-dependent miscompare not understood yet, so no ragged variant
-// is compiled into spills.
+// at four).  The two-word k on the 13- and 16-word frames run at two.  Round 4 lost a build of the ragged 10-word frame at three waves
+// (68 bytes of spills) that returned a wrong sum_canon on 1.2e6 segments of 1000-base reads while a build that differed by the order of
+// two conjuncts passed; round 5 could not get it back (three reconstructions pass: DESIGN section 7) -- the full-input oracle compare
+// and the at-size tests of every ragged frame (tests/test_gpu_fullsize.py, test_gpu_round5.py) are what guards these variants now.
 // (SEG with two-word k: the segment bookkeeping on top of the two-word frame spilled 32..80 bytes at three waves -- same rule.
 // SEG in the 13-word frame, k >= 18: 16 bytes at three waves, which measured 13 % faster than two waves without any (1 000-base
 // reads 0.62 against 0.55 of the roofline) -- kept, and held against the oracle at size by
 // tests/test_gpu_round4.py::test_long_uniform_segments_at_size.)
+// (Round 5: the single-word ragged variants on the 7- and the 10-word frame run at THREE waves.  Round 4 had measured that at +4..10 %
+// with 8..68 bytes of spills; what those spills really cost was where their reloads sat: three per tile, each behind an
+// s_waitcnt vmcnt(0) -- i.e. behind the next tile's rows, the software pipeline drained three times a tile.  With the lane id and
+// the half-wave selects rematerialised at their cold use sites (lane_now, half_word) and the wave's LDS bases scalar, what is left
+// in scratch (0..16 bytes) is parked across the tile loop and read in the epilogue or on a rare path only -- no scratch access on the
+// loop's main path (tools/asm_loop_scratch.py) -- and three waves are +15 % on 2 %-trimmed 150-base reads (3.41 -> 2.97 ms per 1e8,
+// 0.63 of the roofline; profiles/r05_ragged_3waves_final.txt).  The two-word ragged variants (200..350 bytes at three waves, most
+// of it inside the loop) and the 16-word frame (235..250 registers) stay at two.)
 template <int K, int NW, int WPL, bool PACKED, bool RAGGED, bool SEG = false> constexpr int bs_waves() {
-    return (RAGGED || (K > 32 && (NW > 10 || SEG))) ? 2 : 3;
+    return ((RAGGED && (NW > 10 || K > 32)) || (K > 32 && (NW > 10 || SEG))) ? 2 : 3;
 }
 // tiles between two folds of the fp32 accumulators into the 64-bit class sums: a power of two, far below the 2^24 / (8 window
 // blocks x 64 reads) the sums stay exact integers for, and small enough that the full-size runs (~500 tiles per wave) exercise
@@ -180,7 +201,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     static_assert(PLANES >= 2 * RW * S2 && PLANES >= 32 * NW, "plane area");
     const u32 lane = threadIdx.x & 63u;
     const u32 half = lane >> 5, p = lane & 31u;
-    const u32 wib = threadIdx.x >> 6;
+    const u32 wib = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform, and only readfirstlane tells hipcc so: the LDS bases derived from it are scalars, not registers held -- or spilled -- across the tile loop)
     const u32 chunks = 4u * L + ((RAGGED || SEG || lead != 0u) ? 1u : 0u);   // 16-byte chunks a tile may span (+1 for an unaligned start)
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
     u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
@@ -244,8 +265,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // the two offsets of a lane are requested one iteration before anything looks at them (meta_issue / meta_finish)
     u64 raw_o0 = 0, raw_o1 = 0;
     auto meta_issue = [&](u64 t) {
-        raw_o0 = offsets[t * 64u + lane];
-        raw_o1 = ends[t * 64u + lane];
+        const u32 ln = lane_now();
+        raw_o0 = offsets[t * 64u + ln];
+        raw_o1 = ends[t * 64u + ln];
     };
     auto meta_finish = [&](TileMeta& m) {
         const u64 o0 = raw_o0, o1 = raw_o1;
@@ -311,7 +333,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
     auto seg_lane = [&](const SegTile& g) {          // seg_rel / seg_short of the tile that becomes current
         u32 di, j;
-        seg_div(g.j0 + lane, di, j);
+        seg_div(g.j0 + lane_now(), di, j);
         seg_rel = di * seg.L + seg_pos(j) - seg_pos(g.j0);    // (mod 2^32: the true difference is below 64 L)
         seg_short = __ballot(j >= seg.J1);
     };
@@ -497,7 +519,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // Rows of the next tile requested LATE (between pass 1 and pass 2 of phase D) instead of right behind phase A.  The 10-word
     // frame at up to four windows per lane (k = 22..31 on 150-base reads): none -- since the ticket is no longer waited for at once
     // (see ticket_issue) the whole tile requested early is +2 % (160-168 registers, no spills); at five windows per lane the
-    // same costs 8-16 bytes of spills and 7 %, and stays at five late rows.
+    // same costs 8-16 bytes of spills and 7 %, and stays at five late rows.  (The ragged 10-word frame keeps five late rows: at two waves
+    // none measured +3 % at up to four windows per lane and -12 % at five -- profiles/r05_ragged_variants.txt -- and at three waves,
+    // where it runs since round 5, the registers are not there.)
     constexpr int LATE = PACKED ? 0 : NW == 10 ? ((K > 32 || RAGGED || SEG || WPL > 4) ? 5 : 0) : NW < 10 ? (K > 32 ? 0 : 3) : NW == 13 ? 7 : 8;
     u64 tile = ~0ull, next_tile = ~0ull;
     bool seg_ld_next = false;         // SEG: issue_loads is asked for the next tile (nx_g), not for the current one (cur_g)
@@ -757,7 +781,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             // validity: bit o of word o/32 = window o lies inside the read
             const u32 wr = len ? len - (u32)K + 1u : 0u;
-            atomicAdd(reinterpret_cast<unsigned long long*>(&NVR[lane]), (unsigned long long)wr);   // ds_add_u64, no return
+            atomicAdd(reinterpret_cast<unsigned long long*>(&NVR[lane_now()]), (unsigned long long)wr);   // ds_add_u64, no return
             {
                 // Validity planes without transposes: V_o (bit r = read r owns window o <=> wr_r > o) = OR over i > o of E_i,
                 // E_i = the reads with wr == i.  The reads mark E (in the plane area, free until the planes are stored at the end
@@ -774,7 +798,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 const bool is_ref = wr == ref;
                 const u64 bref = __ballot(is_ref);
                 u32* const emh = EM + half * EMS;
-                if (!is_ref) atomicOr(emh + wr, 1u << p);
+                if (!is_ref) atomicOr(emh + wr, 1u << (lane_now() & 31u));
                 if (p == 0u) atomicOr(emh + ref, half ? (u32)(bref >> 32) : (u32)bref);
                 lds_fence();
                 const u32 ob = (u32)NV * (31u - p);
@@ -884,7 +908,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             if constexpr (SEG) {
                 // the planes of bases W-1 .. W+K-2 (the last window) restricted to the short segments: what the closed form takes back out
-                const u32 sh_half = half ? (u32)(seg_short >> 32) : (u32)seg_short;
+                const u32 sh_half = half_word(seg_short);
                 if (seg_short != 0ull) {
                     u32* const tots_l = TOTS + lane;
 #pragma unroll
@@ -986,14 +1010,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             if constexpr (INLINE) {
                 if (valid_reads != ~0ull) {   // (wave-uniform; a clean tile pays the branch)
-                    const u32 vm = set ? (u32)(valid_reads >> 32) : (u32)valid_reads;
+                    const u32 vm = half_word(valid_reads);
 #pragma unroll
                     for (int w = 0; w < WPL; ++w) m[w] &= vm;
                 }
             }
             if constexpr (SEG) {
                 if (seg_short != 0ull) {      // (wave-uniform)
-                    const u32 keep = ~(set ? (u32)(seg_short >> 32) : (u32)seg_short);
+                    const u32 keep = ~half_word(seg_short);
                     const u32 ws = W - 1u - o;                 // which of the lane's windows is window W-1 (none: >= WPL)
 #pragma unroll
                     for (int w = 0; w < WPL; ++w) m[w] = (u32)w == ws ? m[w] & keep : m[w];
@@ -1117,7 +1141,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 const u64 row = __ballot(c < n_chunks && chunk_has_invalid(rb));
                 if (lane == 0) BM[it] = row;
             }
-            if (lane == 0) { BM[NW] = 0; BM[NW + 1] = 0; }
+            if (lane == 0) {
+                u32 z = 0;                       // (made here: as a constant the 64-bit zero was kept -- spilled -- across the tile loop for this rare path)
+                asm volatile("" : "+v"(z));
+                reinterpret_cast<u32*>(BM + NW)[0] = z; reinterpret_cast<u32*>(BM + NW)[1] = z;
+                reinterpret_cast<u32*>(BM + NW)[2] = z; reinterpret_cast<u32*>(BM + NW)[3] = z;
+            }
             lds_fence();
             u32 rd_off = lane * L + lead, rd_len = L;    // the read's bytes, relative to the tile's aligned start
             if constexpr (RAGGED) { rd_off = cur_m.rel; rd_len = cur_m.len; }

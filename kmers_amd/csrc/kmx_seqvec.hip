@@ -1,12 +1,12 @@
 // kmx_seqvec.hip -- SeqVector: the 2-bit packed sequence container of the reference
 // (src/naive_impl/seq_vector.rs) as batch device operations.
 //
-// Layout (seq_vector.rs:346-358 builds it from Kmer::from of 32-base chunks; RawVector is LSB-first): base i occupies
+// Layout (seq_vector.rs:230-242 builds it from Kmer::from of 32-base chunks; RawVector is LSB-first): base i occupies
 // flat bits [2i, 2i+1] of a little-endian u64 word array, codes A0 C1 G2 T3; bits past 2*len are zero.
-//   push_chars / From<&[u8]>   seq_vector.rs:241-262, 346-358   -> seqvec_push_kernel (strict: Kmer::from panics on a bad base)
-//   get_kmer_u64 / get_base    seq_vector.rs:217-224            -> seqvec_get_kmers_kernel
-//   iter_kmers                 seq_vector.rs:236-243, 417-428   -> seqvec_iter_kmers_kernel
-//   String::from(&SeqVector)   seq_vector.rs:272-284            -> seqvec_to_bytes_kernel
+//   push_chars / From<&[u8]>   seq_vector.rs:141-161, 230-242   -> seqvec_push_kernel (strict: Kmer::from panics on a bad base)
+//   get_kmer_u64 / get_base    seq_vector.rs:96-103            -> seqvec_get_kmers_kernel
+//   iter_kmers                 seq_vector.rs:117-124, 341-357   -> seqvec_iter_kmers_kernel
+//   String::from(&SeqVector)   seq_vector.rs:171-182            -> seqvec_to_bytes_kernel
 //   Kmer::minimizer_word       kmer.rs:170-192                  -> minimizer_words_kernel
 //   SeqVecMinimizerIter        seq_vector/minimizers.rs:39-141  -> seqvec_minimizers_kernel
 // and, for reads stored back to back as L-base slices (SeqVector::slice, :226-234), the canonical k-mer scan of
@@ -60,7 +60,7 @@ seqvec_get_kmers_kernel(const u64* __restrict__ words, u64 n_bases, const u64* _
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
         const u64 p = pos[e];
-        if (p >= n_bases || p + k > n_bases) {   // assert!(pos < self.len()), seq_vector.rs:218; the field must lie inside the vector
+        if (p >= n_bases || p + k > n_bases) {   // assert!(pos < self.len()), seq_vector.rs:97; the field must lie inside the vector
             atomicMin(first_bad, (unsigned long long)e);
             out[e] = 0;
         } else {

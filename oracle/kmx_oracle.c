@@ -657,7 +657,7 @@ static uint64_t rawvec_int(const uint64_t *words, size_t n_words, size_t bit_off
 int kmo_seqvec_push_chars(uint64_t *words, size_t n_before, const uint8_t *bytes, size_t n, size_t *bad_index) {
     size_t bit_len = 2 * n_before;
     if ((bit_len & 63) != 0) words[bit_len >> 6] &= (((uint64_t)1 << (bit_len & 63)) - 1);   /* RawVector keeps the tail zero */
-    size_t first_word_len = n % 32;   /* seq_vector.rs:242-243 */
+    size_t first_word_len = n % 32;   /* seq_vector.rs:142-143 */
     size_t done = 0;
     while (done < n) {
         size_t chunk = (done == 0 && first_word_len) ? first_word_len : 32;
@@ -683,7 +683,7 @@ int kmo_seqvec_get_kmer_u64(const uint64_t *words, size_t n_bases, size_t pos, s
 }
 
 void kmo_seqvec_to_bytes(const uint64_t *words, size_t n_bases, uint8_t *out) {
-    static const char bases[4] = {'A', 'C', 'G', 'T'};   /* seq_vector.rs:275 */
+    static const char bases[4] = {'A', 'C', 'G', 'T'};   /* seq_vector.rs:174 */
     for (size_t i = 0; i < n_bases; ++i) {
         uint64_t b = 0;
         kmo_seqvec_get_kmer_u64(words, n_bases, i, 1, &b);

@@ -150,16 +150,16 @@ int kmo_compute_naive_canonical(const uint8_t *b, size_t len, size_t K, uint64_t
 
 /* ---- SeqVector (src/naive_impl/seq_vector.rs) ----
  * `words`: little-endian u64 array, base i at flat bits [2i,2i+1] (RawVector is LSB-first; From<&[u8]> stores
- * Kmer::from(32-base chunk).into_u64() per word, seq_vector.rs:346-358). */
-/* push_chars (seq_vector.rs:241-262): first len%32 bases, then 32-base chunks, each via Kmer::from + push_int.
+ * Kmer::from(32-base chunk).into_u64() per word, seq_vector.rs:230-242). */
+/* push_chars (seq_vector.rs:141-161): first len%32 bases, then 32-base chunks, each via Kmer::from + push_int.
  * n_before = bases already stored; returns KMO_E_INVALID_BASE (with *bad_index) where Kmer::from would panic. */
 int kmo_seqvec_push_chars(uint64_t *words, size_t n_before, const uint8_t *bytes, size_t n, size_t *bad_index);
-/* get_kmer_u64 (seq_vector.rs:217-220): RawVector::int(pos*2, k*2); KMO_E_ARG where the reference asserts (pos >= len)
+/* get_kmer_u64 (seq_vector.rs:96-99): RawVector::int(pos*2, k*2); KMO_E_ARG where the reference asserts (pos >= len)
  * or where the field would leave the vector */
 int kmo_seqvec_get_kmer_u64(const uint64_t *words, size_t n_bases, size_t pos, size_t k, uint64_t *out);
-/* String::from(&SeqVector) (seq_vector.rs:272-284) */
+/* String::from(&SeqVector) (seq_vector.rs:171-182) */
 void kmo_seqvec_to_bytes(const uint64_t *words, size_t n_bases, uint8_t *out);
-/* iter_kmers over slice [start,end) (seq_vector.rs:56-63,417-428): end-start-k+1 forward words; returns the count */
+/* iter_kmers over slice [start,end) (seq_vector.rs:64-71,341-357): end-start-k+1 forward words; returns the count */
 size_t kmo_seqvec_iter_kmers(const uint64_t *words, size_t n_bases, size_t start, size_t end, size_t k, uint64_t *out);
 /* canonical scan of reads stored back to back (read r = slice [r*L,(r+1)*L)): every k-mer of every slice via
  * get_kmer_u64 + Kmer::to_canonical (kmer.rs:68-74); same summary as kmo_canonical_reduce on the decoded letters */

@@ -671,7 +671,7 @@ def test_seqvec_from_bytes_to_bytes_push(ctx, orc):
         words = ctx.seqvec_from_bytes(ctx.to_device(host))
         assert (words.cpu().numpy().view(np.uint64) == sv.words[: (n + 31) // 32]).all(), n
         assert ctx.seqvec_to_bytes(words, n).cpu().numpy().tobytes() == host.tobytes().upper()
-    # push_chars in pieces == one from(); seq_vector.rs:241-262
+    # push_chars in pieces == one from(); seq_vector.rs:141-161
     import torch
 
     n = 700

@@ -40,29 +40,33 @@ def test_bitsliced_kernels_stay_out_of_scratch(kernels):
             continue
         seen += 1
         assert d["Dynamic Stack"] == "False", name
-        # (round 4: the 16-word frame at 8 windows per lane -- reads of 256 bases -- keeps 72 bytes of spills at three waves per
-        # SIMD, measured 4 % faster than two waves without any)
-        assert int(d["ScratchSize [bytes/lane]"]) <= 80, (name, d["ScratchSize [bytes/lane]"])
-        # the ragged variants and the segment variants (long uniform reads): no spills at all (round 4: a spill-dependent wrong
-        # sum at size).  Template flags: PACKED, RAGGED, SEG.
+        # Round 5: with the lane id and the half-wave selects rematerialised at their cold use sites and the wave's LDS bases scalar,
+        # no variant keeps more than 28 bytes in scratch (round 4: up to 80), and what is left is parked across the tile loop for the
+        # epilogue or a rare path -- the loop's main path touches no scratch (tools/asm_loop_scratch.py on a --keep-asm build; a
+        # reload there waits with vmcnt(0) behind the next tile's rows: that, not the spill itself, is what three waves used to cost)
+        assert int(d["ScratchSize [bytes/lane]"]) <= 32, (name, d["ScratchSize [bytes/lane]"])
+        # the ragged variants (three waves on the 7- / 10-word frame since round 5) and the segments of long uniform reads: <= 16 bytes.
+        # Template flags: PACKED, RAGGED, SEG.
         if re.search(r"ELb0ELb1ELb0EEEv|ELb0ELb0ELb1EEEv", name):
-            # (the segments of long reads in the 13-word frame: 16 bytes at three waves, 13 % faster than two waves without)
-            allowed = 16 if re.search(r"ELi13ELi6ELb0ELb0ELb1EEEv", name) else 0
-            assert int(d["ScratchSize [bytes/lane]"]) <= allowed, (name, d["ScratchSize [bytes/lane]"])
+            assert int(d["ScratchSize [bytes/lane]"]) <= 16, (name, d["ScratchSize [bytes/lane]"])
     assert seen >= 100   # every k of the three families, every frame
 
 
 def test_headline_kernel_occupancy(kernels):
     """k = 31, 150 bp (10-word frame, 4 windows per lane): 3 waves per SIMD since pass 2 runs on the matrix pipe (64 fp32
     accumulators, the first and the last block pair sharing one block; four waves of a 32-accumulator form measured slower);
-    the ragged variants 2 (never compiled into spills: see bs_waves), two-word k = 63: 3"""
+    the single-word ragged variants on the 7- / 10-word frame 3 since round 5 (bs_waves), the 16-word ragged frame and the two-word
+    ragged variants 2, two-word k = 63: 3"""
     def occ(pattern):
         hits = [d for n, d in kernels.items() if re.search(pattern, n)]
         assert len(hits) == 1, (pattern, len(hits))
         return int(hits[0]["Occupancy [waves/SIMD]"])
     assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0ELb0EEEv") == 3
-    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb1ELb0EEEv") == 2
-    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi5ELb0ELb1ELb0EEEv") == 2
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb1ELb0EEEv") == 3
+    assert occ(r"scan_bitsliced_kernelILi31ELi10ELi5ELb0ELb1ELb0EEEv") == 3
+    assert occ(r"scan_bitsliced_kernelILi31ELi7ELi3ELb0ELb1ELb0EEEv") == 3
+    assert occ(r"scan_bitsliced_kernelILi31ELi16ELi5ELb0ELb1ELb0EEEv") == 2
+    assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb1ELb0EEEv") == 2
     assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb0ELb0EEEv") == 3
     assert occ(r"scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0ELb1EEEv") == 3   # segments of long uniform reads
     assert occ(r"scan_bitsliced_kernelILi63ELi10ELi4ELb0ELb0ELb1EEEv") == 2
