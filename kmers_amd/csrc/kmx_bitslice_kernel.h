@@ -1531,7 +1531,10 @@ struct BsSegPlan { u32 J, J1, T, NW; };
 static inline BsSegPlan bs_seg_plan(u32 L, u32 k) {
     const u32 wr = L - k + 1u;
     const u32 t10 = 160u - k < 128u ? 160u - k : 128u, t13 = 208u - k < 192u ? 208u - k : 192u;
-    const u32 t_max = t13;   // (two-word k too, round 5: see launch_bs_seg)
+    // (two-word k too, round 5: see launch_bs_seg -- from k = 37 up: below, the 10-word frame's segments of >= 124 windows re-read only a
+    // quarter of their bases and its four windows per lane beat the 13-word frame's six -- k = 33 on 10 000-base reads 0.59 against 0.55,
+    // k = 41 on 1 000-base reads 0.45 against 0.53: profiles/r05_seg2_frames.txt)
+    const u32 t_max = (k > 32u && k <= 36u) ? t10 : t13;
     const u32 J = (wr + t_max - 1u) / t_max, T = (wr + J - 1u) / J;
     return BsSegPlan{J, J - (J * T - wr), T, (T <= t10) ? 10u : 13u};
 }

@@ -208,7 +208,7 @@ int kmo_canonical_windows2(const uint8_t *reads, size_t n_reads, size_t read_len
                            const uint64_t *win_offsets, uint8_t k,
                            uint64_t *out_fw2, uint64_t *out_rc2, uint64_t *out_canon2, uint8_t *out_flags);
 /* FASTA/FASTQ record splitting -- BUILD-DEFINED: the reference has no parser, so nothing pins
- * this; the Python restatement (oracle.fastx_parse, written from the prose spec in DESIGN.md with bytes.split) and
+ * this; the Python restatement (oracle.fastx_parse, written from the prose spec at the top of kmers_amd/csrc/kmx_fastx.hip with bytes.split) and
  * this byte-at-a-time state machine are checked against each other.
  * format: 1 = FASTQ (strict 4-line records: line i is a read iff i % 4 == 1), 2 = FASTA ('>' lines start a record,
  * all other lines up to the next '>' line are its sequence), 0 = by the first byte ('@' / '>').  Lines end at '\n';

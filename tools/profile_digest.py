@@ -85,7 +85,7 @@ if d:
 s = line(os.path.join(src, "bench_sustained3000.json"))
 if s:
     out.append(f"3000 back-to-back steps (`{tag}_bench_sustained3000.json`): {s['sustained']['ms_per_step']:.3f} ms per step = **{s['sustained']['frac']:.3f}** of the roofline.")
-out += ["", f"Counter passes (`{tag}_pmc_summary.txt`, separate `--pmc` runs, no tracing flags): see DESIGN.md 4.2 for the digest."]
+out += ["", f"Counter passes (`{tag}_pmc_summary.txt`, separate `--pmc` runs, no tracing flags): see DESIGN.md 4.1 / profiles/HISTORY.md for the digest."]
 with open(os.path.join(dst, f"{tag}_kernel_trace_summary.md"), "w") as f:
     f.write("\n".join(out) + "\n")
 print("\n".join(out))
