@@ -659,7 +659,7 @@ def worker(args, traffic_raw=None, traffic_err=None):
         elif seg_kernel:
             # reads above 256 bases: equal overlapping segments on the uniform kernel (bs_seg_plan in kmx_bitslice_kernel.h)
             wr, t10 = L - k + 1, min(128, 160 - k)
-            t_max = t10 if 32 < k <= 36 else min(192, 208 - k)
+            t_max = t10 if 32 < k <= 49 else min(192, 208 - k)
             n_seg = -(-wr // t_max)
             t_seg = -(-wr // n_seg)
             kernel_name = "kmx::scan_bitsliced_kernel<%d,%d,*,SEG> (%d segments of %d windows per read)" % (k, 10 if t_seg <= t10 else 13, n_seg, t_seg)

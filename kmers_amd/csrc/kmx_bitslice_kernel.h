@@ -131,10 +131,10 @@ constexpr int bs_acc_blocks(int K) { return (K + 30) / 16 + 1; }
 // (68 bytes of spills) that returned a wrong sum_canon on 1.2e6 segments of 1000-base reads while a build that differed by the order of
 // two conjuncts passed; round 5 could not get it back (three reconstructions pass: DESIGN section 7) -- the full-input oracle compare
 // and the at-size tests of every ragged frame (tests/test_gpu_fullsize.py, test_gpu_round5.py) are what guards these variants now.
-// (SEG with two-word k: the segment bookkeeping on top of the two-word frame spilled 32..80 bytes at three waves -- same rule.
-// SEG in the 13-word frame, k >= 18: 16 bytes at three waves, which measured 13 % faster than two waves without any (1 000-base
-// reads 0.62 against 0.55 of the roofline) -- kept, and held against the oracle at size by
-// tests/test_gpu_round4.py::test_long_uniform_segments_at_size.)
+// (Two-word k, round 4: the 13- and 16-word frames and every segment variant at two waves -- 32..270 bytes of spills at three.  Since
+// round 5's register diet the 13-word frame and the 10-word segment variant fit three waves up to k = 49 with nothing in scratch
+// (uniform 208-base reads at k = 47: profiles/r05_two_word_3waves.txt); the single-word segment variant in the 13-word frame, which
+// kept 16 bytes at three waves in round 4, keeps none.)
 // (Round 5: the single-word ragged variants on the 7- and the 10-word frame run at THREE waves.  Round 4 had measured that at +4..10 %
 // with 8..68 bytes of spills; what those spills really cost was where their reloads sat: three per tile, each behind an
 // s_waitcnt vmcnt(0) -- i.e. behind the next tile's rows, the software pipeline drained three times a tile.  With the lane id and
@@ -144,7 +144,8 @@ constexpr int bs_acc_blocks(int K) { return (K + 30) / 16 + 1; }
 // 0.63 of the roofline; profiles/r05_ragged_3waves_final.txt).  The two-word ragged variants (200..350 bytes at three waves, most
 // of it inside the loop) and the 16-word frame (235..250 registers) stay at two.)
 template <int K, int NW, int WPL, bool PACKED, bool RAGGED, bool SEG = false> constexpr int bs_waves() {
-    return ((RAGGED && (NW > 10 || K > 32)) || (K > 32 && (NW > 10 || SEG))) ? 2 : 3;
+    // two-word k: the 16-word frame, and from k = 50 (six accumulator blocks) the 13-word frame and the segment variants, at two
+    return ((RAGGED && (NW > 10 || K > 32)) || (K > 32 && (NW > 13 || ((NW == 13 || SEG) && K > 49)))) ? 2 : 3;
 }
 // tiles between two folds of the fp32 accumulators into the 64-bit class sums: a power of two, far below the 2^24 / (8 window
 // blocks x 64 reads) the sums stay exact integers for, and small enough that the full-size runs (~500 tiles per wave) exercise
@@ -519,10 +520,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // Rows of the next tile requested LATE (between pass 1 and pass 2 of phase D) instead of right behind phase A.  The 10-word
     // frame at up to four windows per lane (k = 22..31 on 150-base reads): none -- since the ticket is no longer waited for at once
     // (see ticket_issue) the whole tile requested early is +2 % (160-168 registers, no spills); at five windows per lane the
-    // same costs 8-16 bytes of spills and 7 %, and stays at five late rows.  (The ragged 10-word frame keeps five late rows: at two waves
+    // same cost 8-16 bytes of spills and 7 % in round 4; since round 5's register diet it fits without a spill up to k = 17 (three waves
+    // instead of four with five late rows: k = 13 / 17 0.74 -> 0.78) and with ONE late row from k = 18 (k = 21 +1 %; none spills 40 bytes
+    // inside the loop, -8 %) -- profiles/r05_late_rows.txt.  (The ragged 10-word frame keeps five late rows: at two waves
     // none measured +3 % at up to four windows per lane and -12 % at five -- profiles/r05_ragged_variants.txt -- and at three waves,
     // where it runs since round 5, the registers are not there.)
-    constexpr int LATE = PACKED ? 0 : NW == 10 ? ((K > 32 || RAGGED || SEG || WPL > 4) ? 5 : 0) : NW < 10 ? (K > 32 ? 0 : 3) : NW == 13 ? 7 : 8;
+    constexpr int LATE = PACKED ? 0 : NW == 10 ? ((K > 32 || RAGGED || SEG) ? 5 : WPL > 4 ? (K <= 17 ? 0 : 1) : 0) : NW < 10 ? (K > 32 ? 0 : 3) : NW == 13 ? ((K <= 32 && !SEG) ? 3 : 7) : 8;   // (13-word frame, single-word k: 3 late rows +1 % over 7, none spills; 7-word frame: none -3 %: profiles/r05_late_rows.txt)
     u64 tile = ~0ull, next_tile = ~0ull;
     bool seg_ld_next = false;         // SEG: issue_loads is asked for the next tile (nx_g), not for the current one (cur_g)
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
@@ -1531,10 +1534,12 @@ struct BsSegPlan { u32 J, J1, T, NW; };
 static inline BsSegPlan bs_seg_plan(u32 L, u32 k) {
     const u32 wr = L - k + 1u;
     const u32 t10 = 160u - k < 128u ? 160u - k : 128u, t13 = 208u - k < 192u ? 208u - k : 192u;
-    // (two-word k too, round 5: see launch_bs_seg -- from k = 37 up: below, the 10-word frame's segments of >= 124 windows re-read only a
-    // quarter of their bases and its four windows per lane beat the 13-word frame's six -- k = 33 on 10 000-base reads 0.59 against 0.55,
-    // k = 41 on 1 000-base reads 0.45 against 0.53: profiles/r05_seg2_frames.txt)
-    const u32 t_max = (k > 32u && k <= 36u) ? t10 : t13;
+    // Two-word k (round 5): up to k = 49 -- five accumulator blocks -- the 10-word frame's segment variant fits three waves with nothing in
+    // scratch inside the tile loop, and beats the 13-word frame at two waves although it re-reads more (k = 33 on 10 000-base reads
+    // 0.64 against 0.55, k = 36 / 37 on 1 000-base reads 0.58 against 0.50 / 0.52, k = 41 on 300-base reads 0.54 against 0.50; on
+    // 1 000-base reads k = 41 is a tie, 0.52 / 0.53); from k = 50 the 13-word frame at two waves (k = 63 on 1 000-base reads 0.45 against
+    // the 10-word frame's 0.43 at two waves; at three it spills inside the loop) -- profiles/r05_seg2_frames.txt, r05_seg2_3waves.txt.
+    const u32 t_max = (k > 32u && k <= 49u) ? t10 : t13;
     const u32 J = (wr + t_max - 1u) / t_max, T = (wr + J - 1u) / J;
     return BsSegPlan{J, J - (J * T - wr), T, (T <= t10) ? 10u : 13u};
 }
@@ -1548,12 +1553,11 @@ static hipError_t launch_bs_seg(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
     const u32 Lf = pl.T + (u32)K - 1u;
     if constexpr (K <= 31) {
         if (pl.NW == 13u) return launch_bs<K, 13, 6, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
-    } else {
-        // Two-word k in the 13-word frame as well (round 5): of a 10-word segment's <= 159 bases k - 1 = 32..63 are shared with the next
-        // one -- 97 windows per 159 bases loaded at k = 63 -- and the 13-word frame's 207 bases hold 145 (1.43 instead of 1.64 bytes
-        // loaded per byte of input).  ONE instantiation per k: T <= 208 - k windows need five windows per lane from k = 48 up, six below.
-        constexpr int WPL13 = (208 - K <= 160) ? 5 : 6;
-        if (pl.NW == 13u) return launch_bs<K, 13, WPL13, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
+    } else if constexpr (K > 49) {
+        // Two-word k from 50 up in the 13-word frame (round 5; bs_seg_plan says why the smaller ones stay in the 10-word frame): of a
+        // 10-word segment's <= 159 bases k - 1 are shared with the next one -- 97 windows per 159 bases loaded at k = 63 -- and the
+        // 13-word frame's 207 bases hold 145 (1.43 instead of 1.64 bytes loaded per byte of input).  T <= 208 - k <= 158: five windows per lane.
+        if (pl.NW == 13u) return launch_bs<K, 13, 5, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
     }
     if (pl.NW != 10u) return hipErrorInvalidValue;
     if (pl.T <= 96u) return launch_bs<K, 10, 3, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
