@@ -76,3 +76,44 @@ def test_scan_and_histogram_kernels_do_not_call(kernels):
     for name, d in kernels.items():
         if "scan_uniform_kernel" in name or "roll_flagged_kernel" in name or "hist_part_reduce_kernel" in name:
             assert d["Dynamic Stack"] == "False", name
+
+
+def test_hot_tile_loops_do_not_touch_scratch(tmp_path):
+    """Round 5: what a spill costs in the bit-sliced scan is WHERE its reload sits -- inside the tile loop it waits with
+    s_waitcnt vmcnt(0) behind the next tile's rows (the ragged scan at three waves lost 10 % to three such reloads per tile).  The
+    hot instantiations are compiled to assembly here (device only, two translation units in parallel, ~1 minute) and every scratch
+    access inside a loop is counted: none on any main path -- the headline kernel <31,10,4> may keep the two reloads of its
+    invalid-byte path (a tile with an N), a ragged kernel the one of its "read of 2^31 bases" path."""
+    import shutil
+    import subprocess
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import asm_loop_scratch
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    sys.path.insert(0, root)
+    from kmers_amd import build as kb
+
+    def asm(src):
+        out = str(tmp_path / (src + ".s"))
+        r = subprocess.run([hipcc, *kb.CXXFLAGS, "--cuda-device-only", "-S", os.path.join(kb.CSRC, src), "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return out
+
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        head, ragged = ex.map(asm, ["kmx_bitslice.hip", "kmx_bitslice_ragged_k29_31.hip"])
+    seen = 0
+    for path in (head, ragged):
+        for name, (_, in_loads, in_stores) in asm_loop_scratch.scan(path, "scan_bitsliced_kernel").items():
+            seen += 1
+            # (the ragged variants: at most the one reload of a 64-bit constant on the path that flags a read of 2^31 bases or more)
+            allowed = 2 if "scan_bitsliced_kernelILi31ELi10ELi4ELb0ELb0ELb0E" in name else 1 if "ELb0ELb1ELb0E" in name else 0
+            if re.search(r"ELi16ELi\dELb1ELb0ELb0E", name):   # the packed 16-word frame (SeqVector reads of 161..256 bases): not a headline path
+                continue
+            assert in_loads <= allowed and in_stores == 0, (name, in_loads, in_stores)
+    assert seen >= 40
