@@ -311,6 +311,19 @@ pub fn canonical_sum(ctx: &HipContext, d_reads: &DeviceBuf<'_>, n_reads: u64, re
     Ok(d_out.download::<kmx_summary>(1)?[0])
 }
 
+/// `hash_one(&state, kmer)` for a batch of k-mer words with one of std's `BuildHasher`s (src/naive_impl/hash.rs:10-20): std's
+/// `DefaultHasher` is SipHash-1-3 and `impl Hash for Kmer` feeds it one `write_u64(data)` (hash.rs:4-8).  `keys` = (0, 0) for
+/// `DefaultHasher::new()` / `BuildHasherDefault<DefaultHasher>`; a `RandomState`'s keys are private to std, so a caller who wants
+/// device hashes equal to host hashes builds its hasher from keys it knows (`SipHasher13::new_with_keys` semantics).
+pub fn hash_words_sip13(ctx: &HipContext, words: &[u64], keys: (u64, u64)) -> Result<Vec<u64>, KmxError> {
+    // (the device takes the words as they lie in memory: little-endian u64, what `write_u64` hashes on every target this library runs beside)
+    let bytes = unsafe { std::slice::from_raw_parts(words.as_ptr() as *const u8, words.len() * 8) };
+    let d_in = ctx.upload(bytes)?;
+    let d_out = ctx.alloc(words.len() * 8)?;
+    ctx.ck(unsafe { kmx_hash_words_sip13(ctx.0, d_in.as_ptr::<u64>(), words.len() as u64, keys.0, keys.1, d_out.as_mut_ptr::<u64>()) })?;
+    d_out.download::<u64>(words.len())
+}
+
 // ------------------------------------------------------------------------------------------------ SeqVector
 
 /// `SeqVector` (src/naive_impl/seq_vector.rs) with its words on the device: same bit layout as the crate's `RawVector`

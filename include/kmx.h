@@ -60,7 +60,8 @@ typedef struct kmx_ctx kmx_ctx;
  * offsets != NULL: ragged layout, read r = d_bases[offsets[r] .. offsets[r+1]) (n_reads+1 device u64); read_len may
  *   then carry an upper bound of the read lengths (0 = unknown): a bound <= 160 selects the smaller, faster frame of the
  *   tiled kernels, and the tighter it is the fewer windows a lane carries (150 bp reads: 7 % faster at k = 31 with 150
- *   than with 160 or 0).  It is only a hint -- tiles with a longer read take the exact per-read path, and the
+ *   than with 160 or 0).  Reads that are all of ONE length up to the bound (no bound: 160) -- untrimmed FASTQ -- are recognised on the
+ *   device and take the uniform kernels whatever the bound says (round 5).  It is only a hint -- tiles with a longer read take the exact per-read path, and the
  *   histogram's work buffer, sized from it, overflows into exact (slow) global atomics.  A bound ABOVE 256 says "long reads"
  *   (PacBio / ONT reads, contigs): kmx_canonical_reduce (13 <= k <= 31), kmx_canonical_reduce2, kmx_canonical_windows and
  *   kmx_canonical_windows2 (16-byte aligned d_bases) then cut every read into overlapping segments on the device and scan those (two
@@ -193,6 +194,15 @@ int kmx_canonical_words(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint32_t
 
 /* hash_one(&state, Kmer) with state = LexHasherState::new(hasher_k) (hash.rs:10-20,60-71) or identity */
 int kmx_hash_words(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint32_t hasher, uint32_t hasher_k, uint64_t *d_out);
+
+/* hash_one(&state, Kmer) with one of std's BuildHashers (hash.rs:10-20; the reference uses DefaultHasher at kmer.rs:546-557 and
+ * RandomState at :564-575): std's DefaultHasher is SipHash-1-3 (one compression round, three finalisation rounds), `Hash for Kmer`
+ * feeds it ONE write_u64(data) (hash.rs:4-8) -- so d_out[i] = SipHash-1-3(key0, key1; the 8 little-endian bytes of d_in[i]).
+ * DefaultHasher::new() / BuildHasherDefault: key0 = key1 = 0; RandomState: its pair of random keys, which the caller holds.
+ * The algorithm lives in Rust's standard library, not in the crate: restated from the SipHash paper (Aumasson, Bernstein 2012);
+ * the restatement reproduces the paper's SipHash-2-4 test vectors through the same round function (tests/test_oracle_golden.py),
+ * and no reference value for 1-3 exists in the crate (its two tests check properties): parity is pinned to that extent. */
+int kmx_hash_words_sip13(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint64_t key0, uint64_t key1, uint64_t *d_out);
 
 /* CanonicalKmer::get_word_equivalency (canonical_kmer.rs:152-161): out[i] in KMX_{NO,IDENTITY,TWIN}_MATCH */
 int kmx_match_words(kmx_ctx *ctx, const uint64_t *d_fw, const uint64_t *d_rc, const uint64_t *d_other, uint64_t n,

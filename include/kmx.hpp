@@ -334,6 +334,16 @@ inline uint64_t hash_one(const LexHasherState& st, const Kmer& km, Context& ctx 
     ctx.check(kmx_hash_words(ctx.get(), in.data(), 1, KMX_HASH_LEX, static_cast<uint32_t>(st.k), out.data()), "hash_one");
     return out.download()[0];
 }
+// hash_one with one of std's BuildHashers (hash.rs:10-20; kmer.rs:546-575): std's DefaultHasher is SipHash-1-3; DefaultHasher::new() has
+// the keys (0, 0), a RandomState its own random pair
+struct SipHasher13State {
+    uint64_t key0 = 0, key1 = 0;
+};
+inline uint64_t hash_one(const SipHasher13State& st, const Kmer& km, Context& ctx = Context::instance()) {
+    DeviceBuffer<uint64_t> in(ctx, &km.data, 1), out(ctx, 1);
+    ctx.check(kmx_hash_words_sip13(ctx.get(), in.data(), 1, st.key0, st.key1, out.data()), "hash_one");
+    return out.download()[0];
+}
 }  // namespace hash
 
 // Batch form of the streaming loop (what the GPU is for): summary over many reads resident on the device.

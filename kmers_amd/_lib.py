@@ -72,6 +72,7 @@ SIGNATURES = {
     "kmx_revcomp_words": (_int, [_vp, _vp, _u64, _u32, _vp]),
     "kmx_canonical_words": (_int, [_vp, _vp, _u64, _u32, _vp, _vp]),
     "kmx_hash_words": (_int, [_vp, _vp, _u64, _u32, _u32, _vp]),
+    "kmx_hash_words_sip13": (_int, [_vp, _vp, _u64, _u64, _u64, _vp]),
     "kmx_match_words": (_int, [_vp, _vp, _vp, _vp, _u64, _vp]),
     "kmx_ck_append_bases": (_int, [_vp, _vp, _vp, _vp, _u64, _u32, _vp]),
     "kmx_ck_prepend_bases": (_int, [_vp, _vp, _vp, _vp, _u64, _u32, _vp]),

@@ -224,6 +224,13 @@ class Context:
         return out
 
     @_on_ctx_stream
+    def hash_words_sip13(self, words: torch.Tensor, key0: int = 0, key1: int = 0) -> torch.Tensor:
+        """hash_one(&DefaultHasher / RandomState, kmer): SipHash-1-3 of each word (kmx_hash_words_sip13)"""
+        out = torch.empty_like(words)
+        self._ck(self.lib.kmx_hash_words_sip13(self._h, _ptr(words), words.numel(), key0 & (2**64 - 1), key1 & (2**64 - 1), _ptr(out)))
+        return out
+
+    @_on_ctx_stream
     def match_words(self, fw, rc, other) -> torch.Tensor:
         out = self.empty(fw.numel(), torch.uint8)
         self._ck(self.lib.kmx_match_words(self._h, _ptr(fw), _ptr(rc), _ptr(other), fw.numel(), _ptr(out)))

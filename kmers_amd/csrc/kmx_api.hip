@@ -89,6 +89,7 @@ hipError_t launch_kmers_from_bytes(const uint8_t* seqs, u64 n, u32 k, u64* words
 hipError_t launch_revcomp_words(const u64* in, u64 n, u32 k, u64* out, int n_cu, hipStream_t st);
 hipError_t launch_canonical_words(const u64* in, u64 n, u32 k, u64* canon, uint8_t* is_canon, int n_cu, hipStream_t st);
 hipError_t launch_hash_words(const u64* in, u64 n, u32 hasher, u32 hk, u64* out, int n_cu, hipStream_t st);
+hipError_t launch_hash_words_sip13(const u64* in, u64 n, u64 k0, u64 k1, u64* out, int n_cu, hipStream_t st);
 hipError_t launch_match_words(const u64* fw, const u64* rc, const u64* other, u64 n, uint8_t* out, int n_cu, hipStream_t st);
 hipError_t launch_ck_shift(bool append, u64* fw, u64* rc, const uint8_t* bases, u64 n, u32 k, uint8_t* dropped, int n_cu,
                            hipStream_t st);
@@ -104,7 +105,7 @@ hipError_t launch_encoding_rev_comp_bytes(const uint8_t* in, u64 n, u32 K, u32 c
 hipError_t launch_encoding_decode_bytes(const uint8_t* in, u64 total_bytes, u32 nuc_lut, uint8_t* seqs, int n_cu, hipStream_t st);
 hipError_t launch_calib_stream_read(const uint8_t* buf, u64 nbytes, unsigned long long* out, int n_cu, hipStream_t st);
 hipError_t launch_length_range(const u64* offsets, u64 n_reads, u32* out, int n_cu, hipStream_t st);
-hipError_t launch_offsets_uniform_gate(const u64* offsets, u64 n_reads, u32 L, u32* gate, int n_cu, hipStream_t st);
+hipError_t launch_offsets_uniform_gate(const u64* offsets, u64 n_reads, u32 bound, u32 k, u32* gate, int n_cu, hipStream_t st);
 hipError_t launch_fix_hash_fold(kmx_summary* out, u32 k, u32 hasher, u32 hk, hipStream_t st);
 }  // namespace kmx
 
@@ -466,14 +467,16 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
         // Reads behind an offsets array with a length bound L that the uniform bit-sliced kernels take: most FASTQ is
         // untrimmed -- every read exactly L bases -- and the uniform kernel is ~1.4x the ragged one.  Decided on the device:
         // a small kernel checks offsets[i] == i*L, both scans are launched behind its verdict, the one it names runs.
-        const uint32_t Lh = reads->read_len;
+        // (round 5: uniform at ANY length up to the bound -- the gate leaves the length it found for the uniform scan, which is laid out
+        // for the bound; no bound = the 160-base frame the ragged launcher assumes as well)
+        const uint32_t Lh = reads->read_len ? reads->read_len : 160u;
         // (only where BOTH bit-sliced launchers take the call: the ragged one needs a 16-byte aligned base -- with a misaligned
         // base the uniform scan used to be enqueued behind the gate and the generic kernel then counted the batch a second time)
-        if (reads->d_offsets && !want_sumfw && k >= 13 && k <= 31 && Lh >= k && Lh <= 256 &&
+        if (reads->d_offsets && !want_sumfw && k >= 13 && k <= 31 && Lh >= k && Lh <= 256 && reads->read_len <= 256 &&
             (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
             uint32_t* gate = reinterpret_cast<uint32_t*>(ctx->d_scratch + 16 + 513);
             KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 1, 1, ctx->stream));
-            KMX_HIP(ctx, kmx::launch_offsets_uniform_gate(reads->d_offsets, reads->n_reads, Lh, gate, ctx->n_cu, ctx->stream));
+            KMX_HIP(ctx, kmx::launch_offsets_uniform_gate(reads->d_offsets, reads->n_reads, Lh, k, gate, ctx->n_cu, ctx->stream));
             if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
             bool h_u = false, h_r = false;
             KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, Lh, k, want_fold, false, d_out, ctx->d_scratch + 16,
@@ -483,18 +486,18 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
                 KMX_HIP(ctx, kmx::launch_scan_bitsliced_ragged(reads->d_bases, reads->d_offsets, reads->n_reads, Lh, k, want_fold, d_out,
                                                                ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &h_r));
                 if (h_r) {
-                    KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));   // never left armed
+                    KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 2, ctx->stream));   // never left armed
                     if (fix_fold) KMX_HIP(ctx, kmx::launch_fix_hash_fold(d_out, k, hasher, hasher_k, ctx->stream));
                     return KMX_OK;
                 }
                 // The ragged launcher takes every aligned (k, L) the uniform one takes.  Should that ever stop being true, the uniform
                 // scan is already enqueued behind the gate and nothing may run after it: fail loudly, never count twice.
-                KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));
+                KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 2, ctx->stream));
                 KMX_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(kmx_summary), ctx->stream));
                 std::snprintf(ctx->last_error, sizeof ctx->last_error, "kmx: internal -- the ragged scan refused k=%u, L<=%u that the uniform scan accepted", k, Lh);
                 return KMX_E_HIP;
             } else {
-                KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));
+                KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 2, ctx->stream));
             }
         }
         if (!reads->d_offsets) {
@@ -646,13 +649,14 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
         }
         if (int st = prepare_dirty_flags(ctx, segmented && n_seg > reads->n_reads ? n_seg : reads->n_reads, k)) return st;
         bool h_u = false, h_r = false;
-        if (Lh >= k && Lh <= 256) {
+        const uint32_t Lg = Lh ? Lh : 160u;   // (round 5: the gate passes reads that are uniform at ANY length up to the bound; no bound = the 160-base frame)
+        if (Lg >= k && Lg <= 256) {
             KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 1, 1, ctx->stream));
-            KMX_HIP(ctx, kmx::launch_offsets_uniform_gate(reads->d_offsets, reads->n_reads, Lh, gate, ctx->n_cu, ctx->stream));
-            KMX_HIP(ctx, kmx::launch_scan_bitsliced2(reads->d_bases, reads->n_reads, Lh, k, with_hash != 0, d_out, ctx->d_scratch + 16,
+            KMX_HIP(ctx, kmx::launch_offsets_uniform_gate(reads->d_offsets, reads->n_reads, Lg, k, gate, ctx->n_cu, ctx->stream));
+            KMX_HIP(ctx, kmx::launch_scan_bitsliced2(reads->d_bases, reads->n_reads, Lg, k, with_hash != 0, d_out, ctx->d_scratch + 16,
                                                      ctx->n_cu, ctx->stream, &h_u));
             // (not launched: the verdict must not keep the other kernel from running)
-            if (!h_u) KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));
+            if (!h_u) KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 2, ctx->stream));
         }
         if (segmented)
             KMX_HIP(ctx, kmx::launch_scan_bitsliced2_ragged(reads->d_bases, starts, n_seg, 160u, k, with_hash != 0, d_out, ctx->d_scratch + 16, ctx->n_cu,
@@ -661,7 +665,7 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
             KMX_HIP(ctx, kmx::launch_scan_bitsliced2_ragged(reads->d_bases, reads->d_offsets, reads->n_reads, Lh, k, with_hash != 0, d_out,
                                                             ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &h_r));
         if (!h_r) KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8, h_u ? gate : nullptr));
-        if (h_u) KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 1, ctx->stream));   // never left armed
+        if (h_u) KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 2, ctx->stream));   // never left armed
         return KMX_OK;
     }
     KMX_HIP(ctx, kmx::launch_reduce2_generic(reads, k, with_hash, d_out, ctx->n_cu, ctx->stream, ctx->d_scratch + 8, nullptr));
@@ -794,6 +798,14 @@ int kmx_hash_words(kmx_ctx* ctx, const uint64_t* d_in, uint64_t n, uint32_t hash
     if (n == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
     KMX_HIP(ctx, kmx::launch_hash_words(d_in, n, hasher, hasher_k, d_out, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_hash_words_sip13(kmx_ctx* ctx, const uint64_t* d_in, uint64_t n, uint64_t key0, uint64_t key1, uint64_t* d_out) {
+    if (!ctx || (n && (!d_in || !d_out))) return KMX_E_ARG;
+    if (n == 0) return KMX_OK;
+    DeviceGuard g(ctx->device);
+    KMX_HIP(ctx, kmx::launch_hash_words_sip13(d_in, n, key0, key1, d_out, ctx->n_cu, ctx->stream));
     return KMX_OK;
 }
 

@@ -187,6 +187,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     if constexpr (!PACKED) {
         const u32 gate = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513]);
         if (gate == (RAGGED ? 1u : 2u)) return;
+        if constexpr (!RAGGED && !SEG) {
+            // (round 5) the gate found the reads uniform at a length BELOW the bound this launch was laid out for (frame, windows per
+            // lane, LDS): that length is what is scanned -- every quantity below derives from L
+            const u32 gate_len = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513 + 1]);
+            if (gate == 1u && gate_len != 0u) L = gate_len;
+        }
     }
     // Plane storage of one 32-read set: base beta (2 planes = one u64) lives at u64 index
     // (beta & 3) * S2 + (beta >> 2).  In phase D lane g reads bases 4g+i: consecutive lanes then touch
@@ -1346,6 +1352,11 @@ __global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __rest
                                                            const BsSeg seg) {
     u64* const masks = reinterpret_cast<u64*>(queue[515]);
     if (masks == nullptr || queue[512] == 0) return;   // queue[512]: "a tile was marked" (zeroed by the caller with the heads)
+    if constexpr (!RAGGED && !SEG) {   // (the length the gate found, as in scan_bitsliced_kernel: the reads this kernel rolls lie L0 bytes apart)
+        const u32 gate = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513]);
+        const u32 gate_len = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513 + 1]);
+        if (gate == 1u && gate_len != 0u) L = gate_len;
+    }
     __shared__ u64 aside_all[4][64];
     const u32 lane = threadIdx.x & 63u;
     u64* const aside = aside_all[threadIdx.x >> 6];

@@ -106,6 +106,29 @@ hash_words_kernel(const u64* __restrict__ in, u64 n, u32 hasher, u32 hk, u64* __
     else map_words(in, n, out, [](u64 w) { return w; });
 }
 
+// hash_one(&DefaultHasher / RandomState, kmer): SipHash-1-3 of the word's 8 little-endian bytes (kmx.h; hash.rs:4-20).  One full
+// message block m = w, then the final block b = 8 << 56 (length in the top byte, no tail bytes).
+__device__ __forceinline__ u64 rotl64(u64 x, int b) { return (x << b) | (x >> (64 - b)); }
+__device__ __forceinline__ void sip_round(u64& v0, u64& v1, u64& v2, u64& v3) {
+    v0 += v1; v1 = rotl64(v1, 13); v1 ^= v0; v0 = rotl64(v0, 32);
+    v2 += v3; v3 = rotl64(v3, 16); v3 ^= v2;
+    v0 += v3; v3 = rotl64(v3, 21); v3 ^= v0;
+    v2 += v1; v1 = rotl64(v1, 17); v1 ^= v2; v2 = rotl64(v2, 32);
+}
+__device__ __forceinline__ u64 siphash13_u64(u64 w, u64 k0, u64 k1) {
+    u64 v0 = k0 ^ 0x736f6d6570736575ull, v1 = k1 ^ 0x646f72616e646f6dull, v2 = k0 ^ 0x6c7967656e657261ull, v3 = k1 ^ 0x7465646279746573ull;
+    v3 ^= w; sip_round(v0, v1, v2, v3); v0 ^= w;
+    const u64 b = 8ull << 56;
+    v3 ^= b; sip_round(v0, v1, v2, v3); v0 ^= b;
+    v2 ^= 0xffull;
+    sip_round(v0, v1, v2, v3); sip_round(v0, v1, v2, v3); sip_round(v0, v1, v2, v3);
+    return v0 ^ v1 ^ v2 ^ v3;
+}
+__global__ void __launch_bounds__(256)
+hash_words_sip13_kernel(const u64* __restrict__ in, u64 n, u64 k0, u64 k1, u64* __restrict__ out) {
+    map_words(in, n, out, [k0, k1](u64 w) { return siphash13_u64(w, k0, k1); });
+}
+
 // CanonicalKmer::get_word_equivalency (canonical_kmer.rs:152-161)
 __global__ void __launch_bounds__(256)
 match_words_kernel(const u64* __restrict__ fw, const u64* __restrict__ rc, const u64* __restrict__ other, u64 n,
@@ -404,6 +427,10 @@ hipError_t launch_hash_words(const u64* in, u64 n, u32 hasher, u32 hk, u64* out,
     hipLaunchKernelGGL(hash_words_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, in, n, hasher, hk, out);
     return hipGetLastError();
 }
+hipError_t launch_hash_words_sip13(const u64* in, u64 n, u64 k0, u64 k1, u64* out, int n_cu, hipStream_t st) {
+    hipLaunchKernelGGL(hash_words_sip13_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, in, n, k0, k1, out);
+    return hipGetLastError();
+}
 hipError_t launch_match_words(const u64* fw, const u64* rc, const u64* other, u64 n, uint8_t* out, int n_cu, hipStream_t st) {
     hipLaunchKernelGGL(match_words_kernel, dim3(egrid(n, n_cu)), dim3(256), 0, st, fw, rc, other, n, out);
     return hipGetLastError();
@@ -494,11 +521,22 @@ __global__ void __launch_bounds__(256) length_range_kernel(const u64* __restrict
     }
 }
 
-// Are the reads behind `offsets` all exactly L bases, starting at byte 0?  *gate stays 1 ("run the uniform kernels") if so and
-// becomes 2 ("run the ragged kernels") at the first read that is not -- kmx_canonical_reduce launches both scans behind it,
-// each returns at once when the gate names the other (kmx_bitslice_kernel.h), and the host never waits for the answer.
-__global__ void __launch_bounds__(256) offsets_uniform_gate_kernel(const u64* __restrict__ offsets, u64 n_reads, u32 L, u32* __restrict__ gate) {
+// Are the reads behind `offsets` all of ONE length L0, k <= L0 <= bound, starting at byte 0?  *gate stays 1 ("run the uniform kernels") if
+// so and becomes 2 ("run the ragged kernels") at the first read that is not -- kmx_canonical_reduce launches both scans behind it,
+// each returns at once when the gate names the other (kmx_bitslice_kernel.h), and the host never waits for the answer.  gate[1] takes
+// L0: the uniform scan was launched for the bound (frame and windows per lane) and reads the length it scans with from there (round 5:
+// until then the length had to EQUAL the caller's bound -- untrimmed 150-base reads handed over with a bound of 160, or with none, took
+// the ragged kernel: 3.0 instead of 2.6 ms per 1e8).
+__global__ void __launch_bounds__(256) offsets_uniform_gate_kernel(const u64* __restrict__ offsets, u64 n_reads, u32 bound, u32 k, u32* __restrict__ gate) {
     bool bad = false, stop = false;
+    // (every thread reads the first two offsets: one cache line, and the length is needed before anything can be compared)
+    const u64 o0 = offsets[0], len0 = offsets[1] - o0;
+    const u32 L = (u32)len0;
+    if (o0 != 0ull || len0 < k || len0 > bound) {
+        if (blockIdx.x == 0 && threadIdx.x == 0u) atomicMax(gate, 2u);
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0u) gate[1] = L;
     // two offsets per 16-byte load (hipMalloc'ed arrays are 256-byte aligned; an odd tail is looked at by itself)
     const bool al16 = (reinterpret_cast<uintptr_t>(offsets) & 15u) == 0u;
     const u64 n_off = n_reads + 1u, pairs = al16 ? n_off >> 1 : 0u;
@@ -519,11 +557,11 @@ __global__ void __launch_bounds__(256) offsets_uniform_gate_kernel(const u64* __
     if (any_bad && threadIdx.x == 0u && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2u) atomicMax(gate, 2u);
 }
 
-hipError_t launch_offsets_uniform_gate(const u64* offsets, u64 n_reads, u32 L, u32* gate, int n_cu, hipStream_t st) {
+hipError_t launch_offsets_uniform_gate(const u64* offsets, u64 n_reads, u32 bound, u32 k, u32* gate, int n_cu, hipStream_t st) {
     u64 grid = (u64)n_cu * 8u;
     const u64 need = (n_reads / 2u + 256u) / 256u;
     if (grid > need) grid = need;
-    hipLaunchKernelGGL(offsets_uniform_gate_kernel, dim3((unsigned)(grid ? grid : 1)), dim3(256), 0, st, offsets, n_reads, L, gate);
+    hipLaunchKernelGGL(offsets_uniform_gate_kernel, dim3((unsigned)(grid ? grid : 1)), dim3(256), 0, st, offsets, n_reads, bound, k, gate);
     return hipGetLastError();
 }
 

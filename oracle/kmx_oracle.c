@@ -327,6 +327,44 @@ uint64_t kmo_lex_hash_u64(uint64_t word, size_t hasher_k) {
     return sh >= 64 ? 0 : res >> sh;
 }
 
+/* std's DefaultHasher behind hash_one (src/naive_impl/hash.rs:10-20; used at kmer.rs:546-557 with DefaultHasher, :564-575 with
+ * RandomState): SipHash-c-d of a byte string, restated from the SipHash paper (Aumasson, Bernstein 2012, section 2 / appendix A: the
+ * algorithm is in Rust's standard library, not in the crate).  c = 2, d = 4 reproduces the paper's test vectors
+ * (tests/test_oracle_golden.py); DefaultHasher is c = 1, d = 3 over the 8 little-endian bytes of write_u64(data) (hash.rs:4-8). */
+static uint64_t rotl64(uint64_t x, int b) { return (x << b) | (x >> (64 - b)); }
+uint64_t kmo_siphash(unsigned c, unsigned d, uint64_t k0, uint64_t k1, const uint8_t *msg, size_t len) {
+    uint64_t v0 = k0 ^ 0x736f6d6570736575ull, v1 = k1 ^ 0x646f72616e646f6dull, v2 = k0 ^ 0x6c7967656e657261ull, v3 = k1 ^ 0x7465646279746573ull;
+#define KMO_SIPROUND                                                                                   \
+    do {                                                                                               \
+        v0 += v1; v1 = rotl64(v1, 13); v1 ^= v0; v0 = rotl64(v0, 32);                                  \
+        v2 += v3; v3 = rotl64(v3, 16); v3 ^= v2;                                                       \
+        v0 += v3; v3 = rotl64(v3, 21); v3 ^= v0;                                                       \
+        v2 += v1; v1 = rotl64(v1, 17); v1 ^= v2; v2 = rotl64(v2, 32);                                  \
+    } while (0)
+    size_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t m = 0;
+        for (int j = 0; j < 8; ++j) m |= (uint64_t)msg[i + j] << (8 * j);
+        v3 ^= m;
+        for (unsigned r = 0; r < c; ++r) KMO_SIPROUND;
+        v0 ^= m;
+    }
+    uint64_t b = (uint64_t)(len & 0xff) << 56;
+    for (int j = 0; i + j < len; ++j) b |= (uint64_t)msg[i + j] << (8 * j);
+    v3 ^= b;
+    for (unsigned r = 0; r < c; ++r) KMO_SIPROUND;
+    v0 ^= b;
+    v2 ^= 0xff;
+    for (unsigned r = 0; r < d; ++r) KMO_SIPROUND;
+#undef KMO_SIPROUND
+    return v0 ^ v1 ^ v2 ^ v3;
+}
+uint64_t kmo_siphash13_u64(uint64_t word, uint64_t k0, uint64_t k1) {
+    uint8_t m[8];
+    for (int j = 0; j < 8; ++j) m[j] = (uint8_t)(word >> (8 * j));
+    return kmo_siphash(1, 3, k0, k1, m, 8);
+}
+
 /* ----------------------------------------------------------- encoding::Naive */
 
 static unsigned flat_get2(const uint8_t *array, size_t bit) { /* bit_field get_bits(bit..bit+2), bit even */

@@ -100,6 +100,9 @@ int kmo_iter_inc_by(kmo_iter *it, size_t count);                                
 
 /* ---- naive_impl::hash (src/naive_impl/hash.rs) ---- */
 uint64_t kmo_lex_hash_u64(uint64_t word, size_t hasher_k); /* hash.rs:60-71; Hash for Kmer = write_u64(data), :4-8 */
+/* hash_one with std's DefaultHasher / RandomState (hash.rs:10-20): SipHash-c-d (paper: Aumasson, Bernstein 2012); DefaultHasher = 1-3 */
+uint64_t kmo_siphash(unsigned c, unsigned d, uint64_t k0, uint64_t k1, const uint8_t *msg, size_t len);
+uint64_t kmo_siphash13_u64(uint64_t word, uint64_t k0, uint64_t k1);
 
 /* ---- encoding::Naive / Xor10 (src/encoding/naive.rs, xor10.rs) ----
  * Words [P;B] are handled as their flat little-endian bit array (bit_field 0.10:

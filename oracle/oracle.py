@@ -146,6 +146,8 @@ def _bind(lib):
         "kmo_iter_inc": (C.c_int, [C.POINTER(Iter)]),
         "kmo_iter_inc_by": (C.c_int, [C.POINTER(Iter), C.c_size_t]),
         "kmo_lex_hash_u64": (C.c_uint64, [C.c_uint64, C.c_size_t]),
+        "kmo_siphash": (C.c_uint64, [C.c_uint, C.c_uint, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t]),
+        "kmo_siphash13_u64": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64]),
         "kmo_nuc2internal": (C.c_uint8, [C.c_uint8]),
         "kmo_rev_encoding": (C.c_uint8, [C.c_uint8]),
         "kmo_naive_nuc2bits": (C.c_uint8, [C.c_uint8, C.c_uint8]),

@@ -114,6 +114,17 @@ int main() {
         CHECK(hash::hash_one(seed, Kmer::from("caa")) == 0b010000);
         CHECK(hash::hash_one(seed, Kmer::from("cac")) == 0b010001);
     }
+    // ---- src/naive_impl/kmer.rs test_hash (:546-557): DefaultHasher over the k-mer == DefaultHasher over its data word -- one write_u64
+    //      either way; on the device both are kmx_hash_words_sip13 of the same word, so what is left to check is that the hash is a
+    //      function of the word and of the keys (SipHash-1-3 itself is pinned by the oracle tests)
+    {
+        const Kmer km = Kmer::from("ACTTGAT");
+        const hash::SipHasher13State dflt{};   // DefaultHasher::new(): keys (0, 0)
+        const uint64_t h1 = hash::hash_one(dflt, km), h2 = hash::hash_one(dflt, Kmer::from_u64(km.into_u64(), km.len()));
+        CHECK(h1 == h2);
+        CHECK(hash::hash_one(hash::SipHasher13State{1, 2}, km) != h1);
+        CHECK(hash::hash_one(dflt, Kmer::from("ACTTGAA")) != h1);
+    }
     // ---- src/encoding/naive.rs k45pu64 (:388-416), src/kmer.rs kmer_prefix / kmer_naive_encoder (:173-203)
     {
         using encoding::Naive;

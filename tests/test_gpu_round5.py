@@ -96,6 +96,99 @@ def test_long_ragged_reads_at_size(ctx, orc, k, lo, hi, n):
     assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
 
 
+# ------------------------------------------------------------------ hash_one with std's BuildHashers (VERDICT r4 "missing" 5)
+
+@pytest.mark.parametrize("keys", [(0, 0), (0x0706050403020100, 0x0F0E0D0C0B0A0908), (2**64 - 1, 1), (0x9E3779B97F4A7C15, 0xD1B54A32D192ED03)])
+def test_hash_words_sip13_matches_the_oracle(ctx, orc, keys):
+    """kmx_hash_words_sip13 = hash_one(&DefaultHasher / RandomState, kmer) (hash.rs:10-20; kmer.rs:546-575): SipHash-1-3 of every
+    word, keys (0, 0) for DefaultHasher::new().  The oracle's SipHash is pinned to the paper's vectors (tests/test_oracle_golden.py)."""
+    import torch
+
+    rng = np.random.default_rng(keys[0] & 0xFFFF)
+    words = np.concatenate([np.array([0, 1, 2**63, 2**64 - 1, 0x0123456789ABCDEF], dtype=np.uint64),
+                            rng.integers(0, 2**64, 4091, dtype=np.uint64)])
+    got = ctx.hash_words_sip13(ctx.to_device(words), keys[0], keys[1]).cpu().numpy().view(np.uint64)
+    L = orc.lib()
+    exp = np.array([L.kmo_siphash13_u64(int(w), keys[0], keys[1]) for w in words], dtype=np.uint64)
+    assert (got == exp).all()
+    # test_hash (kmer.rs:546-557): the hash of a k-mer is the hash of its data word -- and nothing but the word and the keys enters it
+    again = ctx.hash_words_sip13(ctx.to_device(words[::-1].copy()), keys[0], keys[1]).cpu().numpy().view(np.uint64)
+    assert (again[::-1] == got).all()
+    assert ctx.hash_words_sip13(torch.empty(0, dtype=torch.int64, device=ctx.device)).numel() == 0
+
+
+# ------------------------------------------------------------------ reads behind offsets that are uniform at a length BELOW the bound
+
+def _uniform_behind_offsets(ctx, n, L, seed, p_bad=0.0005, shift=0):
+    rng = np.random.default_rng(seed)
+    offsets = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L)) + np.uint64(shift)
+    bases = ctx.gen_reads(n * L + shift, first_byte=seed)
+    host = bases.cpu().numpy().copy()
+    if p_bad:
+        reads = np.nonzero(rng.random(n) < p_bad)[0]
+        host[shift + reads * L + (rng.random(len(reads)) * L).astype(np.int64)] = ord("N")
+        bases = ctx.to_device(host)
+    return bases, host, offsets
+
+
+@pytest.mark.parametrize("k", [13, 21, 31])
+@pytest.mark.parametrize("L,bound", [(150, 160), (150, 0), (150, 150), (100, 150), (100, 0), (200, 256), (151, 160), (36, 100), (128, 129)])
+def test_reduce_offsets_uniform_below_the_bound(ctx, orc, k, L, bound):
+    """round 5: the device-side gate passes reads that are uniform at ANY length L0, k <= L0 <= bound (no bound: 160), and the uniform
+    scan -- laid out for the bound -- scans with L0 (also the kernel that rolls the reads holding an N).  Until then the length had to
+    equal the bound, and untrimmed reads handed over with a loose bound or none took the ragged kernel."""
+    from kmers_amd import _lib
+
+    n = 64 * 700 + 23
+    bases, host, offsets = _uniform_behind_offsets(ctx, n, L, seed=100 * k + L + bound)
+    o = orc.canonical_reduce(host, n, 0, k, hasher_k=k, offsets=offsets)
+    d_off = ctx.to_device(offsets)
+    for hasher, hk in ((_lib.HASH_LEX, k), (_lib.HASH_NONE, 0), (_lib.HASH_LEX, 7), (_lib.HASH_IDENTITY, 0)):
+        g = ctx.canonical_reduce(bases, n, bound, k, hasher, hk, 0, offsets=d_off)
+        assert (g.n_valid, g.sum_canon) == (o.n_valid, o.sum_canon)
+        if hasher == _lib.HASH_LEX and hk == k:
+            assert g.xor_hash == o.xor_hash
+    # a uniform call right behind it must not see the gate's length (the queue block is cleared per call)
+    gu = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, 0)
+    assert (gu.n_valid, gu.sum_canon, gu.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+
+
+@pytest.mark.parametrize("case", ["shifted_start", "one_shorter", "last_longer", "all_shorter_than_k", "first_read_differs"])
+def test_reduce_offsets_gate_refuses_what_is_not_uniform(ctx, orc, case):
+    from kmers_amd import _lib
+
+    k, L, n = 31, 150, 64 * 300 + 5
+    lens = np.full(n, L, np.int64)
+    shift = 0
+    if case == "shifted_start":
+        shift = 16
+    elif case == "one_shorter":
+        lens[n // 2] = L - 1
+    elif case == "last_longer":
+        lens[-1] = L + 3
+    elif case == "all_shorter_than_k":
+        lens[:] = 20
+    elif case == "first_read_differs":
+        lens[0] = L - 7
+    offsets = (np.concatenate([[0], np.cumsum(lens)]) + shift).astype(np.uint64)
+    bases = ctx.gen_reads(int(offsets[-1]), first_byte=7)
+    host = bases.cpu().numpy()
+    o = orc.canonical_reduce(host, n, 0, k, hasher_k=k, offsets=offsets)
+    for bound in (160, 0, 153):
+        g = ctx.canonical_reduce(bases, n, bound, k, _lib.HASH_LEX, k, 0, offsets=ctx.to_device(offsets))
+        assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash), (case, bound)
+
+
+@pytest.mark.parametrize("k", [33, 47, 63])
+@pytest.mark.parametrize("L,bound", [(150, 160), (150, 0), (120, 150), (200, 250), (150, 150)])
+def test_reduce2_offsets_uniform_below_the_bound(ctx, orc, k, L, bound):
+    n = 64 * 400 + 9
+    bases, host, offsets = _uniform_behind_offsets(ctx, n, L, seed=9 * k + L + bound)
+    o = orc.canonical_reduce2(host, n, 0, k, with_hash=True, offsets=offsets)
+    g = ctx.canonical_reduce2(bases, n, bound, k, with_hash=True, offsets=ctx.to_device(offsets))
+    assert tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
+
+
 # ------------------------------------------------------------------ ADVICE r4
 
 def test_segment_paths_honour_the_work_buffer_limit(orc):

@@ -198,6 +198,32 @@ def _iter_case(orc, kats, case):
     assert it.pos == case["expect_pos"]
 
 
+def test_siphash_matches_the_published_vectors_and_the_std_hasher_shape(orc):
+    """hash_one with std's DefaultHasher / RandomState (hash.rs:10-20; kmer.rs:546-575).  The algorithm is in Rust's standard library, not
+    in the crate: the oracle restates SipHash-c-d from the paper (Aumasson, Bernstein 2012).  Pin: the paper's SipHash-2-4 vectors --
+    key 00..0f, messages 00..(n-1), the reference implementation's table, and the 15-byte example of appendix A -- through the same
+    round function; DefaultHasher is the 1-3 instance over the 8 little-endian bytes of write_u64(data) (hash.rs:4-8).  The crate's own two
+    tests of this path check properties (test_hash: hash(kmer) == hash(kmer.data), kmer.rs:546-557), restated below."""
+    import ctypes as C
+
+    L = orc.lib()
+    k0 = int.from_bytes(bytes(range(8)), "little")
+    k1 = int.from_bytes(bytes(range(8, 16)), "little")
+    vectors = ["310e0edd47db6f72", "fd67dc93c539f874", "5a4fa9d909806c0d", "2d7efbd796666785", "b7877127e09427cf", "8da699cd64557618",
+               "cee3fe586e46c9cb", "37d1018bf50002ab", "6224939a79f5f593"]
+    for n, want in enumerate(vectors):
+        msg = (C.c_uint8 * max(n, 1))(*range(n))
+        assert int(L.kmo_siphash(2, 4, k0, k1, msg, n)).to_bytes(8, "little").hex() == want, n
+    msg = (C.c_uint8 * 15)(*range(15))
+    assert L.kmo_siphash(2, 4, k0, k1, msg, 15) == 0xA129CA6149BE45E5          # the paper's worked example
+    # the std hasher's shape: one write_u64 = the 8 little-endian bytes, so hash(kmer) == hash(kmer.data) holds by construction
+    for w in (0, 1, 0x0123456789ABCDEF, (1 << 64) - 1):
+        m = (C.c_uint8 * 8)(*w.to_bytes(8, "little"))
+        assert L.kmo_siphash13_u64(w, 0, 0) == L.kmo_siphash(1, 3, 0, 0, m, 8)
+        assert L.kmo_siphash13_u64(w, 5, 7) == L.kmo_siphash(1, 3, 5, 7, m, 8)
+    assert L.kmo_siphash13_u64(1, 0, 0) != L.kmo_siphash13_u64(2, 0, 0)
+
+
 def test_iterator_kats(orc, kats):  # canonical_kmer_iterator.rs:123-189
     for case in kats["iterator"]["cases"]:
         _iter_case(orc, kats, case)
@@ -406,7 +432,7 @@ def test_generator_is_uniform_acgt(orc):
 
 # ---------------------------------------------------------------- SeqVector
 
-def test_seq_vector_kats(orc, kats):  # seq_vector.rs:364-428
+def test_seq_vector_kats(orc, kats):  # seq_vector.rs:308-357
     sv_k = kats["seq_vector"]
     # seq_slice_test: a vector adopted from raw words [1, 2, 3]
     sw = sv_k["slice_words"]
