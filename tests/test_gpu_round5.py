@@ -189,6 +189,36 @@ def test_reduce2_offsets_uniform_below_the_bound(ctx, orc, k, L, bound):
     assert tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
 
 
+# ------------------------------------------------------------------ the two-word variants that moved to three waves in round 5, at size
+
+@pytest.mark.parametrize("k,L,n", [(47, 200, 900_000), (41, 180, 1_000_000), (33, 208, 900_000), (49, 170, 1_000_000),     # 13-word frame, three waves up to k = 49
+                                   (50, 200, 900_000), (63, 208, 800_000),                                                # ... two from k = 50
+                                   (33, 10_000, 15_000), (36, 1000, 150_000), (41, 300, 500_000), (47, 500, 300_000), (49, 1000, 150_000),   # 10-word segments, three waves
+                                   (50, 1000, 150_000), (63, 300, 400_000)])                                               # 13-word segments, two waves
+def test_two_word_variants_at_size(ctx, orc, k, L, n):
+    bases = ctx.gen_reads(n * L, first_byte=3 * k + L)
+    host = bases.cpu().numpy().copy()
+    rng = np.random.default_rng(k * L)
+    host[rng.integers(0, n * L, n // 500)] = ord("N")
+    bases = ctx.to_device(host)
+    o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+    g = ctx.canonical_reduce2(bases, n, L, k, with_hash=True)
+    assert tuple(getattr(g, f) for f, _ in g._fields_) == tuple(getattr(o, f) for f, _ in o._fields_)
+
+
+@pytest.mark.parametrize("k", [13, 15, 17, 18, 21, 22])
+def test_small_k_five_windows_per_lane_at_size(ctx, orc, k):
+    """k <= 22 on 150-base reads: five windows per lane; since round 5 without late prefetch rows up to k = 17, one from k = 18"""
+    from kmers_amd import _lib
+
+    n, L = 1_500_000, 150
+    bases = ctx.gen_reads(n * L, first_byte=k)
+    host = bases.cpu().numpy()
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+    g = ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    assert (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw) == (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
+
+
 # ------------------------------------------------------------------ ADVICE r4
 
 def test_segment_paths_honour_the_work_buffer_limit(orc):
