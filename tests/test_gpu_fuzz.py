@@ -40,7 +40,7 @@ def test_reduce_random_configuration(ctx, orc, seed):
 
     rng = np.random.default_rng(1000 + seed)
     k = int(rng.choice([2, 5, 11, 12, 13, 14, 16, 17, 19, 21, 24, 27, 29, 30, 31]))
-    layout = rng.choice(["uniform", "uniform_misaligned", "ragged", "ragged_hint", "ragged_tight"])
+    layout = rng.choice(["uniform", "uniform_misaligned", "ragged", "ragged_hint", "ragged_tight", "uniform_behind_offsets"])
     p_bad = float(rng.choice([0.0, 0.0, 0.0005, 0.004, 0.05]))
     n = int(rng.choice([1, 63, 64, 65, 64 * 7 + 3, 64 * 23 + 41]))
     hasher, hk = [(_lib.HASH_NONE, 0), (_lib.HASH_LEX, k), (_lib.HASH_LEX, max(1, k - 3)), (_lib.HASH_IDENTITY, 0)][int(rng.integers(0, 4))]
@@ -55,6 +55,20 @@ def test_reduce_random_configuration(ctx, orc, seed):
         d = d_all[lead: lead + n * L]
         o = orc.canonical_reduce(host, n, L, k, hasher_k=hk if hasher == _lib.HASH_LEX else 0)
         g = ctx.canonical_reduce(d, n, L, k, hasher, hk, _lib.REDUCE_SUM_FW if want_fw else 0)
+    elif layout == "uniform_behind_offsets":
+        # (round 5) reads of ONE length behind an offsets array, with the bound equal to it, above it, or absent: the device-side gate
+        # hands them to the uniform kernels (laid out for the bound, scanning with the length found); now and then one read differs
+        L = int(rng.choice([k, 36, 50, 100, 111, 125, 150, 160, 200, 256]))
+        L = max(L, k)
+        hint = int(rng.choice([0, L, L + int(rng.integers(1, 40)), 160, 256]))
+        lens = np.full(n, L, dtype=np.int64)
+        if rng.integers(0, 4) == 0:
+            lens[rng.integers(0, n)] = max(0, L - int(rng.integers(1, 20)))
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        host = _bytes(rng, int(offsets[-1]) + 16, p_bad, bool(rng.integers(0, 2)))[: int(offsets[-1])]
+        o = orc.canonical_reduce(host, n, 0, k, hasher_k=hk if hasher == _lib.HASH_LEX else 0, offsets=offsets)
+        g = ctx.canonical_reduce(ctx.to_device(host) if len(host) else ctx.to_device(np.zeros(16, np.uint8)), n, hint, k, hasher, hk, 0,
+                                 offsets=ctx.to_device(offsets))
     else:
         top = int(rng.choice([40, 64, 100, 111, 112, 150, 160, 250]))
         lens = rng.integers(0, top + 1, size=n)

@@ -1,8 +1,4 @@
 # scratch: the command list of the current gpurun call (tools/README.md); the round's profile set is tools/profile_round.sh
-O=$GRAFT_REPO_ROOT/gpurun_out/r5w; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r5x; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
-python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python3 tools/stress_contexts.py 2>&1 | tail -3
-python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; python3 tools/bench_line.py "[driver command]" < $O/bench_default.json
-python3 tools/bench_hist.py 100000000 20 2>/dev/null
+KMX_FUZZ_N=30000 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu > $O/pytest_fuzz30000.txt 2>&1; tail -3 $O/pytest_fuzz30000.txt
