@@ -338,11 +338,17 @@ class Context:
         return mw, mp
 
     @_on_ctx_stream
-    def fastx_parse(self, text: torch.Tensor, fmt: int = 0):
+    def fastx_parse(self, text: torch.Tensor, fmt: int = 0, max_reads: int | None = None):
         """kmx_fastx_parse: FASTA/FASTQ file image (uint8, on the device) -> (bases uint8[n_bases], offsets int64[n_reads+1]).
-        Two calls: the counts, then the emit into exactly sized buffers."""
+        Two calls: the counts, then the emit into exactly sized buffers.  With `max_reads` (a bound on the number of records the
+        caller vouches for): ONE call into buffers sized for the bound; KmxError (KMX_E_NOMEM) if the image holds more records."""
         n = int(text.numel())
         nr, nb = C.c_uint64(0), C.c_uint64(0)
+        if max_reads is not None:
+            bases = self.empty(max(n, 1), torch.uint8)
+            offsets = self.empty(max_reads + 1, torch.int64)
+            self._ck(self.lib.kmx_fastx_parse(self._h, _ptr(text) if n else None, n, fmt, _ptr(bases), _ptr(offsets), max_reads, C.byref(nr), C.byref(nb)))
+            return bases[:nb.value], offsets[:nr.value + 1]
         self._ck(self.lib.kmx_fastx_parse(self._h, _ptr(text) if n else None, n, fmt, None, None, 0, C.byref(nr), C.byref(nb)))
         bases = self.empty(max(nb.value, 1), torch.uint8)
         offsets = self.empty(nr.value + 1, torch.int64)

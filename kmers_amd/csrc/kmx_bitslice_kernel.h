@@ -1540,7 +1540,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
 // largest frame allows, all of T or T - 1 windows.  Single-word k: the 13-word frame (207 bases + the alignment lead, six
 // windows per lane: T <= min(192, 208 - k)) -- k - 1 of every T + k - 1 bases are scanned twice, 30 of 158 in the 10-word frame
 // and 30 of 207 here (1 000-base reads 0.59 -> 0.64 of the roofline) -- unless the segments that come out fit the 10-word frame
-// (reads of 257..~450 bases).  Two-word k (round 5): the same choice -- the 13-word frame at two waves per SIMD.
+// (reads of 257..~450 bases).  Two-word k: the 10-word frame up to k = 49, the 13-word frame from k = 50 (below).
 struct BsSegPlan { u32 J, J1, T, NW; };
 static inline BsSegPlan bs_seg_plan(u32 L, u32 k) {
     const u32 wr = L - k + 1u;

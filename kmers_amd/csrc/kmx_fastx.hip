@@ -42,10 +42,10 @@ constexpr u32 FX_PFX_WORDS = 4;              // u64 per chunk prefix: entry stat
 // line types of the FASTA state (0 = "whatever the chunk / row was entered with")
 constexpr u32 T_NONE = 0, T_SEQ = 2, T_HDR = 3;
 
-// inclusive scan over the block (blockDim.x a multiple of 64); `tmp` holds blockDim.x/64 elements
-template <class T, class Op>
+// inclusive scan over the block of NW waves; `tmp` holds NW elements
+template <u32 NW, class T, class Op>
 __device__ __forceinline__ T block_scan_incl(T v, Op op, T* tmp, T& total) {
-    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const T o = __shfl_up(v, d, WAVE);
@@ -56,7 +56,8 @@ __device__ __forceinline__ T block_scan_incl(T v, Op op, T* tmp, T& total) {
     __syncthreads();
     T pre = v, acc = v;
     bool have = false;
-    for (u32 w = 0; w < nw; ++w) {
+#pragma unroll
+    for (u32 w = 0; w < NW; ++w) {
         const T x = tmp[w];
         if (w < wv) { pre = have ? op(pre, x) : x; have = true; }
         acc = w == 0 ? x : op(acc, x);
@@ -216,16 +217,20 @@ __device__ __forceinline__ void fq_classes(const FqLane& a, u32 first, u64& c0, 
 }
 // newlines before the lane in the block's row, mod 4 (all the FASTQ state there is), from two ballots of the lanes' counts
 // instead of a shuffle scan; `tmp`: one word per wave; total = the row's newlines mod 4
+// PRE = false: the caller vouches that nobody still reads `tmp` from an earlier call (another barrier lies between, or the calls alternate
+// between two arrays) -- one barrier per call instead of two
+template <u32 NW, bool PRE = true>
 __device__ __forceinline__ u32 block_prefix_mod4(u32 c, u32* tmp, u32& total) {
-    const u32 wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const u32 wv = threadIdx.x >> 6;
     const u64 e0 = __ballot((c & 1u) != 0u), e1 = __ballot((c & 2u) != 0u);
     const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(e0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e0, 0u)) +
                       2u * __builtin_amdgcn_mbcnt_hi((u32)(e1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)e1, 0u));
-    __syncthreads();                  // tmp may still be read from the previous call
+    if constexpr (PRE) __syncthreads();                  // tmp may still be read from the previous call
     if ((threadIdx.x & 63u) == 0u) tmp[wv] = pc64(e0) + 2u * pc64(e1);
     __syncthreads();
     u32 pre = 0, acc = 0;
-    for (u32 w = 0; w < nw; ++w) {
+#pragma unroll
+    for (u32 w = 0; w < NW; ++w) {    // (NW a constant: with blockDim.x >> 6 hipcc builds a vectorised loop and its remainders -- 90 instructions -- around these four words)
         const u32 x = tmp[w];
         pre += w < wv ? x : 0u;
         acc += x;
@@ -234,19 +239,21 @@ __device__ __forceinline__ u32 block_prefix_mod4(u32 c, u32* tmp, u32& total) {
     return (pre + below) & 3u;
 }
 // inclusive add scan over the block, the wave part as six DPP adds (row shifts, then the two row broadcasts)
+template <u32 NW, bool PRE = true>
 __device__ __forceinline__ u32 block_scan_add_dpp(u32 v, u32* tmp, u32& total) {
-    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
-    __syncthreads();
+    if constexpr (PRE) __syncthreads();
     if (lane == 63u) tmp[wv] = v;
     __syncthreads();
     u32 pre = 0, acc = 0;
-    for (u32 w = 0; w < nw; ++w) {
+#pragma unroll
+    for (u32 w = 0; w < NW; ++w) {
         const u32 x = tmp[w];
         pre += w < wv ? x : 0u;
         acc += x;
@@ -331,7 +338,7 @@ __device__ __forceinline__ void emit_bytes(const Lane64& d, u64 ks, uint8_t* __r
 template <bool FASTA>
 __global__ void __launch_bounds__(FX_THREADS)
 fastx_summarise_kernel(const uint8_t* __restrict__ text, u64 n, u32* __restrict__ summ) {
-    __shared__ u32 tmp32[FX_THREADS / 64];
+    __shared__ u32 tmp32[2][FX_THREADS / 64];
     __shared__ u32 wave_last[FX_THREADS / 64];
     __shared__ u32 red[8];
     const u64 chunk = blockIdx.x;
@@ -350,7 +357,7 @@ fastx_summarise_kernel(const uint8_t* __restrict__ text, u64 n, u32* __restrict_
         if constexpr (!FASTA) {
             const FqLane a = fq_analyse<true>(d, acc[5]);
             u32 tot;
-            const u32 ph = (state + block_prefix_mod4(pc64(a.nl), tmp32, tot)) & 3u;   // line number (relative to the chunk) at the lane's first byte
+            const u32 ph = (state + block_prefix_mod4<FX_THREADS / 64, false>(pc64(a.nl), tmp32[row & 1u], tot)) & 3u;   // line number (relative to the chunk) at the lane's first byte (the rows alternate between two arrays: one barrier per row)
             u64 c0m, c1m;
             fq_classes(a, ph, c0m, c1m);
             acc[0] += pc64(a.keep & ~c1m & ~c0m);
@@ -363,7 +370,7 @@ fastx_summarise_kernel(const uint8_t* __restrict__ text, u64 n, u32* __restrict_
             const FaLane a = fa_analyse<true>(d, acc[5]);
             u32 tot;
             const u32 key = a.def ? (((threadIdx.x + 1u) << 2) | a.def) : 0u;
-            const u32 incl = block_scan_incl(key, OpMax32{}, tmp32, tot);
+            const u32 incl = block_scan_incl<FX_THREADS / 64>(key, OpMax32{}, tmp32[0], tot);
             const u32 ex = __shfl_up(incl, 1, WAVE);            // exclusive: the lane before (across waves through LDS)
             __syncthreads();
             if ((threadIdx.x & 63u) == 63u) wave_last[threadIdx.x >> 6] = incl;
@@ -412,7 +419,7 @@ constexpr u32 FX_SCAN_THREADS = 1024;
 constexpr u32 FX_AGG_WORDS = 12;
 // exclusive max-scan of the line-type keys over the block: the key of the nearest thread before this one that has one (0: none)
 __device__ __forceinline__ u32 block_prev_key(u32 key, u32* tmp, u32* wave_last, u32& tot) {
-    const u32 incl = block_scan_incl(key, OpMax32{}, tmp, tot);
+    const u32 incl = block_scan_incl<FX_SCAN_THREADS / 64>(key, OpMax32{}, tmp, tot);
     const u32 ex = __shfl_up(incl, 1, WAVE);
     __syncthreads();
     if ((threadIdx.x & 63u) == 63u) wave_last[threadIdx.x >> 6] = incl;
@@ -437,7 +444,7 @@ fastx_scan_blocks_kernel(const u32* __restrict__ summ, u64 n_chunks, u32* __rest
     u64 v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u32 what;     // what the block does to the state
     if constexpr (!FASTA) {
-        const u32 pre = block_prefix_mod4(S & 3u, tmp32, what);     // (its barriers also cover red[])
+        const u32 pre = block_prefix_mod4<FX_SCAN_THREADS / 64>(S & 3u, tmp32, what);     // (its barriers also cover red[])
 #pragma unroll
         for (u32 j = 0; j < 4; ++j) {      // the block's line number j is the chunk's j - pre
             v[j] = pick4(K, (j - pre) & 3u);
@@ -514,7 +521,7 @@ fastx_scan_chunks_kernel(const u32* __restrict__ summ, u64 n_chunks, const u32* 
     u32 in, kept, recs;
     if constexpr (!FASTA) {
         u32 tot;
-        in = ((u32)state + block_prefix_mod4(S & 3u, tmp32, tot)) & 3u;
+        in = ((u32)state + block_prefix_mod4<FX_SCAN_THREADS / 64>(S & 3u, tmp32, tot)) & 3u;
         kept = pick4(K, (1u - in) & 3u);
         recs = pick4(R, (1u - in) & 3u);
     } else {
@@ -525,8 +532,8 @@ fastx_scan_chunks_kernel(const u32* __restrict__ summ, u64 n_chunks, const u32* 
         recs = K.z;
     }
     u32 tk, tr;
-    const u32 ik = block_scan_add_dpp(kept, tmp32, tk);
-    const u32 ir = block_scan_add_dpp(recs, tmp32, tr);
+    const u32 ik = block_scan_add_dpp<FX_SCAN_THREADS / 64>(kept, tmp32, tk);
+    const u32 ir = block_scan_add_dpp<FX_SCAN_THREADS / 64>(recs, tmp32, tr);
     if (live) {
         u64* pf = prefix + c * FX_PFX_WORDS;
         *reinterpret_cast<ulonglong2*>(pf) = make_ulonglong2((u64)in, out_pos + (ik - kept));
@@ -545,6 +552,7 @@ __device__ __forceinline__ void fastx_emit_rows(const uint8_t* __restrict__ text
     // (the next row's 64 bytes are requested before this row is analysed: one HBM round trip per row hidden)
     Lane64 d_next = c0 < n ? load_lane(text, n, c0 + threadIdx.x * FX_LANE) : Lane64{};
     u32 unused = 0;
+    u32 foreign = 0;      // leading bytes of the current row's piece 0 that belong to the chunk before
     for (u32 row = 0; row < FX_ROWS; ++row) {
         const u64 p = c0 + (u64)row * FX_ROW + threadIdx.x * FX_LANE;
         if (c0 + (u64)row * FX_ROW >= n) break;
@@ -554,7 +562,7 @@ __device__ __forceinline__ void fastx_emit_rows(const uint8_t* __restrict__ text
         u32 tot;
         if constexpr (!FASTA) {
             const FqLane a = fq_analyse<CR>(d, unused);
-            const u32 in = (state + block_prefix_mod4(pc64(a.nl), tmp32, tot)) & 3u;   // the file's line number (mod 4) at the lane's first byte
+            const u32 in = (state + block_prefix_mod4<FX_THREADS / 64, false>(pc64(a.nl), tmp32, tot)) & 3u;   // the file's line number (mod 4) at the lane's first byte (no barrier before: the row's other two lie between two uses of tmp32)
             state = (state + tot) & 3u;
             u64 c0m, c1m;
             fq_classes(a, in, c0m, c1m);
@@ -563,7 +571,7 @@ __device__ __forceinline__ void fastx_emit_rows(const uint8_t* __restrict__ text
         } else {
             const FaLane a = fa_analyse<CR>(d, unused);
             const u32 key = a.def ? (((threadIdx.x + 1u) << 2) | a.def) : 0u;
-            const u32 incl = block_scan_incl(key, OpMax32{}, tmp32, tot);
+            const u32 incl = block_scan_incl<FX_THREADS / 64>(key, OpMax32{}, tmp32, tot);
             const u32 ex = __shfl_up(incl, 1, WAVE);
             __syncthreads();
             if ((threadIdx.x & 63u) == 63u) wave_last[threadIdx.x >> 6] = incl;
@@ -577,28 +585,43 @@ __device__ __forceinline__ void fastx_emit_rows(const uint8_t* __restrict__ text
         // output positions: bytes and records packed into one scan (a row emits <= 16384 of either)
         const u32 kept = pc64(ks), recs = pc64(rs);
         u32 tkr;
-        const u32 ikr = block_scan_add_dpp(kept | (recs << 16), tmp32, tkr);
+        // (FASTQ: through wave_last, which that path does not use otherwise -- again the row's other barriers lie between two uses)
+        const u32 ikr = FASTA ? block_scan_add_dpp<FX_THREADS / 64>(kept | (recs << 16), tmp32, tkr)
+                              : block_scan_add_dpp<FX_THREADS / 64, false>(kept | (recs << 16), wave_last, tkr);
         const u64 o = out_pos + ((ikr & 0xFFFFu) - kept);
         u64 r = rec + ((ikr >> 16) - recs);
         {
             // The row's bytes go out through LDS: the lanes deposit their pieces where they will lie (same offset modulo 16 as in
             // memory), then the block writes whole 16-byte pieces, consecutive lanes consecutive addresses -- full lines instead of
             // four 16-byte stores per lane at a 64-byte stride.  Two buffers: the next row deposits while this one is still read.
+            // The row's LAST piece, if the row ends inside it, is not written: it is handed to the next row's buffer (piece 0 there:
+            // the next row begins at that offset modulo 16) and goes out whole with it -- only the chunk's first and last piece,
+            // shared with other blocks, are written byte by byte (round 5: until then every row's were, up to 30 single-byte copies
+            // by one lane of two of the four waves).
             uint8_t* const ob = stage + (row & 1u) * FX_OB;
+            uint8_t* const ob_next = stage + ((row + 1u) & 1u) * FX_OB;
             const u32 row_kept = tkr & 0xFFFFu;
             const u32 al = (u32)((reinterpret_cast<uintptr_t>(bases) + out_pos) & 15u);       // where the row's first byte sits in its 16-byte piece
+            if (row == 0u) foreign = al;
             if (ks) emit_bytes(d, ks, ob + al + (u32)(o - out_pos));
             __syncthreads();
             uint8_t* const g0 = bases + out_pos - al;                                          // 16-byte aligned
             const u32 end = al + row_kept;
+            const bool last_row = row + 1u == FX_ROWS || c0 + (u64)(row + 1u) * FX_ROW >= n;
             for (u32 lo = 16u * threadIdx.x; lo < end; lo += 16u * FX_THREADS) {
-                if (lo >= al && lo + 16u <= end) {
-                    { typedef u32 v4u __attribute__((ext_vector_type(4))); __builtin_nontemporal_store(*reinterpret_cast<const v4u*>(ob + lo), reinterpret_cast<v4u*>(g0 + lo)); }
-                } else {                       // the first and the last piece of a row: shared with the rows around it, byte by byte
-                    const u32 b0 = lo > al ? lo : al, b1 = lo + 16u < end ? lo + 16u : end;
+                typedef u32 v4u __attribute__((ext_vector_type(4)));
+                const u32 b0 = lo == 0u ? foreign : lo;       // the first byte of the piece that is this chunk's
+                if (b0 == lo && lo + 16u <= end) {
+                    __builtin_nontemporal_store(*reinterpret_cast<const v4u*>(ob + lo), reinterpret_cast<v4u*>(g0 + lo));
+                } else if (lo + 16u > end && !last_row) {
+                    *reinterpret_cast<v4u*>(ob_next) = *reinterpret_cast<const v4u*>(ob + lo);
+                } else {                       // the chunk's first and last piece: shared with the chunks around it, byte by byte
+                    const u32 b1 = lo + 16u < end ? lo + 16u : end;
                     for (u32 b = b0; b < b1; ++b) g0[b] = ob[b];
                 }
             }
+            // (what of the next row's piece 0 is not this chunk's: still the chunk's first piece, or nothing)
+            if (end >= 16u) foreign = 0u;
         }
         out_pos += tkr & 0xFFFFu;
         rec += tkr >> 16;

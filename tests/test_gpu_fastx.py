@@ -27,6 +27,11 @@ def _check(ctx, orc, text, fmt=0):
     bases, offsets = ctx.fastx_parse(ctx.to_device(text) if len(text) else ctx.empty(0, __import__("torch").uint8), fmt)
     assert np.array_equal(u64_numpy(offsets), eo)
     assert np.array_equal(bases.cpu().numpy(), eb)
+    # the single call into buffers sized for a bound on the records: exact and generous bound
+    for bound in (len(eo) - 1, len(text) // 2 + 1):
+        b1, o1 = ctx.fastx_parse(ctx.to_device(text) if len(text) else ctx.empty(0, __import__("torch").uint8), fmt, max_reads=bound)
+        assert np.array_equal(u64_numpy(o1), eo)
+        assert np.array_equal(b1.cpu().numpy(), eb)
     return bases, offsets, eb, eo
 
 
@@ -73,6 +78,29 @@ def test_wrong_format(ctx):
         ctx.fastx_parse(ctx.to_device(b"ACGT\nACGT\n"))
     with pytest.raises(KmxError):
         ctx.fastx_parse(ctx.to_device(b">x\nACGT\n"), 1)
+    with pytest.raises(KmxError):
+        ctx.fastx_parse(ctx.to_device(b">x\nACGT\n"), 1, max_reads=4)
+
+
+def test_more_records_than_the_bound(ctx, orc):
+    """the single call with a bound the image exceeds: KMX_E_NOMEM, the counts come back, nothing is written past the buffers"""
+    import ctypes as C
+
+    import torch
+
+    from kmers_amd import _lib
+    from kmers_amd.api import _ptr, u64_numpy
+
+    rng = np.random.default_rng(3)
+    text = fastq_text(rng, 5000, 20, 200)
+    eb, eo = orc.fastx_parse(text, 0)
+    d = ctx.to_device(text)
+    bases = ctx.empty(len(text), torch.uint8)
+    offsets = torch.full((1000 + 1 + 64,), -1, dtype=torch.int64, device=bases.device)
+    nr, nb = C.c_uint64(0), C.c_uint64(0)
+    rc = ctx.lib.kmx_fastx_parse(ctx._h, _ptr(d), d.numel(), 1, _ptr(bases), _ptr(offsets), 1000, C.byref(nr), C.byref(nb))
+    assert rc == _lib.E_NOMEM and nr.value == len(eo) - 1 and nb.value == len(eb)
+    assert bool((offsets[1001:] == -1).all())
 
 
 @pytest.mark.parametrize("k", [21, 31])
