@@ -20,8 +20,10 @@
 //      (through an LDS image of each row's output, written back in whole aligned 16-byte pieces) and writes the offsets.
 // Traffic: the text is read twice, the bases written once (HBM-bound byte work: no LDS staging of the text, a lane
 // owns 64 consecutive bytes per step and turns them into 64-bit masks -- newlines, line classes, bytes to keep -- a dword
-// at a time; only the 16-byte pieces with a line end inside are then copied byte by byte).  One pass over the text with
-// chained tile descriptors was built and measured (profiles/r03_fastx_one_pass.txt): 6x slower on this machine.
+// at a time; only the 16-byte pieces with a line end inside are then copied byte by byte).  Both passes run near both of their limits
+// (5.4-6.1 TB/s, 70-80 % VALU issue: profiles/r05_pmc_fastq.txt).  One pass over the text with chained tile descriptors was built and
+// measured twice: 16 KiB tiles, two look-backs (round 3, profiles/r03_fastx_one_pass.txt): 6x slower; 64 KiB tiles held in registers, one
+// look-back of 1024 descriptors per round trip (round 5, profiles/r05_fastq_one_pass.txt, tools/patches/fastq_one_pass.patch): 1.5x slower.
 #include "kmx_device.h"
 
 namespace kmx {
