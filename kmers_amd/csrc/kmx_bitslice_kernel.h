@@ -218,7 +218,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // only, the first of them (W - 1) >> 4: the whole frame's worth cost the 13-word frame its third block per CU
     constexpr u32 TOTS_G = (K - 1) / 16 + 2;
     constexpr u32 TOTS_DW = SEG ? 64u * TOTS_G : 0u;
-    u32* P = lds + wib * (ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW + TOTS_DW);
+    const u32 wave_dw = ldsw + 4u * PLANES + 2u * VS + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW + TOTS_DW;   // a wave's area; behind the four: 64 dwords of the block's (the end of the kernel)
+    u32* P = lds + wib * wave_dw;
     u32* PL = P + ldsw;                                      // [2][PLANES] plane array, 16-byte aligned
 
     const u64 n_full = n_reads >> 6;
@@ -1331,12 +1332,30 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
     }
 
-    // ---- one set of atomics per wave
-    if constexpr (FB_FLUSH)
-        emit_sums(bs_n, bs_s0, bs_s1, bs_x0, bs_x1, bs_fw);
-    else
-        emit_sums(wave_sum(fb_all.n) + bs_n, wave_sum(fb_all.s0) + bs_s0, wave_sum(fb_all.s1) + bs_s1, wave_xor(fb_all.x0) ^ bs_x0,
-                  wave_xor(fb_all.x1) ^ bs_x1, wave_sum(fb_all.fw) + bs_fw);
+    // ---- one set of atomics per BLOCK (round 5; until then per wave).  The waves of a batch that is not huge finish within
+    // microseconds of each other, and their 3-5 atomics each on the ONE cache line of the summary are then served one after the
+    // other at ~6 ns apiece: ~100 us per call for every batch from 1e6 to 2e7 reads (1e6 reads: 205 us per call, 24 us of them
+    // the bytes at the scan's rate) -- profiles/r05_small_batches.txt.  The four waves meet once, here, at a block barrier (every
+    // wave gets here: the gate above returns for the whole grid or for nobody).
+    if constexpr (!FB_FLUSH) {
+        bs_n += wave_sum(fb_all.n); bs_s0 += wave_sum(fb_all.s0); bs_s1 += wave_sum(fb_all.s1);
+        bs_x0 ^= wave_xor(fb_all.x0); bs_x1 ^= wave_xor(fb_all.x1); bs_fw += wave_sum(fb_all.fw);
+    }
+    u64* const BLK = reinterpret_cast<u64*>(lds + 4u * wave_dw);
+    if (lane == 0) {
+        u64* const mine = BLK + 6u * wib;
+        mine[0] = bs_n; mine[1] = bs_s0; mine[2] = bs_s1; mine[3] = bs_x0; mine[4] = bs_x1; mine[5] = bs_fw;
+    }
+    __syncthreads();
+    if (wib == 0u) {
+        u64 v[6];
+#pragma unroll
+        for (u32 i = 0; i < 6u; ++i) {
+            const u64 a = BLK[i], b = BLK[6u + i], c = BLK[12u + i], d = BLK[18u + i];
+            v[i] = (i == 3u || i == 4u) ? (a ^ b ^ c ^ d) : (a + b + c + d);
+        }
+        if (v[0] != 0ull) emit_sums(v[0], v[1], v[2], v[3], v[4], v[5]);   // (no k-mer: nothing to add -- every word is zero then)
+    }
 }
 
 // ------------------------------------------------------------------ the reads the main pass blanked out
@@ -1502,7 +1521,8 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
     constexpr u32 CSA_DW = 4u * ((K + 1) / 2);
     constexpr u32 TOTS_DW = SEG ? 64u * ((K - 1) / 16 + 2) : 0u;
-    const size_t lds_bytes = (size_t)(ldsw + 4u * (u32)bs_plane_dwords(NW) + (RAGGED ? 2u * (32u * NV + 8u) : 0u) + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW + TOTS_DW) * 4u * 4u;
+    // (four waves' areas + the 64 dwords in which they combine their sums at the end)
+    const size_t lds_bytes = (size_t)(ldsw + 4u * (u32)bs_plane_dwords(NW) + (RAGGED ? 2u * (32u * NV + 8u) : 0u) + (RAGGED ? 64u * (NE + 2) : 0u) + CSA_DW + TOTS_DW) * 4u * 4u + 256u;
     // blocks per CU, cached per host thread and device (one thread per context / GPU is the ABI's model: a plain static
     // would be shared, and written, by all of them)
     static thread_local int bpc = 0, bpc_dev = -1;

@@ -1,0 +1,22 @@
+"""dev tool: kmx_canonical_reduce on small batches -- what a call costs beside its kernel (uniform 150-bp reads, k = 31; whole call incl. the summary's way back)"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import _timing  # noqa: F401
+from kmers_amd.api import Context
+from kmers_amd import _lib
+
+ctx = Context(0)
+k, L = 31, 150
+for n in (10_000, 100_000, 1_000_000, 4_000_000, 16_000_000):
+    bases = ctx.gen_reads(L * n)
+    f = lambda: ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, 0)
+    for _ in range(20):
+        f()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter(); f(); ts.append((time.perf_counter() - t0) * 1e6)
+    ts.sort()
+    ideal = n * L / 6.3e12 * 1e6
+    print(f"n = {n:>9}: call {ts[len(ts)//2]:8.1f} us (best {ts[0]:8.1f});  the bytes at 6.3 TB/s: {ideal:7.1f} us")
