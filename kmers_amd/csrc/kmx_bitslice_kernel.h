@@ -582,24 +582,41 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // (Handing each head a contiguous region instead changed nothing: 2.50 vs 2.55 ms compute-free, equal in the full kernel.)
     constexpr u32 NQ = 32;
     u32 qid = (blockIdx.x & 255u) >> 3;
-    u32 heads_left = NQ;                                // heads this wave has not yet seen exhausted
+    u32 heads_left = NQ;                                // non-zero: some head may still hold a ticket (dequeue() clears it)
     // Every ticket from the NEXT head (round 4): a wave that stayed with "its" head tied the head's pace to the 24 blocks that
     // share it, the heads drifted apart, and with them the addresses in flight -- the HBM stream is measurably better when the
     // tiles being read lie close together (+1..2 %; tools/stream_patterns.hip).  Until the first head is seen exhausted: from
-    // then on the heads are swept once, in order, as before.
+    // then on a wave stays with the nearest head that still holds a ticket (dequeue).
     bool rot = !RAGGED;   // (the ragged variants measured 10 % SLOWER with it, same box, same day: profiles/r04_rotation_ragged.txt)
+    // A head seen drained (round 5): ALL heads at a glance -- lane i reads head i's counter, coherently -- and the next ticket from the
+    // nearest head that still holds one.  Until then a wave swept the 32 heads one synchronous device atomic after the other before it
+    // believed the queue empty: ~40 us at the end of EVERY launch, all waves at once and nothing else running (1e6 reads: 38 of a wave's
+    // 63 us; profiles/r05_small_batches.txt).  Now the end costs one failed atomic and one look.  (A head's counter only grows, and a
+    // failed atomic leaves it drained: the loop ends.)
     auto dequeue = [&]() -> u64 {
-        while (heads_left != 0u) {
+        for (;;) {
+            // (the low word: a head hands out fewer than 2^32 tickets; lanes 32..63 look at the heads again -- same answer, no branch)
+            const u32 ln = lane_now() & (NQ - 1u);
+            const u32 c = __hip_atomic_load(reinterpret_cast<const u32*>(queue) + ln * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 live = (u32)__ballot((u64)c * NQ + ln < n_full);
+            if (live == 0u) break;
+            const u32 from = (live >> qid) | (qid ? live << (NQ - qid) : 0u);          // bit i: head qid + i
+            qid = (qid + (u32)__builtin_ctz(from)) & (NQ - 1u);
             unsigned long long v = 0;
-            if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);   // heads are 128 bytes apart
+            if (lane_now() == 0u) v = atomicAdd(queue + qid * 16u, 1ull);               // heads are 128 bytes apart
             const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
             const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
             if (t < n_full) return t;
-            rot = false;
-            qid = (qid + 1u) & (NQ - 1u);               // this head is drained: help with the next one
-            heads_left -= 1u;
         }
+        heads_left = 0u;
         return ~0ull;
+    };
+    auto take_now = [&]() -> u64 {   // a ticket from the wave's own head, synchronously: the first two tiles
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);
+        const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+        const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
+        return t < n_full ? t : dequeue();
     };
     // The ticket for tile t+2 is requested in iteration t right behind phase A -- after the wave has taken its rows and asked for
     // the first rows of tile t+1 -- and looked at when the iteration ends: phases B-D later.  (Requested at the very end of the
@@ -630,7 +647,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         if (t < n_full) return t;
         rot = false;
         qid = (pend_qid + 1u) & (NQ - 1u);   // that head is drained: move on, synchronously (rare)
-        heads_left -= 1u;
         return dequeue();
     };
     auto prefetch = [&](u64 t, u64 fallback_t, int row0 = 0, int row1 = 64) {   // clamped => unconditional, one basic block, pinned by sched barriers
@@ -1114,8 +1130,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
 
     // Pipeline order 1: [A of tile t] [issue loads of tile t+1] [B,C,D of tile t]
-    tile = uniform_u64(dequeue());
-    next_tile = uniform_u64(dequeue());
+    tile = uniform_u64(take_now());
+    next_tile = uniform_u64(take_now());
     if constexpr (RAGGED) {
         if (tile < n_full) {
             meta_issue(tile);

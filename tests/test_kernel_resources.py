@@ -41,10 +41,11 @@ def test_bitsliced_kernels_stay_out_of_scratch(kernels):
         seen += 1
         assert d["Dynamic Stack"] == "False", name
         # Round 5: with the lane id and the half-wave selects rematerialised at their cold use sites and the wave's LDS bases scalar,
-        # no variant keeps more than 28 bytes in scratch (round 4: up to 80), and what is left is parked across the tile loop for the
+        # no variant keeps more than 40 bytes in scratch (round 4: up to 80; 28 before the queue's end was read at a glance -- the
+        # two-word k at four windows per lane parks 8 bytes more since), and what is left is parked across the tile loop for the
         # epilogue or a rare path -- the loop's main path touches no scratch (tools/asm_loop_scratch.py on a --keep-asm build; a
         # reload there waits with vmcnt(0) behind the next tile's rows: that, not the spill itself, is what three waves used to cost)
-        assert int(d["ScratchSize [bytes/lane]"]) <= 32, (name, d["ScratchSize [bytes/lane]"])
+        assert int(d["ScratchSize [bytes/lane]"]) <= 40, (name, d["ScratchSize [bytes/lane]"])
         # the ragged variants (three waves on the 7- / 10-word frame since round 5) and the segments of long uniform reads: <= 16 bytes.
         # Template flags: PACKED, RAGGED, SEG.
         if re.search(r"ELb0ELb1ELb0EEEv|ELb0ELb0ELb1EEEv", name):
