@@ -127,8 +127,11 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     // tile ahead; removes the under-occupied tail that static striding leaves behind
     constexpr u32 NQ = 32;
     u32 qid = (blockIdx.x & 255u) >> 3;
-    u32 heads_left = NQ;
+    u32 heads_left = NQ;   // non-zero: some head may still hold a ticket
     bool rot = true;   // every ticket from the next head until the first head is seen exhausted (kmx_bitslice_kernel.h: the heads keep pace, the tiles in flight stay close together)
+    // (round 5) a head seen drained: the 32 counters at a glance -- lane i reads head i, coherently -- and the next ticket from the nearest
+    // head that still holds one, instead of a sweep of the heads with one synchronous device atomic each (~40 us at the end of every
+    // launch: kmx_bitslice_kernel.h, profiles/r05_small_batches.txt)
     auto dequeue = [&]() -> u64 {
         while (heads_left != 0u) {
             unsigned long long v = 0;
@@ -140,8 +143,16 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
                 return t;
             }
             rot = false;
-            qid = (qid + 1u) & (NQ - 1u);
-            heads_left -= 1u;
+            // (the low word: a head hands out fewer than 2^32 tickets; lanes 32..63 look at the heads again -- same answer, no branch)
+            const u32 ln = lane & (NQ - 1u);
+            const u32 c = __hip_atomic_load(reinterpret_cast<const u32*>(queue) + ln * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 live = (u32)__ballot((u64)c * NQ + ln < n_full);
+            if (live == 0u) {
+                heads_left = 0u;
+                break;
+            }
+            const u32 from = (live >> qid) | (qid ? live << (NQ - qid) : 0u);          // bit i: head qid + i
+            qid = (qid + (u32)__builtin_ctz(from)) & (NQ - 1u);
         }
         return ~0ull;
     };
