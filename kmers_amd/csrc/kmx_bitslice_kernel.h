@@ -581,7 +581,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // three co-resident blocks of 8 CUs (old and young waves alike), so heads drain at equal rates.
     // (Handing each head a contiguous region instead changed nothing: 2.50 vs 2.55 ms compute-free, equal in the full kernel.)
     constexpr u32 NQ = 32;
-    u32 qid = (blockIdx.x & 255u) >> 3;
+    // (a grid of fewer than 256 blocks -- a small batch -- spreads over all 32 heads too: crowded on gridDim / 8 of them, most waves found their
+    // head drained at once and walked the others in step, one round trip per head: 1e4 reads took longer than 1e5)
+    u32 qid = ((blockIdx.x & 255u) * NQ) / (gridDim.x < 256u ? gridDim.x : 256u);
     u32 heads_left = NQ;                                // non-zero: some head may still hold a ticket (dequeue() clears it)
     // Every ticket from the NEXT head (round 4): a wave that stayed with "its" head tied the head's pace to the 24 blocks that
     // share it, the heads drifted apart, and with them the addresses in flight -- the HBM stream is measurably better when the
@@ -600,8 +602,10 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             const u32 c = __hip_atomic_load(reinterpret_cast<const u32*>(queue) + ln * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 live = (u32)__ballot((u64)c * NQ + ln < n_full);
             if (live == 0u) break;
-            const u32 from = (live >> qid) | (qid ? live << (NQ - qid) : 0u);          // bit i: head qid + i
-            qid = (qid + (u32)__builtin_ctz(from)) & (NQ - 1u);
+            // (the nearest live head counted from a place that differs from wave to wave: the waves that fail together do not all fall on one head)
+            const u32 at = (qid + (u32)wave_id) & (NQ - 1u);
+            const u32 from = (live >> at) | (at ? live << (NQ - at) : 0u);             // bit i: head at + i
+            qid = (at + (u32)__builtin_ctz(from)) & (NQ - 1u);
             unsigned long long v = 0;
             if (lane_now() == 0u) v = atomicAdd(queue + qid * 16u, 1ull);               // heads are 128 bytes apart
             const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));

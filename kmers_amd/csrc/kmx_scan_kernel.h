@@ -126,7 +126,9 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
     // dynamic tile queue (see kmx_bitslice.hip): NQ interleaved heads, one tile per ticket, ticket fetched one
     // tile ahead; removes the under-occupied tail that static striding leaves behind
     constexpr u32 NQ = 32;
-    u32 qid = (blockIdx.x & 255u) >> 3;
+    // (a grid of fewer than 256 blocks -- a small batch -- spreads over all 32 heads too: crowded on gridDim / 8 of them, most waves found their
+    // head drained at once and walked the others in step, one round trip per head: 1e4 reads took longer than 1e5)
+    u32 qid = ((blockIdx.x & 255u) * NQ) / (gridDim.x < 256u ? gridDim.x : 256u);
     u32 heads_left = NQ;   // non-zero: some head may still hold a ticket
     bool rot = true;   // every ticket from the next head until the first head is seen exhausted (kmx_bitslice_kernel.h: the heads keep pace, the tiles in flight stay close together)
     // (round 5) a head seen drained: the 32 counters at a glance -- lane i reads head i, coherently -- and the next ticket from the nearest
@@ -151,8 +153,10 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
                 heads_left = 0u;
                 break;
             }
-            const u32 from = (live >> qid) | (qid ? live << (NQ - qid) : 0u);          // bit i: head qid + i
-            qid = (qid + (u32)__builtin_ctz(from)) & (NQ - 1u);
+            // (the nearest live head counted from a place that differs from wave to wave: the waves that fail together do not all fall on one head)
+            const u32 at = (qid + (u32)wave_id) & (NQ - 1u);
+            const u32 from = (live >> at) | (at ? live << (NQ - at) : 0u);             // bit i: head at + i
+            qid = (at + (u32)__builtin_ctz(from)) & (NQ - 1u);
         }
         return ~0ull;
     };

@@ -7,8 +7,10 @@ from kmers_amd.api import Context
 from kmers_amd import _lib
 
 ctx = Context(0)
-k, L = 31, 150
-for n in (10_000, 100_000, 1_000_000, 4_000_000, 16_000_000):
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 31
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+sizes = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else (10_000, 100_000, 1_000_000, 4_000_000, 16_000_000)
+for n in sizes:
     bases = ctx.gen_reads(L * n)
     f = lambda: ctx.canonical_reduce(bases, n, L, k, _lib.HASH_LEX, k, 0)
     for _ in range(20):
