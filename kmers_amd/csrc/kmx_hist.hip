@@ -352,7 +352,9 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
                     e = hipFuncSetAttribute(reinterpret_cast<const void*>(red), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_bytes);
                     if (e != hipSuccess) return e;
                 }
-                const u32 groups = n_waves < 16u ? n_waves : 16u;
+                // (eight blocks per partition: 16 measured the same at 1.25e8 reads and 35 us slower per call up to 4e6 -- every block flushes a whole
+                // table --, one or two slower again: profiles/r05_small_batches.txt)
+                const u32 groups = n_waves < 8u ? n_waves : 8u;
                 hipLaunchKernelGGL(red, dim3(64, groups, halves ? 2 : 1), dim3(512), nb_bytes, stream, static_cast<const uint16_t*>(pp.stream), pp.seg_len,
                                    pp.cap, n_waves, log2_buckets, counts, (u64)0, 0u);
                 e = hipGetLastError();
