@@ -145,10 +145,10 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
                 return t;
             }
             rot = false;
-            // (the low word: a head hands out fewer than 2^32 tickets; lanes 32..63 look at the heads again -- same answer, no branch)
+            // (lanes 32..63 look at the heads again -- same answer, no branch)
             const u32 ln = lane & (NQ - 1u);
-            const u32 c = __hip_atomic_load(reinterpret_cast<const u32*>(queue) + ln * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u32 live = (u32)__ballot((u64)c * NQ + ln < n_full);
+            const u64 c = __hip_atomic_load(queue + ln * 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 live = (u32)__ballot(c < (1ull << 58) && c * NQ + ln < n_full);
             if (live == 0u) {
                 heads_left = 0u;
                 break;
