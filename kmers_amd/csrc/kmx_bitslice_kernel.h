@@ -592,8 +592,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     bool rot = !RAGGED;   // (the ragged variants measured 10 % SLOWER with it, same box, same day: profiles/r04_rotation_ragged.txt)
     // A head seen drained (round 5): ALL heads at a glance -- lane i reads head i's counter, coherently -- and the next ticket from the
     // nearest head that still holds one.  Until then a wave swept the 32 heads one synchronous device atomic after the other before it
-    // believed the queue empty: ~40 us at the end of EVERY launch, all waves at once and nothing else running (1e6 reads: 38 of a wave's
-    // 63 us; profiles/r05_small_batches.txt).  Now the end costs one failed atomic and one look.  (A head's counter only grows, and a
+    // believed the queue empty: ~40 us at the end of EVERY launch, all waves at once (1e6 reads: 38 of a wave's 63 us; at 1e8 reads, where the
+    // waves do not all get there together, 15 us = 0.6 % of the launch: profiles/r05_small_batches.txt, r05_box_spread.txt).  Now the end
+    // costs one failed atomic and one look.  (A head's counter only grows, and a
     // failed atomic leaves it drained: the loop ends.)
     auto dequeue = [&]() -> u64 {
         for (;;) {
