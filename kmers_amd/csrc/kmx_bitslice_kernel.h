@@ -413,7 +413,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             const u64 o0 = offsets[read], o1 = ends[read];
             if (read_too_long(o1 - o0, queue + KMX_TOOLONG_FROM_QUEUE)) return;   // (not scanned; kmx_ctx_synchronize reports it)
             if constexpr (K <= 32) {
-                roll_read(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
+                roll_read<false>(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
                     const u64 canon = fw < rc ? fw : rc;
                     fb.n += 1;
                     fb.s0 += canon;
@@ -421,7 +421,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     fb.fw += fw;
                 });
             } else {
-                roll_read2(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, U128 fw, U128 rc) {
+                roll_read2<false>(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, U128 fw, U128 rc) {
                     const U128 c = lt128(fw, rc) ? fw : rc;
                     const U128 h = lex_hash128(c, (u32)K);
                     fb.n += 1;
@@ -443,7 +443,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         } else if constexpr (SEG && K <= 32) {
             const u64 i = read / seg.J;
             const u32 j = (u32)(read - i * seg.J);
-            roll_read(bases + i * (u64)seg.L + seg_pos(j), L - (j >= seg.J1 ? 1u : 0u), (u32)K, [&](u32, u64 fw, u64 rc) {
+            roll_read<false>(bases + i * (u64)seg.L + seg_pos(j), L - (j >= seg.J1 ? 1u : 0u), (u32)K, [&](u32, u64 fw, u64 rc) {
                 const u64 canon = fw < rc ? fw : rc;
                 fb.n += 1;
                 fb.s0 += canon;
@@ -453,7 +453,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         } else if constexpr (SEG) {
             const u64 i = read / seg.J;
             const u32 j = (u32)(read - i * seg.J);
-            roll_read2(bases + i * (u64)seg.L + seg_pos(j), L - (j >= seg.J1 ? 1u : 0u), (u32)K, [&](u32, U128 fw, U128 rc) {
+            roll_read2<false>(bases + i * (u64)seg.L + seg_pos(j), L - (j >= seg.J1 ? 1u : 0u), (u32)K, [&](u32, U128 fw, U128 rc) {
                 const U128 c = lt128(fw, rc) ? fw : rc;
                 const U128 h = lex_hash128(c, (u32)K);
                 fb.n += 1;
@@ -463,7 +463,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 fb.x1 ^= h.hi;
             });
         } else if constexpr (K <= 32) {
-            roll_read(s, L, (u32)K, [&](u32, u64 fw, u64 rc) {
+            roll_read<false>(s, L, (u32)K, [&](u32, u64 fw, u64 rc) {
                 const u64 canon = fw < rc ? fw : rc;
                 fb.n += 1;
                 fb.s0 += canon;
@@ -471,7 +471,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 fb.fw += fw;
             });
         } else {
-            roll_read2(s, L, (u32)K, [&](u32, U128 fw, U128 rc) {
+            roll_read2<false>(s, L, (u32)K, [&](u32, U128 fw, U128 rc) {
                 const U128 c = lt128(fw, rc) ? fw : rc;
                 const U128 h = lex_hash128(c, (u32)K);
                 fb.n += 1;

@@ -191,7 +191,7 @@ __device__ __forceinline__ void flush_acc(const Acc& a, kmx_summary* out, bool w
 // CanonicalKmerIterator::find_next (src/naive_impl/canonical_kmer_iterator.rs:42-70) with
 // CanonicalKmer::append_base (canonical_kmer.rs:90-94): one lane walks one read.
 // `emit(pos, fw, rc)` is called for every yielded window, in increasing pos.
-template <typename Emit>
+template <bool AHEAD = true, typename Emit>
 __device__ __forceinline__ void roll_read(const uint8_t* __restrict__ s, u32 len, u32 k, Emit&& emit) {
     const u64 mask = mask2k(k);
     const u32 top = 2u * k - 2u;
@@ -207,12 +207,30 @@ __device__ __forceinline__ void roll_read(const uint8_t* __restrict__ s, u32 len
             last_invalid = (int)l;
         }
     };
+    // 8 bases per (unaligned) global_load_dwordx2, the loads TWO groups ahead of the walk (round 5): a lane's walk is a chain of dependent
+    // steps, and with the load issued where its bytes were wanted every group of 8 bases began with a full memory round trip -- the rolled
+    // reads of a dirty batch cost what their latencies add up to, not what the walk computes (profiles/r05_dirty_bench.txt)
+    // (AHEAD = false: the rare per-lane path INSIDE the tiled scan, where four more registers across the walk push the widest variants into
+    // scratch: there the load sits where its bytes are wanted, as it always did)
     u32 l = 0;
-    for (; l + 8u <= len; l += 8u) {   // 8 bases per (unaligned) global_load_dwordx2
-        u64 v;
-        __builtin_memcpy(&v, s + l, 8);
+    if constexpr (AHEAD) {
+        u64 v1 = 0, v2 = 0;
+        if (8u <= len) __builtin_memcpy(&v1, s, 8);
+        if (16u <= len) __builtin_memcpy(&v2, s + 8u, 8);
+        for (; l + 8u <= len; l += 8u) {
+            const u64 v = v1;
+            v1 = v2;
+            if (l + 24u <= len) __builtin_memcpy(&v2, s + l + 16u, 8);
 #pragma unroll
-        for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
+            for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
+        }
+    } else {
+        for (; l + 8u <= len; l += 8u) {
+            u64 v;
+            __builtin_memcpy(&v, s + l, 8);
+#pragma unroll
+            for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
+        }
     }
     for (; l < len; ++l) step(s[l], l);
 }
@@ -293,7 +311,7 @@ __device__ __forceinline__ U128 lex_hash128(U128 c, u32 k) {
 }
 
 // same control flow as the iterator (canonical_kmer_iterator.rs:42-70), arithmetic of kmer.rs:91-102 on 128 bits
-template <typename Emit>
+template <bool AHEAD = true, typename Emit>
 __device__ __forceinline__ void roll_read2(const uint8_t* __restrict__ s, u32 len, u32 k, Emit&& emit) {
     const u32 kb = 2u * k;  // 66..128
     const U128 mask = {~0ull, kb >= 128u ? ~0ull : ((1ull << (kb - 64u)) - 1ull)};
@@ -313,11 +331,24 @@ __device__ __forceinline__ void roll_read2(const uint8_t* __restrict__ s, u32 le
         }
     };
     u32 l = 0;
-    for (; l + 8u <= len; l += 8u) {
-        u64 v;
-        __builtin_memcpy(&v, s + l, 8);
+    if constexpr (AHEAD) {        // (the loads two groups ahead of the walk: roll_read)
+        u64 v1 = 0, v2 = 0;
+        if (8u <= len) __builtin_memcpy(&v1, s, 8);
+        if (16u <= len) __builtin_memcpy(&v2, s + 8u, 8);
+        for (; l + 8u <= len; l += 8u) {
+            const u64 v = v1;
+            v1 = v2;
+            if (l + 24u <= len) __builtin_memcpy(&v2, s + l + 16u, 8);
 #pragma unroll
-        for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
+            for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
+        }
+    } else {
+        for (; l + 8u <= len; l += 8u) {
+            u64 v;
+            __builtin_memcpy(&v, s + l, 8);
+#pragma unroll
+            for (u32 j = 0; j < 8u; ++j) step((u32)(v >> (8u * j)) & 0xFFu, l + j);
+        }
     }
     for (; l < len; ++l) step(s[l], l);
 }
