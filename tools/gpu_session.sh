@@ -1,5 +1,5 @@
 #!/bin/bash
 # scratch: the GPU session of the moment
-bash tools/profile_round.sh gpurun_out/r05e > gpurun_out/r05e.log 2>&1
-python3 tools/bench_line.py "[default]" < gpurun_out/r05e/bench_default.json
-timeout 300 python3 tools/bench_fastq_pipeline.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_fastq_pipeline.txt
+timeout 3000 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 | cut -c1-400
