@@ -277,7 +277,7 @@ def measure_traffic(argv, log=sys.stderr):
                     if row["Counter_Name"] != ctr:
                         continue
                     name = row["Kernel_Name"]
-                    key = "calib" if "calib_stream_read_kernel" in name else ("scan" if ("scan_" in name or "reduce" in name or "hist" in name or "roll_flagged" in name) else None)
+                    key = "calib" if "calib_stream_read_kernel" in name else ("scan" if ("scan_" in name or "reduce" in name or "hist" in name or "sweep_flagged" in name) else None)
                     if key:
                         per.setdefault(key, {}).setdefault(name, []).append(float(row["Counter_Value"]))
             res[ctr] = per

@@ -126,7 +126,7 @@ namespace {
 void* big_scratch(void* user, size_t bytes);
 
 // The bit-sliced scan blanks the reads that hold an invalid byte out of their tile and leaves their 64-bit mask (8 bytes
-// per tile) for roll_flagged_kernel (kmx_bitslice_kernel.h, "reads with an invalid byte").  The masks are the context's
+// per tile) for sweep_flagged_kernel (kmx_sweep.hip; kmx_bitslice_kernel.h, "reads with an invalid byte").  The masks are the context's
 // own grow-only array, zeroed when it is allocated; the rolling kernel clears every mask it consumes, so it is all-zero
 // again when a call ends and nothing has to be cleared per call.  Its address sits behind the 32 tile-queue heads (d_scratch[16 + 515]), rewritten only
 // when it changes.  No array: 0, and such tiles take the per-lane path as a whole, as they do for k without a bit-sliced kernel.

@@ -25,8 +25,8 @@
 //   D. pass 1: lane = (set, WPL adjacent windows): the ripples over 2 ceil(k/2) plane pairs (ds_read_b64) -> mask words m;
 //      pass 2: mask words and planes become matrix operands, <= 4 WPL matrix instructions accumulate G for every tile.
 // The final partial tile takes roll_read (exact iterator semantics, canonical_kmer_iterator.rs:42-70).  A tile with a
-// non-ACGTacgt byte is scanned with the offending reads blanked out; those are rolled separately, 64 at a time, by
-// roll_flagged_kernel -- see "reads with an invalid byte" in the kernel.
+// non-ACGTacgt byte is scanned with the offending reads blanked out; those are swept separately, 64 at a time, by
+// sweep_flagged_kernel (kmx_sweep.hip) -- see "reads with an invalid byte" in the kernel.
 #pragma once
 #include "kmx_device.h"
 
@@ -376,9 +376,9 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // made the scan 3.4x slower.  Rounds 1-2 had a second instantiation of this kernel scan the flagged tiles again with the
     // offending reads blanked out (+38 % at 0.5 %).  Now this pass scans such a tile itself, with those reads blanked out
     // -- bases zeroed, windows masked out of m, nk counting the others only -- and leaves the tile's 64-bit mask of those
-    // reads in the array behind queue[515] (8 bytes per tile, all zero between calls); roll_flagged_kernel then rolls just
+    // reads in the array behind queue[515] (8 bytes per tile, all zero between calls); sweep_flagged_kernel (kmx_sweep.hip) then handles just
     // those reads, 64 at a time: blanked in place such a tile costs what every tile costs.
-    // queue[515] == 0: no array, such tiles roll as a whole here; queue[512] = "a tile was marked" (lets roll_flagged_kernel
+    // queue[515] == 0: no array, such tiles roll as a whole here; queue[512] = "a tile was marked" (lets sweep_flagged_kernel
     // return at once on clean input).
     constexpr bool INLINE = !PACKED;              // (packed input has no invalid codes)
     u64 valid_reads = ~0ull;                      // reads of the current tile that are not blanked (bit = lane = read)
@@ -1156,7 +1156,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         bool bad_tile;
         // INLINE: which reads hold the invalid bytes?  The tile is still in w[]: its chunks' verdicts again, one ballot per row
         // (the bitmap parks in the plane area, free until phase C), every lane looks up the chunks of its read, and the reads'
-        // mask goes to the array behind queue[515] for roll_flagged_kernel.  The tile is then scanned with those reads blanked.
+        // mask goes to the array behind queue[515] for sweep_flagged_kernel.  The tile is then scanned with those reads blanked.
         auto blank_dirty_reads = [&](u32 n_chunks) -> bool {
             u64* const masks = reinterpret_cast<u64*>(queue[515]);
             if (masks == nullptr) {
@@ -1380,141 +1380,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 }
 
 // ------------------------------------------------------------------ the reads the main pass blanked out
-// masks[t] (behind queue[515]) = the reads of tile t that hold an invalid byte, left by the main pass,
-// which scanned the tile without them.  A lane takes the mask of one tile, the wave gathers the reads 64 at a time (one
-// ballot + one v_mbcnt per round: no list in memory, no atomics) and rolls them, one lane per read, with the reference's
-// iterator semantics (roll_read).  Every mask goes back to zero: the caller never clears the array.
-// Arguments as scan_bitsliced_kernel's.
-template <int K, bool RAGGED, bool SEG = false>
-__global__ void __launch_bounds__(256) roll_flagged_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 want_hash,
-                                                           u32 want_sumfw, void* __restrict__ out, unsigned long long* __restrict__ queue,
-                                                           const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends,
-                                                           const BsSeg seg) {
-    u64* const masks = reinterpret_cast<u64*>(queue[515]);
-    if (masks == nullptr || queue[512] == 0) return;   // queue[512]: "a tile was marked" (zeroed by the caller with the heads)
-    if constexpr (!RAGGED && !SEG) {   // (the length the gate found, as in scan_bitsliced_kernel: the reads this kernel rolls lie L0 bytes apart)
-        const u32 gate = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513]);
-        const u32 gate_len = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513 + 1]);
-        if (gate == 1u && gate_len != 0u) L = gate_len;
-    }
-    __shared__ u64 aside_all[4][64];
-    const u32 lane = threadIdx.x & 63u;
-    u64* const aside = aside_all[threadIdx.x >> 6];
-    const u64 n_full = n_reads >> 6;
-    u64 a_n = 0, a_s0 = 0, a_s1 = 0, a_x0 = 0, a_x1 = 0, a_fw = 0;
-    u32 n_aside = 0;
-    auto roll = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // Few reads set aside (the usual case: an N in 0.1 % of the reads leaves ~5 per wave): 8, 4 or 2 lanes share a read, each
-        // rolling its own run of windows from a fresh start -- a window depends on its own k bases only, so the runs add up to
-        // exactly the read's windows, and the walk, whose length is what this kernel costs, is 45-90 bases instead of 150.
-        const u32 sh = n_aside <= 8u ? 3u : n_aside <= 16u ? 2u : n_aside <= 32u ? 1u : 0u;   // (wave-uniform)
-        const u32 slot = lane >> sh, part = lane & ((1u << sh) - 1u);
-        if (slot < n_aside) {
-            const u64 read = aside[slot];
-            const uint8_t* sp = bases + lead + read * (u64)L;
-            u32 len = L;
-            if constexpr (SEG) {     // segment `read` of a long uniform read (scan_bitsliced_kernel<.., SEG>)
-                const u64 i = read / seg.J;
-                const u32 j = (u32)(read - i * seg.J), w = L - (u32)K + 1u;
-                sp = bases + i * (u64)seg.L + (j * w - (j > seg.J1 ? j - seg.J1 : 0u));
-                len = L - (j >= seg.J1 ? 1u : 0u);
-            }
-            if constexpr (RAGGED) {
-                const u64 o0 = offsets[read], o1 = ends[read];
-                sp = bases + o0;
-                len = (u32)(o1 - o0);
-            }
-            {
-                const u32 wr = len >= (u32)K ? len - (u32)K + 1u : 0u;            // windows of the read
-                const u32 per = (wr + (1u << sh) - 1u) >> sh;                      // ... of a part
-                const u32 w0 = part * per < wr ? part * per : wr, w1 = w0 + per < wr ? w0 + per : wr;
-                sp += w0;
-                len = w1 > w0 ? (w1 - w0) + (u32)(K - 1) : 0u;
-            }
-            if constexpr (K <= 32) {
-                roll_read(sp, len, (u32)K, [&](u32, u64 fw, u64 rc) {
-                    const u64 canon = fw < rc ? fw : rc;
-                    a_n += 1;
-                    a_s0 += canon;
-                    a_x0 ^= lex_hash(canon, (u32)K);
-                    a_fw += fw;
-                });
-            } else {
-                roll_read2(sp, len, (u32)K, [&](u32, U128 fw, U128 rc) {
-                    const U128 c = lt128(fw, rc) ? fw : rc;
-                    const U128 h = lex_hash128(c, (u32)K);
-                    a_n += 1;
-                    a_s0 += c.lo;
-                    a_s1 += c.hi;
-                    a_x0 ^= h.lo;
-                    a_x1 ^= h.hi;
-                });
-            }
-        }
-        n_aside = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    const u64 n_groups = (n_full + 63u) >> 6;
-    for (u64 g = (u64)blockIdx.x * 4u + (threadIdx.x >> 6); g < n_groups; g += (u64)gridDim.x * 4u) {
-        const u64 t = g * 64u + lane;
-        u64 m = t < n_full ? masks[t] : 0ull;
-        if (m != 0ull) masks[t] = 0ull;
-        for (;;) {
-            const bool has = m != 0ull;
-            const u64 b = __ballot(has);
-            if (b == 0ull) break;
-            const u32 nd = (u32)__builtin_popcountll(b);
-            if (n_aside + nd > 64u) roll();
-            const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u));
-            if (has) {
-                aside[n_aside + rank] = t * 64u + (u32)__builtin_ctzll(m);
-                m &= m - 1ull;
-            }
-            n_aside += nd;
-        }
-    }
-    if (n_aside) roll();
-    // One set of atomics per BLOCK: the waves of this kernel all finish within microseconds of each other, and 4 x 4096 atomics on
-    // the one cache line of the summary were most of its ~110 us (whether 0.1 % or 0.5 % of the reads had been set aside).
-    __shared__ u64 part[4][6];
-    {
-        const u64 wn = wave_sum(a_n), ws0 = wave_sum(a_s0), ws1 = wave_sum(a_s1), wx0 = wave_xor(a_x0), wx1 = wave_xor(a_x1), wf = wave_sum(a_fw);
-        if (lane == 0) {
-            u64* pw = part[threadIdx.x >> 6];
-            pw[0] = wn; pw[1] = ws0; pw[2] = ws1; pw[3] = wx0; pw[4] = wx1; pw[5] = wf;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    const u64 n = part[0][0] + part[1][0] + part[2][0] + part[3][0];
-    if (n == 0) return;   // nothing rolled: no atomics
-    const u64 s0 = part[0][1] + part[1][1] + part[2][1] + part[3][1], s1 = part[0][2] + part[1][2] + part[2][2] + part[3][2];
-    const u64 x0 = part[0][3] ^ part[1][3] ^ part[2][3] ^ part[3][3], x1 = part[0][4] ^ part[1][4] ^ part[2][4] ^ part[3][4];
-    const u64 f = part[0][5] + part[1][5] + part[2][5] + part[3][5];
-    {
-        if constexpr (K <= 32) {
-            kmx_summary* o = static_cast<kmx_summary*>(out);
-            atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
-            atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)s0);
-            if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)x0);
-            if (want_sumfw != 0u) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
-        } else {
-            kmx_summary2* o = static_cast<kmx_summary2*>(out);
-            atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
-            atomicAdd((unsigned long long*)&o->sum_lo, (unsigned long long)s0);
-            atomicAdd((unsigned long long*)&o->sum_hi, (unsigned long long)s1);
-            if (want_hash) {
-                atomicXor((unsigned long long*)&o->xor_lo, (unsigned long long)x0);
-                atomicXor((unsigned long long*)&o->xor_hi, (unsigned long long)x1);
-            }
-        }
-    }
-}
+// masks[t] (behind queue[515]) = the reads of tile t that hold an invalid byte, left by the main pass, which scanned the tile
+// without them.  sweep_flagged_kernel (kmx_sweep.hip, round 6) gathers them 64 at a time and handles each 64 as a tile of the
+// word domain with one validity bit per window -- exactly the windows the reference's iterator yields
+// (canonical_kmer_iterator.rs:50-66).  Every mask goes back to zero: the caller never clears the array.
+// Arguments as scan_bitsliced_kernel's; `ragged` / `is_seg` name the variant whose reads these are.
+hipError_t launch_sweep_flagged(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 want_hash, u32 want_sumfw, void* out,
+                                unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets, u32 lead, const u64* ends,
+                                const BsSeg& seg, bool ragged, bool is_seg);
 
 // ------------------------------------------------------------------ launcher
 
@@ -1568,11 +1441,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
     if constexpr (!PACKED) {
         // the reads the main pass blanked out (none on clean input: the waves return at once)
-        u64 grid1 = (u64)n_cu * 4u;
-        const u64 need1 = ((n_reads >> 6) + 255u) / 256u;   // a wave takes 64 masks at a time
-        if (grid1 > need1) grid1 = need1;
-        hipLaunchKernelGGL((roll_flagged_kernel<K, RAGGED, SEG>), dim3((unsigned)(grid1 ? grid1 : 1)), dim3(256), 0, stream, bases, n_reads, L, want_hash,
-                           want_sumfw, out, queue, offsets, lead, ends, seg);
+        return launch_sweep_flagged(bases, n_reads, L, (u32)K, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, lead, ends, seg, RAGGED, SEG);
     }
     return hipGetLastError();
 }

@@ -1,0 +1,339 @@
+// kmx_sweep.hip -- the reads the bit-sliced scan blanked out (round 6): swept 64 at a time as a TILE of the word domain.
+//
+// scan_bitsliced_kernel (kmx_bitslice_kernel.h, "reads with an invalid byte") scans a tile that holds a non-ACGTacgt byte with
+// the offending reads blanked out and leaves their 64-bit mask behind queue[515].  Until round 5 those reads were then ROLLED --
+// one lane walking one read base by base with the reference's iterator (canonical_kmer_iterator.rs:42-70): a chain of
+// dependent steps fed by 8-byte loads, 0.5 TB/s of dirty reads, so that 2 % of the reads cost 42 % of the time and 10 % cost
+// 2.2x (profiles/r05_dirty_bench.txt).  Here a wave gathers 64 of them and handles them as the word-domain scan handles a clean
+// tile: every lane loads ITS read with 16-byte loads straight into registers, packs it (encode16), and forms all windows with
+// funnel shifts -- fw from the packed words, rc from the complemented, group-reversed words.  What the iterator's last_invalid
+// rule (canonical_kmer_iterator.rs:50-66) yields is exactly the windows that hold no invalid base; so a lane keeps one bit per
+// base ("invalid", and every position past the read's end), smears it over the k positions before it (five shift-ORs of the
+// multi-word mask), and has one bit per WINDOW.  An invalid window enters the sums as fw = 0, rc = MASK[k]: canon = 0, and the
+// LexHasher(k) term MASK ^ fw ^ rc ^ canon = 0 -- three more instructions per window, no branch.  Every k from 13 to 64: a
+// window is V1 + 1 dwords (V1 = (k - 1) / 16), compared from the top dword down.
+#include "kmx_bitslice_kernel.h"
+
+#include <utility>
+
+namespace kmx {
+
+// encode16 (kmx_device.h) + one bit per byte: "not one of ACGTacgt" (the accept set of encode_binary_u8, mod.rs:40-50)
+__device__ __forceinline__ u32 encode16_inv(const uint4 w, u32& inv16) {
+    constexpr u32 TBL_LO = 0x00430041u, TBL_HI = 0x00470054u, W4 = 0x40100401u;   // as in encode16
+    const u32 t0 = w.x & 0x06060606u, t1 = w.y & 0x06060606u, t2 = w.z & 0x06060606u, t3 = w.w & 0x06060606u;
+    const u32 x0 = w.x ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t0);
+    const u32 x1 = w.y ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t1);
+    const u32 x2 = w.z ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t2);
+    const u32 x3 = w.w ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t3);
+    // a byte of x is 0x00 or 0x20 for a valid letter: bit 7 of ((x & 0x5F) + 0x7F) | x is set <=> the byte is anything else
+    auto nz = [](u32 x) { return __builtin_amdgcn_bitop3_b32((x & 0x5F5F5F5Fu) + 0x7F7F7F7Fu, x, 0x80808080u, 0xA8 /* (a | b) & c */); };
+    // v_dot4_u32_u8 gathers the four marks of a dword: 0x80 * (b0 + 2 b1 + 4 b2 + 8 b3), the second dword on top at 16 .. 128
+    const u32 a = __builtin_amdgcn_udot4(nz(x1), 0x80402010u, __builtin_amdgcn_udot4(nz(x0), 0x08040201u, 0u, false), false);
+    const u32 b = __builtin_amdgcn_udot4(nz(x3), 0x80402010u, __builtin_amdgcn_udot4(nz(x2), 0x08040201u, 0u, false), false);
+    inv16 = (a >> 7) | (b << 1);
+    const u32 d0 = __builtin_amdgcn_udot4(t0, W4, 0u, false);
+    const u32 d1 = __builtin_amdgcn_udot4(t1, W4, 0u, false);
+    const u32 d2 = __builtin_amdgcn_udot4(t2, W4, 0u, false);
+    const u32 d3 = __builtin_amdgcn_udot4(t3, W4, 0u, false);
+    u32 p = (d1 << 8) | d0;
+    p = (d2 << 16) | p;
+    p = (d3 << 23) | (p >> 1);
+    return __builtin_amdgcn_bitop3_b32(p >> 1, p, vgpr_const<0x55555555u>(), 0x6c);   // internal (ACTG) -> naive_impl (ACGT) codes
+}
+
+template <typename F, int... I>
+__device__ __forceinline__ void for_each_index_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void for_each_index(F&& f) {
+    for_each_index_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// NW: packed dwords per read (10: reads of up to 160 bases, 16: up to 256).  V1 = (k - 1) / 16: a k-mer is V1 + 1 dwords.
+// RAGGED / SEG and the arguments: as scan_bitsliced_kernel's -- `n_reads` counts what that kernel calls a read (a segment, for
+// SEG and for the long ragged reads), `L` is its frame.
+template <int NW, int V1, bool RAGGED, bool SEG>
+__global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, u32 want_hash,
+                                                            u32 want_sumfw, void* __restrict__ out, unsigned long long* __restrict__ queue,
+                                                            const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends,
+                                                            const BsSeg seg) {
+    u64* const masks = reinterpret_cast<u64*>(queue[515]);
+    if (masks == nullptr || queue[512] == 0) return;   // queue[512]: "a tile was marked" (zeroed by the caller with the heads)
+    if constexpr (!RAGGED && !SEG) {   // (the length the gate found, as in scan_bitsliced_kernel: the reads lie L0 bytes apart)
+        const u32 gate = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513]);
+        const u32 gate_len = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513 + 1]);
+        if (gate == 1u && gate_len != 0u) L = gate_len;
+    }
+    constexpr int DWN = V1 + 1;          // dwords of a k-mer
+    constexpr int NB = NW / 2;           // 32-bit words of a lane's per-base / per-window marks
+    constexpr int NBLK = NW - V1;        // blocks of 16 windows a frame can hold (16 NW - k + 1 <= 16 (NW - V1))
+    static_assert(NW % 2 == 0 && V1 >= 0 && V1 <= 3, "frames of whole mark words; k <= 64");
+    __shared__ u64 aside_all[4][64];
+    __shared__ u64 part[4][6];
+    const u32 lane = threadIdx.x & 63u;
+    u64* const aside = aside_all[threadIdx.x >> 6];
+    const u64 n_full = n_reads >> 6;
+    // the last byte any read of the batch owns: a lane's 16-byte loads run up to 15 bytes past ITS read, never past this
+    const uint8_t* buf_end;
+    if constexpr (RAGGED) buf_end = bases + ends[n_reads - 1u];
+    else if constexpr (SEG) buf_end = bases + (n_reads / seg.J) * (u64)seg.L;
+    else buf_end = bases + lead + n_reads * (u64)L;
+    const u32 top_bits = 2u * k - 32u * (u32)V1;                       // bits of the k-mer's top dword (2 .. 32)
+    const u32 mtop = top_bits >= 32u ? ~0u : (1u << top_bits) - 1u;
+    const u32 cg = (k - 1u) & 15u;                                      // the rc stream is delayed by cg groups: window 16 i + s then sits at sub-shift 30 - 2 s of G[NW - i - V1 - 1 ..]
+    const u32 wmax = L - k + 1u;                                        // windows of the longest read
+    u64 a_n = 0, a_s0 = 0, a_s1 = 0, a_x0 = 0, a_x1 = 0, a_fw = 0;
+    u32 n_aside = 0;
+    auto sweep = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- this lane's read
+        const uint8_t* sp = bases;
+        u32 len = 0;
+        if (lane < n_aside) {
+            const u64 read = aside[lane];
+            sp = bases + lead + read * (u64)L;
+            len = L;
+            if constexpr (SEG) {     // segment `read` of a long uniform read (scan_bitsliced_kernel<.., SEG>)
+                const u64 i = read / seg.J;
+                const u32 j = (u32)(read - i * seg.J), w = L - k + 1u;
+                sp = bases + i * (u64)seg.L + (j * w - (j > seg.J1 ? j - seg.J1 : 0u));
+                len = L - (j >= seg.J1 ? 1u : 0u);
+            }
+            if constexpr (RAGGED) {
+                const u64 o0 = offsets[read], o1 = ends[read];
+                sp = bases + o0;
+                len = (u32)(o1 - o0);
+                if (len > 16u * NW) __builtin_trap();    // (the scan blanks reads of tiles INSIDE the frame only: never silently uncounted)
+            }
+        }
+        // ---- its bytes: all loads in flight before the first is looked at (unconditional: a chunk past the read's end, or one that
+        // would run past the batch's last byte, reads the batch's first 16 bytes instead -- what it returns is marked below)
+        uint4 v[NW];
+#pragma unroll
+        for (int g = 0; g < NW; ++g) {
+            const uint8_t* p = sp + 16u * g;
+            const bool direct = 16u * g < len && p + 16 <= buf_end;
+            __builtin_memcpy(&v[g], direct ? p : bases + lead, 16);
+        }
+#pragma unroll
+        for (int g = 0; g < NW; ++g) {
+            const uint8_t* p = sp + 16u * g;
+            if (16u * g < len && p + 16 > buf_end) {      // the batch's last bytes, one by one (at most one lane of one wave)
+                u32 t[4] = {0u, 0u, 0u, 0u};
+                for (u32 b = 0; b < 16u && p + b < buf_end; ++b) t[b >> 2] |= (u32)p[b] << (8u * (b & 3u));
+                v[g] = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+        }
+        // ---- packed words F, and one mark per base: not ACGTacgt, or past the read's end
+        u32 F[NW + V1 + 2], inv[NB + 1];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            u32 i0, i1;
+            F[2 * j] = encode16_inv(v[2 * j], i0);
+            F[2 * j + 1] = encode16_inv(v[2 * j + 1], i1);
+            const u32 lo = 32u * j;
+            const u32 past = len <= lo ? ~0u : (len >= lo + 32u ? 0u : ~0u << (len - lo));
+            inv[j] = i0 | (i1 << 16) | past;
+        }
+        inv[NB] = ~0u;
+#pragma unroll
+        for (int j = NW; j < NW + V1 + 2; ++j) F[j] = 0u;
+        // ---- one mark per WINDOW: window o holds a marked base <=> OR of the marks o .. o + k - 1
+        for (u32 cover = 1u; cover < k;) {
+            u32 s = cover < k - cover ? cover : k - cover;           // 1, 2, 4, 8, 16, 16, ... and the rest: below 32, one funnel shift per word
+            s = s < 16u ? s : 16u;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) inv[j] |= alignbit(inv[j + 1], inv[j], s);
+            cover += s;
+        }
+        u32 nv = 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) nv += (u32)__builtin_popcount(~inv[j]);
+        a_n += nv;
+        // ---- the complemented, group-reversed words, delayed by cg groups
+        u32 G[NW + V1 + 2];
+        {
+            u32 R[NW + 1];
+#pragma unroll
+            for (int m = 0; m < NW; ++m) R[m] = revgroups32(~F[NW - 1 - m]);
+            R[NW] = 0u;
+            const u32 sh = (32u - 2u * cg) & 31u;
+#pragma unroll
+            for (int m = 0; m <= NW; ++m) G[m] = cg ? alignbit(R[m], m ? R[m - 1] : 0u, sh) : R[m];
+#pragma unroll
+            for (int m = NW + 1; m < NW + V1 + 2; ++m) G[m] = 0u;
+        }
+        // ---- windows o = 16 i + s: fw = F[i ..] >> 2 s, rc = G[NW - i - V1 - 1 ..] >> (30 - 2 s)
+        // (a fold over the block indices, not a loop: the optimizer gives up on unrolling 16 blocks of 16 windows, and F[i] / G[M] then
+        // live in scratch)
+        for_each_index<NBLK>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (16u * (u32)i >= wmax) return;         // (wave-uniform: past the last window of the frame's longest read)
+            constexpr int M = NW - i - V1 - 1;
+            // opaque copies made inside the block: the funnel shifts of every block are otherwise hoisted above the chain of uniform
+            // branches and kept live (kmx_scan_kernel.h)
+            u32 f[DWN + 1], gq[DWN + 1];
+#pragma unroll
+            for (int j = 0; j <= DWN; ++j) {
+                f[j] = F[i + j];
+                gq[j] = G[M + j];
+                asm volatile("" : "+v"(f[j]), "+v"(gq[j]));
+            }
+            const u32 wv = inv[i >> 1];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                u32 vi = (u32)__builtin_amdgcn_sbfe((int)wv, 16 * (i & 1) + s, 1);   // all ones: the window is not yielded
+                asm volatile("" : "+v"(vi));   // (opaque: hipcc otherwise turns the masks into a branch around every window)
+                u32 fw[4] = {0u, 0u, 0u, 0u}, rc[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int j = 0; j < DWN; ++j) {
+                    const u32 a = s ? alignbit(f[j + 1], f[j], 2u * s) : f[j];
+                    const u32 b = alignbit(gq[j + 1], gq[j], 30u - 2u * s);
+                    if (j == DWN - 1) {
+                        fw[j] = __builtin_amdgcn_bitop3_b32(a, mtop, vi, 0x40 /* a & b & ~c */);
+                        rc[j] = __builtin_amdgcn_bitop3_b32(b, vi, mtop, 0xA8 /* (a | b) & c */);
+                    } else {
+                        fw[j] = a & ~vi;
+                        rc[j] = b | vi;
+                    }
+                }
+                // fw < rc (canonical_kmer.rs:113-119; [u64;2]: the build-defined order of kmx.h -- the high word first)
+                const u64 fw_lo = ((u64)fw[1] << 32) | fw[0], rc_lo = ((u64)rc[1] << 32) | rc[0];
+                const u64 fw_hi = ((u64)fw[3] << 32) | fw[2], rc_hi = ((u64)rc[3] << 32) | rc[2];
+                bool lt;
+                if constexpr (DWN == 1) lt = fw[0] < rc[0];
+                else if constexpr (DWN == 2) lt = fw_lo < rc_lo;
+                else lt = fw_hi < rc_hi || (fw_hi == rc_hi && fw_lo < rc_lo);
+                // LexHasher(k)(canon) = MASK[k] ^ max(fw, rc) (kmx_scan.hip, SinkReduce).  The MASK terms are left out: a lane folds
+                // whole blocks of 16 windows, an invalid window with max = MASK -- an even number of MASKs in all, which cancel.
+                u32 cn[4], mx[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cn[j] = j < DWN ? (lt ? fw[j] : rc[j]) : 0u;
+                    mx[j] = j < DWN ? (lt ? rc[j] : fw[j]) : 0u;
+                }
+                a_s0 += ((u64)cn[1] << 32) | cn[0];
+                a_x0 ^= ((u64)mx[1] << 32) | mx[0];
+                if constexpr (DWN > 2) {
+                    a_s1 += ((u64)cn[3] << 32) | cn[2];
+                    a_x1 ^= ((u64)mx[3] << 32) | mx[2];
+                } else {
+                    a_fw += fw_lo;
+                }
+                // (pinned order: left alone, the ~250 adds of a tile become a balanced tree with every window's words live)
+                asm volatile("" : "+v"(a_s0), "+v"(a_x0));
+                if constexpr (DWN > 2) asm volatile("" : "+v"(a_s1), "+v"(a_x1));
+                else asm volatile("" : "+v"(a_fw));
+            }
+        });
+        n_aside = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // A lane takes the mask of one tile, the wave gathers the reads 64 at a time (one ballot + one v_mbcnt per round: no list in
+    // memory, no atomics) and sweeps whenever the next round would not fit.  Every mask goes back to zero: the caller never clears
+    // the array.  (ONE call site of the sweep: it is ~10 000 instructions, and inlined twice -- or not at all, with its arrays in
+    // scratch -- it is worse off.)
+    const u64 n_groups = (n_full + 63u) >> 6;
+    u64 g = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);
+    u64 t = 0, m = 0;
+    for (bool more = true; more;) {
+        for (;;) {
+            const u64 b = __ballot(m != 0ull);
+            if (b == 0ull) {                 // the next 64 masks
+                if (g >= n_groups) {
+                    more = false;
+                    break;
+                }
+                t = g * 64u + lane;
+                m = t < n_full ? masks[t] : 0ull;
+                if (m != 0ull) masks[t] = 0ull;
+                g += (u64)gridDim.x * 4u;
+                continue;
+            }
+            const u32 nd = (u32)__builtin_popcountll(b);
+            if (n_aside + nd > 64u) break;   // sweep first
+            const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u));
+            if (m != 0ull) {
+                aside[n_aside + rank] = t * 64u + (u32)__builtin_ctzll(m);
+                m &= m - 1ull;
+            }
+            n_aside += nd;
+        }
+        if (n_aside != 0u) sweep();
+    }
+    // one set of atomics per BLOCK (the waves all finish within microseconds of each other: profiles/r03_dirty_breakdown.txt)
+    {
+        const u64 wn = wave_sum(a_n), ws0 = wave_sum(a_s0), ws1 = wave_sum(a_s1), wx0 = wave_xor(a_x0), wx1 = wave_xor(a_x1), wf = wave_sum(a_fw);
+        if (lane == 0) {
+            u64* pw = part[threadIdx.x >> 6];
+            pw[0] = wn; pw[1] = ws0; pw[2] = ws1; pw[3] = wx0; pw[4] = wx1; pw[5] = wf;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const u64 n = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+    if (n == 0) return;   // nothing yielded: no atomics
+    const u64 s0 = part[0][1] + part[1][1] + part[2][1] + part[3][1], s1 = part[0][2] + part[1][2] + part[2][2] + part[3][2];
+    const u64 x0 = part[0][3] ^ part[1][3] ^ part[2][3] ^ part[3][3], x1 = part[0][4] ^ part[1][4] ^ part[2][4] ^ part[3][4];
+    const u64 f = part[0][5] + part[1][5] + part[2][5] + part[3][5];
+    if constexpr (V1 <= 1) {
+        kmx_summary* o = static_cast<kmx_summary*>(out);
+        atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
+        atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)s0);
+        if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)x0);
+        if (want_sumfw != 0u) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
+    } else {
+        kmx_summary2* o = static_cast<kmx_summary2*>(out);
+        atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
+        atomicAdd((unsigned long long*)&o->sum_lo, (unsigned long long)s0);
+        atomicAdd((unsigned long long*)&o->sum_hi, (unsigned long long)s1);
+        if (want_hash) {
+            atomicXor((unsigned long long*)&o->xor_lo, (unsigned long long)x0);
+            atomicXor((unsigned long long*)&o->xor_hi, (unsigned long long)x1);
+        }
+    }
+}
+
+template <int NW, bool RAGGED, bool SEG>
+static hipError_t launch_sweep_v(u32 v1, dim3 grid, hipStream_t stream, const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 want_hash, u32 want_sumfw,
+                                 void* out, unsigned long long* queue, const u64* offsets, u32 lead, const u64* ends, const BsSeg& seg) {
+    switch (v1) {
+    case 0: hipLaunchKernelGGL((sweep_flagged_kernel<NW, 0, RAGGED, SEG>), grid, dim3(256), 0, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg); break;
+    case 1: hipLaunchKernelGGL((sweep_flagged_kernel<NW, 1, RAGGED, SEG>), grid, dim3(256), 0, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg); break;
+    case 2: hipLaunchKernelGGL((sweep_flagged_kernel<NW, 2, RAGGED, SEG>), grid, dim3(256), 0, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg); break;
+    case 3: hipLaunchKernelGGL((sweep_flagged_kernel<NW, 3, RAGGED, SEG>), grid, dim3(256), 0, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// The launch behind every scan_bitsliced_kernel on ASCII input (launch_bs): arguments as that kernel's.
+hipError_t launch_sweep_flagged(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 want_hash, u32 want_sumfw, void* out,
+                                unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets, u32 lead, const u64* ends,
+                                const BsSeg& seg, bool ragged, bool is_seg) {
+    if (k < 2u || k > 64u || k == 32u || L < k || L > 256u) return hipErrorInvalidValue;
+    u64 grid1 = (u64)n_cu * 4u;
+    const u64 need1 = ((n_reads >> 6) + 255u) / 256u;   // a wave takes 64 masks at a time
+    if (grid1 > need1) grid1 = need1;
+    const dim3 grid((unsigned)(grid1 ? grid1 : 1));
+    const u32 v1 = (k - 1u) / 16u;
+    const bool big = L > 160u;
+    if (ragged) {
+        if (big) return launch_sweep_v<16, true, false>(v1, grid, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
+        return launch_sweep_v<10, true, false>(v1, grid, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
+    }
+    if (is_seg) {
+        if (big) return launch_sweep_v<16, false, true>(v1, grid, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
+        return launch_sweep_v<10, false, true>(v1, grid, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
+    }
+    if (big) return launch_sweep_v<16, false, false>(v1, grid, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
+    return launch_sweep_v<10, false, false>(v1, grid, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
+}
+
+}  // namespace kmx

@@ -143,7 +143,7 @@ def test_full_size_counts_linearity_and_prefix(ctx, orc, big, k):
 @pytest.mark.parametrize("k", [31, 21])
 def test_full_size_half_a_percent_of_dirty_reads(ctx, orc, big, k):
     """5e5 reads with an N (27 % of the tiles hold one): the reads are blanked out of their tiles in the main pass and rolled by
-    roll_flagged_kernel.  Window accounting, shard linearity with the dirt in, the ragged kernel on the same bytes, an
+    sweep_flagged_kernel (kmx_sweep.hip).  Window accounting, shard linearity with the dirt in, the ragged kernel on the same bytes, an
     oracle-checked prefix, and the array of masks back to all-zero (a second call gives the same)."""
     import torch
     from kmers_amd import _lib

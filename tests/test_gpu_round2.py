@@ -468,7 +468,7 @@ def test_reads_length_range(ctx):
 @pytest.mark.parametrize("k,L", [(31, 150), (21, 150), (13, 100), (47, 150), (64, 150), (31, 159)])
 @pytest.mark.parametrize("layout", ["uniform", "offsets"])
 def test_blanked_reads_in_every_position(ctx, orc, k, L, layout):
-    """the reads with an invalid byte are blanked out of their tile in the main pass and rolled by roll_flagged_kernel: a tile
+    """the reads with an invalid byte are blanked out of their tile in the main pass and handled by sweep_flagged_kernel: a tile
     with ALL its reads dirty, with exactly one, N at the first / last byte of a read (the chunk it shares with its neighbour
     blanks both: they are rolled exactly), N in every read's k-th base, two calls in a row (the masks must be back to zero)"""
     from kmers_amd import _lib

@@ -68,7 +68,7 @@ def test_scan_r3_every_length_of_the_frame(ctx, orc, L):
 
 @pytest.mark.parametrize("p_bad", [0.0002, 0.002, 0.02])
 def test_scan_r3_dirty_reads(ctx, orc, p_bad):
-    """reads with an invalid byte: blanked in phase B, masked out of m, rolled by roll_flagged_kernel"""
+    """reads with an invalid byte: blanked in phase B, masked out of m, handled by sweep_flagged_kernel"""
     from kmers_amd import _lib
 
     L, k, n_reads = 150, 31, 64 * 300 + 17
@@ -434,9 +434,10 @@ def test_reduce_eight_word_frame(ctx, orc, L, k):
 @pytest.mark.parametrize("n_dirty", [1, 3, 8, 9, 16, 17, 32, 33, 64, 65, 200])
 @pytest.mark.parametrize("k,ragged", [(31, False), (21, False), (31, True), (63, False)])
 def test_rolled_reads_shared_by_lanes(ctx, orc, n_dirty, k, ragged):
-    """roll_flagged_kernel lets 8 / 4 / 2 lanes share a read when a wave has gathered at most 8 / 16 / 32 of them (every part
-    rolls its own run of windows from a fresh start) and ends with one set of atomics per block: each regime, single- and
-    two-word k, uniform and ragged reads, invalid bytes at the ends, in the middle and twice in a read -- against the oracle"""
+    """the kernel behind the blanked reads (round 3: roll_flagged_kernel, 8 / 4 / 2 lanes sharing a read; round 6:
+    sweep_flagged_kernel, 64 reads as a tile of the word domain) with 1 .. 200 reads to gather, one set of atomics per block:
+    single- and two-word k, uniform and ragged reads, invalid bytes at the ends, in the middle and twice in a read -- against
+    the oracle"""
     from kmers_amd import _lib
 
     L, n_reads = 150, 64 * 40          # 40 tiles: their masks are one group, gathered by one wave

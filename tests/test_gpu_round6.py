@@ -1,0 +1,241 @@
+"""Round-6 GPU parity tests (through the C ABI, bit-exact against the CPU oracle).
+
+  * sweep_flagged_kernel (kmx_sweep.hip): the reads the bit-sliced scan blanks out of their tile -- an invalid byte somewhere in
+    them -- are no longer rolled by one lane each but gathered 64 at a time and handled as a tile of the word domain with one
+    validity bit per window.  Every instantiation is driven here: both frames (reads up to 160 / up to 256 bases), every k-mer
+    width (k = 13..16, 17..31, 33..48, 49..64: one to four dwords per window), uniform reads, reads behind offsets (ragged, and
+    uniform ones through the device-side gate), segments of long uniform and of long ragged reads; invalid bytes at both ends,
+    in runs, several per read, whole reads of N, and in the batch's very last read (whose 16-byte loads must not leave the
+    buffer).  The semantics at stake are the iterator's skip rule, canonical_kmer_iterator.rs:50-66: exactly the windows that
+    hold no invalid byte are yielded.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from kmers_amd.api import Context
+
+    c = Context()
+    yield c
+    c.close()
+
+
+def _dirty(host, n_reads, starts, lens, rng, share, kinds=("one", "two", "run", "ends", "all")):
+    """a share of the reads gets invalid bytes: one, two, a run, both ends, the whole read"""
+    reads = np.nonzero(rng.random(n_reads) < share)[0]
+    for i, r in enumerate(reads):
+        s, ln = int(starts[r]), int(lens[r])
+        if ln == 0:
+            continue
+        kind = kinds[i % len(kinds)]
+        if kind == "one":
+            host[s + int(rng.integers(0, ln))] = ord("N")
+        elif kind == "two":
+            host[s + int(rng.integers(0, ln))] = ord("n")
+            host[s + int(rng.integers(0, ln))] = ord("-")
+        elif kind == "run":
+            a = int(rng.integers(0, ln))
+            host[s + a : s + min(ln, a + int(rng.integers(2, 40)))] = ord("N")
+        elif kind == "ends":
+            host[s] = 0
+            host[s + ln - 1] = 255
+        else:
+            host[s : s + ln] = ord("N")
+    return reads
+
+
+def _check1(g, o, with_fw=True):
+    assert g.n_valid == o.n_valid
+    assert g.sum_canon == o.sum_canon
+    assert g.xor_hash == o.xor_hash
+    if with_fw:
+        assert g.sum_fw == o.sum_fw
+
+
+def _check2(g, o):
+    assert (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi) == (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+
+# (k, L): V1 = 0 / 1 on the 10-word frame, on the 16-word frame; L odd, L a multiple of 16, L at the frame's limit
+UNIFORM1 = [(13, 150), (16, 100), (17, 150), (21, 151), (31, 150), (31, 160), (31, 36), (27, 112),
+            (13, 200), (16, 256), (17, 161), (31, 250), (31, 256), (24, 208)]
+
+
+@pytest.mark.parametrize("k,L", UNIFORM1)
+@pytest.mark.parametrize("share", [0.02, 0.3])
+def test_sweep_uniform(ctx, orc, k, L, share):
+    from kmers_amd import _lib
+
+    n = 64 * 300 + 17
+    rng = np.random.default_rng(1000 * k + L)
+    host = ctx.gen_reads(n * L, first_byte=k * L).cpu().numpy().copy()
+    starts = np.arange(n, dtype=np.int64) * L
+    _dirty(host, n, starts, np.full(n, L), rng, share)
+    host[(n - 40) * L + 3] = ord("N")            # a read of the last full tile ...
+    host[(64 * 300 - 1) * L + L - 1] = ord("N")  # ... and its last byte
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+    g = ctx.canonical_reduce(ctx.to_device(host), n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _check1(g, o)
+
+
+@pytest.mark.parametrize("k,L", [(31, 150), (21, 100), (13, 250)])
+def test_sweep_last_read_of_the_buffer(ctx, orc, k, L):
+    """n a multiple of 64: the batch's last read sits in a full tile, is dirty, and ends with the allocation -- its last 16-byte
+    load would run past it.  The device buffer is exactly n * L bytes, from an offset that is not 16-byte aligned too."""
+    import torch
+    from kmers_amd import _lib
+
+    n = 64 * 8
+    rng = np.random.default_rng(k + L)
+    host = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * L)].copy()
+    host[(n - 1) * L + L // 2] = ord("N")
+    host[(n - 1) * L + L - 1] = ord("N")
+    host[(n - 2) * L] = ord("N")
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+    g = ctx.canonical_reduce(ctx.to_device(host), n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _check1(g, o)
+    for lead in (1, 7):
+        big = torch.empty(n * L + lead, dtype=torch.uint8, device="cuda")
+        big[lead:] = torch.from_numpy(host).cuda()
+        g = ctx.canonical_reduce(big[lead:], n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        _check1(g, o)
+
+
+# two-word k: V1 = 2 (33..48) and 3 (49..64) on both frames
+UNIFORM2 = [(33, 150), (40, 150), (48, 160), (49, 150), (63, 150), (64, 150), (33, 250), (47, 208), (50, 256), (63, 250), (64, 200)]
+
+
+@pytest.mark.parametrize("k,L", UNIFORM2)
+def test_sweep_uniform_two_word(ctx, orc, k, L):
+    n = 64 * 200 + 5
+    rng = np.random.default_rng(1000 * k + L)
+    host = ctx.gen_reads(n * L, first_byte=k * L).cpu().numpy().copy()
+    _dirty(host, n, np.arange(n, dtype=np.int64) * L, np.full(n, L), rng, 0.1)
+    host[(64 * 200 - 1) * L + L - 1] = ord("N")
+    o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+    g = ctx.canonical_reduce2(ctx.to_device(host), n, L, k, with_hash=True)
+    _check2(g, o)
+
+
+def _ragged(ctx, n, lo, hi, seed, k, share):
+    rng = np.random.default_rng(seed)
+    lens = np.where(rng.random(n) < 0.7, hi, rng.integers(lo, hi + 1, n)).astype(np.int64)
+    lens[rng.random(n) < 0.01] = rng.integers(0, k, 1)[0]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = ctx.gen_reads(int(offs[-1]), first_byte=seed).cpu().numpy().copy()
+    _dirty(host, n, offs[:-1].astype(np.int64), lens, rng, share)
+    # the batch's last read, if it sits in a full tile
+    if lens[-1] > 0:
+        host[int(offs[-1]) - 1] = ord("N")
+    return host, offs
+
+
+@pytest.mark.parametrize("k,bound,lo,hi", [(31, 150, 36, 150), (13, 160, 100, 160), (21, 100, 30, 100), (31, 250, 100, 250), (16, 256, 200, 256), (31, 0, 100, 160)])
+def test_sweep_ragged(ctx, orc, k, bound, lo, hi):
+    from kmers_amd import _lib
+
+    n = 64 * 256
+    host, offs = _ragged(ctx, n, lo, hi, 77 * k + bound, k, 0.1)
+    o = orc.canonical_reduce(host, n, bound, k, hasher_k=k, offsets=offs)
+    g = ctx.canonical_reduce(ctx.to_device(host), n, bound, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=ctx.to_device(offs))
+    _check1(g, o)
+
+
+@pytest.mark.parametrize("k,bound,lo,hi", [(33, 150, 36, 150), (47, 160, 100, 160), (55, 150, 60, 150), (64, 160, 64, 160), (63, 250, 100, 250)])
+def test_sweep_ragged_two_word(ctx, orc, k, bound, lo, hi):
+    n = 64 * 256
+    host, offs = _ragged(ctx, n, lo, hi, 77 * k + bound, k, 0.1)
+    o = orc.canonical_reduce2(host, n, bound, k, with_hash=True, offsets=offs)
+    g = ctx.canonical_reduce2(ctx.to_device(host), n, bound, k, with_hash=True, offsets=ctx.to_device(offs))
+    _check2(g, o)
+
+
+@pytest.mark.parametrize("k,L", [(31, 150), (21, 250), (63, 150), (40, 200)])
+def test_sweep_uniform_behind_offsets(ctx, orc, k, L):
+    """reads of one length behind an offsets array (untrimmed FASTQ): the device-side gate hands them to the uniform kernels, whose
+    blanked reads the sweep then finds at the length the gate left"""
+    from kmers_amd import _lib
+
+    n = 64 * 128
+    rng = np.random.default_rng(k * L)
+    host = ctx.gen_reads(n * L, first_byte=k).cpu().numpy().copy()
+    _dirty(host, n, np.arange(n, dtype=np.int64) * L, np.full(n, L), rng, 0.2)
+    offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    bound = 160 if L <= 160 else 256
+    if k <= 31:
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(ctx.to_device(host), n, bound, k, _lib.HASH_LEX, k, 0, offsets=ctx.to_device(offs))
+        _check1(g, o, with_fw=False)
+    else:
+        o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+        g = ctx.canonical_reduce2(ctx.to_device(host), n, bound, k, with_hash=True, offsets=ctx.to_device(offs))
+        _check2(g, o)
+
+
+@pytest.mark.parametrize("k,L", [(31, 300), (31, 1000), (13, 257), (21, 5000), (33, 300), (49, 1000), (63, 300), (64, 1000), (50, 400)])
+def test_sweep_segments_of_long_uniform_reads(ctx, orc, k, L):
+    from kmers_amd import _lib
+
+    n = max(64 * 40, (64 * 600 * 150) // L)
+    rng = np.random.default_rng(k + L)
+    host = ctx.gen_reads(n * L, first_byte=L).cpu().numpy().copy()
+    _dirty(host, n, np.arange(n, dtype=np.int64) * L, np.full(n, L), rng, 0.3, kinds=("one", "two", "run", "ends"))
+    host[n * L - 1] = ord("N")
+    if k <= 31:
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(ctx.to_device(host), n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        _check1(g, o)
+    else:
+        o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+        g = ctx.canonical_reduce2(ctx.to_device(host), n, L, k, with_hash=True)
+        _check2(g, o)
+
+
+@pytest.mark.parametrize("k", [31, 21, 63, 40])
+def test_sweep_segments_of_long_ragged_reads(ctx, orc, k):
+    from kmers_amd import _lib
+
+    n = 4000
+    rng = np.random.default_rng(k)
+    lens = rng.integers(200, 3000, n).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = ctx.gen_reads(int(offs[-1]), first_byte=k).cpu().numpy().copy()
+    _dirty(host, n, offs[:-1].astype(np.int64), lens, rng, 0.5, kinds=("one", "two", "run", "ends"))
+    host[int(offs[-1]) - 1] = ord("N")
+    if k <= 31:
+        o = orc.canonical_reduce(host, n, 3000, k, hasher_k=k, offsets=offs)
+        g = ctx.canonical_reduce(ctx.to_device(host), n, 3000, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW, offsets=ctx.to_device(offs))
+        _check1(g, o)
+    else:
+        o = orc.canonical_reduce2(host, n, 3000, k, with_hash=True, offsets=offs)
+        g = ctx.canonical_reduce2(ctx.to_device(host), n, 3000, k, with_hash=True, offsets=ctx.to_device(offs))
+        _check2(g, o)
+
+
+@pytest.mark.parametrize("k,L", [(31, 150), (63, 150)])
+def test_sweep_at_size_every_read_dirty(ctx, orc, k, L):
+    """1e6 reads, every one of them dirty: the sweep is the whole scan (every wave sweeps many times, the masks of every tile
+    are consumed and cleared) -- twice in a row on one context, the second call finding the masks as the first left them"""
+    from kmers_amd import _lib
+
+    n = 1_000_000
+    rng = np.random.default_rng(k)
+    host = ctx.gen_reads(n * L, first_byte=99).cpu().numpy().copy()
+    host[np.arange(n, dtype=np.int64) * L + rng.integers(0, L, n)] = ord("N")
+    dev = ctx.to_device(host)
+    for _ in range(2):
+        if k <= 31:
+            o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+            g = ctx.canonical_reduce(dev, n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+            _check1(g, o)
+        else:
+            o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+            g = ctx.canonical_reduce2(dev, n, L, k, with_hash=True)
+            _check2(g, o)

@@ -75,7 +75,7 @@ def test_headline_kernel_occupancy(kernels):
 
 def test_scan_and_histogram_kernels_do_not_call(kernels):
     for name, d in kernels.items():
-        if "scan_uniform_kernel" in name or "roll_flagged_kernel" in name or "hist_part_reduce_kernel" in name:
+        if "scan_uniform_kernel" in name or "sweep_flagged_kernel" in name or "hist_part_reduce_kernel" in name:
             assert d["Dynamic Stack"] == "False", name
 
 

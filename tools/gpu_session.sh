@@ -1,5 +1,10 @@
 #!/bin/bash
 # scratch: the GPU session of the moment
-timeout 3000 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python3 bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 | cut -c1-400
+mkdir -p gpurun_out/r6a
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+for f in 0.0 0.001 0.02 0.1; do
+  rm -rf /tmp/tr_$f
+  FRACS=$f rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$f -o t -- python3 $R/tools/bench_dirty.py > /tmp/log_$f 2>&1
+  echo "== frac $f"; python3 $R/tools/trace_kernels.py /tmp/tr_$f 2.0 | head -8
+done 2>&1 | tee $R/gpurun_out/r6a/dirty_trace.txt
