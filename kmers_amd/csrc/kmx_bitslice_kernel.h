@@ -25,8 +25,8 @@
 //   D. pass 1: lane = (set, WPL adjacent windows): the ripples over 2 ceil(k/2) plane pairs (ds_read_b64) -> mask words m;
 //      pass 2: mask words and planes become matrix operands, <= 4 WPL matrix instructions accumulate G for every tile.
 // The final partial tile takes roll_read (exact iterator semantics, canonical_kmer_iterator.rs:42-70).  A tile with a
-// non-ACGTacgt byte is scanned with the offending reads blanked out; those are swept separately, 64 at a time, by
-// sweep_flagged_kernel (kmx_sweep.hip) -- see "reads with an invalid byte" in the kernel.
+// non-ACGTacgt byte is scanned as it is; the windows that hold such a byte -- the ones the iterator does not yield -- are taken
+// back out by sweep_flagged_kernel (kmx_sweep.hip) -- see "reads with an invalid byte" in the kernel.
 #pragma once
 #include "kmx_device.h"
 
@@ -120,6 +120,12 @@ __device__ __forceinline__ bs_v8i fp4_operand_a(u32 m) {
 // an invalid byte, take the per-lane rolling path as before.
 // dwords of one set's plane area (the kernel and launch_bs size the LDS from it)
 constexpr int bs_plane_dwords(int NW) { return 32 * NW + 16; }
+// dwords of a wave's packed region (kernel and launch_bs)
+template <int NW, bool PACKED> __host__ __device__ constexpr unsigned bs_packed_dwords(unsigned chunks, unsigned wpl) {
+    if (!PACKED) return 64u * (NW + 1);
+    unsigned ldsw = (chunks + 4u + 6u + 3u) & ~3u;
+    return ldsw < 64u * wpl ? 64u * wpl : ldsw;
+}
 constexpr int BS_LOAD_NT = 2;   // cache policy of the tile loads (aux bit 1 = nt: streamed once; +1.6 % over none, sc0 / sc1 nothing -- profiles/r03_load_policy_variants.txt)
 // fp32 accumulator blocks (16 registers each) of pass 2: window block i (32 windows) meets the planes of bases 32i .. 32i+K+30,
 // i.e. the blocks of 16 bases (32 planes) 2i .. 2i + bs_acc_blocks(K) - 1
@@ -211,8 +217,13 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 wib = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform, and only readfirstlane tells hipcc so: the LDS bases derived from it are scalars, not registers held -- or spilled -- across the tile loop)
     const u32 chunks = 4u * L + ((RAGGED || SEG || lead != 0u) ? 1u : 0u);   // 16-byte chunks a tile may span (+1 for an unaligned start)
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
-    u32 ldsw = (chunks + PAD + 6u + 3u) & ~3u;         // packed region (as in kmx_scan.hip)
-    if (ldsw < 64u * WPL) ldsw = 64u * WPL;            // (it holds the mask words of pass 2 afterwards)
+    // packed region (as in kmx_scan.hip; it holds the mask words of pass 2 afterwards).  ASCII input (round 6): a multiple of 64 dwords
+    // fixed by the frame -- phase A leaves the VALIDATION word of chunk c (expected letters ^ bytes) exactly XOFF dwords behind its packed
+    // word, in the plane area (free until phase C), with the same LDS instruction (ds_write2st64_b32: two dwords a compile-time multiple
+    // of 256 bytes apart); see "reads with an invalid byte"
+    u32 ldsw = bs_packed_dwords<NW, PACKED>(chunks, WPL);
+    constexpr u32 XOFF = 64u * (NW + 1);
+    static_assert(PACKED || (XOFF >= 64u * WPL && 1u + 64u * NW <= 2u * (u32)bs_plane_dwords(NW)), "the validation words fit the plane area");
     constexpr u32 CSA_DW = 4u * ((K + 1) / 2);         // 2 * NT 64-bit sums of the counter classes
     // SEG: per-plane totals of the SHORT segments (as TOT, [group][lane]) -- of the groups that hold the last window's K bases
     // only, the first of them (W - 1) >> 4: the whole frame's worth cost the 13-word frame its third block per CU
@@ -315,7 +326,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     SegTile cur_g, nx_g;
     u32 seg_rel = 0;            // this lane's segment of the CURRENT tile: first byte - the tile's first byte
     u64 seg_short = 0;          // the current tile's short segments (bit = lane = segment)
-    u32 n_short = 0;            // short segments (not blanked) in this wave's scanned tiles: one window less each
+    u32 n_short = 0;            // short segments in this wave's scanned tiles: one window less each
     auto seg_pos = [&](u32 j) -> u32 { return j * W - (j > seg.J1 ? j - seg.J1 : 0u); };
     auto seg_div = [&](u32 n, u32& q, u32& r) {      // n < J + 64
         q = seg.J >= 64u ? (n >= seg.J ? 1u : 0u) : __umulhi(n, seg.magic);
@@ -372,17 +383,19 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
     };
     // ---- reads with an invalid byte (ASCII input, uniform or ragged).  A tile that holds one used to go to the per-lane path
-    // as a whole -- 64 reads rolled at 6.5x the cost of a bit-sliced tile, so 0.5 % of reads with an N (27 % of the tiles)
-    // made the scan 3.4x slower.  Rounds 1-2 had a second instantiation of this kernel scan the flagged tiles again with the
-    // offending reads blanked out (+38 % at 0.5 %).  Now this pass scans such a tile itself, with those reads blanked out
-    // -- bases zeroed, windows masked out of m, nk counting the others only -- and leaves the tile's 64-bit mask of those
-    // reads in the array behind queue[515] (8 bytes per tile, all zero between calls); sweep_flagged_kernel (kmx_sweep.hip) then handles just
-    // those reads, 64 at a time: blanked in place such a tile costs what every tile costs.
-    // queue[515] == 0: no array, such tiles roll as a whole here; queue[512] = "a tile was marked" (lets sweep_flagged_kernel
-    // return at once on clean input).
+    // as a whole (64 reads rolled at 6.5x the cost of a bit-sliced tile); rounds 3-5 scanned such a tile with the offending reads
+    // BLANKED and had them rolled, later swept, elsewhere -- but finding those reads re-validated the whole tile from w[], 150
+    // instructions per dirty tile (73 % of the tiles when 2 % of the reads hold an N: +16 % on the scan), and the code's mere presence --
+    // w[] alive past phase A, the prefetch behind it -- cost 2.7 % on CLEAN input (profiles/r06_dirty_variants.txt).  Round 6:
+    //   * phase A parks every chunk's validation word in LDS at no instruction's cost (XOFF above); a dirty tile looks its reads'
+    //     chunks up there -- LDS only, the next tile's rows already requested -- and leaves the 64-bit mask of the reads that touch a
+    //     bad chunk in the array behind queue[515] (8 bytes per tile, all zero between calls; queue[512] = "a tile was marked");
+    //   * nothing is blanked: the tile is scanned as it is, an invalid byte counting as the base its bits (b >> 1) & 3 spell, and
+    //     sweep_flagged_kernel (kmx_sweep.hip) takes the windows that hold such a byte -- exactly those the reference's iterator does
+    //     not yield (canonical_kmer_iterator.rs:50-66) -- back OUT of the sums, from the same codes.
+    // queue[515] == 0: no array; a ragged tile then rolls as a whole here (uniform input: the host side always provides the array).
     constexpr bool INLINE = !PACKED;              // (packed input has no invalid codes)
-    u64 valid_reads = ~0ull;                      // reads of the current tile that are not blanked (bit = lane = read)
-    u32 n_blanked = 0;                            // reads blanked in this wave's tiles
+    u64* const masks = INLINE ? reinterpret_cast<u64*>(uniform_u64(queue[515])) : nullptr;   // (read once: two scalar registers)
     // word-domain accumulators of the fallback path (tiles with invalid bytes, the final partial tile)
     struct FbAcc { u64 n = 0, s0 = 0, s1 = 0, x0 = 0, x1 = 0, fw = 0; };
     auto emit_sums = [&](u64 n, u64 r0, u64 r1, u64 h0, u64 h1, u64 f) {   // wave-uniform values, one set of atomics
@@ -667,7 +680,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // (one asm statement each, so that nothing else is scheduled into them), the full-rate ones (v_and, v_xor,
     // v_bitop3, v_lshrrev) around them at base priority.
     const u32 k55 = 0x55555555u;   // (a literal: an SGPR or literal source does not keep a full-rate instruction from pairing -- profiles/r02_valu_coissue_ubench9.txt)
-    auto encode_prio = [&](const uint4& wv, u32& bad) -> u32 {
+    auto encode_prio = [&](const uint4& wv, u32& bad) -> u32 {   // bad = expected letters ^ bytes, ORed over the chunk's four dwords (a valid chunk: 0x00 / 0x20 in every byte)
         constexpr u32 TBL_LO = 0x00430041u, TBL_HI = 0x00470054u, W4 = 0x40100401u;   // as in encode16
         u32 t0 = wv.x & 0x06060606u, t1 = wv.y & 0x06060606u, t2 = wv.z & 0x06060606u, t3 = wv.w & 0x06060606u;
         u32 e0, e1, e2, e3;
@@ -680,7 +693,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                      : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
                      : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(TBL_HI), "v"(TBL_LO));
         // bad |= expected ^ actual, one v_bitop3_b32 per dword (S0 | (S1 ^ S2) = 0xF6) instead of 4 v_xor + 2 three-input ORs
-        bad = __builtin_amdgcn_bitop3_b32(bad, e0, wv.x, 0xF6);
+        bad = e0 ^ wv.x;
         bad = __builtin_amdgcn_bitop3_b32(bad, e1, wv.y, 0xF6);
         bad = __builtin_amdgcn_bitop3_b32(bad, e2, wv.z, 0xF6);
         bad = __builtin_amdgcn_bitop3_b32(bad, e3, wv.w, 0xF6);
@@ -700,24 +713,21 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                      : "s"(W4));
         return __builtin_amdgcn_bitop3_b32(t0 >> 1, t0, k55, 0x6c);   // internal (ACTG) -> naive_impl (ACGT) codes
     };
-    auto phase_A = [&]() -> bool {   // pack + validate the tile sitting in w[] into the packed LDS buffer
-        u32 bad = 0;
-        if constexpr (RAGGED) {      // the tile spans cur_m.n_ch chunks from its aligned start (neighbouring tiles' bytes at both ends)
-            if (cur_m.n_ch >= 64u * (NW - 1)) {   // wave-uniform: only the last row is partial (64 reads of 150: 600 or 601 chunks)
-#pragma unroll
-                for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
-                const u32 c = (NW - 1) * 64u + lane;
-                if (c < cur_m.n_ch) P[1u + c] = encode_prio(w[NW - 1], bad);
-            } else {
-                // (row bound on the scalar side, compared with the lane id: ten per-row chunk indices would sit in registers across the tile loop)
-#pragma unroll
-                for (int it = 0; it < NW; ++it) {
-                    const int left = (int)cur_m.n_ch - 64 * it;
-                    if ((int)lane < left) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
-                }
+    auto phase_A = [&]() -> bool {   // pack + validate the tile sitting in w[] into the packed LDS buffer; true: some chunk holds an invalid byte
+        // one chunk: its packed word and, XOFF dwords behind it, its validation word (hipcc merges the two stores into ONE
+        // ds_write2st64_b32).  `any` collects the validation words two rows at a time (a three-input OR at full rate).
+        u32 any = 0, held = 0;
+        auto row = [&](const int it, const bool mine) {
+            u32 r = 0;
+            if (mine) {
+                const u32 code = encode_prio(w[it], r);
+                P[1u + (u32)it * 64u + lane] = code;
+                P[1u + XOFF + (u32)it * 64u + lane] = r;
             }
-            return __any(chunk_has_invalid(bad));
-        } else if constexpr (PACKED) {      // already 2-bit codes: 16 bytes = 4 packed dwords per lane and load
+            if (it & 1) any = __builtin_amdgcn_bitop3_b32(any, held, r, 0xFE);
+            else held = r;
+        };
+        if constexpr (PACKED) {      // already 2-bit codes: 16 bytes = 4 packed dwords per lane and load
 #pragma unroll
             for (int it = 0; it < NLD; ++it) {
                 const u32 c = it * 64u + lane;
@@ -725,27 +735,20 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             }
             return false;
         } else {
-            if (SEG) {     // the tile's own chunk count
-                const u32 n_ch = (cur_g.nbytes + 15u) >> 4;
+            // the chunks of the tile: ragged -- cur_m.n_ch from its aligned start (neighbouring tiles' bytes at both ends); SEG -- the
+            // tile's own count; uniform -- `chunks`
+            const u32 n_ch = RAGGED ? cur_m.n_ch : SEG ? (cur_g.nbytes + 15u) >> 4 : chunks;
+            if (!SEG && n_ch >= 64u * (NW - 1)) {   // wave-uniform: only the last row is partial (64 reads of 150: 600 or 601 chunks)
 #pragma unroll
-                for (int it = 0; it < NW; ++it) {
-                    const int left = (int)n_ch - 64 * it;
-                    if ((int)lane < left) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
-                }
-            } else if (chunks >= 64u * (NW - 1)) {
-                // wave-uniform: only the last row of chunks is partial (L = 150: 600 = 9*64 + 24)
-#pragma unroll
-                for (int it = 0; it < NW - 1; ++it) P[1u + it * 64u + lane] = encode_prio(w[it], bad);
-                const u32 c = (NW - 1) * 64u + lane;
-                if (c < chunks) P[1u + c] = encode_prio(w[NW - 1], bad);
+                for (int it = 0; it < NW - 1; ++it) row(it, true);
+                row(NW - 1, (NW - 1) * 64u + lane < n_ch);
             } else {
+                // (row bound on the scalar side, compared with the lane id: ten per-row chunk indices would sit in registers across the tile loop)
 #pragma unroll
-                for (int it = 0; it < NW; ++it) {
-                    const u32 c = it * 64u + lane;
-                    if (c < chunks) P[1u + c] = encode_prio(w[it], bad);
-                }
+                for (int it = 0; it < NW; ++it) row(it, (int)lane < (int)n_ch - 64 * it);
             }
-            return __any(chunk_has_invalid(bad));
+            if (NW & 1) any |= held;
+            return __any(chunk_has_invalid(any));
         }
     };
     auto lds_fence = [&]() {
@@ -777,27 +780,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(0);
         }
-        if constexpr (INLINE) {
-            if (valid_reads != ~0ull) {
-                // (from an opaque copy of the lane id, made here: hipcc otherwise keeps 1 << lane and its complement, two
-                // 64-bit values, in registers across the tile loop for this rare branch)
-                u32 ln_o = lane;
-                asm volatile("" : "+v"(ln_o));
-                const bool blank = ((valid_reads >> ln_o) & 1ull) == 0ull;
-#pragma unroll
-                for (int g = 0; g < NW; ++g) F[g] = blank ? 0u : F[g];
-            }
-        }
         if constexpr (RAGGED) {
-            bool set_aside = false;   // a read with an invalid byte: rolled elsewhere
-            if constexpr (INLINE) {
-                if (valid_reads != ~0ull) {
-                    u32 ln_o = lane;   // (opaque copy: see above)
-                    asm volatile("" : "+v"(ln_o));
-                    set_aside = ((valid_reads >> ln_o) & 1ull) == 0ull;
-                }
-            }
-            const u32 len = (cur_m.len >= (u32)K && !set_aside) ? cur_m.len : 0u;   // a read shorter than k owns no window: it is blanked out entirely
+            const u32 len = cur_m.len >= (u32)K ? cur_m.len : 0u;   // a read shorter than k owns no window: it is blanked out entirely
             // bases past the end of the read belong to the next read.  They stay: a window that holds one is masked out of m by
             // its validity plane, and the plane totals count a plane through the validity plane of its base (below)
             // the last K-1 bases of the read, base len-K+1+i at position i of the NE dwords
@@ -1039,13 +1023,6 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                     m[w] = ((u32)w < nwin) ? lt[w] : 0u;
                 }
             }
-            if constexpr (INLINE) {
-                if (valid_reads != ~0ull) {   // (wave-uniform; a clean tile pays the branch)
-                    const u32 vm = half_word(valid_reads);
-#pragma unroll
-                    for (int w = 0; w < WPL; ++w) m[w] &= vm;
-                }
-            }
             if constexpr (SEG) {
                 if (seg_short != 0ull) {      // (wave-uniform)
                     const u32 keep = ~half_word(seg_short);
@@ -1129,7 +1106,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #undef KMX_PLANE_AT
         if (run) n_bs_tiles += 1;
         if constexpr (SEG) {
-            if (run) n_short += (u32)__builtin_popcountll(seg_short & valid_reads);
+            if (run) n_short += (u32)__builtin_popcountll(seg_short);
         }
         if (run && (n_bs_tiles & (BS_FOLD_TILES - 1u)) == 0u) fold_acc();   // (wave-uniform, rare: keeps every fp32 accumulator an exact integer)
     };
@@ -1153,61 +1130,50 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     }
     while (tile < n_full) {
         if constexpr (SEG) seg_lane(cur_g);
-        bool bad_tile;
-        // INLINE: which reads hold the invalid bytes?  The tile is still in w[]: its chunks' verdicts again, one ballot per row
-        // (the bitmap parks in the plane area, free until phase C), every lane looks up the chunks of its read, and the reads'
-        // mask goes to the array behind queue[515] for sweep_flagged_kernel.  The tile is then scanned with those reads blanked.
-        auto blank_dirty_reads = [&](u32 n_chunks) -> bool {
-            u64* const masks = reinterpret_cast<u64*>(queue[515]);
+        // A tile with an invalid byte: which reads touch a bad chunk?  Every lane ORs the validation words of its read's chunks (phase A
+        // left them in the plane area, free until phase C) -- a chunk shared by two reads marks both, the sweep looks at the bytes -- and
+        // the reads' mask goes to the array behind queue[515].  LDS reads and ONE global store.
+        auto mark_dirty_reads = [&]() -> bool {
             if (masks == nullptr) {
                 if constexpr (!RAGGED) __builtin_trap();   // (the host side always provides the array)
                 return false;
             }
-            u64* BM = reinterpret_cast<u64*>(PL);
-#pragma unroll
-            for (int it = 0; it < NW; ++it) {
-                const u32 c = it * 64u + lane;
-                u32 rb = 0;
-                (void)encode16(w[it], rb);
-                const u64 row = __ballot(c < n_chunks && chunk_has_invalid(rb));
-                if (lane == 0) BM[it] = row;
-            }
-            if (lane == 0) {
-                u32 z = 0;                       // (made here: as a constant the 64-bit zero was kept -- spilled -- across the tile loop for this rare path)
-                asm volatile("" : "+v"(z));
-                reinterpret_cast<u32*>(BM + NW)[0] = z; reinterpret_cast<u32*>(BM + NW)[1] = z;
-                reinterpret_cast<u32*>(BM + NW)[2] = z; reinterpret_cast<u32*>(BM + NW)[3] = z;
-            }
-            lds_fence();
-            u32 rd_off = lane * L + lead, rd_len = L;    // the read's bytes, relative to the tile's aligned start
+            u32 rd_off = lane_now() * L + lead, rd_len = L;    // the read's bytes, relative to the tile's aligned start
             if constexpr (RAGGED) { rd_off = cur_m.rel; rd_len = cur_m.len; }
-            if constexpr (SEG) { rd_off = seg_rel + cur_g.lead; rd_len = L - (u32)((seg_short >> lane) & 1ull); }
-            // a read is blanked if any chunk it touches is bad (a chunk shared by two reads blanks both: they are rolled exactly anyway)
+            if constexpr (SEG) { rd_off = seg_rel + cur_g.lead; rd_len = L - (u32)((seg_short >> lane_now()) & 1ull); }
             const u32 c0 = rd_off >> 4, c1 = rd_len ? (rd_off + rd_len - 1u) >> 4 : c0;
-            const u32 q0 = c0 >> 6, b0 = c0 & 63u;
-            const u64 lo = BM[q0], hi = BM[q0 + 1u];
-            const u64 bits = b0 ? ((lo >> b0) | (hi << (64u - b0))) : lo;
-            const bool dirty = rd_len != 0u && (bits & ((1ull << (c1 - c0 + 1u)) - 1ull)) != 0ull;
-            const u64 dm = uniform_u64(__ballot(dirty));
-            if (lane == 0) {
-                u32 one = 1u;   // (made here: hoisted out of the tile loop these constants each hold a register for good)
-                asm volatile("" : "+v"(one));
-                masks[tile] = dm;
-                queue[512] = one;
+            const u32* const xs = P + (1u + XOFF) + c0;
+            u32 x = 0;
+#pragma unroll
+            for (int j = 0; j <= NW; ++j) {      // (a read of 16 NW bases touches at most NW + 1 chunks)
+                const u32 v = xs[j];             // (past the read's last chunk: whatever lies there -- inside the wave's own area -- is not looked at)
+                x |= c0 + (u32)j <= c1 ? v : 0u;
             }
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see flag_tile
-            valid_reads = ~dm;
-            n_blanked += (u32)__builtin_popcountll(dm);
-            lds_fence();
+            const u64 dm = uniform_u64(__ballot(rd_len != 0u && chunk_has_invalid(x)));
+            if (dm != 0ull) {
+                // (buffer stores: the addresses stay on the scalar side.  A flat store's 64-bit address and the constants around it
+                // cost the widest variants registers ACROSS the tile loop -- the two-word k on the 10-word frame spilled 24..160 bytes
+                // with reloads on the loop's main path, the ticket among them)
+                typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+                const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(uniform_u64(reinterpret_cast<u64>(masks + tile))), 0, 8, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(uniform_u64(reinterpret_cast<u64>(queue + 512))), 0, 8, 0x00020000);
+                if (lane_now() == 0u) {
+                    u32x2 dv = {(u32)dm, (u32)(dm >> 32)}, ov = {1u, 0u};
+                    __builtin_amdgcn_raw_buffer_store_b64(dv, rm, 0, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(ov, rq, 0, 0, 0);
+                }
+            }
             return true;
         };
-        if constexpr (INLINE) valid_reads = ~0ull;
+        bool bad_tile = false;      // a tile that is not scanned here: it rolls per lane, as a whole
         if constexpr (RAGGED) {
-            bad_tile = !cur_m.fits || phase_A();
-            if constexpr (INLINE) {
-                if (bad_tile && cur_m.fits && blank_dirty_reads(cur_m.n_ch)) bad_tile = false;   // (tiles outside the frame roll as a whole)
-            }
+            const bool dirty = cur_m.fits && phase_A();
+            bad_tile = !cur_m.fits;
             if constexpr (LATE > 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the uniform branch
+            if (dirty) {     // (before the next tile's rows are asked for: their registers are still free here)
+                lds_fence();
+                if (!mark_dirty_reads()) bad_tile = true;   // (no mask array: exact, the slow way)
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (next_tile < n_full) {
                 meta_finish(nx_m);            // offsets requested a whole iteration ago
@@ -1216,20 +1182,23 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             __builtin_amdgcn_sched_barrier(0);
             ticket_issue();
         } else {
-            bad_tile = phase_A();
+            const bool dirty = phase_A();
             // LATE > 0: the waits for the rows' loads sit under branches of phase A (lanes past the tile skip their chunk), so
             // for hipcc a row may still be in flight afterwards, and the first write to one of its registers -- they are free
             // until the late rows go out -- would cost an s_waitcnt vmcnt(0) with the next tile's loads already out.  Here, on
             // every path, the wait is free: the wave has just used all of them.
             if constexpr (LATE > 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             if constexpr (INLINE) {
-                if (bad_tile && blank_dirty_reads(SEG ? (cur_g.nbytes + 15u) >> 4 : chunks)) bad_tile = false;
+                if (dirty) {     // (before the next tile's rows are asked for: their registers are still free here)
+                    lds_fence();
+                    (void)mark_dirty_reads();
+                }
             }
             prefetch(next_tile, tile, 0, NLD - LATE);
             ticket_issue();
         }
         lds_fence();
-        if (bad_tile) {   // not blanked in place: a ragged tile outside the frame (packed input has no such tiles, uniform ASCII reads never get here)
+        if (bad_tile) {   // a ragged tile outside the frame (packed input has no such tiles, uniform ASCII reads never get here)
             if constexpr (RAGGED) fallback_read(tile * 64u + lane, true);
         }
         {
@@ -1263,7 +1232,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u64 bs_n = 0, bs_s0 = 0, bs_s1 = 0, bs_x0 = 0, bs_x1 = 0, bs_fw = 0;
     if (n_bs_tiles != 0u) {
         // k-mers handled bit-sliced by this wave
-        const u64 nk = RAGGED ? wave_sum(NVR[lane]) : ((u64)n_bs_tiles * 64u - n_blanked) * (u64)W - n_short;   // (SEG: a short segment holds one window less)
+        const u64 nk = RAGGED ? wave_sum(NVR[lane]) : (u64)n_bs_tiles * 64u * (u64)W - n_short;   // (SEG: a short segment holds one window less)
         bs_n = nk;
         u64 fwall = 0;
         u32 tot[NW];
@@ -1379,11 +1348,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     }
 }
 
-// ------------------------------------------------------------------ the reads the main pass blanked out
-// masks[t] (behind queue[515]) = the reads of tile t that hold an invalid byte, left by the main pass, which scanned the tile
-// without them.  sweep_flagged_kernel (kmx_sweep.hip, round 6) gathers them 64 at a time and handles each 64 as a tile of the
-// word domain with one validity bit per window -- exactly the windows the reference's iterator yields
-// (canonical_kmer_iterator.rs:50-66).  Every mask goes back to zero: the caller never clears the array.
+// ------------------------------------------------------------------ the reads the main pass marked
+// masks[t] (behind queue[515]) = the reads of tile t that touch a chunk with an invalid byte, left by the main pass, which
+// scanned the tile as it is.  sweep_flagged_kernel (kmx_sweep.hip, round 6) gathers them 64 at a time, finds the windows that
+// hold an invalid byte -- exactly those the reference's iterator does not yield (canonical_kmer_iterator.rs:50-66) -- and
+// subtracts them.  Every mask goes back to zero: the caller never clears the array.
 // Arguments as scan_bitsliced_kernel's; `ragged` / `is_seg` name the variant whose reads these are.
 hipError_t launch_sweep_flagged(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 want_hash, u32 want_sumfw, void* out,
                                 unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets, u32 lead, const u64* ends,
@@ -1409,8 +1378,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
         if ((reinterpret_cast<uintptr_t>(bases) & 15u) != 0u || 4u * L + 1u > 64u * (u32)NW) return hipErrorInvalidValue;
     }
     const u32 chunks = 4u * L + ((RAGGED || SEG || lead != 0u) ? 1u : 0u);
-    u32 ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
-    if (ldsw < 64u * (u32)WPL) ldsw = 64u * (u32)WPL;
+    const u32 ldsw = bs_packed_dwords<NW, PACKED>(chunks, (u32)WPL);
     constexpr u32 NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;
     constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
     constexpr u32 CSA_DW = 4u * ((K + 1) / 2);
@@ -1440,7 +1408,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
     if constexpr (!PACKED) {
-        // the reads the main pass blanked out (none on clean input: the waves return at once)
+        // the windows with an invalid byte, out again (none on clean input: the waves return at once)
         return launch_sweep_flagged(bases, n_reads, L, (u32)K, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, lead, ends, seg, RAGGED, SEG);
     }
     return hipGetLastError();

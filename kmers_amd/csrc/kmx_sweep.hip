@@ -1,20 +1,20 @@
-// kmx_sweep.hip -- the reads the bit-sliced scan blanked out (round 6): swept 64 at a time as a TILE of the word domain.
+// kmx_sweep.hip -- the windows that hold an invalid byte, taken back out of the bit-sliced scan's sums (round 6).
 //
-// scan_bitsliced_kernel (kmx_bitslice_kernel.h, "reads with an invalid byte") scans a tile that holds a non-ACGTacgt byte with
-// the offending reads blanked out and leaves their 64-bit mask behind queue[515].  Until round 5 those reads were then ROLLED --
-// one lane walking one read base by base with the reference's iterator (canonical_kmer_iterator.rs:42-70): a chain of
-// dependent steps fed by 8-byte loads, 0.5 TB/s of dirty reads, so that 2 % of the reads cost 42 % of the time and 10 % cost
-// 2.2x (profiles/r05_dirty_bench.txt).  Here a wave gathers 64 of them and handles them as the word-domain scan handles a clean
-// tile: every lane loads ITS read with 16-byte loads straight into registers, packs it (encode16), and forms all windows with
-// funnel shifts -- fw from the packed words, rc from the complemented, group-reversed words.  What the iterator's last_invalid
-// rule (canonical_kmer_iterator.rs:50-66) yields is exactly the windows that hold no invalid base; so a lane keeps one bit per
-// base ("invalid", and every position past the read's end), smears it over the k positions before it (five shift-ORs of the
-// multi-word mask), and has one bit per WINDOW.  An invalid window enters the sums as fw = 0, rc = MASK[k]: canon = 0, and the
-// LexHasher(k) term MASK ^ fw ^ rc ^ canon = 0 -- three more instructions per window, no branch.  Every k from 13 to 64: a
-// window is V1 + 1 dwords (V1 = (k - 1) / 16), compared from the top dword down.
+// scan_bitsliced_kernel (kmx_bitslice_kernel.h, "reads with an invalid byte") scans a tile that holds a non-ACGTacgt byte as it is --
+// such a byte counts as the base its bits (b >> 1) & 3 spell -- and leaves the 64-bit mask of the reads that touch a bad chunk
+// behind queue[515].  What the reference's iterator does NOT yield is exactly the windows that hold an invalid byte (the
+// last_invalid rule, canonical_kmer_iterator.rs:50-66): this kernel evaluates those windows, from the same codes, and subtracts them.
+// Until round 5 the scan blanked such reads and they were ROLLED, one lane walking one read base by base: 0.5 TB/s of dirty
+// reads, 2 % of the reads cost 42 % of the time, 10 % cost 2.2x (profiles/r05_dirty_bench.txt).
+//
+// A wave gathers 64 marked reads; every lane loads ITS read with 16-byte loads straight into registers, packs it (encode16) and
+// keeps one bit per base, "invalid", which five shift-ORs of the multi-word mask smear over the k positions before it: one bit
+// per WINDOW.  One N spoils k windows of a read's ~120, so a lane does not walk its read: it takes the first spoiled window a,
+// pulls the packed words (and the complemented, group-reversed ones the rc side reads) back from its LDS row re-aligned to a,
+// and evaluates the 32 windows from there with funnel shifts at compile-time positions, masked by the window bits -- again
+// while any lane has windows left (a read of nothing but N: four rounds).  Every k from 13 to 64: a window is V1 + 1 dwords
+// (V1 = (k - 1) / 16), compared from the top dword down.
 #include "kmx_bitslice_kernel.h"
-
-#include <utility>
 
 namespace kmx {
 
@@ -42,18 +42,12 @@ __device__ __forceinline__ u32 encode16_inv(const uint4 w, u32& inv16) {
     return __builtin_amdgcn_bitop3_b32(p >> 1, p, vgpr_const<0x55555555u>(), 0x6c);   // internal (ACTG) -> naive_impl (ACGT) codes
 }
 
-template <typename F, int... I>
-__device__ __forceinline__ void for_each_index_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void for_each_index(F&& f) {
-    for_each_index_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-
 // NW: packed dwords per read (10: reads of up to 160 bases, 16: up to 256).  V1 = (k - 1) / 16: a k-mer is V1 + 1 dwords.
 // RAGGED / SEG and the arguments: as scan_bitsliced_kernel's -- `n_reads` counts what that kernel calls a read (a segment, for
 // SEG and for the long ragged reads), `L` is its frame.
+template <int NW, int V1> constexpr int sweep_pitch() {     // dwords of a lane's LDS row: F, G, the window bits (odd: lane-strided access without bank conflicts)
+    return ((NW + V1 + 4) + (NW + 4) + (NW / 2 + 1)) | 1;
+}
 template <int NW, int V1, bool RAGGED, bool SEG>
 __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, u32 want_hash,
                                                             u32 want_sumfw, void* __restrict__ out, unsigned long long* __restrict__ queue,
@@ -67,13 +61,20 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
         if (gate == 1u && gate_len != 0u) L = gate_len;
     }
     constexpr int DWN = V1 + 1;          // dwords of a k-mer
-    constexpr int NB = NW / 2;           // 32-bit words of a lane's per-base / per-window marks
-    constexpr int NBLK = NW - V1;        // blocks of 16 windows a frame can hold (16 NW - k + 1 <= 16 (NW - V1))
-    static_assert(NW % 2 == 0 && V1 >= 0 && V1 <= 3, "frames of whole mark words; k <= 64");
+    constexpr int NB = NW / 2;           // 32-bit words of a lane's per-base / per-window bits
+    constexpr int NWW = V1 + 3;          // dwords that hold 32 windows: 31 + k bases
+    static_assert(NW % 2 == 0 && V1 >= 0 && V1 <= 3, "frames of whole bit words; k <= 64");
+    // a lane's LDS row: FR[0 .. NW) packed words, zeros up to NW + NWW | GR: two zero words, G[0 .. NW], a zero | WR: window bits, a zero
+    constexpr int FR = 0, FRN = NW + NWW + 1, GR = FRN, GRN = NW + 4, WR = GR + GRN, PITCH = sweep_pitch<NW, V1>();
+    static_assert(WR + NB + 1 <= PITCH, "row layout");
     __shared__ u64 aside_all[4][64];
     __shared__ u64 part[4][6];
+    __shared__ u32 rows_all[4][64 * PITCH];
     const u32 lane = threadIdx.x & 63u;
     u64* const aside = aside_all[threadIdx.x >> 6];
+    u32* const row = rows_all[threadIdx.x >> 6] + lane * PITCH;
+#pragma unroll
+    for (int j = 0; j < PITCH; ++j) row[j] = 0u;      // (the pads stay zero for good)
     const u64 n_full = n_reads >> 6;
     // the last byte any read of the batch owns: a lane's 16-byte loads run up to 15 bytes past ITS read, never past this
     const uint8_t* buf_end;
@@ -82,8 +83,7 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
     else buf_end = bases + lead + n_reads * (u64)L;
     const u32 top_bits = 2u * k - 32u * (u32)V1;                       // bits of the k-mer's top dword (2 .. 32)
     const u32 mtop = top_bits >= 32u ? ~0u : (1u << top_bits) - 1u;
-    const u32 cg = (k - 1u) & 15u;                                      // the rc stream is delayed by cg groups: window 16 i + s then sits at sub-shift 30 - 2 s of G[NW - i - V1 - 1 ..]
-    const u32 wmax = L - k + 1u;                                        // windows of the longest read
+    const u32 cg = (k - 1u) & 15u;                                      // the rc stream is delayed by cg groups: the rc of window o then starts at group 16 (NW - V1) - 1 - o
     u64 a_n = 0, a_s0 = 0, a_s1 = 0, a_x0 = 0, a_x1 = 0, a_fw = 0;
     u32 n_aside = 0;
     auto sweep = [&]() {
@@ -107,11 +107,11 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
                 const u64 o0 = offsets[read], o1 = ends[read];
                 sp = bases + o0;
                 len = (u32)(o1 - o0);
-                if (len > 16u * NW) __builtin_trap();    // (the scan blanks reads of tiles INSIDE the frame only: never silently uncounted)
+                if (len > 16u * NW) __builtin_trap();    // (the scan marks reads of tiles INSIDE the frame only)
             }
         }
         // ---- its bytes: all loads in flight before the first is looked at (unconditional: a chunk past the read's end, or one that
-        // would run past the batch's last byte, reads the batch's first 16 bytes instead -- what it returns is marked below)
+        // would run past the batch's last byte, reads the batch's first 16 bytes instead -- what it returns is masked below)
         uint4 v[NW];
 #pragma unroll
         for (int g = 0; g < NW; ++g) {
@@ -128,77 +128,107 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
                 v[g] = make_uint4(t[0], t[1], t[2], t[3]);
             }
         }
-        // ---- packed words F, and one mark per base: not ACGTacgt, or past the read's end
-        u32 F[NW + V1 + 2], inv[NB + 1];
+        // ---- packed words F (an invalid byte: the code its bits spell, as the scan took it), and one bit per base: invalid, inside the read
+        u32 F[NW], wb[NB + 1];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             u32 i0, i1;
             F[2 * j] = encode16_inv(v[2 * j], i0);
             F[2 * j + 1] = encode16_inv(v[2 * j + 1], i1);
             const u32 lo = 32u * j;
-            const u32 past = len <= lo ? ~0u : (len >= lo + 32u ? 0u : ~0u << (len - lo));
-            inv[j] = i0 | (i1 << 16) | past;
+            const u32 inside = len <= lo ? 0u : (len >= lo + 32u ? ~0u : ~(~0u << (len - lo)));
+            wb[j] = (i0 | (i1 << 16)) & inside;
         }
-        inv[NB] = ~0u;
-#pragma unroll
-        for (int j = NW; j < NW + V1 + 2; ++j) F[j] = 0u;
-        // ---- one mark per WINDOW: window o holds a marked base <=> OR of the marks o .. o + k - 1
+        wb[NB] = 0u;
+        // ---- one bit per WINDOW: window o holds an invalid base <=> OR of the bits o .. o + k - 1; only the windows of the read
         for (u32 cover = 1u; cover < k;) {
             u32 s = cover < k - cover ? cover : k - cover;           // 1, 2, 4, 8, 16, 16, ... and the rest: below 32, one funnel shift per word
             s = s < 16u ? s : 16u;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) inv[j] |= alignbit(inv[j + 1], inv[j], s);
+            for (int j = 0; j < NB; ++j) wb[j] |= alignbit(wb[j + 1], wb[j], s);
             cover += s;
         }
-        u32 nv = 0;
+        u32 ng = 0;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) nv += (u32)__builtin_popcount(~inv[j]);
-        a_n += nv;
-        // ---- the complemented, group-reversed words, delayed by cg groups
-        u32 G[NW + V1 + 2];
+        for (int j = 0; j < NB; ++j) {
+            const u32 lo = 32u * j, lastw = len - k;     // (len < k: no window)
+            const u32 keep = len < k ? 0u : (lastw >= lo + 31u ? ~0u : (lastw < lo ? 0u : (2u << (lastw - lo)) - 1u));
+            wb[j] &= keep;
+            ng += (u32)__builtin_popcount(wb[j]);
+            row[WR + j] = wb[j];
+        }
+        a_n += ng;
+        // ---- the row: the packed words, and the complemented, group-reversed ones delayed by cg groups
         {
             u32 R[NW + 1];
 #pragma unroll
-            for (int m = 0; m < NW; ++m) R[m] = revgroups32(~F[NW - 1 - m]);
+            for (int m = 0; m < NW; ++m) {
+                row[FR + m] = F[m];
+                R[m] = revgroups32(~F[NW - 1 - m]);
+            }
             R[NW] = 0u;
             const u32 sh = (32u - 2u * cg) & 31u;
 #pragma unroll
-            for (int m = 0; m <= NW; ++m) G[m] = cg ? alignbit(R[m], m ? R[m - 1] : 0u, sh) : R[m];
-#pragma unroll
-            for (int m = NW + 1; m < NW + V1 + 2; ++m) G[m] = 0u;
+            for (int m = 0; m <= NW; ++m) row[GR + 2 + m] = cg ? alignbit(R[m], m ? R[m - 1] : 0u, sh) : R[m];
         }
-        // ---- windows o = 16 i + s: fw = F[i ..] >> 2 s, rc = G[NW - i - V1 - 1 ..] >> (30 - 2 s)
-        // (a fold over the block indices, not a loop: the optimizer gives up on unrolling 16 blocks of 16 windows, and F[i] / G[M] then
-        // live in scratch)
-        for_each_index<NBLK>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if (16u * (u32)i >= wmax) return;         // (wave-uniform: past the last window of the frame's longest read)
-            constexpr int M = NW - i - V1 - 1;
-            // opaque copies made inside the block: the funnel shifts of every block are otherwise hoisted above the chain of uniform
-            // branches and kept live (kmx_scan_kernel.h)
-            u32 f[DWN + 1], gq[DWN + 1];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- rounds of 32 windows from the lane's first spoiled one
+        u64 r_x0 = 0, r_x1 = 0;
+        for (;;) {
+            u32 a = 0;
+            bool active = false;
 #pragma unroll
-            for (int j = 0; j <= DWN; ++j) {
-                f[j] = F[i + j];
-                gq[j] = G[M + j];
-                asm volatile("" : "+v"(f[j]), "+v"(gq[j]));
+            for (int j = NB - 1; j >= 0; --j) {
+                if (wb[j] != 0u) {
+                    a = 32u * j + (u32)__builtin_ctz(wb[j]);
+                    active = true;
+                }
             }
-            const u32 wv = inv[i >> 1];
+            if (__ballot(active) == 0ull) break;
+            // the bits of the windows a .. a + 31 (everything below a is clear); then everything below a + 32 is done
+            const u32 q = a >> 5;
+            u32 wv = alignbit(row[WR + q + 1u], row[WR + q], a & 31u);
+            wv = active ? wv : 0u;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                u32 vi = (u32)__builtin_amdgcn_sbfe((int)wv, 16 * (i & 1) + s, 1);   // all ones: the window is not yielded
+            for (int j = 0; j < NB; ++j) {
+                const u32 lo = 32u * j, e = a + 32u;
+                wb[j] &= lo >= e ? ~0u : (lo + 32u <= e ? 0u : ~0u << (e - lo));
+            }
+            // the packed stream from base a; the rc stream from the group where window a + 31 starts (window a + j: 31 - j groups on)
+            u32 F2[NWW], G2[NWW];
+            {
+                const u32 qa = a >> 4, sf = 2u * (a & 15u);
+                const u32 p = 16u * (NW - V1) - a, qg = p >> 4, sg = 2u * (p & 15u);   // (group p of the ROW: its two zero words ahead of G[0] are 32 groups)
+                u32 t[NWW + 1], u[NWW + 1];
+#pragma unroll
+                for (int j = 0; j <= NWW; ++j) {
+                    t[j] = row[FR + qa + j];
+                    u[j] = row[GR + qg + j];
+                }
+#pragma unroll
+                for (int j = 0; j < NWW; ++j) {
+                    F2[j] = alignbit(t[j + 1], t[j], sf);
+                    G2[j] = alignbit(u[j + 1], u[j], sg);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int i = j >> 4, s = j & 15, iu = (31 - j) >> 4, su = (31 - j) & 15;
+                u32 vi = (u32)__builtin_amdgcn_sbfe((int)wv, j, 1);   // all ones: a spoiled window of this read
                 asm volatile("" : "+v"(vi));   // (opaque: hipcc otherwise turns the masks into a branch around every window)
                 u32 fw[4] = {0u, 0u, 0u, 0u}, rc[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int j = 0; j < DWN; ++j) {
-                    const u32 a = s ? alignbit(f[j + 1], f[j], 2u * s) : f[j];
-                    const u32 b = alignbit(gq[j + 1], gq[j], 30u - 2u * s);
-                    if (j == DWN - 1) {
-                        fw[j] = __builtin_amdgcn_bitop3_b32(a, mtop, vi, 0x40 /* a & b & ~c */);
-                        rc[j] = __builtin_amdgcn_bitop3_b32(b, vi, mtop, 0xA8 /* (a | b) & c */);
+                for (int w = 0; w < DWN; ++w) {
+                    const u32 x = s ? alignbit(F2[i + w + 1], F2[i + w], 2u * s) : F2[i + w];
+                    const u32 y = su ? alignbit(G2[iu + w + 1], G2[iu + w], 2u * su) : G2[iu + w];
+                    if (w == DWN - 1) {
+                        fw[w] = __builtin_amdgcn_bitop3_b32(x, mtop, vi, 0x80 /* a & b & c */);
+                        rc[w] = __builtin_amdgcn_bitop3_b32(y, mtop, vi, 0x80);
                     } else {
-                        fw[j] = a & ~vi;
-                        rc[j] = b | vi;
+                        fw[w] = x & vi;
+                        rc[w] = y & vi;
                     }
                 }
                 // fw < rc (canonical_kmer.rs:113-119; [u64;2]: the build-defined order of kmx.h -- the high word first)
@@ -208,28 +238,34 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
                 if constexpr (DWN == 1) lt = fw[0] < rc[0];
                 else if constexpr (DWN == 2) lt = fw_lo < rc_lo;
                 else lt = fw_hi < rc_hi || (fw_hi == rc_hi && fw_lo < rc_lo);
-                // LexHasher(k)(canon) = MASK[k] ^ max(fw, rc) (kmx_scan.hip, SinkReduce).  The MASK terms are left out: a lane folds
-                // whole blocks of 16 windows, an invalid window with max = MASK -- an even number of MASKs in all, which cancel.
+                // LexHasher(k)(canon) = MASK[k] ^ max(fw, rc) (kmx_scan.hip, SinkReduce); the MASKs: once per read, by the parity of its count
                 u32 cn[4], mx[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    cn[j] = j < DWN ? (lt ? fw[j] : rc[j]) : 0u;
-                    mx[j] = j < DWN ? (lt ? rc[j] : fw[j]) : 0u;
+                for (int w = 0; w < 4; ++w) {
+                    cn[w] = w < DWN ? (lt ? fw[w] : rc[w]) : 0u;
+                    mx[w] = w < DWN ? (lt ? rc[w] : fw[w]) : 0u;
                 }
                 a_s0 += ((u64)cn[1] << 32) | cn[0];
-                a_x0 ^= ((u64)mx[1] << 32) | mx[0];
+                r_x0 ^= ((u64)mx[1] << 32) | mx[0];
                 if constexpr (DWN > 2) {
                     a_s1 += ((u64)cn[3] << 32) | cn[2];
-                    a_x1 ^= ((u64)mx[3] << 32) | mx[2];
+                    r_x1 ^= ((u64)mx[3] << 32) | mx[2];
                 } else {
                     a_fw += fw_lo;
                 }
-                // (pinned order: left alone, the ~250 adds of a tile become a balanced tree with every window's words live)
-                asm volatile("" : "+v"(a_s0), "+v"(a_x0));
-                if constexpr (DWN > 2) asm volatile("" : "+v"(a_s1), "+v"(a_x1));
+                // (pinned order: left alone, the adds of a round become a balanced tree with every window's words live)
+                asm volatile("" : "+v"(a_s0), "+v"(r_x0));
+                if constexpr (DWN > 2) asm volatile("" : "+v"(a_s1), "+v"(r_x1));
                 else asm volatile("" : "+v"(a_fw));
             }
-        });
+        }
+        if (ng & 1u) {      // an odd number of MASK[k]s
+            const u32 kb = 2u * k;
+            r_x0 ^= kb >= 64u ? ~0ull : (1ull << kb) - 1ull;
+            if (kb > 64u) r_x1 ^= kb >= 128u ? ~0ull : (1ull << (kb - 64u)) - 1ull;
+        }
+        a_x0 ^= r_x0;
+        a_x1 ^= r_x1;
         n_aside = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -237,8 +273,7 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
     };
     // A lane takes the mask of one tile, the wave gathers the reads 64 at a time (one ballot + one v_mbcnt per round: no list in
     // memory, no atomics) and sweeps whenever the next round would not fit.  Every mask goes back to zero: the caller never clears
-    // the array.  (ONE call site of the sweep: it is ~10 000 instructions, and inlined twice -- or not at all, with its arrays in
-    // scratch -- it is worse off.)
+    // the array.  (ONE call site of the sweep.)
     const u64 n_groups = (n_full + 63u) >> 6;
     u64 g = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);
     u64 t = 0, m = 0;
@@ -267,7 +302,8 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
         }
         if (n_aside != 0u) sweep();
     }
-    // one set of atomics per BLOCK (the waves all finish within microseconds of each other: profiles/r03_dirty_breakdown.txt)
+    // what the scan counted and the reference does not yield: taken back out (wrapping sums, a self-inverse fold).  One set of
+    // atomics per BLOCK (the waves all finish within microseconds of each other: profiles/r03_dirty_breakdown.txt)
     {
         const u64 wn = wave_sum(a_n), ws0 = wave_sum(a_s0), ws1 = wave_sum(a_s1), wx0 = wave_xor(a_x0), wx1 = wave_xor(a_x1), wf = wave_sum(a_fw);
         if (lane == 0) {
@@ -278,21 +314,21 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
     __syncthreads();
     if (threadIdx.x != 0) return;
     const u64 n = part[0][0] + part[1][0] + part[2][0] + part[3][0];
-    if (n == 0) return;   // nothing yielded: no atomics
+    if (n == 0) return;   // nothing to take out: no atomics
     const u64 s0 = part[0][1] + part[1][1] + part[2][1] + part[3][1], s1 = part[0][2] + part[1][2] + part[2][2] + part[3][2];
     const u64 x0 = part[0][3] ^ part[1][3] ^ part[2][3] ^ part[3][3], x1 = part[0][4] ^ part[1][4] ^ part[2][4] ^ part[3][4];
     const u64 f = part[0][5] + part[1][5] + part[2][5] + part[3][5];
     if constexpr (V1 <= 1) {
         kmx_summary* o = static_cast<kmx_summary*>(out);
-        atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
-        atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)s0);
+        atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)(0ull - n));
+        atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)(0ull - s0));
         if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)x0);
-        if (want_sumfw != 0u) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
+        if (want_sumfw != 0u) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)(0ull - f));
     } else {
         kmx_summary2* o = static_cast<kmx_summary2*>(out);
-        atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
-        atomicAdd((unsigned long long*)&o->sum_lo, (unsigned long long)s0);
-        atomicAdd((unsigned long long*)&o->sum_hi, (unsigned long long)s1);
+        atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)(0ull - n));
+        atomicAdd((unsigned long long*)&o->sum_lo, (unsigned long long)(0ull - s0));
+        atomicAdd((unsigned long long*)&o->sum_hi, (unsigned long long)(0ull - s1));
         if (want_hash) {
             atomicXor((unsigned long long*)&o->xor_lo, (unsigned long long)x0);
             atomicXor((unsigned long long*)&o->xor_hi, (unsigned long long)x1);
