@@ -389,13 +389,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // w[] alive past phase A, the prefetch behind it -- cost 2.7 % on CLEAN input (profiles/r06_dirty_variants.txt).  Round 6:
     //   * phase A parks every chunk's validation word in LDS at no instruction's cost (XOFF above); a dirty tile looks its reads'
     //     chunks up there -- LDS only, the next tile's rows already requested -- and leaves the 64-bit mask of the reads that touch a
-    //     bad chunk in the array behind queue[515] (8 bytes per tile, all zero between calls; queue[512] = "a tile was marked");
+    //     bad chunk in the array behind queue[515] (8 bytes per tile, all zero between calls; queue[512] = how many reads were marked);
     //   * nothing is blanked: the tile is scanned as it is, an invalid byte counting as the base its bits (b >> 1) & 3 spell, and
     //     sweep_flagged_kernel (kmx_sweep.hip) takes the windows that hold such a byte -- exactly those the reference's iterator does
     //     not yield (canonical_kmer_iterator.rs:50-66) -- back OUT of the sums, from the same codes.
     // queue[515] == 0: no array; a ragged tile then rolls as a whole here (uniform input: the host side always provides the array).
     constexpr bool INLINE = !PACKED;              // (packed input has no invalid codes)
     u64* const masks = INLINE ? reinterpret_cast<u64*>(uniform_u64(queue[515])) : nullptr;   // (read once: two scalar registers)
+    u32 n_marked = 0;                             // reads this wave marked (wave-uniform); their total, in queue[512], tells the sweep how many waves to field
     // word-domain accumulators of the fallback path (tiles with invalid bytes, the final partial tile)
     struct FbAcc { u64 n = 0, s0 = 0, s1 = 0, x0 = 0, x1 = 0, fw = 0; };
     auto emit_sums = [&](u64 n, u64 r0, u64 r1, u64 h0, u64 h1, u64 f) {   // wave-uniform values, one set of atomics
@@ -1156,12 +1157,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 // with reloads on the loop's main path, the ticket among them)
                 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
                 const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(uniform_u64(reinterpret_cast<u64>(masks + tile))), 0, 8, 0x00020000);
-                const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(uniform_u64(reinterpret_cast<u64>(queue + 512))), 0, 8, 0x00020000);
                 if (lane_now() == 0u) {
-                    u32x2 dv = {(u32)dm, (u32)(dm >> 32)}, ov = {1u, 0u};
+                    u32x2 dv = {(u32)dm, (u32)(dm >> 32)};
                     __builtin_amdgcn_raw_buffer_store_b64(dv, rm, 0, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(ov, rq, 0, 0, 0);
                 }
+                n_marked += (u32)__builtin_popcountll(dm);
             }
             return true;
         };
@@ -1331,20 +1331,23 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         bs_n += wave_sum(fb_all.n); bs_s0 += wave_sum(fb_all.s0); bs_s1 += wave_sum(fb_all.s1);
         bs_x0 ^= wave_xor(fb_all.x0); bs_x1 ^= wave_xor(fb_all.x1); bs_fw += wave_sum(fb_all.fw);
     }
+    // (The block is FOUR waves -- __launch_bounds__(256), and launch_bs starts nothing else: BLK holds four slots of seven words -- and
+    // every early return above this barrier is grid-uniform; a wave that scanned nothing leaves zeros in its slot.)
     u64* const BLK = reinterpret_cast<u64*>(lds + 4u * wave_dw);
     if (lane == 0) {
-        u64* const mine = BLK + 6u * wib;
-        mine[0] = bs_n; mine[1] = bs_s0; mine[2] = bs_s1; mine[3] = bs_x0; mine[4] = bs_x1; mine[5] = bs_fw;
+        u64* const mine = BLK + 7u * wib;
+        mine[0] = bs_n; mine[1] = bs_s0; mine[2] = bs_s1; mine[3] = bs_x0; mine[4] = bs_x1; mine[5] = bs_fw; mine[6] = (u64)n_marked;
     }
     __syncthreads();
     if (wib == 0u) {
-        u64 v[6];
+        u64 v[7];
 #pragma unroll
-        for (u32 i = 0; i < 6u; ++i) {
-            const u64 a = BLK[i], b = BLK[6u + i], c = BLK[12u + i], d = BLK[18u + i];
+        for (u32 i = 0; i < 7u; ++i) {
+            const u64 a = BLK[i], b = BLK[7u + i], c = BLK[14u + i], d = BLK[21u + i];
             v[i] = (i == 3u || i == 4u) ? (a ^ b ^ c ^ d) : (a + b + c + d);
         }
         if (v[0] != 0ull) emit_sums(v[0], v[1], v[2], v[3], v[4], v[5]);   // (no k-mer: nothing to add -- every word is zero then)
+        if (v[6] != 0ull && lane == 0) atomicAdd(queue + 512, (unsigned long long)v[6]);
     }
 }
 

@@ -54,7 +54,18 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
                                                             const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends,
                                                             const BsSeg seg) {
     u64* const masks = reinterpret_cast<u64*>(queue[515]);
-    if (masks == nullptr || queue[512] == 0) return;   // queue[512]: "a tile was marked" (zeroed by the caller with the heads)
+    const u64 n_marked = queue[512];                   // how many reads the scan marked (zeroed by the caller with the heads)
+    if (masks == nullptr || n_marked == 0) return;
+    // A sweep costs the same for 5 reads as for 64: as many waves as fill their sweeps (~48 reads each), not as many as were launched
+    // -- 0.1 % of 2e7 reads dirty: 33 us with every wave of the grid sweeping 5 reads, 16 us with a quarter of them
+    // (profiles/r06_sweep_variants.txt).  The waves that stay stride over the mask groups by their own number.
+    const u64 n_waves_all = (u64)gridDim.x * 4u;
+    u64 n_waves = (n_marked + 47u) / 48u;
+    n_waves = n_waves < 64u ? 64u : n_waves;
+    n_waves = n_waves > n_waves_all ? n_waves_all : n_waves;
+    // (waves 4b .. 4b + 3 are block b: the active ones are the first blocks, which the dispatcher spreads over the CUs)
+    const u64 wave_id = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const bool idle = wave_id >= n_waves;
     if constexpr (!RAGGED && !SEG) {   // (the length the gate found, as in scan_bitsliced_kernel: the reads lie L0 bytes apart)
         const u32 gate = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513]);
         const u32 gate_len = __builtin_amdgcn_readfirstlane(reinterpret_cast<const u32*>(queue)[2 * 513 + 1]);
@@ -110,23 +121,49 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
                 if (len > 16u * NW) __builtin_trap();    // (the scan marks reads of tiles INSIDE the frame only)
             }
         }
-        // ---- its bytes: all loads in flight before the first is looked at (unconditional: a chunk past the read's end, or one that
-        // would run past the batch's last byte, reads the batch's first 16 bytes instead -- what it returns is masked below)
+        // ---- its bytes: all loads in flight before the first is looked at.  From the DWORD-aligned address below the read -- a
+        // 16-byte load from an address that is not a multiple of 4 is taken apart by the memory pipeline, and a sweep then cost what
+        // its 640 loads did, not what it computes (profiles/r06_sweep_parts.txt) -- and shifted into place afterwards (v_alignbyte_b32).
+        // Unconditional: a chunk past the read's end, or one that would run past the batch's last byte, reads the batch's first 16
+        // bytes instead -- what it returns is masked below.
+        const u32 rsh = (u32)(reinterpret_cast<uintptr_t>(sp) & 3u);
+        const uint8_t* const a4 = sp - rsh;
         uint4 v[NW];
+        u32 vx = 0u;                                     // the dword behind the last chunk
 #pragma unroll
         for (int g = 0; g < NW; ++g) {
-            const uint8_t* p = sp + 16u * g;
-            const bool direct = 16u * g < len && p + 16 <= buf_end;
-            __builtin_memcpy(&v[g], direct ? p : bases + lead, 16);
+            const uint8_t* p = a4 + 16u * g;
+            const bool direct = 16u * g < len + rsh && p + 16 <= buf_end;
+            __builtin_memcpy(&v[g], __builtin_assume_aligned(direct ? p : bases, 4), 16);
+        }
+        {
+            const uint8_t* p = a4 + 16u * NW;
+            const bool direct = 16u * NW < len + rsh && p + 4 <= buf_end;
+            __builtin_memcpy(&vx, __builtin_assume_aligned(direct ? p : bases, 4), 4);
+        }
+        if (__any(len != 0u && a4 + 16u * ((len + rsh + 15u) >> 4) > buf_end)) {     // the batch's last bytes, one by one (at most one lane of one wave)
+#pragma unroll
+            for (int g = 0; g <= NW; ++g) {
+                const uint8_t* p = a4 + 16u * g;
+                if (16u * g < len + rsh && p + (g < NW ? 16 : 4) > buf_end) {
+                    u32 t[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+                    for (u32 b = 0; b < 16u && p + b < buf_end; ++b) {
+                        const u32 x = (u32)p[b] << (8u * (b & 3u));
+                        t[0] |= (b >> 2) == 0u ? x : 0u; t[1] |= (b >> 2) == 1u ? x : 0u; t[2] |= (b >> 2) == 2u ? x : 0u; t[3] |= (b >> 2) == 3u ? x : 0u;
+                    }
+                    if (g < NW) v[g < NW ? g : 0] = make_uint4(t[0], t[1], t[2], t[3]);
+                    else vx = t[0];
+                }
+            }
         }
 #pragma unroll
         for (int g = 0; g < NW; ++g) {
-            const uint8_t* p = sp + 16u * g;
-            if (16u * g < len && p + 16 > buf_end) {      // the batch's last bytes, one by one (at most one lane of one wave)
-                u32 t[4] = {0u, 0u, 0u, 0u};
-                for (u32 b = 0; b < 16u && p + b < buf_end; ++b) t[b >> 2] |= (u32)p[b] << (8u * (b & 3u));
-                v[g] = make_uint4(t[0], t[1], t[2], t[3]);
-            }
+            const u32 nx = g + 1 < NW ? v[g + 1 < NW ? g + 1 : 0].x : vx;
+            v[g].x = __builtin_amdgcn_alignbyte(v[g].y, v[g].x, rsh);
+            v[g].y = __builtin_amdgcn_alignbyte(v[g].z, v[g].y, rsh);
+            v[g].z = __builtin_amdgcn_alignbyte(v[g].w, v[g].z, rsh);
+            v[g].w = __builtin_amdgcn_alignbyte(nx, v[g].w, rsh);
         }
         // ---- packed words F (an invalid byte: the code its bits spell, as the scan took it), and one bit per base: invalid, inside the read
         u32 F[NW], wb[NB + 1];
@@ -275,28 +312,43 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
     // memory, no atomics) and sweeps whenever the next round would not fit.  Every mask goes back to zero: the caller never clears
     // the array.  (ONE call site of the sweep.)
     const u64 n_groups = (n_full + 63u) >> 6;
-    u64 g = (u64)blockIdx.x * 4u + (threadIdx.x >> 6);
-    u64 t = 0, m = 0;
+    u64 g = idle ? n_groups : wave_id;
+    // (the masks of FOUR groups are requested together: one after the other, a wave that strides over a dozen groups to find its
+    // reads spent more time waiting for masks than sweeping)
+    u64 m0 = 0, m1 = 0, m2 = 0, m3 = 0, t = 0;   // m0: the masks being taken apart, of the tiles t (this lane's) -- m1..m3: of the groups n_waves, 2 n_waves, 3 n_waves on
+    u32 left = 0;
+    auto fetch = [&](u64 gi) -> u64 {
+        const u64 ti = gi * 64u + lane;
+        u64 mi = (gi < n_groups && ti < n_full) ? masks[ti] : 0ull;
+        if (mi != 0ull) masks[ti] = 0ull;
+        return mi;
+    };
     for (bool more = true; more;) {
         for (;;) {
-            const u64 b = __ballot(m != 0ull);
-            if (b == 0ull) {                 // the next 64 masks
+            const u64 b = __ballot(m0 != 0ull);
+            if (b == 0ull) {
+                if (left > 1u) {                 // the next group of the four
+                    m0 = m1; m1 = m2; m2 = m3; m3 = 0ull;
+                    t += 64u * n_waves;
+                    left -= 1u;
+                    continue;
+                }
                 if (g >= n_groups) {
                     more = false;
                     break;
                 }
+                m0 = fetch(g); m1 = fetch(g + n_waves); m2 = fetch(g + 2u * n_waves); m3 = fetch(g + 3u * n_waves);
                 t = g * 64u + lane;
-                m = t < n_full ? masks[t] : 0ull;
-                if (m != 0ull) masks[t] = 0ull;
-                g += (u64)gridDim.x * 4u;
+                left = 4u;
+                g += 4u * n_waves;
                 continue;
             }
             const u32 nd = (u32)__builtin_popcountll(b);
             if (n_aside + nd > 64u) break;   // sweep first
             const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u));
-            if (m != 0ull) {
-                aside[n_aside + rank] = t * 64u + (u32)__builtin_ctzll(m);
-                m &= m - 1ull;
+            if (m0 != 0ull) {
+                aside[n_aside + rank] = t * 64u + (u32)__builtin_ctzll(m0);
+                m0 &= m0 - 1ull;
             }
             n_aside += nd;
         }
@@ -354,7 +406,7 @@ hipError_t launch_sweep_flagged(const uint8_t* bases, u64 n_reads, u32 L, u32 k,
                                 unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets, u32 lead, const u64* ends,
                                 const BsSeg& seg, bool ragged, bool is_seg) {
     if (k < 2u || k > 64u || k == 32u || L < k || L > 256u) return hipErrorInvalidValue;
-    u64 grid1 = (u64)n_cu * 4u;
+    u64 grid1 = (u64)n_cu * 2u;     // (eight waves per CU: 10 % of 2e7 reads dirty 184 us, sixteen 223, four 212 -- profiles/r06_sweep_variants.txt)
     const u64 need1 = ((n_reads >> 6) + 255u) / 256u;   // a wave takes 64 masks at a time
     if (grid1 > need1) grid1 = need1;
     const dim3 grid((unsigned)(grid1 ? grid1 : 1));
