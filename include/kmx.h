@@ -301,6 +301,20 @@ int kmx_minimizer_words(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n, uint3
 int kmx_seqvec_minimizers(kmx_ctx *ctx, const uint64_t *d_words, uint64_t n_reads, uint32_t read_len, uint32_t k,
                           uint32_t w, uint32_t hasher, uint32_t hasher_k, uint64_t *d_word, uint32_t *d_pos);
 
+/* The same iterator over READS (round 6): what SeqVector::from(read).slice(..).iter_minimizers(k, w, hasher) yields
+ * (seq_vector.rs:73-80, 230-242; minimizers.rs:39-141) for every read of a batch -- ASCII, one length or behind offsets, as
+ * kmx_fastx_parse hands them over -- without building the SeqVector.  MappedMinimizer{word, pos} of k-mer i of read r at slot
+ * r*(read_len-k+1) + i (uniform; read_len >= k) or d_win_offsets[r] + i (ragged: n_reads + 1 entries as for kmx_canonical_windows;
+ * a read shorter than k owns no slot), pos relative to the read.  1 <= w <= k, w <= 32.
+ * A byte outside ACGTacgt: the reference panics (Kmer::from, kmer.rs:45-60).  With h_first_bad != NULL the call synchronises, stores
+ * the index of the first read that holds one (else ~0) and returns KMX_E_INVALID_BASE; that read's slots then hold what the codes
+ * (byte >> 1) & 3 spell.  With NULL nothing is checked on the host and the call stays asynchronous for uniform reads (reads behind
+ * offsets cost one host round trip: their longest length selects the kernel).
+ * Reads of up to 256 bases, and uniform reads of any length (cut into pieces of 256 bases), take the sliding-minimum kernel when the
+ * hash fits 56 bits (w <= 28; LexHasher: hasher_k <= 28); anything else a lane-per-k-mer kernel. */
+int kmx_minimizers(kmx_ctx *ctx, const kmx_reads *reads, const uint64_t *d_win_offsets, uint32_t k, uint32_t w, uint32_t hasher,
+                   uint32_t hasher_k, uint64_t *d_word, uint32_t *d_pos, uint64_t *h_first_bad);
+
 /* ---------------------------------------------------------------- FASTA / FASTQ ingestion ----
  * BUILD-DEFINED: the reference has no parser (its iterators take `&[u8]` reads, canonical_kmer_iterator.rs:72-83);
  * this call produces, from a file image in device memory, the ragged-reads input of the calls above:

@@ -87,6 +87,7 @@ SIGNATURES = {
     "kmx_seqvec_canonical_reduce": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp]),
     "kmx_minimizer_words": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _vp]),
     "kmx_seqvec_minimizers": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "kmx_minimizers": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "kmx_fastx_parse": (_int, [_vp, _vp, _u64, _u32, _vp, _vp, _u64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kmx_sub_kmer_words": (_int, [_vp, _vp, _u64, _u32, _u32, _u32, _vp]),
     "kmx_kmers_to_strings": (_int, [_vp, _vp, _u64, _u32, _vp]),

@@ -338,6 +338,22 @@ class Context:
         return mw, mp
 
     @_on_ctx_stream
+    def minimizers(self, bases, n_reads: int, read_len: int, k: int, w: int, hasher: int, hasher_k: int = 0, offsets=None, win_offsets=None,
+                   check: bool = True):
+        """kmx_minimizers: SeqVecMinimizerIter over every READ (ASCII; uniform, or ragged with offsets + win_offsets) ->
+        (word int64, pos int32).  check: ask for the first read with an invalid byte (KmxError KMX_E_INVALID_BASE if there is one)"""
+        if offsets is None:
+            tot = n_reads * max(read_len - k + 1, 0)
+        else:
+            tot = int(win_offsets[-1].item()) if n_reads else 0
+        mw, mp = self.empty(tot, torch.int64), self.empty(tot, torch.int32)
+        r = self._reads(bases, n_reads, read_len, offsets)
+        bad = C.c_uint64(0)
+        self._ck(self.lib.kmx_minimizers(self._h, C.byref(r), _ptr(win_offsets) if win_offsets is not None else None, k, w, hasher, hasher_k,
+                                         _ptr(mw) if tot else None, _ptr(mp) if tot else None, C.byref(bad) if check else None))
+        return mw, mp
+
+    @_on_ctx_stream
     def fastx_parse(self, text: torch.Tensor, fmt: int = 0, max_reads: int | None = None):
         """kmx_fastx_parse: FASTA/FASTQ file image (uint8, on the device) -> (bases uint8[n_bases], offsets int64[n_reads+1]).
         Two calls: the counts, then the emit into exactly sized buffers.  With `max_reads` (a bound on the number of records the

@@ -103,6 +103,9 @@ hipError_t launch_kmers_to_bytes(const u64* in, u64 n, u32 k, bool upper, uint8_
 hipError_t launch_encode_kmers_bytes(const uint8_t* seqs, u64 n, u32 seq_len, u32 enc, u32 nb, uint8_t* arrays, int n_cu, hipStream_t st);
 hipError_t launch_encoding_rev_comp_bytes(const uint8_t* in, u64 n, u32 K, u32 comp_lut, u32 nb, uint8_t* out, int n_cu, hipStream_t st);
 hipError_t launch_encoding_decode_bytes(const uint8_t* in, u64 total_bytes, u32 nuc_lut, uint8_t* seqs, int n_cu, hipStream_t st);
+hipError_t launch_minimizers_reads(const uint8_t* bases, u64 total_bytes, const u64* offsets, const u64* win_offsets, u64 n_reads, u32 L,
+                                   u32 bound, u32 k, u32 w, u32 hasher, u32 hk, u64* out_word, u32* out_pos,
+                                   unsigned long long* first_bad, int n_cu, hipStream_t st, bool* tiled);
 hipError_t launch_calib_stream_read(const uint8_t* buf, u64 nbytes, unsigned long long* out, int n_cu, hipStream_t st);
 hipError_t launch_length_range(const u64* offsets, u64 n_reads, u32* out, int n_cu, hipStream_t st);
 hipError_t launch_offsets_uniform_gate(const u64* offsets, u64 n_reads, u32 bound, u32 k, u32* gate, int n_cu, hipStream_t st);
@@ -1085,6 +1088,44 @@ int kmx_seqvec_minimizers(kmx_ctx* ctx, const uint64_t* d_words, uint64_t n_read
     if (n_reads == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
     KMX_HIP(ctx, kmx::launch_seqvec_minimizers(d_words, n_reads, read_len, k, w, hasher, hasher_k, d_word, d_pos, ctx->n_cu, ctx->stream));
+    return KMX_OK;
+}
+
+int kmx_minimizers(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* d_win_offsets, uint32_t k, uint32_t w, uint32_t hasher,
+                   uint32_t hasher_k, uint64_t* d_word, uint32_t* d_pos, uint64_t* h_first_bad) {
+    if (!ctx || !reads_ok(reads)) return KMX_E_ARG;
+    if (k < 1 || w < 1 || w > k || w > 32) return KMX_E_K_RANGE;
+    if (int st = mm_hasher_ok(hasher, hasher_k)) return st;
+    if (h_first_bad) *h_first_bad = ~0ull;
+    if (reads->n_reads == 0) return KMX_OK;
+    if (!d_word || !d_pos) return KMX_E_ARG;
+    if (reads->d_offsets && !d_win_offsets) return KMX_E_ARG;
+    if (!reads->d_offsets && reads->read_len < k) return KMX_E_ARG;   // SeqVecMinimizerIter::new: assert!(sv.len() >= k) (a ragged read shorter than k owns no slot)
+    DeviceGuard g(ctx->device);
+    uint64_t total_bytes = reads->n_reads * (uint64_t)reads->read_len;
+    uint32_t bound = reads->read_len;
+    if (reads->d_offsets) {
+        // the batch's last byte and its longest read (the bound of kmx_reads is a hint; the key of the sliding minimum holds 8 bits
+        // of position): one host round trip
+        uint32_t lo = 0, hi = 0;
+        if (int st = kmx_reads_length_range(ctx, reads->d_offsets, reads->n_reads, &lo, &hi)) return st;
+        KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, reads->d_offsets + reads->n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        total_bytes = ctx->h_pinned[0];
+        bound = hi;
+        if (hi < k) return KMX_OK;      // no read holds a k-mer
+    }
+    KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0xFF, 8, ctx->stream));
+    bool tiled = false;
+    KMX_HIP(ctx, kmx::launch_minimizers_reads(reads->d_bases, total_bytes, reads->d_offsets, d_win_offsets, reads->n_reads, reads->read_len, bound, k, w,
+                                              hasher, hasher_k, d_word, d_pos, ctx->d_scratch, ctx->n_cu, ctx->stream, &tiled));
+    if (!h_first_bad) return KMX_OK;
+    KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pinned[0] != ~0ull) {
+        *h_first_bad = ctx->h_pinned[0];
+        return KMX_E_INVALID_BASE;
+    }
     return KMX_OK;
 }
 

@@ -1,0 +1,290 @@
+// kmx_minimizers.hip -- SeqVecMinimizerIter (seq_vector/minimizers.rs:39-141) over READS (round 6): what
+// SeqVector::from(read).iter_minimizers(k, w, hasher) yields for every read of a batch -- ASCII, one length or behind an offsets
+// array -- without building the SeqVector: the reads kmx_fastx_parse hands over go straight in.
+//
+// The algorithm is the sliding-window minimum of kmx_seqvec.hip (seqvec_minimizers_slide_kernel): every l-mer of a read becomes
+// the key (hash << 8) | position -- the minimum of keys is the leftmost minimum-hash l-mer, the tie rule of the reference's
+// monotone deque (minimizers.rs:61-81: `backmer.hash <= dqmer.hash` keeps the earlier of equals) -- and the minimum over the
+// k - w + 1 keys of a k-mer's window is min(M[i], M[i + span - len]) with M the minima over len = 2^J <= span consecutive
+// keys, built by J doubling passes in LDS.  What differs is either end:
+//   * in: a block packs its RB reads from ASCII (16 bases per dword, encode16; a byte outside ACGTacgt -- the reference's
+//     SeqVector::from panics on it, seq_vector.rs:230-242 / kmer.rs:45-60 -- leaves the read's index in *first_bad), each read
+//     from its own start: reads of one length, reads behind offsets, or the SEGMENTS a read longer than 256 bases is cut into
+//     (positions are 8 bits of the key);
+//   * out: the k-mers of a block's reads are consecutive slots -- one run of whole 128-byte lines when the batch is uniform --
+//     written by consecutive threads.
+#include "kmx_device.h"
+
+namespace kmx {
+
+__device__ __forceinline__ u64 mmr_field(const u32* __restrict__ a, u32 bitoff, u32 nbits /* <= 56 */) {
+    const u32 q = bitoff >> 5, sh = bitoff & 31u;
+    const u64 lo = (u64)a[q] | ((u64)a[q + 1u] << 32);
+    const u64 v = sh ? ((lo >> sh) | ((u64)a[q + 2u] << (64u - sh))) : lo;
+    return v & ((1ull << nbits) - 1ull);
+}
+
+// how the reads of a batch lie: read R of the kernel's index space = piece (R % J) of read R / J (J = 1: the reads themselves)
+struct MmrGeom {
+    const u64* offsets;      // ragged: read r = bases[offsets[r], offsets[r+1]); nullptr: uniform
+    const u64* win_offsets;  // ragged: slot of k-mer 0 of read r
+    u64 n_reads;             // reads (not pieces)
+    u32 L;                   // uniform: bases per read
+    u32 J, T;                // pieces per read, k-mers per piece (the last one: what is left)
+};
+
+// MODE 0: identity hasher, 1: LexHasher(hk == w), 2: LexHasher(any hk).  RAGGED: reads behind offsets (J == 1).
+template <int THREADS, int RB, int MODE, bool RAGGED>
+__global__ void __launch_bounds__(THREADS)
+minimizers_reads_kernel(const uint8_t* __restrict__ bases, u64 total_bytes, const MmrGeom geo, u32 Lmax, u32 k, u32 w, u32 hk,
+                        u64* __restrict__ out_word, u32* __restrict__ out_pos, unsigned long long* __restrict__ first_bad) {
+    static_assert(THREADS == 16 * RB, "16 threads per read");
+    extern __shared__ __attribute__((aligned(16))) u64 hs[];   // keys [2][RB][NLS], then FW [RB][ND], RV [RB][ND] (u32), then the reads' geometry
+    const u32 NLS = Lmax - w + 1u, span = k - w + 1u;
+    const u32 ND = ((2u * Lmax + 31u) >> 5) + 2u;               // dwords of a staged read (+2: the field reads look ahead)
+    u32* FW = reinterpret_cast<u32*>(hs + 2u * RB * NLS);
+    u32* RV = FW + RB * ND;
+    u64* SLOT = reinterpret_cast<u64*>(RV + RB * ND + ((RB * ND) & 1u));   // [RB] slot of the piece's first k-mer
+    u32* LEN = reinterpret_cast<u32*>(SLOT + RB);               // [RB] bases of the piece
+    u32* PBASE = LEN + RB;                                      // [RB] position of the piece inside its read
+    u32* CUM = PBASE + RB;                                      // [RB + 1] k-mers of the pieces before
+    const u32 r = threadIdx.x >> 4, j16 = threadIdx.x & 15u;
+    const u64 n_pieces = geo.n_reads * geo.J;
+    const uint8_t* const buf_end = bases + total_bytes;
+    for (u64 r0 = (u64)blockIdx.x * RB; r0 < n_pieces; r0 += (u64)gridDim.x * RB) {
+        const u32 nr = (u32)(n_pieces - r0 < RB ? n_pieces - r0 : RB);
+        u64* A = hs;
+        u64* B = hs + RB * NLS;
+        // ---- where this thread's piece lies
+        const uint8_t* sp = bases;
+        u32 len = 0;
+        if (r < nr) {
+            const u64 R = r0 + r;
+            if constexpr (RAGGED) {
+                const u64 o0 = geo.offsets[R], o1 = geo.offsets[R + 1u];
+                sp = bases + o0;
+                len = (u32)(o1 - o0 > (u64)Lmax ? 0u : o1 - o0);        // (a read above the bound: the caller took another kernel)
+                if (j16 == 0u) {
+                    SLOT[r] = geo.win_offsets[R];
+                    PBASE[r] = 0u;
+                }
+            } else {
+                const u64 rd = R / geo.J;
+                const u32 j = (u32)(R - rd * geo.J);
+                sp = bases + rd * (u64)geo.L + (u64)j * geo.T;
+                const u32 left = geo.L - j * geo.T;                         // bases from the piece's first
+                len = left < geo.T + k - 1u ? left : geo.T + k - 1u;
+                if (j16 == 0u) {
+                    SLOT[r] = rd * (u64)(geo.L - k + 1u) + (u64)j * geo.T;
+                    PBASE[r] = j * geo.T;
+                }
+            }
+            if (j16 == 0u) LEN[r] = len;
+        } else if (j16 == 0u) {
+            LEN[r] = 0u;
+        }
+        // ---- the piece, packed: dword d = its bases [16 d, 16 d + 16) (what follows it in the buffer comes along: never looked at)
+        if (r < nr) {
+            for (u32 d = j16; d < ND; d += 16u) {
+                u32 code = 0u;
+                if (16u * d < len) {
+                    const uint8_t* p = sp + 16u * d;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    const u32 rsh = (u32)(reinterpret_cast<uintptr_t>(p) & 3u);
+                    if (p + 20 <= buf_end && p - rsh >= bases) {      // dword-aligned loads, shifted into place (a 16-byte load from an odd address is taken apart by the memory pipeline)
+                        const u32* a4 = reinterpret_cast<const u32*>(p - rsh);
+                        const u32 x0 = a4[0], x1 = a4[1], x2 = a4[2], x3 = a4[3], x4 = a4[4];
+                        v = make_uint4(__builtin_amdgcn_alignbyte(x1, x0, rsh), __builtin_amdgcn_alignbyte(x2, x1, rsh),
+                                       __builtin_amdgcn_alignbyte(x3, x2, rsh), __builtin_amdgcn_alignbyte(x4, x3, rsh));
+                    } else {                      // the batch's last bytes, one by one
+                        u32 t[4] = {0u, 0u, 0u, 0u};
+                        for (u32 b = 0; b < 16u && p + b < buf_end; ++b) t[b >> 2] |= (u32)p[b] << (8u * (b & 3u));
+                        v = make_uint4(t[0], t[1], t[2], t[3]);
+                    }
+                    u32 inv16;
+                    code = encode16_inv(v, inv16);
+                    const u32 inside = len - 16u * d >= 16u ? 0xFFFFu : (1u << (len - 16u * d)) - 1u;
+                    if ((inv16 & inside) != 0u) atomicMin(first_bad, (unsigned long long)((r0 + r) / geo.J));
+                }
+                FW[r * ND + d] = code;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {          // k-mers of the pieces before (RB additions)
+            u32 c = 0;
+            for (u32 i = 0; i < RB; ++i) {
+                CUM[i] = c;
+                const u32 l = LEN[i];
+                c += l >= k ? l - k + 1u : 0u;
+            }
+            CUM[RB] = c;
+        }
+        if (MODE == 1 && r < nr) {
+            // base-reversed copy: dword d holds bases len-1-16d-j (j = 0..15) = the 32 bits at base offset len-16d-16, group-reversed
+            for (u32 d = j16; d < ND; d += 16u) {
+                const int off = (int)len - 16 * (int)d - 16;      // may be negative: the piece has fewer bases left
+                u32 x;
+                if (off >= 0) x = (u32)mmr_field(FW + r * ND, 2u * (u32)off, 32u);
+                else x = off > -16 ? FW[r * ND] << (2u * (u32)(-off)) : 0u;
+                RV[r * ND + d] = revgroups32(x);
+            }
+        }
+        if (MODE == 1) __syncthreads();
+        const u32 NL = len >= w ? len - w + 1u : 0u;             // l-mers of the piece
+        if (r < nr) {
+            for (u32 p = j16; p < NL; p += 16u) {
+                u64 h;
+                if (MODE == 1) h = mmr_field(RV + r * ND, 2u * (len - p - w), 2u * w);
+                else {
+                    const u64 lm = mmr_field(FW + r * ND, 2u * p, 2u * w);
+                    h = MODE == 0 ? lm : lex_hash(lm, hk);
+                }
+                A[r * NLS + p] = (h << 8) | p;
+            }
+        }
+        __syncthreads();
+        // minima over lenw consecutive keys: lenw x 4 per pass while that fits the span (two passes at span = 17 where doubling took four:
+        // half the LDS writes and block barriers), then one doubling if there is room for it
+        u32 lenw = 1;
+        while (4u * lenw <= span) {
+            if (r < nr) {
+                for (u32 p = j16; p < NL; p += 16u) {
+                    const u64* const ap = A + r * NLS + p;
+                    u64 m = ap[0];
+                    const u64 b = p + lenw < NL ? ap[lenw] : m, c = p + 2u * lenw < NL ? ap[2u * lenw] : m, d = p + 3u * lenw < NL ? ap[3u * lenw] : m;
+                    m = m < b ? m : b;
+                    const u64 m2 = c < d ? c : d;
+                    B[r * NLS + p] = m < m2 ? m : m2;
+                }
+            }
+            __syncthreads();
+            u64* t = A; A = B; B = t;
+            lenw *= 4u;
+        }
+        if (2u * lenw <= span) {
+            if (r < nr) {
+                for (u32 p = j16; p < NL; p += 16u) {
+                    const u64 a = A[r * NLS + p];
+                    const u64 b = p + lenw < NL ? A[r * NLS + p + lenw] : a;
+                    B[r * NLS + p] = a < b ? a : b;
+                }
+            }
+            __syncthreads();
+            u64* t = A; A = B; B = t;
+            lenw *= 2u;
+        }
+        const u32 second = span - lenw;      // the window [i, i+span) = [i, i+lenw) u [i+second, i+second+lenw)
+        const u32 total = CUM[RB];
+        for (u32 e = threadIdx.x; e < total; e += THREADS) {
+            u32 rr = 0;      // the piece that holds k-mer e of the block (CUM is non-decreasing: four halvings)
+#pragma unroll
+            for (u32 step = RB / 2u; step != 0u; step >>= 1) rr += e >= CUM[rr + step] ? step : 0u;
+            const u32 i = e - CUM[rr];
+            const u64 a = A[rr * NLS + i], b = A[rr * NLS + i + second];
+            const u64 key = a < b ? a : b;
+            const u32 pos = (u32)(key & 0xFFu);
+            const u64 slot = SLOT[rr] + i;
+            // the l-mer itself: the key's hash IS it (identity), or it with its bases reversed (LexHasher(w) on w bases)
+            const u64 word = MODE == 0 ? key >> 8 : MODE == 1 ? lex_hash(key >> 8, w) : mmr_field(FW + rr * ND, 2u * pos, 2u * w);
+            __builtin_nontemporal_store(word, &out_word[slot]);
+            __builtin_nontemporal_store(pos + PBASE[rr], &out_pos[slot]);
+        }
+        __syncthreads();
+    }
+}
+
+// Any read, any (k, w, hasher): a wave per read, a lane per k-mer, the window's l-mers evaluated one after the other from the bytes
+// (leftmost minimum).  What the tiled kernel does not take: reads above 256 bases behind offsets, hashes above 56 bits.
+__global__ void __launch_bounds__(256)
+minimizers_reads_generic_kernel(const uint8_t* __restrict__ bases, const MmrGeom geo, u32 k, u32 w, u32 hasher, u32 hk,
+                                u64* __restrict__ out_word, u32* __restrict__ out_pos, unsigned long long* __restrict__ first_bad) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 R = wave; R < geo.n_reads; R += n_waves) {
+        u64 o0 = R * (u64)geo.L, len = geo.L, slot = R * (u64)(geo.L - k + 1u);
+        if (geo.offsets) {
+            o0 = geo.offsets[R];
+            len = geo.offsets[R + 1u] - o0;
+            slot = geo.win_offsets[R];
+        }
+        const uint8_t* s = bases + o0;
+        bool bad = false;
+        for (u64 i = lane; i < len; i += 64u) bad |= encode_base(s[i]) >= 4u;
+        if (__any(bad) && lane == 0) atomicMin(first_bad, (unsigned long long)R);
+        if (len < k) continue;
+        for (u64 i = lane; i + k <= len; i += 64u) {
+            u64 best = 0, best_h = 0;
+            u32 best_p = 0;
+            for (u32 p = 0; p + w <= k; ++p) {
+                u64 lm = 0;
+                for (u32 b = 0; b < w; ++b) {
+                    const u32 c = s[i + p + b];
+                    const u32 ic = (c >> 1) & 3u;
+                    lm |= (u64)(ic ^ (ic >> 1)) << (2u * b);
+                }
+                const u64 h = hasher == KMX_HASH_LEX ? lex_hash(lm, hk) : lm;
+                if (p == 0u || h < best_h) {
+                    best = lm;
+                    best_h = h;
+                    best_p = p;
+                }
+            }
+            out_word[slot + i] = best;
+            out_pos[slot + i] = (u32)(i + best_p);
+        }
+    }
+}
+
+// bound: the longest read (uniform: L).  *tiled: whether the sliding-minimum kernel ran (the caller's diagnostics / tests)
+hipError_t launch_minimizers_reads(const uint8_t* bases, u64 total_bytes, const u64* offsets, const u64* win_offsets, u64 n_reads, u32 L,
+                                   u32 bound, u32 k, u32 w, u32 hasher, u32 hk, u64* out_word, u32* out_pos,
+                                   unsigned long long* first_bad, int n_cu, hipStream_t st, bool* tiled) {
+    MmrGeom geo{offsets, win_offsets, n_reads, L, 1u, 0u};
+    const u32 hash_bits = hasher == KMX_HASH_LEX ? 2u * hk : 2u * w;
+    *tiled = false;
+    const bool keys_fit = hash_bits <= 56u && w <= 28u && k > w;
+    u32 Lmax = bound;
+    if (!offsets && L > 256u) {          // pieces of at most 256 bases: T k-mers each, the same for every read
+        geo.T = 256u - k + 1u;
+        geo.J = (L - k + 1u + geo.T - 1u) / geo.T;
+        Lmax = 256u;
+    } else if (!offsets) {
+        geo.T = L - k + 1u;
+    }
+    if (keys_fit && Lmax <= 256u && Lmax >= k && n_reads < (1ull << 40)) {
+        constexpr int RB = 16;
+        const u64 n_pieces = n_reads * geo.J;
+        u64 grid = (n_pieces + RB - 1u) / RB;
+        const u64 cap = (u64)n_cu * 8u;
+        if (grid > cap) grid = cap;
+        const u32 NLS = Lmax - w + 1u, ND = ((2u * Lmax + 31u) >> 5) + 2u;
+        const size_t lds = (size_t)2u * RB * NLS * 8u + (size_t)(2u * RB * ND + ((RB * ND) & 1u)) * 4u + (size_t)RB * 8u + (size_t)(3u * RB + 1u) * 4u + 16u;
+        const int mode = hasher != KMX_HASH_LEX ? 0 : (hk == w ? 1 : 2);
+#define KMX_MMR_LAUNCH(M, RG)                                                                                                          \
+    do {                                                                                                                               \
+        auto kern = minimizers_reads_kernel<256, RB, M, RG>;                                                                           \
+        if (lds > 64u * 1024u) {                                                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                                             \
+        }                                                                                                                              \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(grid ? grid : 1)), dim3(256), lds, st, bases, total_bytes, geo, Lmax, k, w, hk, out_word, \
+                           out_pos, first_bad);                                                                                        \
+    } while (0)
+        if (offsets) {
+            if (mode == 0) KMX_MMR_LAUNCH(0, true); else if (mode == 1) KMX_MMR_LAUNCH(1, true); else KMX_MMR_LAUNCH(2, true);
+        } else {
+            if (mode == 0) KMX_MMR_LAUNCH(0, false); else if (mode == 1) KMX_MMR_LAUNCH(1, false); else KMX_MMR_LAUNCH(2, false);
+        }
+#undef KMX_MMR_LAUNCH
+        *tiled = true;
+        return hipGetLastError();
+    }
+    u64 grid = (n_reads + 3u) / 4u;
+    const u64 cap = (u64)n_cu * 16u;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(minimizers_reads_generic_kernel, dim3((unsigned)(grid ? grid : 1)), dim3(256), 0, st, bases, geo, k, w, hasher, hk, out_word,
+                       out_pos, first_bad);
+    return hipGetLastError();
+}
+
+}  // namespace kmx

@@ -18,30 +18,6 @@
 
 namespace kmx {
 
-// encode16 (kmx_device.h) + one bit per byte: "not one of ACGTacgt" (the accept set of encode_binary_u8, mod.rs:40-50)
-__device__ __forceinline__ u32 encode16_inv(const uint4 w, u32& inv16) {
-    constexpr u32 TBL_LO = 0x00430041u, TBL_HI = 0x00470054u, W4 = 0x40100401u;   // as in encode16
-    const u32 t0 = w.x & 0x06060606u, t1 = w.y & 0x06060606u, t2 = w.z & 0x06060606u, t3 = w.w & 0x06060606u;
-    const u32 x0 = w.x ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t0);
-    const u32 x1 = w.y ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t1);
-    const u32 x2 = w.z ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t2);
-    const u32 x3 = w.w ^ __builtin_amdgcn_perm(TBL_HI, TBL_LO, t3);
-    // a byte of x is 0x00 or 0x20 for a valid letter: bit 7 of ((x & 0x5F) + 0x7F) | x is set <=> the byte is anything else
-    auto nz = [](u32 x) { return __builtin_amdgcn_bitop3_b32((x & 0x5F5F5F5Fu) + 0x7F7F7F7Fu, x, 0x80808080u, 0xA8 /* (a | b) & c */); };
-    // v_dot4_u32_u8 gathers the four marks of a dword: 0x80 * (b0 + 2 b1 + 4 b2 + 8 b3), the second dword on top at 16 .. 128
-    const u32 a = __builtin_amdgcn_udot4(nz(x1), 0x80402010u, __builtin_amdgcn_udot4(nz(x0), 0x08040201u, 0u, false), false);
-    const u32 b = __builtin_amdgcn_udot4(nz(x3), 0x80402010u, __builtin_amdgcn_udot4(nz(x2), 0x08040201u, 0u, false), false);
-    inv16 = (a >> 7) | (b << 1);
-    const u32 d0 = __builtin_amdgcn_udot4(t0, W4, 0u, false);
-    const u32 d1 = __builtin_amdgcn_udot4(t1, W4, 0u, false);
-    const u32 d2 = __builtin_amdgcn_udot4(t2, W4, 0u, false);
-    const u32 d3 = __builtin_amdgcn_udot4(t3, W4, 0u, false);
-    u32 p = (d1 << 8) | d0;
-    p = (d2 << 16) | p;
-    p = (d3 << 23) | (p >> 1);
-    return __builtin_amdgcn_bitop3_b32(p >> 1, p, vgpr_const<0x55555555u>(), 0x6c);   // internal (ACTG) -> naive_impl (ACGT) codes
-}
-
 // NW: packed dwords per read (10: reads of up to 160 bases, 16: up to 256).  V1 = (k - 1) / 16: a k-mer is V1 + 1 dwords.
 // RAGGED / SEG and the arguments: as scan_bitsliced_kernel's -- `n_reads` counts what that kernel calls a read (a segment, for
 // SEG and for the long ragged reads), `L` is its frame.

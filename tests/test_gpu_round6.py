@@ -1,13 +1,15 @@
 """Round-6 GPU parity tests (through the C ABI, bit-exact against the CPU oracle).
 
-  * sweep_flagged_kernel (kmx_sweep.hip): the reads the bit-sliced scan blanks out of their tile -- an invalid byte somewhere in
-    them -- are no longer rolled by one lane each but gathered 64 at a time and handled as a tile of the word domain with one
-    validity bit per window.  Every instantiation is driven here: both frames (reads up to 160 / up to 256 bases), every k-mer
-    width (k = 13..16, 17..31, 33..48, 49..64: one to four dwords per window), uniform reads, reads behind offsets (ragged, and
-    uniform ones through the device-side gate), segments of long uniform and of long ragged reads; invalid bytes at both ends,
-    in runs, several per read, whole reads of N, and in the batch's very last read (whose 16-byte loads must not leave the
-    buffer).  The semantics at stake are the iterator's skip rule, canonical_kmer_iterator.rs:50-66: exactly the windows that
-    hold no invalid byte are yielded.
+  * sweep_flagged_kernel (kmx_sweep.hip): the bit-sliced scan no longer blanks the reads that hold an invalid byte -- it scans
+    the tile as it is and marks them; the sweep gathers the marked reads 64 at a time, finds the windows that hold an invalid
+    byte and takes them back OUT of the sums.  Every instantiation is driven here: both frames (reads up to 160 / up to 256
+    bases), every k-mer width (k = 13..16, 17..31, 33..48, 49..64: one to four dwords per window), uniform reads, reads behind
+    offsets (ragged, and uniform ones through the device-side gate), segments of long uniform and of long ragged reads; invalid
+    bytes at both ends, in runs, several per read, whole reads of N, and in the batch's very last read (whose 16-byte loads
+    must not leave the buffer).  The semantics at stake are the iterator's skip rule, canonical_kmer_iterator.rs:50-66:
+    exactly the windows that hold no invalid byte are yielded.
+  * kmx_minimizers: SeqVecMinimizerIter (seq_vector/minimizers.rs:39-141) over READS -- ASCII, uniform or behind offsets --
+    against the oracle's monotone deque on SeqVector::from(read), and the reference's own vectors (minimizers.rs:237-290).
 """
 import numpy as np
 import pytest
@@ -239,3 +241,98 @@ def test_sweep_at_size_every_read_dirty(ctx, orc, k, L):
             o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
             g = ctx.canonical_reduce2(dev, n, L, k, with_hash=True)
             _check2(g, o)
+
+
+# ---------------------------------------------------------------- kmx_minimizers: SeqVecMinimizerIter over READS (seq_vector/minimizers.rs:39-141)
+def _acgt(rng, n):
+    return np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+
+
+def _mm_oracle_uniform(orc, host, n, L, k, w, hk):
+    return orc.seqvec_minimizers(orc.SeqVector(host.tobytes()), n, L, k, w, hk)
+
+
+def _mm_oracle_ragged(orc, host, offs, k, w, hk):
+    """the reference's iterator over SeqVector::from(read) of every read with at least k bases, one after the other"""
+    words, pos = [], []
+    for r in range(len(offs) - 1):
+        rd = host[int(offs[r]): int(offs[r + 1])]
+        if len(rd) < k:
+            continue
+        for a, b in orc.seqvec_iter_minimizers(orc.SeqVector(rd.tobytes()), k, w, hk):
+            words.append(a)
+            pos.append(b)
+    return np.array(words, np.uint64), np.array(pos, np.uint32)
+
+
+def test_minimizers_reads_kats(ctx, kats):
+    """the reference's own minimizer iterator vectors (minimizers.rs:237-290), the read handed over as ASCII"""
+    from kmers_amd import _lib
+
+    for t in kats["minimizers"]["iter"]:
+        s = np.frombuffer(t["seq"].encode(), np.uint8)
+        hasher = _lib.HASH_LEX if t["hasher_k"] else _lib.HASH_IDENTITY
+        mw, mp = ctx.minimizers(ctx.to_device(s), 1, len(s), t["k"], t["w"], hasher, t["hasher_k"])
+        got = [[int(a), int(b)] for a, b in zip(mw.cpu().numpy().view(np.uint64), mp.cpu().numpy())]
+        assert got == t["expect"], t["name"]
+
+
+@pytest.mark.parametrize("L,k,w,hk", [(150, 31, 15, 15), (150, 21, 11, 0), (100, 9, 3, 32), (151, 31, 28, 28), (256, 31, 15, 15), (36, 31, 15, 6),
+                                      (150, 31, 29, 29), (150, 32, 16, 16), (31, 31, 15, 15), (257, 31, 15, 15), (1000, 31, 15, 15), (700, 21, 11, 0),
+                                      (5000, 40, 7, 7)])
+def test_minimizers_uniform_reads(ctx, orc, L, k, w, hk):
+    """ASCII reads of one length: up to 256 bases the sliding-minimum kernel on the reads, above it on pieces of 256 bases;
+    hashes above 56 bits the lane-per-k-mer kernel; from an odd address too"""
+    import torch
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(L * 1000 + k * 10 + w)
+    n = max(16 * 5 + 3, 40000 // L)
+    host = _acgt(rng, n * L)
+    host[: 8 * L] = np.frombuffer(b"ACAC", np.uint8)[rng.integers(0, 2, 8 * L) * 2]   # two-letter reads: ties everywhere, the leftmost wins
+    host[8 * L: 10 * L] = ord("a")                                                    # lower case is a base too
+    ow, op = _mm_oracle_uniform(orc, host, n, L, k, w, hk)
+    hasher = _lib.HASH_LEX if hk else _lib.HASH_IDENTITY
+    for lead in (0, 3):
+        big = torch.empty(n * L + lead, dtype=torch.uint8, device="cuda")
+        big[lead:] = torch.from_numpy(host).cuda()
+        mw, mp = ctx.minimizers(big[lead:], n, L, k, w, hasher, hk)
+        assert (mw.cpu().numpy().view(np.uint64) == ow).all()
+        assert (mp.cpu().numpy().view(np.uint32) == op).all()
+
+
+@pytest.mark.parametrize("k,w,hk,lo,hi", [(31, 15, 15, 20, 150), (21, 11, 0, 21, 100), (31, 15, 6, 100, 256), (15, 5, 5, 0, 60), (31, 15, 15, 100, 400)])
+def test_minimizers_ragged_reads(ctx, orc, k, w, hk, lo, hi):
+    """reads behind offsets (what kmx_fastx_parse hands over): reads shorter than k own no slot; a batch whose longest read is above
+    256 bases takes the lane-per-k-mer kernel"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(k * 1000 + w + hi)
+    n = 16 * 20 + 7
+    lens = rng.integers(lo, hi + 1, n).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    wins = np.concatenate([[0], np.cumsum(np.maximum(lens - k + 1, 0))]).astype(np.uint64)
+    host = _acgt(rng, int(offs[-1]))
+    ow, op = _mm_oracle_ragged(orc, host, offs, k, w, hk)
+    hasher = _lib.HASH_LEX if hk else _lib.HASH_IDENTITY
+    mw, mp = ctx.minimizers(ctx.to_device(host), n, hi, k, w, hasher, hk, offsets=ctx.to_device(offs), win_offsets=ctx.to_device(wins))
+    assert len(ow) == int(wins[-1])
+    assert (mw.cpu().numpy().view(np.uint64) == ow).all()
+    assert (mp.cpu().numpy().view(np.uint32) == op).all()
+
+
+def test_minimizers_invalid_byte_is_reported(ctx):
+    """SeqVector::from panics on a byte outside ACGTacgt (seq_vector.rs:230-242): the call names the first such read"""
+    from kmers_amd import _lib
+    from kmers_amd.api import KmxError
+
+    rng = np.random.default_rng(5)
+    n, L = 100, 150
+    host = _acgt(rng, n * L)
+    host[57 * L + 149] = ord("N")
+    host[80 * L] = ord("N")
+    with pytest.raises(KmxError) as ei:
+        ctx.minimizers(ctx.to_device(host), n, L, 31, 15, _lib.HASH_LEX, 15)
+    assert ei.value.status == _lib.E_INVALID_BASE
+    mw, mp = ctx.minimizers(ctx.to_device(host), n, L, 31, 15, _lib.HASH_LEX, 15, check=False)     # asked not to look: no error
+    assert mw.numel() == n * 120
