@@ -133,10 +133,10 @@ void* big_scratch(void* user, size_t bytes);
 // own grow-only array, zeroed when it is allocated; the rolling kernel clears every mask it consumes, so it is all-zero
 // again when a call ends and nothing has to be cleared per call.  Its address sits behind the 32 tile-queue heads (d_scratch[16 + 515]), rewritten only
 // when it changes.  No array: 0, and such tiles take the per-lane path as a whole, as they do for k without a bit-sliced kernel.
-int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k) {
+int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k, bool any_k = false) {
     const uint64_t n_tiles = n_reads >> 6;
     uint8_t* buf = nullptr;
-    if (n_tiles && ((k >= 13 && k <= 31) || (k >= 33 && k <= 64))) {   // the k with a bit-sliced kernel
+    if (n_tiles && (any_k || (k >= 13 && k <= 31) || (k >= 33 && k <= 64))) {   // the k with a bit-sliced kernel (any_k: the word-domain scan's histogram sinks mark too)
         if (8u * n_tiles > ctx->flags_bytes) {   // one 64-bit read mask per tile
             if (ctx->d_flags) {
                 (void)hipStreamSynchronize(ctx->stream);
@@ -736,7 +736,11 @@ int kmx_histogram(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t has
     ctx->fx_valid = false;   // (the partitioned histogram writes its id streams over the work buffer)
     {
         bool handled = false;
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 16, ctx->stream));   // queue heads + the count of marked reads + the gate
+        // (the histogram sinks mark the reads of a dirty tile like the bit-sliced scan does; without the array they roll such tiles, exactly)
+        if (k >= 2 && k <= 31) {
+            if (int st = prepare_dirty_flags(ctx, reads->n_reads, k, true)) return st;
+        }
         KMX_HIP(ctx, kmx::launch_hist_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, hasher, hasher_k,
                                               log2_buckets, d_counts, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled,
                                               &big_scratch, ctx, hist_scratch_budget(ctx->big_bytes, ctx->big_limit), reads->d_offsets));

@@ -19,6 +19,7 @@ struct SinkHist {
     static constexpr u32 kLdsDwordsPerWave = 0;
     __device__ __forceinline__ void block_done(u64, u32, u32) {}
     static constexpr bool kRagged = true;
+    static constexpr bool kMarksDirty = true;   // (a tile with an invalid byte: fast path + marks, kmx_scan_kernel.h; launch_hist_uniform sweeps behind every scan)
     static u32 block_lds_dwords(const HistParams&) { return 0; }
     __device__ SinkHist(const HistParams& p, u32 k_, u32, u32*, u32, u32*, u32)
         : counts(p.counts), maskk(mask2k(k_)), hasher(p.hasher), hk(p.hk), k(k_), b(p.log2_buckets) {}
@@ -51,6 +52,7 @@ struct SinkHistLds {
     u32 hasher, hk, k, b, tid;
     static constexpr u32 kLdsDwordsPerWave = 0;
     static constexpr bool kRagged = true;
+    static constexpr bool kMarksDirty = true;   // (a tile with an invalid byte: fast path + marks, kmx_scan_kernel.h; launch_hist_uniform sweeps behind every scan)
     static u32 block_lds_dwords(const HistParams& p) { return 1u << p.log2_buckets; }
     __device__ SinkHistLds(const HistParams& p, u32 k_, u32, u32*, u32, u32* block_lds, u32 tid_)
         : counts(p.counts), tab(block_lds), maskk(mask2k(k_)), hasher(p.hasher), hk(p.hk), k(k_), b(p.log2_buckets), tid(tid_) {
@@ -211,14 +213,27 @@ hist_repartition_kernel(const u32* __restrict__ stream1, const u32* __restrict__
     sink.finish(p2);
 }
 
+hipError_t launch_sweep_hist(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 hasher, u32 hk, u32 log2_buckets, u64* counts,
+                             unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets);
+
 // Larger tables, or no scratch: device-scope u64 atomics (SinkHist).
+// Every scan is followed by the sweep that takes the windows with an invalid byte back out of the counters (round 6: the sinks mark
+// the reads of a dirty tile instead of rolling it -- kmx_scan_kernel.h, SinkMarksDirty; a no-op on clean input).
 hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 hasher, u32 hk, u32 log2_buckets,
                                u64* counts, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled,
                                void* (*get_scratch)(void*, size_t), void* user, size_t scratch_budget, const u64* offsets) {
     *handled = offsets ? scan_domain_ragged(bases, L, k) : scan_domain(bases, n_reads, L, k);
     if (!*handled) return hipSuccess;
     const HistParams p{counts, hasher, hk, log2_buckets};
-    if (log2_buckets <= 14u) return dispatch<SinkHistLds>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
+    auto sweep = [&](const uint8_t* b, u64 n, const u64* o) { return launch_sweep_hist(b, n, L, k, hasher, hk, log2_buckets, counts, queue, n_cu, stream, o); };
+    auto atomic_scan = [&](const uint8_t* b, u64 n, const u64* o) -> hipError_t {
+        hipError_t e = dispatch<SinkHist>(b, n, L, k, p, queue, n_cu, stream, NoPre(), o);
+        return e != hipSuccess ? e : sweep(b, n, o);
+    };
+    if (log2_buckets <= 14u) {
+        hipError_t e = dispatch<SinkHistLds>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
+        return e != hipSuccess ? e : sweep(bases, n_reads, offsets);
+    }
     if (log2_buckets >= 23u && log2_buckets <= 28u && get_scratch != nullptr && n_reads >= 4096u) {
         // Two levels of 64 partitions each (round 3; these sizes took device atomics before: 0.5 s per 1e8 reads).  Pass 1 as
         // below but with the whole bucket per id (u32 entries); hist_repartition_kernel splits each partition's stream by the
@@ -263,7 +278,7 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
                     return true;
                 };
                 if (first != 0) {
-                    hipError_t e = hipMemsetAsync(queue, 0, 32 * 128, stream);
+                    hipError_t e = hipMemsetAsync(queue, 0, 32 * 128 + 8, stream);   // (the heads, and the count of marked reads behind them)
                     if (e != hipSuccess) return e;
                 }
                 const uint8_t* cb = offsets ? bases : bases + first * (u64)L;
@@ -271,8 +286,10 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
                 hipError_t e = dispatch_part_u32(cb, n, L, k, pp, queue, n_cu, stream, make_hist_pre(pre), co);
                 if (e == hipErrorOutOfMemory) {   // no scratch: the atomic sink handles the rest
                     (void)hipGetLastError();
-                    return dispatch<SinkHist>(cb, n_reads - first, L, k, p, queue, n_cu, stream, NoPre(), co);
+                    return atomic_scan(cb, n_reads - first, co);
                 }
+                if (e != hipSuccess) return e;
+                e = sweep(cb, n, co);
                 if (e != hipSuccess) return e;
                 typedef SinkHistPartT<1, uint16_t> Sink2;
                 const HistPartParams dummy{};
@@ -331,7 +348,7 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
                     return true;
                 };
                 if (first != 0) {
-                    hipError_t e = hipMemsetAsync(queue, 0, 32 * 128, stream);
+                    hipError_t e = hipMemsetAsync(queue, 0, 32 * 128 + 8, stream);   // (the heads, and the count of marked reads behind them)
                     if (e != hipSuccess) return e;
                 }
                 // the hook fills pp through the reference captured above; dispatch takes its params by value, so hand it
@@ -342,8 +359,10 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
                 hipError_t e = dispatch_part<HistPartPre>(cb, n, L, k, pp, queue, n_cu, stream, make_hist_pre(pre), co);
                 if (e == hipErrorOutOfMemory) {   // no scratch: the atomic sink handles the rest
                     (void)hipGetLastError();
-                    return dispatch<SinkHist>(cb, n_reads - first, L, k, p, queue, n_cu, stream, NoPre(), co);
+                    return atomic_scan(cb, n_reads - first, co);
                 }
+                if (e != hipSuccess) return e;
+                e = sweep(cb, n, co);
                 if (e != hipSuccess) return e;
                 const bool halves = log2_buckets == 22u;   // 2^16 buckets per partition: two blocks of 2^15 each
                 const u32 nb_bytes = 4u << (log2_buckets - 6u - (halves ? 1u : 0u));
@@ -363,7 +382,7 @@ hipError_t launch_hist_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
             return hipSuccess;
         }
     }
-    return dispatch<SinkHist>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
+    return atomic_scan(bases, n_reads, offsets);
 }
 
 }  // namespace kmx

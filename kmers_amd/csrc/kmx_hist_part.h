@@ -47,7 +47,8 @@ struct SinkHistPartT {
     // (mix >> 26 | base >> 13 << 6) << 7 -- one v_alignbit_b32 with the wave's base in the high word -- plus the slot bytes
     static constexpr u32 kLdsDwordsPerWave = 2u * NP + NP / 4u;
     static constexpr u32 kBlockLdsAlign = 2048u;   // dwords (8 KB)
-    static constexpr bool kRagged = true;   // (ragged reads come window by window through fast(): no batches)
+    static constexpr bool kRagged = true;
+    static constexpr bool kMarksDirty = true;   // (a tile with an invalid byte: fast path + marks, kmx_scan_kernel.h; launch_hist_uniform sweeps behind every scan)   // (ragged reads come window by window through fast(): no batches)
     static constexpr u32 kRingDwords = 4u * NP * 32u;   // 4 waves x 64 rings x 128 bytes
     static u32 block_lds_dwords(const HistPartParams&) { return kRingDwords; }
     HistPartParams p;

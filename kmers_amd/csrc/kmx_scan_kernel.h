@@ -55,6 +55,13 @@ template <typename S> struct SinkWavesBig<S, decltype((void)S::kWavesBig)> { sta
 // words, and a wave's LDS operations complete in order
 template <typename S, typename = void> struct SinkAliasPacked { static constexpr bool value = false; };
 template <typename S> struct SinkAliasPacked<S, decltype((void)S::kAliasPacked)> { static constexpr bool value = S::kAliasPacked; };
+// a sink whose windows a later pass can take back (static constexpr bool kMarksDirty; round 6): a tile that holds an invalid byte is
+// then NOT rolled per lane -- it takes the fast path as it is, an invalid byte counting as the base its bits (b >> 1) & 3 spell, and
+// the reads that touch a bad chunk are marked in the array behind queue[515] exactly as the bit-sliced scan marks them; what the
+// windows with an invalid byte added is subtracted by sweep_flagged_kernel (kmx_sweep.hip).  The bucket histograms: a rolled tile
+// cost 2-3 tiles, and with an N in 2 % of the reads 73 % of the tiles rolled (+62 %: profiles/r05_dirty_bench.txt).
+template <typename S, typename = void> struct SinkMarksDirty { static constexpr bool value = false; };
+template <typename S> struct SinkMarksDirty<S, decltype((void)S::kMarksDirty)> { static constexpr bool value = S::kMarksDirty; };
 template <typename S, int NW> constexpr int sink_waves() { return NW <= 10 ? SinkWaves<S>::value : SinkWavesBig<S>::value; }
 template <int NW, int V, int DW, typename Sink, typename Params, bool RAGGED = false>
 __global__ void __launch_bounds__(256, (sink_waves<Sink, NW>()))
@@ -160,6 +167,9 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         }
         return ~0ull;
     };
+    constexpr bool MARK = SinkMarksDirty<Sink>::value;
+    [[maybe_unused]] u64* const dirty_masks = MARK ? reinterpret_cast<u64*>(queue[515]) : nullptr;
+    [[maybe_unused]] u32 n_marked = 0;
     u64 next_tile = dequeue();
     constexpr bool PF = SinkPrefetch<Sink>::value && !RAGGED && NW <= 10;   // (the 16-word frame: 80 more registers do not fit two waves)
     [[maybe_unused]] u32 E[NW];          // PF: the next tile, encoded (chunk it * 64 + lane)
@@ -267,7 +277,34 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        if (!tile_fits || __any(chunk_has_invalid(bad))) {
+        bool roll_tile = !tile_fits || __any(chunk_has_invalid(bad));
+        if constexpr (MARK) {
+            if (roll_tile && tile_fits && dirty_masks != nullptr) {
+                // which reads touch a chunk with an invalid byte?  The tile's chunks once more (they are in the L2), one ballot per row;
+                // every lane keeps the two rows' ballots its read's chunks lie in (a chunk shared by two reads marks both: the sweep looks
+                // at the bytes)
+                const u32 rd_off = posF - 16u, rd_len = RAGGED ? my_len : L;     // the read's bytes, relative to the tile's aligned start
+                const u32 c0 = rd_off >> 4, c1 = rd_len ? (rd_off + rd_len - 1u) >> 4 : c0, q0 = c0 >> 6, b0 = c0 & 63u;
+                u64 lo = 0, hi = 0;
+#pragma unroll
+                for (int it = 0; it < NW; ++it) {
+                    const u32 c = it * 64u + lane;
+                    uint4 wv = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+                    if (c < chunks) wv = tb[c];
+                    u32 rb = 0;
+                    (void)encode16(wv, rb);
+                    const u64 row = __ballot(chunk_has_invalid(rb));
+                    lo = q0 == (u32)it ? row : lo;
+                    hi = q0 + 1u == (u32)it ? row : hi;
+                }
+                const u64 bits = b0 ? ((lo >> b0) | (hi << (64u - b0))) : lo;
+                const u64 dm = __ballot(rd_len != 0u && (bits & ((1ull << (c1 - c0 + 1u)) - 1ull)) != 0ull);
+                if (lane == 0 && dm != 0ull) dirty_masks[tile] = dm;
+                n_marked += (u32)__builtin_popcountll(dm);
+                roll_tile = false;
+            }
+        }
+        if (roll_tile) {
             // ---- rare: a non-ACGTacgt byte somewhere in this tile (or a ragged tile outside the frame) -> exact iterator semantics
             sink.tile_slow_begin(read);
             u32 roll_max = L;
@@ -382,6 +419,9 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
             roll_read(bases + lead + read * (u64)L, L, k, [&](u32 pos, u64 fw, u64 rc) { sink.slow(pos, fw, rc); });
         }
         sink.end_read();
+    }
+    if constexpr (MARK) {
+        if (n_marked != 0u && lane == 0) atomicAdd(queue + 512, (unsigned long long)n_marked);   // (how many waves the sweep fields)
     }
     sink.finish(params);
 }

@@ -24,7 +24,9 @@ namespace kmx {
 template <int NW, int V1> constexpr int sweep_pitch() {     // dwords of a lane's LDS row: F, G, the window bits (odd: lane-strided access without bank conflicts)
     return ((NW + V1 + 4) + (NW + 4) + (NW / 2 + 1)) | 1;
 }
-template <int NW, int V1, bool RAGGED, bool SEG>
+// HIST: the windows are taken out of a bucket histogram instead of a summary (the word-domain scan's histogram sinks mark their dirty
+// reads the same way: kmx_scan_kernel.h, SinkMarksDirty) -- `out` = the counters, want_hash = the hasher, want_sumfw = hasher_k | log2_buckets << 8.
+template <int NW, int V1, bool RAGGED, bool SEG, bool HIST = false>
 __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, u32 want_hash,
                                                             u32 want_sumfw, void* __restrict__ out, unsigned long long* __restrict__ queue,
                                                             const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends,
@@ -258,6 +260,16 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
                     cn[w] = w < DWN ? (lt ? fw[w] : rc[w]) : 0u;
                     mx[w] = w < DWN ? (lt ? rc[w] : fw[w]) : 0u;
                 }
+                if constexpr (HIST) {
+                    // SinkHist::emit (kmx_hist.hip): the bucket of hash(canonical word), one device atomic per spoiled window
+                    if (vi != 0u) {
+                        const u64 canon = ((u64)cn[1] << 32) | cn[0], mxw = ((u64)mx[1] << 32) | mx[0];
+                        const u32 hk = want_sumfw & 0xFFu, lb = want_sumfw >> 8;
+                        const u64 h = want_hash == KMX_HASH_LEX ? (hk == k ? mask2k(k) ^ mxw : lex_hash(canon, hk)) : canon;
+                        atomicAdd(static_cast<unsigned long long*>(out) + bucket_of(h, lb), ~0ull);
+                    }
+                    continue;
+                }
                 a_s0 += ((u64)cn[1] << 32) | cn[0];
                 r_x0 ^= ((u64)mx[1] << 32) | mx[0];
                 if constexpr (DWN > 2) {
@@ -340,7 +352,7 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
         }
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (HIST || threadIdx.x != 0) return;
     const u64 n = part[0][0] + part[1][0] + part[2][0] + part[3][0];
     if (n == 0) return;   // nothing to take out: no atomics
     const u64 s0 = part[0][1] + part[1][1] + part[2][1] + part[3][1], s1 = part[0][2] + part[1][2] + part[2][2] + part[3][2];
@@ -398,6 +410,39 @@ hipError_t launch_sweep_flagged(const uint8_t* bases, u64 n_reads, u32 L, u32 k,
     }
     if (big) return launch_sweep_v<16, false, false>(v1, grid, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
     return launch_sweep_v<10, false, false>(v1, grid, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
+}
+
+// Behind a word-domain scan whose sink marks dirty reads (the bucket histograms): what the windows with an invalid byte added to the
+// counters is subtracted.  Uniform reads (L) or reads behind offsets (L = their bound, 0: none -- the 16-word frame); k <= 31.
+hipError_t launch_sweep_hist(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u32 hasher, u32 hk, u32 log2_buckets, u64* counts,
+                             unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets) {
+    if (k < 2u || k > 31u) return hipErrorInvalidValue;
+    u32 lead = 0;
+    if (!offsets) {       // (as launch_one: streamed from the aligned address below an unaligned base)
+        lead = (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
+        bases -= lead;
+    }
+    u64 grid1 = (u64)n_cu * 2u;
+    const u64 need1 = ((n_reads >> 6) + 255u) / 256u;
+    if (grid1 > need1) grid1 = need1;
+    const dim3 grid((unsigned)(grid1 ? grid1 : 1));
+    const bool big = L > 160u || (offsets && L == 0u);
+    const u32 Lf = offsets ? (big ? 256u : 160u) : L;
+    if (Lf < k) return hipErrorInvalidValue;
+    const BsSeg seg{0, 0, 0, 0, 0};
+    const u32 packed = hk | (log2_buckets << 8);
+    const u64* ends = offsets ? offsets + 1 : nullptr;
+#define KMX_SWEEP_HIST(NWv, V1v, RG) hipLaunchKernelGGL((sweep_flagged_kernel<NWv, V1v, RG, false, true>), grid, dim3(256), 0, stream, bases, n_reads, Lf, k, hasher, packed, static_cast<void*>(counts), queue, offsets, lead, ends, seg)
+    const bool v1 = k >= 17u;
+    if (offsets) {
+        if (big) { if (v1) KMX_SWEEP_HIST(16, 1, true); else KMX_SWEEP_HIST(16, 0, true); }
+        else     { if (v1) KMX_SWEEP_HIST(10, 1, true); else KMX_SWEEP_HIST(10, 0, true); }
+    } else {
+        if (big) { if (v1) KMX_SWEEP_HIST(16, 1, false); else KMX_SWEEP_HIST(16, 0, false); }
+        else     { if (v1) KMX_SWEEP_HIST(10, 1, false); else KMX_SWEEP_HIST(10, 0, false); }
+    }
+#undef KMX_SWEEP_HIST
+    return hipGetLastError();
 }
 
 }  // namespace kmx
