@@ -61,14 +61,18 @@ typedef struct kmx_ctx kmx_ctx;
  *   then carry an upper bound of the read lengths (0 = unknown): a bound <= 160 selects the smaller, faster frame of the
  *   tiled kernels, and the tighter it is the fewer windows a lane carries (150 bp reads: 7 % faster at k = 31 with 150
  *   than with 160 or 0).  Reads that are all of ONE length up to the bound (no bound: 160) -- untrimmed FASTQ -- are recognised on the
- *   device and take the uniform kernels whatever the bound says (round 5).  It is only a hint -- tiles with a longer read take the exact per-read path, and the
+ *   device and take the uniform kernels whatever the bound says (round 5) in kmx_canonical_reduce (13 <= k <= 31, 16-byte aligned
+ *   d_bases, a bound of at most 256, no KMX_REDUCE_SUM_FW) and in kmx_canonical_reduce2 (16-byte aligned d_bases, a bound of at most
+ *   256); kmx_histogram, kmx_canonical_windows(2), kmx_minimizers and the Sum-fw reduce take such reads through their ragged kernels.
+ *   It is only a hint -- tiles with a longer read take the exact per-read path, and the
  *   histogram's work buffer, sized from it, overflows into exact (slow) global atomics.  A bound ABOVE 256 says "long reads"
  *   (PacBio / ONT reads, contigs): kmx_canonical_reduce (13 <= k <= 31), kmx_canonical_reduce2, kmx_canonical_windows and
  *   kmx_canonical_windows2 (16-byte aligned d_bases) then cut every read into overlapping segments on the device and scan those (two
  *   host round trips: the batch's first and last offset, the number of segments; the segment arrays live in the context's work
  *   buffer); with 0 or a bound <= 256 a long read costs its tile the per-read path.  (kmx_canonical_reduce2 cuts ragged reads with
  *   any bound above 160 this way: the two-word ragged kernel holds 160 bases; with a bound of 161..256 it first reads the batch's
- *   first and last offset back -- one host round trip -- and skips the cut when they say "untrimmed".)
+ *   first and last offset back -- one host round trip -- and skips the cut when they say "one length, k .. bound" -- untrimmed reads at
+ *   the bound or below it; the device-side gate then confirms it, and the lane-per-read kernel counts if it does not.)
  *   EVERY call that takes one of these routes SYNCHRONISES the context's stream on the host (once or twice) and cannot be captured
  *   in a HIP graph; all other scan calls only enqueue work.
  * d_bases must be a device pointer whenever n_reads > 0, also when every read is empty (KMX_E_ARG otherwise). */

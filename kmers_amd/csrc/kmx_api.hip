@@ -642,7 +642,10 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
             KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, reads->d_offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
             KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned + 1, reads->d_offsets + reads->n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
             KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->h_pinned[0] == 0 && ctx->h_pinned[1] == reads->n_reads * (uint64_t)Lh) cut = false;
+            // (round 6: at ANY one length up to the bound -- 150-base reads handed over with a bound of 250 paid the segment cut, three host
+            // round trips and a second set of marks, for the uniform kernel to run in the end: the gate passes every uniform length)
+            const uint64_t o_first = ctx->h_pinned[0], o_last = ctx->h_pinned[1];
+            if (o_first == 0 && o_last % reads->n_reads == 0 && o_last / reads->n_reads >= k && o_last / reads->n_reads <= Lh) cut = false;
         }
         if (cut) {
             const int st = long_ragged_segments(ctx, reads, k, 161u - k, &starts, &ends, &n_seg);

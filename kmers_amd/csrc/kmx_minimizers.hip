@@ -38,7 +38,7 @@ template <int THREADS, int RB, int MODE, bool RAGGED>
 __global__ void __launch_bounds__(THREADS)
 minimizers_reads_kernel(const uint8_t* __restrict__ bases, u64 total_bytes, const MmrGeom geo, u32 Lmax, u32 k, u32 w, u32 hk,
                         u64* __restrict__ out_word, u32* __restrict__ out_pos, unsigned long long* __restrict__ first_bad) {
-    static_assert(THREADS == 16 * RB, "16 threads per read");
+    static_assert(THREADS == 16 * RB, "16 threads per read");   // (and a piece is at most 256 bases = 16 + 2 dwords: two per thread)
     extern __shared__ __attribute__((aligned(16))) u64 hs[];   // keys [2][RB][NLS], then FW [RB][ND], RV [RB][ND] (u32), then the reads' geometry
     const u32 NLS = Lmax - w + 1u, span = k - w + 1u;
     const u32 ND = ((2u * Lmax + 31u) >> 5) + 2u;               // dwords of a staged read (+2: the field reads look ahead)
@@ -51,51 +51,70 @@ minimizers_reads_kernel(const uint8_t* __restrict__ bases, u64 total_bytes, cons
     const u32 r = threadIdx.x >> 4, j16 = threadIdx.x & 15u;
     const u64 n_pieces = geo.n_reads * geo.J;
     const uint8_t* const buf_end = bases + total_bytes;
+    // where piece R lies (this thread's: r of the block's RB), and -- j16 == 0 -- its slot and position for the block
+    struct Piece { const uint8_t* sp; u32 len; u64 slot; u32 pbase; };
+    auto piece_of = [&](u64 R) -> Piece {
+        Piece q{bases, 0u, 0ull, 0u};
+        if (R >= n_pieces) return q;
+        if constexpr (RAGGED) {
+            const u64 o0 = geo.offsets[R], o1 = geo.offsets[R + 1u];
+            q.sp = bases + o0;
+            q.len = (u32)(o1 - o0 > (u64)Lmax ? 0u : o1 - o0);        // (a read above the bound: the caller took another kernel)
+            q.slot = geo.win_offsets[R];
+        } else {
+            const u64 rd = R / geo.J;
+            const u32 j = (u32)(R - rd * geo.J);
+            q.sp = bases + rd * (u64)geo.L + (u64)j * geo.T;
+            const u32 left = geo.L - j * geo.T;                         // bases from the piece's first
+            q.len = left < geo.T + k - 1u ? left : geo.T + k - 1u;
+            q.slot = rd * (u64)(geo.L - k + 1u) + (u64)j * geo.T;
+            q.pbase = j * geo.T;
+        }
+        return q;
+    };
+    // A thread packs the dwords j16 and j16 + 16 of its piece (a piece is at most 18 dwords).  Their bytes are REQUESTED one block
+    // iteration ahead -- dword-aligned loads: a 16-byte load from an odd address is taken apart by the memory pipeline -- so that a
+    // block never starts by waiting for memory (the 16 reads of an iteration are 2.4 KB: nothing else hides the latency).
+    u32 xa[2][5];
+    auto request = [&](const Piece& q) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32 d = j16 + 16u * h;
+            const uint8_t* p = q.sp + 16u * d;
+            const u32 rsh = (u32)(reinterpret_cast<uintptr_t>(p) & 3u);
+            const bool fast = 16u * d < q.len && p + 20 <= buf_end && p - rsh >= bases;
+            const u32* a4 = reinterpret_cast<const u32*>(fast ? p - rsh : bases - (reinterpret_cast<uintptr_t>(bases) & 3u) + 4u);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) xa[h][i] = a4[i];
+        }
+    };
+    Piece cur = piece_of((u64)blockIdx.x * RB + r);
+    request(cur);
     for (u64 r0 = (u64)blockIdx.x * RB; r0 < n_pieces; r0 += (u64)gridDim.x * RB) {
         const u32 nr = (u32)(n_pieces - r0 < RB ? n_pieces - r0 : RB);
         u64* A = hs;
         u64* B = hs + RB * NLS;
-        // ---- where this thread's piece lies
-        const uint8_t* sp = bases;
-        u32 len = 0;
-        if (r < nr) {
-            const u64 R = r0 + r;
-            if constexpr (RAGGED) {
-                const u64 o0 = geo.offsets[R], o1 = geo.offsets[R + 1u];
-                sp = bases + o0;
-                len = (u32)(o1 - o0 > (u64)Lmax ? 0u : o1 - o0);        // (a read above the bound: the caller took another kernel)
-                if (j16 == 0u) {
-                    SLOT[r] = geo.win_offsets[R];
-                    PBASE[r] = 0u;
-                }
-            } else {
-                const u64 rd = R / geo.J;
-                const u32 j = (u32)(R - rd * geo.J);
-                sp = bases + rd * (u64)geo.L + (u64)j * geo.T;
-                const u32 left = geo.L - j * geo.T;                         // bases from the piece's first
-                len = left < geo.T + k - 1u ? left : geo.T + k - 1u;
-                if (j16 == 0u) {
-                    SLOT[r] = rd * (u64)(geo.L - k + 1u) + (u64)j * geo.T;
-                    PBASE[r] = j * geo.T;
-                }
-            }
-            if (j16 == 0u) LEN[r] = len;
-        } else if (j16 == 0u) {
-            LEN[r] = 0u;
+        const uint8_t* const sp = cur.sp;
+        const u32 len = cur.len;
+        if (j16 == 0u) {
+            SLOT[r] = cur.slot;
+            PBASE[r] = cur.pbase;
+            LEN[r] = len;
         }
         // ---- the piece, packed: dword d = its bases [16 d, 16 d + 16) (what follows it in the buffer comes along: never looked at)
         if (r < nr) {
-            for (u32 d = j16; d < ND; d += 16u) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32 d = j16 + 16u * h;
+                if (d >= ND) continue;
                 u32 code = 0u;
                 if (16u * d < len) {
                     const uint8_t* p = sp + 16u * d;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    uint4 v;
                     const u32 rsh = (u32)(reinterpret_cast<uintptr_t>(p) & 3u);
-                    if (p + 20 <= buf_end && p - rsh >= bases) {      // dword-aligned loads, shifted into place (a 16-byte load from an odd address is taken apart by the memory pipeline)
-                        const u32* a4 = reinterpret_cast<const u32*>(p - rsh);
-                        const u32 x0 = a4[0], x1 = a4[1], x2 = a4[2], x3 = a4[3], x4 = a4[4];
-                        v = make_uint4(__builtin_amdgcn_alignbyte(x1, x0, rsh), __builtin_amdgcn_alignbyte(x2, x1, rsh),
-                                       __builtin_amdgcn_alignbyte(x3, x2, rsh), __builtin_amdgcn_alignbyte(x4, x3, rsh));
+                    if (p + 20 <= buf_end && p - rsh >= bases) {
+                        v = make_uint4(__builtin_amdgcn_alignbyte(xa[h][1], xa[h][0], rsh), __builtin_amdgcn_alignbyte(xa[h][2], xa[h][1], rsh),
+                                       __builtin_amdgcn_alignbyte(xa[h][3], xa[h][2], rsh), __builtin_amdgcn_alignbyte(xa[h][4], xa[h][3], rsh));
                     } else {                      // the batch's last bytes, one by one
                         u32 t[4] = {0u, 0u, 0u, 0u};
                         for (u32 b = 0; b < 16u && p + b < buf_end; ++b) t[b >> 2] |= (u32)p[b] << (8u * (b & 3u));
@@ -109,6 +128,8 @@ minimizers_reads_kernel(const uint8_t* __restrict__ bases, u64 total_bytes, cons
                 FW[r * ND + d] = code;
             }
         }
+        cur = piece_of(r0 + (u64)gridDim.x * RB + r);      // the next iteration's piece: its bytes are on their way while this one is worked on
+        request(cur);
         __syncthreads();
         if (threadIdx.x == 0) {          // k-mers of the pieces before (RB additions)
             u32 c = 0;

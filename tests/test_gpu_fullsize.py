@@ -142,8 +142,8 @@ def test_full_size_counts_linearity_and_prefix(ctx, orc, big, k):
 
 @pytest.mark.parametrize("k", [31, 21])
 def test_full_size_half_a_percent_of_dirty_reads(ctx, orc, big, k):
-    """5e5 reads with an N (27 % of the tiles hold one): the reads are blanked out of their tiles in the main pass and rolled by
-    sweep_flagged_kernel (kmx_sweep.hip).  Window accounting, shard linearity with the dirt in, the ragged kernel on the same bytes, an
+    """5e5 reads with an N (27 % of the tiles hold one): the scan marks them and sweep_flagged_kernel (kmx_sweep.hip) takes the windows
+    that hold the N back out.  Window accounting, shard linearity with the dirt in, the ragged kernel on the same bytes, an
     oracle-checked prefix, and the array of masks back to all-zero (a second call gives the same)."""
     import torch
     from kmers_amd import _lib
@@ -179,6 +179,62 @@ def test_full_size_half_a_percent_of_dirty_reads(ctx, orc, big, k):
         o = orc.canonical_reduce(big[: n_chk * L].cpu().numpy(), n_chk, L, k, hasher_k=k)
         g = ctx.canonical_reduce(big[: n_chk * L], n_chk, L, k, _lib.HASH_LEX, k, 0)
         assert (g.n_valid, g.sum_canon, g.xor_hash) == (o.n_valid, o.sum_canon, o.xor_hash)
+    finally:
+        big[idx] = saved
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_full_input_two_percent_dirty_against_the_oracle(ctx, orc, big, k):
+    """Round 6 (the full-size dirty test checked the oracle on a prefix only): 2e6 of the 1e8 reads get invalid bytes -- one
+    N, two bytes, a run, both ends, the whole read; 73 % of the tiles hold one -- and ONE whole-buffer GPU call equals the oracle over
+    ALL reads: the scan's marks and the sweep's subtraction at full size, single- and two-word k
+    (canonical_kmer_iterator.rs:50-66)."""
+    import torch
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(600 + k)
+    nd = N_FULL // 50
+    reads = np.sort(rng.choice(N_FULL, size=nd, replace=False)).astype(np.int64)
+    kind = np.arange(nd) % 5
+    pos = rng.integers(0, L, size=nd)
+    idx = [reads * L + pos]                                                   # every dirty read: one byte
+    two = kind == 1
+    idx.append(reads[two] * L + rng.integers(0, L, size=int(two.sum())))       # a second one
+    run = np.nonzero(kind == 2)[0]
+    for j in range(1, 24):                                                     # a run of up to 24
+        sel = run[pos[run] + j < L]
+        idx.append(reads[sel] * L + pos[sel] + j)
+    ends = kind == 3
+    idx.append(reads[ends] * L)
+    idx.append(reads[ends] * L + (L - 1))
+    whole = np.nonzero(kind == 4)[0][:20000]
+    idx.append((reads[whole][:, None] * L + np.arange(L)[None, :]).ravel())
+    idx = torch.from_numpy(np.unique(np.concatenate(idx))).to(big.device)
+    saved = big[idx].clone()
+    big[idx] = ord("N")
+    try:
+        if k <= 31:
+            g = ctx.canonical_reduce(big, N_FULL, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+            got = (g.n_valid, g.sum_canon, g.xor_hash, g.sum_fw)
+
+            def part(host, n):
+                o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+                return (o.n_valid, o.sum_canon, o.xor_hash, o.sum_fw)
+
+            def comb(a, b):
+                return (a[0] + b[0], (a[1] + b[1]) & M64, a[2] ^ b[2], (a[3] + b[3]) & M64)
+        else:
+            g = ctx.canonical_reduce2(big, N_FULL, L, k, with_hash=True)
+            got = (g.n_valid, g.sum_lo, g.sum_hi, g.xor_lo, g.xor_hi)
+
+            def part(host, n):
+                o = orc.canonical_reduce2(host, n, L, k, with_hash=True)
+                return (o.n_valid, o.sum_lo, o.sum_hi, o.xor_lo, o.xor_hi)
+
+            def comb(a, b):
+                return (a[0] + b[0], (a[1] + b[1]) & M64, (a[2] + b[2]) & M64, a[3] ^ b[3], a[4] ^ b[4])
+
+        assert got == _oracle_over_device_buffer(big, N_FULL, L, part, comb)
     finally:
         big[idx] = saved
 

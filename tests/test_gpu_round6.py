@@ -336,3 +336,32 @@ def test_minimizers_invalid_byte_is_reported(ctx):
     assert ei.value.status == _lib.E_INVALID_BASE
     mw, mp = ctx.minimizers(ctx.to_device(host), n, L, 31, 15, _lib.HASH_LEX, 15, check=False)     # asked not to look: no error
     assert mw.numel() == n * 120
+
+
+# ---------------------------------------------------------------- kmx_histogram on dirty reads: marks + the histogram form of the sweep
+@pytest.mark.parametrize("b", [10, 14, 16, 20, 22, 24, 29])
+@pytest.mark.parametrize("k,L,hk,ragged", [(31, 150, 31, False), (21, 100, 0, False), (13, 250, 13, False), (31, 150, 31, True), (17, 250, 9, True), (5, 150, 5, False)])
+def test_histogram_with_dirty_reads(ctx, orc, b, k, L, hk, ragged):
+    """every histogram sink (block-private LDS tables <= 2^14, one- and two-level partitions, device atomics) no longer rolls a tile
+    that holds an invalid byte: the tile takes the fast path, its reads are marked, and the histogram form of the sweep subtracts
+    the windows that hold the byte -- every bucket against the oracle, two calls in a row into one table"""
+    from kmers_amd import _lib
+
+    n = 64 * 700 + 11
+    rng = np.random.default_rng(1000 * b + k + L)
+    if ragged:
+        host, offs = _ragged(ctx, n, max(L // 3, 1), L, 31 * b + k, k, 0.15)
+        o = orc.histogram(host, n, L, k, hk, b, offsets=offs)
+        d_off = ctx.to_device(offs)
+    else:
+        host = ctx.gen_reads(n * L, first_byte=b * k).cpu().numpy().copy()
+        _dirty(host, n, np.arange(n, dtype=np.int64) * L, np.full(n, L), rng, 0.15)
+        host[(64 * 700 - 1) * L + L - 1] = ord("N")
+        o = orc.histogram(host, n, L, k, hk, b)
+        d_off = None
+    hasher = _lib.HASH_LEX if hk else _lib.HASH_IDENTITY
+    dev = ctx.to_device(host)
+    g = ctx.histogram(dev, n, L, k, hasher, hk, b, offsets=d_off)
+    assert np.array_equal(g.cpu().numpy().view(np.uint64), o)
+    ctx.histogram(dev, n, L, k, hasher, hk, b, offsets=d_off, counts=g)
+    assert np.array_equal(g.cpu().numpy().view(np.uint64), 2 * o)

@@ -1,5 +1,5 @@
 #!/bin/bash
 # scratch: the GPU session of the moment
-mkdir -p gpurun_out/r6e
-timeout 3000 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -5
-HIST=20 python3 tools/bench_dirty.py 2>&1 | tee gpurun_out/r6e/dirty_bench.txt
+timeout 1500 python3 -m pytest tests/test_gpu_round6.py -x -q -k "histogram" 2>&1 | tail -5
+timeout 2500 python3 -m pytest tests/test_gpu_fullsize.py -x -q -k "dirty" 2>&1 | tail -5
+timeout 600 python3 -m pytest tests/test_gpu_round4.py tests/test_gpu_round5.py -x -q 2>&1 | tail -3
