@@ -324,6 +324,25 @@ pub fn hash_words_sip13(ctx: &HipContext, words: &[u64], keys: (u64, u64)) -> Re
     d_out.download::<u64>(words.len())
 }
 
+/// `SeqVector::from(read).iter_minimizers(k, w, LexHasherState::new(lex_hasher_k))` (seq_vector.rs:73-80, minimizers.rs:39-141)
+/// for every read of a uniform batch already on the device, without building the `SeqVector`s: `(word, pos)` of k-mer `i` of read
+/// `r` at index `r * (read_len - k + 1) + i`.  A byte outside ACGTacgt is the panic of `Kmer::from` (kmer.rs:45-60): `Err` with
+/// `KMX_E_INVALID_BASE`.
+pub fn minimizers_of_reads(ctx: &HipContext, d_reads: &DeviceBuf<'_>, n_reads: u64, read_len: u32, k: u8, w: u8, lex_hasher_k: u8)
+                           -> Result<Vec<(u64, u32)>, KmxError> {
+    assert!(n_reads as u128 * read_len as u128 <= d_reads.len() as u128, "reads past the end of the device buffer");
+    assert!(read_len >= k as u32, "SeqVecMinimizerIter::new: assertion failed: sv.len() >= k");
+    let n = (n_reads * (read_len - k as u32 + 1) as u64) as usize;
+    let d_word = ctx.alloc(n * 8)?;
+    let d_pos = ctx.alloc(n * 4)?;
+    let r = kmx_reads { d_bases: d_reads.as_ptr(), n_reads, read_len, d_offsets: ptr::null() };
+    let mut first_bad = u64::MAX;
+    ctx.ck(unsafe { kmx_minimizers(ctx.0, &r, ptr::null(), k as u32, w as u32, KMX_HASH_LEX, lex_hasher_k as u32, d_word.as_mut_ptr::<u64>(),
+                                   d_pos.as_mut_ptr::<u32>(), &mut first_bad) })?;
+    let (a, b) = (d_word.download::<u64>(n)?, d_pos.download::<u32>(n)?);
+    Ok(a.into_iter().zip(b).collect())
+}
+
 // ------------------------------------------------------------------------------------------------ SeqVector
 
 /// `SeqVector` (src/naive_impl/seq_vector.rs) with its words on the device: same bit layout as the crate's `RawVector`

@@ -120,10 +120,23 @@ __device__ __forceinline__ bs_v8i fp4_operand_a(u32 m) {
 // an invalid byte, take the per-lane rolling path as before.
 // dwords of one set's plane area (the kernel and launch_bs size the LDS from it)
 constexpr int bs_plane_dwords(int NW) { return 32 * NW + 16; }
+// rows of the next tile requested LATE (between pass 1 and pass 2 of phase D): see the kernel, "rows of the prefetch requested late"
+template <int K, int NW, int WPL, bool PACKED, bool RAGGED, bool SEG> constexpr int bs_late() {
+    return PACKED ? 0 : NW == 10 ? ((K > 32 || RAGGED || SEG) ? 5 : WPL > 4 ? (K <= 17 ? 0 : 1) : 0) : NW < 10 ? (K > 32 ? 0 : 3) : NW == 13 ? ((K <= 32 && !SEG) ? 3 : 7) : 8;
+}
+// PARK (round 6): phase A leaves every chunk's validation word in LDS beside its packed word, and a tile with an invalid byte
+// looks its reads up there (30 instructions) instead of validating the tile a second time from w[] (150).  The second dword per
+// chunk is LDS time, though, and the variants that are short of it pay on CLEAN input: interleaved with round 5's build on one box the
+// headline <31,10,4> and k = 13 lost nothing, k = 21 (five windows per lane, a late row) 0.6 %, the two-word k = 63 2 %, the 7- / 13- /
+// 16-word frames 2-3 % (profiles/r06_ab_r5_r6.txt).  So: the uniform 10-word frame without late rows -- k = 13..17 and 22..31 on
+// 150-base reads, the metric's shape -- parks; every other variant finds its dirty reads the round-5 way.
+template <int K, int NW, int WPL, bool PACKED, bool RAGGED, bool SEG> constexpr bool bs_park() {
+    return !PACKED && !RAGGED && !SEG && NW == 10 && K <= 32 && bs_late<K, NW, WPL, PACKED, RAGGED, SEG>() == 0;
+}
 // dwords of a wave's packed region (kernel and launch_bs)
-template <int NW, bool PACKED> __host__ __device__ constexpr unsigned bs_packed_dwords(unsigned chunks, unsigned wpl) {
-    if (!PACKED) return 64u * (NW + 1);
-    unsigned ldsw = (chunks + 4u + 6u + 3u) & ~3u;
+template <int NW, bool PACKED, bool PARK> __host__ __device__ constexpr unsigned bs_packed_dwords(unsigned chunks, unsigned wpl) {
+    if (PARK) return 64u * (NW + 1);
+    unsigned ldsw = (chunks + (PACKED ? 4u : 1u) + 6u + 3u) & ~3u;
     return ldsw < 64u * wpl ? 64u * wpl : ldsw;
 }
 constexpr int BS_LOAD_NT = 2;   // cache policy of the tile loads (aux bit 1 = nt: streamed once; +1.6 % over none, sc0 / sc1 nothing -- profiles/r03_load_policy_variants.txt)
@@ -217,13 +230,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     const u32 wib = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform, and only readfirstlane tells hipcc so: the LDS bases derived from it are scalars, not registers held -- or spilled -- across the tile loop)
     const u32 chunks = 4u * L + ((RAGGED || SEG || lead != 0u) ? 1u : 0u);   // 16-byte chunks a tile may span (+1 for an unaligned start)
     constexpr u32 PAD = PACKED ? 4u : 1u;                    // front pad of the packed region (4: keeps ds_write_b128 aligned)
-    // packed region (as in kmx_scan.hip; it holds the mask words of pass 2 afterwards).  ASCII input (round 6): a multiple of 64 dwords
-    // fixed by the frame -- phase A leaves the VALIDATION word of chunk c (expected letters ^ bytes) exactly XOFF dwords behind its packed
+    // packed region (as in kmx_scan.hip; it holds the mask words of pass 2 afterwards).  The variants that PARK (round 6): a multiple of 64
+    // dwords fixed by the frame -- phase A leaves the VALIDATION word of chunk c (expected letters ^ bytes) exactly XOFF dwords behind its packed
     // word, in the plane area (free until phase C), with the same LDS instruction (ds_write2st64_b32: two dwords a compile-time multiple
     // of 256 bytes apart); see "reads with an invalid byte"
-    u32 ldsw = bs_packed_dwords<NW, PACKED>(chunks, WPL);
+    constexpr bool PARK = bs_park<K, NW, WPL, PACKED, RAGGED, SEG>();
+    u32 ldsw = bs_packed_dwords<NW, PACKED, PARK>(chunks, WPL);
     constexpr u32 XOFF = 64u * (NW + 1);
-    static_assert(PACKED || (XOFF >= 64u * WPL && 1u + 64u * NW <= 2u * (u32)bs_plane_dwords(NW)), "the validation words fit the plane area");
+    static_assert(!PARK || (XOFF >= 64u * WPL && 1u + 64u * NW <= 2u * (u32)bs_plane_dwords(NW)), "the validation words fit the plane area");
     constexpr u32 CSA_DW = 4u * ((K + 1) / 2);         // 2 * NT 64-bit sums of the counter classes
     // SEG: per-plane totals of the SHORT segments (as TOT, [group][lane]) -- of the groups that hold the last window's K bases
     // only, the first of them (W - 1) >> 4: the whole frame's worth cost the 13-word frame its third block per CU
@@ -546,7 +560,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // inside the loop, -8 %) -- profiles/r05_late_rows.txt.  (The ragged 10-word frame keeps five late rows: at two waves
     // none measured +3 % at up to four windows per lane and -12 % at five -- profiles/r05_ragged_variants.txt -- and at three waves,
     // where it runs since round 5, the registers are not there.)
-    constexpr int LATE = PACKED ? 0 : NW == 10 ? ((K > 32 || RAGGED || SEG) ? 5 : WPL > 4 ? (K <= 17 ? 0 : 1) : 0) : NW < 10 ? (K > 32 ? 0 : 3) : NW == 13 ? ((K <= 32 && !SEG) ? 3 : 7) : 8;   // (13-word frame, single-word k: 3 late rows +1 % over 7, none spills; 7-word frame: none -3 %: profiles/r05_late_rows.txt)
+    constexpr int LATE = bs_late<K, NW, WPL, PACKED, RAGGED, SEG>();
     u64 tile = ~0ull, next_tile = ~0ull;
     bool seg_ld_next = false;         // SEG: issue_loads is asked for the next tile (nx_g), not for the current one (cur_g)
     auto issue_loads = [&](u64 tile, int row0 = 0, int row1 = 64) {
@@ -642,7 +656,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // iteration, as rounds 2-4 had it, the atomic was the youngest operation in flight when phase A waited for its last rows,
     // and loads and atomics complete in one order on gfx9: every tile waited for a fresh device atomic.  Reading the return
     // value right away, as dequeue() does, costs the same round trip.)
-    u32 pend = 0;            // (the low word: a head hands out fewer than 2^32 tickets -- launch_bs checks the tile count)
+    // (BOTH words of the atomic's return stay live until ticket_take (round 6): only the low one is used -- a head hands out fewer than 2^32
+    // tickets, launch_bs checks the tile count -- but the atomic writes a register PAIR when it returns, and with the high word dead hipcc
+    // hands that register to the next instruction that needs one, behind an `s_waitcnt vmcnt(0)`: the wave then waits for the ticket
+    // AND for the rows just requested at the top of phase B, every tile.  Which variants were hit was the allocator's lottery: round 5's
+    // k = 63 was not, this round's was, 2.6 % (profiles/r06_ab_r5_r6.txt).)
+    unsigned long long pend = 0;
     u32 pend_qid = 0;
     auto ticket_issue = [&]() {
         pend_qid = qid;
@@ -655,13 +674,17 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             // rows of the next tile, every tile (~17 % of a wave's cycles sat there since round 3: profiles/r04_phase_timing*.txt).
             u32 zero = 0;
             asm volatile("" : "+v"(zero));
-            pend = (u32)atomicAdd(queue + qid * 16u + zero, one);
+            pend = atomicAdd(queue + qid * 16u + zero, one);
         }
         if (rot) qid = (qid + 1u) & (NQ - 1u);
     };
     auto ticket_take = [&]() -> u64 {
         if (heads_left == 0u) return ~0ull;
-        const u32 lo = __builtin_amdgcn_readfirstlane(pend);
+        {
+            u32 pend_hi = (u32)(pend >> 32);
+            asm volatile("" : : "v"(pend_hi));      // (the use that keeps the pair together: no instruction)
+        }
+        const u32 lo = __builtin_amdgcn_readfirstlane((u32)pend);
         const u64 t = (u64)lo * NQ + pend_qid;
         if (t < n_full) return t;
         rot = false;
@@ -694,7 +717,8 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                      : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
                      : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "s"(TBL_HI), "v"(TBL_LO));
         // bad |= expected ^ actual, one v_bitop3_b32 per dword (S0 | (S1 ^ S2) = 0xF6) instead of 4 v_xor + 2 three-input ORs
-        bad = e0 ^ wv.x;
+        if constexpr (PARK) bad = e0 ^ wv.x;                                   // a word per chunk
+        else bad = __builtin_amdgcn_bitop3_b32(bad, e0, wv.x, 0xF6);            // one running word per lane
         bad = __builtin_amdgcn_bitop3_b32(bad, e1, wv.y, 0xF6);
         bad = __builtin_amdgcn_bitop3_b32(bad, e2, wv.z, 0xF6);
         bad = __builtin_amdgcn_bitop3_b32(bad, e3, wv.w, 0xF6);
@@ -719,14 +743,18 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         // ds_write2st64_b32).  `any` collects the validation words two rows at a time (a three-input OR at full rate).
         u32 any = 0, held = 0;
         auto row = [&](const int it, const bool mine) {
-            u32 r = 0;
-            if (mine) {
-                const u32 code = encode_prio(w[it], r);
-                P[1u + (u32)it * 64u + lane] = code;
-                P[1u + XOFF + (u32)it * 64u + lane] = r;
+            if constexpr (PARK) {
+                u32 r = 0;
+                if (mine) {
+                    const u32 code = encode_prio(w[it], r);
+                    P[1u + (u32)it * 64u + lane] = code;
+                    P[1u + XOFF + (u32)it * 64u + lane] = r;
+                }
+                if (it & 1) any = __builtin_amdgcn_bitop3_b32(any, held, r, 0xFE);
+                else held = r;
+            } else {
+                if (mine) P[1u + (u32)it * 64u + lane] = encode_prio(w[it], any);
             }
-            if (it & 1) any = __builtin_amdgcn_bitop3_b32(any, held, r, 0xFE);
-            else held = r;
         };
         if constexpr (PACKED) {      // already 2-bit codes: 16 bytes = 4 packed dwords per lane and load
 #pragma unroll
@@ -748,7 +776,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
                 for (int it = 0; it < NW; ++it) row(it, (int)lane < (int)n_ch - 64 * it);
             }
-            if (NW & 1) any |= held;
+            if (PARK && (NW & 1)) any |= held;
             return __any(chunk_has_invalid(any));
         }
     };
@@ -805,34 +833,55 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 // the higher o -- ORs its own marks downwards and gets the marks of all higher o from a prefix-OR across the lanes
                 // (4 row shifts + the row broadcast).  The reads that share lane 0's wr (all of them, in untrimmed FASTQ) are
                 // marked by ONE lane per half with the whole ballot: 64 atomics on one LDS word would serialise.
+                // (Round 6) A tile of trimmed FASTQ holds a handful of reads that differ from the rest: with at most RG_EXC of them the
+                // planes follow from the common count and the exceptions themselves -- V_o = (ref > o ? the reads at ref : 0) | the
+                // exceptions with wr > o, each broadcast from its lane -- no marks, no LDS atomics, one fence instead of three.
                 constexpr u32 EMS = 32u * NV + 4u;      // dwords per half-wave: E_0 .. E_(32 NV)
-                u32* const EM = PL;
-                static_assert(2u * EMS <= 2u * PLANES, "end marks fit the plane area");
-                for (u32 i = 4u * lane; i < 2u * EMS; i += 256u) *reinterpret_cast<uint4*>(EM + i) = make_uint4(0u, 0u, 0u, 0u);
-                lds_fence();
+                constexpr u32 RG_EXC = 4u;
                 const u32 ref = (u32)__builtin_amdgcn_readfirstlane(wr);
                 const bool is_ref = wr == ref;
                 const u64 bref = __ballot(is_ref);
-                u32* const emh = EM + half * EMS;
-                if (!is_ref) atomicOr(emh + wr, 1u << (lane_now() & 31u));
-                if (p == 0u) atomicOr(emh + ref, half ? (u32)(bref >> 32) : (u32)bref);
-                lds_fence();
                 const u32 ob = (u32)NV * (31u - p);
-                u32 e[NV];
-#pragma unroll
-                for (int j = 0; j < NV; ++j) e[j] = emh[ob + 1u + j];
-#pragma unroll
-                for (int j = NV - 2; j >= 0; --j) e[j] |= e[j + 1];
-                u32 x = e[0];
-                x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
-                x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
-                x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
-                x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
-                u32 c = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);        // the lanes below, within the row of 16
-                c |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);      // rows 1 and 3: all of the row before
                 u32* const vh = VAL + half * VS + ob;
+                if ((u32)__builtin_popcountll(~bref) <= RG_EXC) {          // (wave-uniform)
+                    const u32 refm = half_word(bref);
+                    u32 e[NV];
 #pragma unroll
-                for (int j = 0; j < NV; ++j) vh[j] = e[j] | c;
+                    for (int j = 0; j < NV; ++j) e[j] = ref > ob + (u32)j ? refm : 0u;
+                    for (u64 left = ~bref; left != 0ull; left &= left - 1ull) {
+                        const u32 sl = (u32)__builtin_ctzll(left);
+                        const u32 wr_s = (u32)__builtin_amdgcn_readlane((int)wr, (int)sl);
+                        const u32 add = (lane_now() >> 5) == (sl >> 5) ? 1u << (sl & 31u) : 0u;
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) e[j] |= wr_s > ob + (u32)j ? add : 0u;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) vh[j] = e[j];
+                } else {
+                    u32* const EM = PL;
+                    static_assert(2u * EMS <= 2u * PLANES, "end marks fit the plane area");
+                    // (addresses from the lane id as it is now: hoisted out of the tile loop they are spilled, and reloaded behind the next tile's rows)
+                    for (u32 i = 4u * lane_now(); i < 2u * EMS; i += 256u) *reinterpret_cast<uint4*>(EM + i) = make_uint4(0u, 0u, 0u, 0u);
+                    lds_fence();
+                    u32* const emh = EM + (lane_now() >> 5) * EMS;
+                    if (!is_ref) atomicOr(emh + wr, 1u << (lane_now() & 31u));
+                    if (p == 0u) atomicOr(emh + ref, half ? (u32)(bref >> 32) : (u32)bref);
+                    lds_fence();
+                    u32 e[NV];
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) e[j] = emh[ob + 1u + j];
+#pragma unroll
+                    for (int j = NV - 2; j >= 0; --j) e[j] |= e[j + 1];
+                    u32 x = e[0];
+                    x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+                    x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+                    x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+                    x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+                    u32 c = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);        // the lanes below, within the row of 16
+                    c |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);      // rows 1 and 3: all of the row before
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) vh[j] = e[j] | c;
+                }
                 lds_fence();
             }
         }
@@ -895,8 +944,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             if constexpr (RAGGED) {
                 // plane (g, p) holds base beta = 16g + p/2 of the set's reads: only the reads that HAVE a base beta count
                 // (len > beta <=> wr > beta - (K-1): validity plane V_(beta-K+1); below K-1 every read that owns a window at all)
-                const u32* const vh = VAL + half * VS;
-                const u32 b0 = p >> 1;
+                // (from the lane id as it is now: held across the tile loop these two addresses are what the three-wave variants spill, and
+                // reload right here behind the next tile's rows)
+                const u32 ln_v = lane_now();
+                const u32* const vh = VAL + (ln_v >> 5) * VS;
+                const u32 b0 = (ln_v & 31u) >> 1;
 #pragma unroll
                 for (int g = 0; g < NW; ++g) {
                     u32 vm;
@@ -1134,7 +1186,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         // A tile with an invalid byte: which reads touch a bad chunk?  Every lane ORs the validation words of its read's chunks (phase A
         // left them in the plane area, free until phase C) -- a chunk shared by two reads marks both, the sweep looks at the bytes -- and
         // the reads' mask goes to the array behind queue[515].  LDS reads and ONE global store.
-        auto mark_dirty_reads = [&]() -> bool {
+        auto mark_dirty_reads = [&]([[maybe_unused]] const u32 n_chunks) -> bool {
             if (masks == nullptr) {
                 if constexpr (!RAGGED) __builtin_trap();   // (the host side always provides the array)
                 return false;
@@ -1143,14 +1195,41 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             if constexpr (RAGGED) { rd_off = cur_m.rel; rd_len = cur_m.len; }
             if constexpr (SEG) { rd_off = seg_rel + cur_g.lead; rd_len = L - (u32)((seg_short >> lane_now()) & 1ull); }
             const u32 c0 = rd_off >> 4, c1 = rd_len ? (rd_off + rd_len - 1u) >> 4 : c0;
-            const u32* const xs = P + (1u + XOFF) + c0;
-            u32 x = 0;
+            bool dirty_read;
+            if constexpr (PARK) {
+                const u32* const xs = P + (1u + XOFF) + c0;
+                u32 x = 0;
 #pragma unroll
-            for (int j = 0; j <= NW; ++j) {      // (a read of 16 NW bases touches at most NW + 1 chunks)
-                const u32 v = xs[j];             // (past the read's last chunk: whatever lies there -- inside the wave's own area -- is not looked at)
-                x |= c0 + (u32)j <= c1 ? v : 0u;
+                for (int j = 0; j <= NW; ++j) {      // (a read of 16 NW bases touches at most NW + 1 chunks)
+                    const u32 v = xs[j];             // (past the read's last chunk: whatever lies there -- inside the wave's own area -- is not looked at)
+                    x |= c0 + (u32)j <= c1 ? v : 0u;
+                }
+                dirty_read = chunk_has_invalid(x);
+            } else {
+                // the round-5 way: the tile is still in w[] (the next tile's rows are not yet asked for) -- its chunks' verdicts again, one
+                // ballot per row, the bitmap parked in the plane area (free until phase C); every lane looks up the chunks of its read
+                u64* BM = reinterpret_cast<u64*>(PL);
+#pragma unroll
+                for (int it = 0; it < NW; ++it) {
+                    const u32 c = it * 64u + lane;
+                    u32 rb = 0;
+                    (void)encode16(w[it], rb);
+                    const u64 row = __ballot(c < n_chunks && chunk_has_invalid(rb));
+                    if (lane == 0) BM[it] = row;
+                }
+                if (lane == 0) {
+                    u32 z = 0;                       // (made here: as a constant the 64-bit zero was kept -- spilled -- across the tile loop for this rare path)
+                    asm volatile("" : "+v"(z));
+                    reinterpret_cast<u32*>(BM + NW)[0] = z; reinterpret_cast<u32*>(BM + NW)[1] = z;
+                    reinterpret_cast<u32*>(BM + NW)[2] = z; reinterpret_cast<u32*>(BM + NW)[3] = z;
+                }
+                lds_fence();
+                const u32 q0 = c0 >> 6, b0 = c0 & 63u;
+                const u64 lo = BM[q0], hi = BM[q0 + 1u];
+                const u64 bits = b0 ? ((lo >> b0) | (hi << (64u - b0))) : lo;
+                dirty_read = (bits & ((1ull << (c1 - c0 + 1u)) - 1ull)) != 0ull;
             }
-            const u64 dm = uniform_u64(__ballot(rd_len != 0u && chunk_has_invalid(x)));
+            const u64 dm = uniform_u64(__ballot(rd_len != 0u && dirty_read));
             if (dm != 0ull) {
                 // (buffer stores: the addresses stay on the scalar side.  A flat store's 64-bit address and the constants around it
                 // cost the widest variants registers ACROSS the tile loop -- the two-word k on the 10-word frame spilled 24..160 bytes
@@ -1172,7 +1251,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             if constexpr (LATE > 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the uniform branch
             if (dirty) {     // (before the next tile's rows are asked for: their registers are still free here)
                 lds_fence();
-                if (!mark_dirty_reads()) bad_tile = true;   // (no mask array: exact, the slow way)
+                if (!mark_dirty_reads(cur_m.n_ch)) bad_tile = true;   // (no mask array: exact, the slow way)
             }
             __builtin_amdgcn_sched_barrier(0);
             if (next_tile < n_full) {
@@ -1191,7 +1270,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             if constexpr (INLINE) {
                 if (dirty) {     // (before the next tile's rows are asked for: their registers are still free here)
                     lds_fence();
-                    (void)mark_dirty_reads();
+                    (void)mark_dirty_reads(SEG ? (cur_g.nbytes + 15u) >> 4 : chunks);
                 }
             }
             prefetch(next_tile, tile, 0, NLD - LATE);
@@ -1381,7 +1460,7 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
         if ((reinterpret_cast<uintptr_t>(bases) & 15u) != 0u || 4u * L + 1u > 64u * (u32)NW) return hipErrorInvalidValue;
     }
     const u32 chunks = 4u * L + ((RAGGED || SEG || lead != 0u) ? 1u : 0u);
-    const u32 ldsw = bs_packed_dwords<NW, PACKED>(chunks, (u32)WPL);
+    const u32 ldsw = bs_packed_dwords<NW, PACKED, bs_park<K, NW, WPL, PACKED, RAGGED, SEG>()>(chunks, (u32)WPL);
     constexpr u32 NV = RAGGED ? (16 * NW - K + 1 + 31) / 32 : 0;
     constexpr u32 NE = RAGGED ? (K - 1 + 15) / 16 : 0;
     constexpr u32 CSA_DW = 4u * ((K + 1) / 2);

@@ -53,7 +53,7 @@ for a, b in (("trace/t_kernel_stats.csv", "kernel_stats.csv"), ("trace_k21/t_ker
              ("trace_hist20/t_kernel_stats.csv", "kernel_stats_hist20.csv"), ("pmc_summary.txt", "pmc_summary.txt"),
              ("k_sweep.txt", "k_sweep.txt"), ("len_sweep.txt", "len_sweep.txt"), ("ragged_bench.txt", "ragged_bench.txt"), ("ragged2_bench.txt", "ragged2_bench.txt"),
              ("dirty_bench.txt", "dirty_bench.txt"), ("windows_bench.txt", "windows_bench.txt"), ("windows_len.txt", "windows_len.txt"), ("hist_bench.txt", "hist_bench.txt"),
-             ("minimizers_bench.txt", "minimizers_bench.txt"), ("windows2_bench.txt", "windows2_bench.txt"), ("k2_long.txt", "k2_long.txt"), ("settle.txt", "settle.txt"), ("fastx_bench.txt", "fastx_bench.txt"), ("fastq_pipeline.txt", "fastq_pipeline.txt"), ("step_times_cold.txt", "step_times_cold.txt")):
+             ("minimizers_bench.txt", "minimizers_bench.txt"), ("windows2_bench.txt", "windows2_bench.txt"), ("k2_long.txt", "k2_long.txt"), ("settle.txt", "settle.txt"), ("fastx_bench.txt", "fastx_bench.txt"), ("fastq_pipeline.txt", "fastq_pipeline.txt"), ("step_times_cold.txt", "step_times_cold.txt"), ("small_batches.txt", "small_batches.txt")):
     copy(a, b)
 
 out = [f"# Round {tag[1:]} -- rocprofv3 --kernel-trace --stats of `python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --sustain-steps 0` (MI355X, 1 GPU)",

@@ -52,4 +52,5 @@ python3 tools/bench_minimizers.py > $out/minimizers_bench.txt 2>/dev/null
 python3 tools/bench_fastx.py > $out/fastx_bench.txt 2>/dev/null
 python3 tools/bench_fastq_pipeline.py 2>/dev/null | grep -v amdgpu.ids > $out/fastq_pipeline.txt
 python3 tools/step_times.py > $out/step_times_cold.txt 2>/dev/null
+python3 tools/bench_small_batches.py 2>/dev/null | grep -v amdgpu.ids > $out/small_batches.txt
 ls $out
