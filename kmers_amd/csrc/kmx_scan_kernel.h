@@ -167,6 +167,35 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         }
         return ~0ull;
     };
+    // (round 6) Uniform reads, no prefetching sink: the ticket of the NEXT tile is requested at the top of an iteration and looked at when
+    // the iteration ends -- dequeue() reads the atomic's return at once, a device round trip at the top of every tile that the other
+    // waves of the SIMD have to cover.  (Ragged reads and the prefetching materialise sink want the next tile's number early: its
+    // offsets / its bytes are requested under this tile's windows.)  BOTH words of the return stay live until then: with the high word
+    // dead hipcc hands its register out behind an s_waitcnt vmcnt(0) (kmx_bitslice_kernel.h, "the atomic's return").
+    constexpr bool ASYNC_TICKET = !RAGGED && !(SinkPrefetch<Sink>::value && NW <= 10);
+    unsigned long long pend = 0;
+    u32 pend_qid = 0;
+    bool pend_any = false;
+    auto ticket_issue = [&]() {
+        pend_any = heads_left != 0u;
+        pend_qid = qid;
+        if (pend_any && lane == 0) {
+            unsigned long long one = 1ull;
+            u32 zero = 0;        // (the head's address through a VGPR the compiler cannot see through: a wave-uniform address lets hipcc's atomic optimizer rewrite the add and wait for its result at once)
+            asm volatile("" : "+v"(one), "+v"(zero));
+            pend = atomicAdd(queue + qid * 16u + zero, one);
+        }
+        if (rot) qid = (qid + 1u) & (NQ - 1u);
+    };
+    auto ticket_take = [&]() -> u64 {
+        if (!pend_any) return ~0ull;
+        const u32 lo = __builtin_amdgcn_readfirstlane((u32)pend), hi = __builtin_amdgcn_readfirstlane((u32)(pend >> 32));
+        const u64 t = (((u64)hi << 32) | lo) * NQ + pend_qid;
+        if (t < n_full) return t;
+        rot = false;
+        qid = (pend_qid + 1u) & (NQ - 1u);   // that head is drained: on, synchronously (rare)
+        return dequeue();
+    };
     constexpr bool MARK = SinkMarksDirty<Sink>::value;
     [[maybe_unused]] u64* const dirty_masks = MARK ? reinterpret_cast<u64*>(queue[515]) : nullptr;
     [[maybe_unused]] u32 n_marked = 0;
@@ -204,8 +233,9 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         nx_off = offsets[next_tile * 64u + lane];
         nx_end = ends[next_tile * 64u + lane];
     }
-    for (u64 tile = next_tile; tile < n_full; tile = next_tile) {
-        next_tile = dequeue();
+    for (u64 tile = next_tile; tile < n_full; tile = ASYNC_TICKET ? (next_tile = ticket_take()) : next_tile) {
+        if constexpr (ASYNC_TICKET) ticket_issue();
+        else next_tile = dequeue();
         const u64 read = tile * 64u + lane;
         const uint4* __restrict__ tb = reinterpret_cast<const uint4*>(bases + tile * 64u * (u64)L);
         u64 my_off = 0;
