@@ -305,10 +305,11 @@ impl HipCanonicalKmerBatch {
 /// reads: count, wrapping sum of canonical words, xor of `hash_one(LexHasherState::new(k), ..)`, wrapping sum of fw words.
 pub fn canonical_sum(ctx: &HipContext, d_reads: &DeviceBuf<'_>, n_reads: u64, read_len: u32, k: u8) -> Result<kmx_summary, KmxError> {
     assert!(n_reads as u128 * read_len as u128 <= d_reads.len() as u128, "reads past the end of the device buffer");
-    let d_out = ctx.alloc(std::mem::size_of::<kmx_summary>())?;
     let r = kmx_reads { d_bases: d_reads.as_ptr(), n_reads, read_len, d_offsets: ptr::null() };
-    ctx.ck(unsafe { kmx_canonical_reduce(ctx.0, &r, k as u32, KMX_HASH_LEX, k as u32, KMX_REDUCE_SUM_FW, d_out.as_mut_ptr()) })?;
-    Ok(d_out.download::<kmx_summary>(1)?[0])
+    // (the summary straight into host memory: one kernel launch for clean reads of up to 256 bases, no device allocation, no copy)
+    let mut out = std::mem::MaybeUninit::<kmx_summary>::zeroed();
+    ctx.ck(unsafe { kmx_canonical_reduce_host(ctx.0, &r, k as u32, KMX_HASH_LEX, k as u32, KMX_REDUCE_SUM_FW, out.as_mut_ptr()) })?;
+    Ok(unsafe { out.assume_init() })
 }
 
 /// `hash_one(&state, kmer)` for a batch of k-mer words with one of std's `BuildHasher`s (src/naive_impl/hash.rs:10-20): std's

@@ -148,6 +148,16 @@ int kmx_memset(kmx_ctx *ctx, void *d_dst, int value, size_t nbytes);
 int kmx_canonical_reduce(kmx_ctx *ctx, const kmx_reads *reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
                          uint32_t flags, kmx_summary *d_out);
 
+/* The same call with its answer in HOST memory when it returns (round 6): what a caller that reduces one small
+ * batch at a time -- the reference's iterator over one read set, canonical_kmer_iterator.rs:42-116 -- pays is
+ * the launch and the wait, not the bytes.  Uniform reads of up to 256 bases, k in [13,31], hasher NONE or
+ * LEX(hasher_k == k): ONE kernel launch whose last block writes the summary to pinned host words this call
+ * watches (1e5 reads of 150 bases: ~25 us against ~70 us for kmx_canonical_reduce + kmx_memcpy_d2h); a batch
+ * with invalid bytes adds the sweep and a copy.  Every other input: kmx_canonical_reduce + the copy.
+ * `reads` in device memory as always; *h_out is OVERWRITTEN.  Synchronous on the context's stream. */
+int kmx_canonical_reduce_host(kmx_ctx *ctx, const kmx_reads *reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
+                              uint32_t flags, kmx_summary *h_out);
+
 /* Same pass, materialising per-window state: slot(read r, pos p) = win_off(r) + p with
  * win_off(r) = r*(read_len-k+1) (uniform) or d_win_offsets[r] (ragged; n_reads+1 device u64,
  * exclusive prefix sum of max(len-k+1,0)).  Any of the four outputs may be NULL.

@@ -63,6 +63,7 @@ SIGNATURES = {
     "kmx_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "kmx_memset": (_int, [_vp, _vp, _int, C.c_size_t]),
     "kmx_canonical_reduce": (_int, [_vp, _RP, _u32, _u32, _u32, _u32, _vp]),
+    "kmx_canonical_reduce_host": (_int, [_vp, _RP, _u32, _u32, _u32, _u32, _vp]),
     "kmx_canonical_windows": (_int, [_vp, _RP, _vp, _u32, _vp, _vp, _vp, _vp]),
     "kmx_canonical_reduce2": (_int, [_vp, _RP, _u32, _u32, _vp]),
     "kmx_canonical_windows2": (_int, [_vp, _RP, _vp, _u32, _vp, _vp, _vp, _vp]),

@@ -143,6 +143,14 @@ class Context:
         v = u64_numpy(out)
         return Summary(int(v[0]), int(v[1]), int(v[2]), int(v[3]))
 
+    @_on_ctx_stream
+    def canonical_reduce_host(self, bases, n_reads, read_len, k, hasher=HASH_NONE, hasher_k=0, flags=0, offsets=None) -> Summary:
+        """kmx_canonical_reduce_host: the summary in host memory when the call returns (one launch for clean uniform reads)."""
+        out = Summary()
+        r = self._reads(bases, n_reads, read_len, offsets)
+        self._ck(self.lib.kmx_canonical_reduce_host(self._h, C.byref(r), k, hasher, hasher_k, flags, C.byref(out)))
+        return out
+
     def win_offsets(self, n_reads, read_len, k, offsets=None) -> np.ndarray:
         if offsets is None:
             w = max(read_len - k + 1, 0)

@@ -29,8 +29,10 @@ size_t uniform_segments_scratch_bytes(u64 n_seg);
 hipError_t launch_uniform_segments_plan(u64 n_reads, u32 L, u32 k, u32 T, void* scratch, const u64** starts, const u64** ends, const u64** wins, u64* n_seg_out,
                                         hipStream_t stream);
 // kmx_bitslice.hip
-hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
+hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, u32 mode /* KMX_BS_* (kmx_device.h): bit 0 = sum_fw */,
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
+hipError_t launch_sweep_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw, kmx_summary* out,
+                                unsigned long long* queue, int n_cu, hipStream_t stream);
 hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, kmx_summary2* out,
                                   unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled);
 u64 bitsliced_segments_per_read(u32 L, u32 k);
@@ -127,6 +129,13 @@ using kmx::fail_hip;
 namespace {
 
 void* big_scratch(void* user, size_t bytes);
+
+// Zero the first `bytes` of the context's queue block (ticket heads, then the marked-reads count and the gate) ahead of a launch
+// that takes tickets.  The bit-sliced scans put back what they use (kmx_device.h); every other user leaves its tickets behind.
+hipError_t queue_clear(kmx_ctx* ctx, size_t bytes) {
+    ctx->queue_clean = false;
+    return hipMemsetAsync(ctx->d_scratch + 16, 0, bytes, ctx->stream);
+}
 
 // The bit-sliced scan blanks the reads that hold an invalid byte out of their tile and leaves their 64-bit mask (8 bytes
 // per tile) for sweep_flagged_kernel (kmx_sweep.hip; kmx_bitslice_kernel.h, "reads with an invalid byte").  The masks are the context's
@@ -292,6 +301,9 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, kmx_ctx*
     c->owns_stream = owns;
     c->d_scratch = nullptr;
     c->h_pinned = nullptr;
+    c->h_pub = nullptr;
+    c->pub_token = 0;
+    c->queue_clean = false;
     c->d_big = nullptr;
     c->big_bytes = 0;
     c->big_limit = 0;
@@ -308,11 +320,24 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, kmx_ctx*
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), 64, hipHostMallocDefault);
     // (the dirty-list descriptor behind the queue heads starts as "no list"; cleared on the context's own stream so that
     // the clear is ordered before every kernel the context launches)
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_pub), 64, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_scratch, 0, 8192, c->stream);
+    if (e == hipSuccess) {
+        // the pinned words as the device addresses them, left in the queue block once (kmx_device.h, KMX_Q_HOST)
+        void* dev_view = nullptr;
+        e = hipHostGetDevicePointer(&dev_view, c->h_pub, 0);
+        if (e == hipSuccess) {
+            for (int i = 0; i < 8; ++i) c->h_pub[i] = 0;
+            c->h_pinned[7] = (unsigned long long)reinterpret_cast<uintptr_t>(dev_view);
+            e = hipMemcpyAsync(c->d_scratch + 16 + 517, c->h_pinned + 7, 8, hipMemcpyHostToDevice, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (c->d_scratch) (void)hipFree(c->d_scratch);
         if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        if (c->h_pub) (void)hipHostFree(c->h_pub);
         if (owns && c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return KMX_E_HIP;
@@ -333,6 +358,7 @@ void kmx_ctx_destroy(kmx_ctx* ctx) {
     DeviceGuard g(ctx->device);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->h_pub) (void)hipHostFree(ctx->h_pub);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_big) (void)hipFree(ctx->d_big);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -450,23 +476,49 @@ static int long_ragged_segments(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k
     return 0;
 }
 
-int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
-                         uint32_t flags, kmx_summary* d_out) {
+// The body of kmx_canonical_reduce.  `host_mode` (kmx_canonical_reduce_host): KMX_BS_PUBLISH | KMX_BS_NO_SWEEP | token << 8 for
+// the launch that can end the call by itself -- uniform reads on the bit-sliced scan, no second kernel behind it; `*published`
+// says whether that launch was made.
+static int reduce_impl(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t hasher, uint32_t hasher_k, uint32_t flags,
+                       kmx_summary* d_out, uint32_t host_mode, bool* published) {
+    if (published) *published = false;
     if (!ctx || !reads_ok(reads) || !d_out) return KMX_E_ARG;
     if (k < 1 || k > 31) return KMX_E_K_RANGE;  // MASK_TABLE[32]==0 (kmer.rs:617) breaks the reference's own rolling at 32
     if (hasher > KMX_HASH_IDENTITY) return KMX_E_ARG;
     if (hasher == KMX_HASH_LEX && (hasher_k < 1 || hasher_k > 32)) return KMX_E_K_RANGE;
     DeviceGuard g(ctx->device);
-    KMX_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(kmx_summary), ctx->stream));
-    if (reads->n_reads == 0) return KMX_OK;
+    if (reads->n_reads == 0) {
+        KMX_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(kmx_summary), ctx->stream));
+        return KMX_OK;
+    }
     const bool want_sumfw = (flags & KMX_REDUCE_SUM_FW) != 0;
     // The tiled kernels fold LexHasher(k); the fold under LexHasher(hasher_k != k) or the identity hasher follows from it
     // (fix_hash_fold_kernel: every hasher offered is linear over GF(2)), so no hasher sends a call to the per-lane kernel.
     const bool want_fold = hasher != KMX_HASH_NONE;
     const bool fix_fold = want_fold && !(hasher == KMX_HASH_LEX && hasher_k == k);
+    // Uniform reads on the bit-sliced scan (round 6): its last block STORES the summary and puts the queue block back as it found
+    // it (kmx_device.h), so neither `d_out` nor -- after a launch of that kind -- the queue block is cleared here: two fill kernels
+    // and the gaps around them were 11 us of the 70 a batch of 1e5 reads took (profiles/r06_small_batches.txt).
+    if (!reads->d_offsets) {
+        bool handled = false;
+        if (!ctx->queue_clean) KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));
+        // (reads longer than a frame are scanned as segments: a mask word per 64 of THOSE)
+        if (int st = prepare_dirty_flags(ctx, reads->n_reads * kmx::bitsliced_segments_per_read(reads->read_len, k), k)) return st;
+        const bool alone = host_mode != 0u && !fix_fold && reads->read_len <= 256u;   // (segments: the sweep's geometry is the launcher's)
+        const uint32_t mode = (want_sumfw ? 1u : 0u) | 2u /* KMX_BS_STORE */ | (alone ? host_mode : 0u);
+        KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, want_fold, mode, d_out,
+                                                ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
+        if (handled) {
+            ctx->queue_clean = true;
+            if (published) *published = alone;
+            if (fix_fold) KMX_HIP(ctx, kmx::launch_fix_hash_fold(d_out, k, hasher, hasher_k, ctx->stream));
+            return KMX_OK;
+        }
+    }
+    KMX_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(kmx_summary), ctx->stream));
     {
         bool handled = false;
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 16, ctx->stream));  // 32 tile-queue heads, 128 B apart, + the "a tile was flagged" word + the uniform/ragged gate
+        KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));  // 32 tile-queue heads, 128 B apart, + the "a tile was flagged" word + the uniform/ragged gate
         // Reads behind an offsets array with a length bound L that the uniform bit-sliced kernels take: most FASTQ is
         // untrimmed -- every read exactly L bases -- and the uniform kernel is ~1.4x the ragged one.  Decided on the device:
         // a small kernel checks offsets[i] == i*L, both scans are launched behind its verdict, the one it names runs.
@@ -482,7 +534,7 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
             KMX_HIP(ctx, kmx::launch_offsets_uniform_gate(reads->d_offsets, reads->n_reads, Lh, k, gate, ctx->n_cu, ctx->stream));
             if (int st = prepare_dirty_flags(ctx, reads->n_reads, k)) return st;
             bool h_u = false, h_r = false;
-            KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, Lh, k, want_fold, false, d_out, ctx->d_scratch + 16,
+            KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, Lh, k, want_fold, 0u, d_out, ctx->d_scratch + 16,
                                                     ctx->n_cu, ctx->stream, &h_u));
             if (h_u) {
                 // (the uniform scan took tickets from the queue heads only if it ran; if it did not they are still zero)
@@ -502,12 +554,6 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
             } else {
                 KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 2, ctx->stream));
             }
-        }
-        if (!reads->d_offsets) {
-            // (reads longer than a frame are scanned as segments: a mask word per 64 of THOSE)
-            if (int st = prepare_dirty_flags(ctx, reads->n_reads * kmx::bitsliced_segments_per_read(reads->read_len, k), k)) return st;
-            KMX_HIP(ctx, kmx::launch_scan_bitsliced(reads->d_bases, reads->n_reads, reads->read_len, k, want_fold, want_sumfw,
-                                                    d_out, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         }
         if (!handled && reads->d_offsets && reads->read_len > 256 && k >= 13 && k <= 31 &&
             (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
@@ -545,6 +591,58 @@ int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint3
     return KMX_OK;
 }
 
+int kmx_canonical_reduce(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
+                         uint32_t flags, kmx_summary* d_out) {
+    return reduce_impl(ctx, reads, k, hasher, hasher_k, flags, d_out, 0u, nullptr);
+}
+
+// The summary straight into host memory, the call returning when it is there (round 6; kmx.h).  Uniform reads of up to 256
+// bases on the bit-sliced scan: ONE kernel launch -- its last block leaves {token, marked reads, summary} in the context's
+// pinned words, which this thread watches -- and, only if the scan marked reads with an invalid byte, the sweep and a copy
+// back.  Everything else: kmx_canonical_reduce into a summary of the context's own, a copy, a wait.
+int kmx_canonical_reduce_host(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t hasher, uint32_t hasher_k,
+                              uint32_t flags, kmx_summary* h_out) {
+    if (!ctx || !h_out) return KMX_E_ARG;
+    kmx_summary* const d_res = reinterpret_cast<kmx_summary*>(ctx->d_scratch + 16 + 528);   // (eight free words of the queue block)
+    uint32_t token = (ctx->pub_token + 1u) & 0xFFFFFFu;
+    if (token == 0u) token = 1u;                       // (the pinned word starts at 0)
+    bool published = false;
+    const int st = reduce_impl(ctx, reads, k, hasher, hasher_k, flags, d_res, 4u /* KMX_BS_PUBLISH */ | 8u /* KMX_BS_NO_SWEEP */ | (token << 8), &published);
+    if (st != KMX_OK) return st;
+    DeviceGuard g(ctx->device);
+    if (published) {
+        ctx->pub_token = token;
+        volatile unsigned long long* const hp = ctx->h_pub;
+        unsigned spins = 0, done_seen = 0;
+        while (hp[0] != (unsigned long long)token) {
+            if ((++spins & 0x3FFFu) == 0u) {           // (a launch that died never writes the token)
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q != hipErrorNotReady) {
+                    if (q != hipSuccess) return fail_hip(ctx, q, "kmx_canonical_reduce_host");
+                    if (++done_seen > 64u) {
+                        std::snprintf(ctx->last_error, sizeof ctx->last_error, "kmx: internal -- the scan ended without publishing its summary");
+                        return KMX_E_HIP;
+                    }
+                }
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (hp[1] == 0ull) {                           // no read was marked: what the scan left is the answer
+            h_out->n_valid = hp[2]; h_out->sum_canon = hp[3]; h_out->xor_hash = hp[4]; h_out->sum_fw = hp[5];
+            return KMX_OK;
+        }
+        KMX_HIP(ctx, kmx::launch_sweep_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, hasher != KMX_HASH_NONE,
+                                               (flags & KMX_REDUCE_SUM_FW) != 0, d_res, ctx->d_scratch + 16, ctx->n_cu, ctx->stream));
+    }
+    KMX_HIP(ctx, hipMemcpyAsync(ctx->h_pinned + 2, d_res, sizeof(kmx_summary), hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    h_out->n_valid = ctx->h_pinned[2]; h_out->sum_canon = ctx->h_pinned[3]; h_out->xor_hash = ctx->h_pinned[4]; h_out->sum_fw = ctx->h_pinned[5];
+    return KMX_OK;
+}
+
 int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* d_win_offsets, uint32_t k,
                           uint64_t* d_fw, uint64_t* d_rc, uint64_t* d_canon, uint8_t* d_flags) {
     if (!ctx || !reads_ok(reads)) return KMX_E_ARG;
@@ -554,7 +652,7 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
     DeviceGuard g(ctx->device);
     if (!reads->d_offsets && !d_win_offsets) {   // uniform layout: fast word-domain kernel
         bool handled = false;
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+        KMX_HIP(ctx, queue_clear(ctx, 32 * 128));
         KMX_HIP(ctx, kmx::launch_windows_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, d_fw, d_rc, d_canon,
                                                  d_flags, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
@@ -572,7 +670,7 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
                 const uint64_t *starts = nullptr, *ends = nullptr, *wins = nullptr;
                 uint64_t n_seg = 0;
                 KMX_HIP(ctx, kmx::launch_uniform_segments_plan(reads->n_reads, L, k, T, scratch, &starts, &ends, &wins, &n_seg, ctx->stream));
-                KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+                KMX_HIP(ctx, queue_clear(ctx, 32 * 128));
                 KMX_HIP(ctx, kmx::launch_windows_ragged(reads->d_bases, starts, wins, n_seg, 256u, k, d_fw, d_rc, d_canon, d_flags, ctx->d_scratch + 16, ctx->n_cu,
                                                         ctx->stream, &handled, ends));
                 if (handled) return KMX_OK;
@@ -589,7 +687,7 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
         if (st == 0) {
             if (n_seg == 0) return KMX_OK;      // no read holds a window
             bool handled = false;
-            KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+            KMX_HIP(ctx, queue_clear(ctx, 32 * 128));
             KMX_HIP(ctx, kmx::launch_windows_ragged(reads->d_bases, starts, wins, n_seg, 256u, k, d_fw, d_rc, d_canon, d_flags, ctx->d_scratch + 16, ctx->n_cu,
                                                     ctx->stream, &handled, ends));
             if (handled) return KMX_OK;
@@ -597,7 +695,7 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
     }
     if (reads->d_offsets && d_win_offsets) {     // ragged reads: the tiled word-domain kernel (read_len = optional length bound)
         bool handled = false;
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+        KMX_HIP(ctx, queue_clear(ctx, 32 * 128));
         KMX_HIP(ctx, kmx::launch_windows_ragged(reads->d_bases, reads->d_offsets, d_win_offsets, reads->n_reads, reads->read_len, k,
                                                 d_fw, d_rc, d_canon, d_flags, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
@@ -614,7 +712,7 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
     if (reads->n_reads == 0) return KMX_OK;
     if (!reads->d_offsets) {
         bool handled = false;
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 16, ctx->stream));   // queue heads + the "a tile was flagged" word + the uniform / ragged gate
+        KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));   // queue heads + the "a tile was flagged" word + the uniform / ragged gate
         if (int st = prepare_dirty_flags(ctx, reads->n_reads * kmx::bitsliced_segments_per_read(reads->read_len, k), k)) return st;
         KMX_HIP(ctx, kmx::launch_scan_bitsliced2(reads->d_bases, reads->n_reads, reads->read_len, k, with_hash != 0, d_out,
                                                  ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
@@ -627,7 +725,7 @@ int kmx_canonical_reduce2(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint
     const uint32_t Lh = reads->read_len;
     if (reads->d_offsets && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
         uint32_t* gate = reinterpret_cast<uint32_t*>(ctx->d_scratch + 16 + 513);
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 16, ctx->stream));
+        KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));
         // A bound above the 10-word frame (161...: 250-base reads, long reads): the ragged kernel scans SEGMENTS of at most 161 - k
         // windows, cut on the device as kmx_canonical_reduce does for long reads (two host round trips) -- first of all, so that the
         // masks of the dirty reads are sized once for whichever kernel will run.
@@ -739,7 +837,7 @@ int kmx_histogram(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_t has
     ctx->fx_valid = false;   // (the partitioned histogram writes its id streams over the work buffer)
     {
         bool handled = false;
-        KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128 + 16, ctx->stream));   // queue heads + the count of marked reads + the gate
+        KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));   // queue heads + the count of marked reads + the gate
         // (the histogram sinks mark the reads of a dirty tile like the bit-sliced scan does; without the array they roll such tiles, exactly)
         if (k >= 2 && k <= 31) {
             if (int st = prepare_dirty_flags(ctx, reads->n_reads, k, true)) return st;
@@ -1058,7 +1156,7 @@ int kmx_seqvec_canonical_reduce(kmx_ctx* ctx, const uint64_t* d_words, uint64_t 
     const bool want_hash = hasher != KMX_HASH_NONE, want_sumfw = (flags & KMX_REDUCE_SUM_FW) != 0;
     const bool fix_fold = want_hash && !(hasher == KMX_HASH_LEX && hasher_k == k);   // (as in kmx_canonical_reduce)
     bool handled = false;
-    KMX_HIP(ctx, hipMemsetAsync(ctx->d_scratch + 16, 0, 32 * 128, ctx->stream));
+    KMX_HIP(ctx, queue_clear(ctx, 32 * 128));
     KMX_HIP(ctx, kmx::launch_scan_bitsliced_packed(d_words, n_reads, read_len, k, want_hash, want_sumfw, d_out,
                                                    ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
     if (!handled)

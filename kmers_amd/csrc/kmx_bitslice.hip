@@ -24,7 +24,7 @@ static bool bs_domain(const void* p, u64 n_reads, u32 L, u32 k, bool packed) {
 
 // handled=false when (L,k) is outside the instantiated bit-sliced kernels
 // `queue`: 32 zeroed u64 tile-queue heads, 128 B apart, owned by the caller for the duration of the launch
-hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw,
+hipError_t launch_scan_bitsliced(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, u32 want_sumfw /* KMX_BS_*: bit 0 = sum_fw, the rest how the launch ends */,
                                  kmx_summary* out, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = false;
     if (!bs_domain(bases, n_reads, L, k, false)) return hipSuccess;

@@ -290,7 +290,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         NVR[lane] = 0;
         if (lane < 16u) VAL[(lane >> 3) * VS + 32u * NV + (lane & 7u)] = 0;   // the zero words (never written again)
     }
-    const bool sumfw_on = want_sumfw != 0u;
+    const bool sumfw_on = (want_sumfw & KMX_BS_SUMFW) != 0u;   // (the other bits: how the launch ends, kmx_device.h)
     const u64 total_bytes = RAGGED ? ends[n_reads - 1u] : 0;
     // ragged: per-tile geometry of the current and of the next tile (rel/len per lane, the rest wave-uniform)
     struct TileMeta { u32 rel = 0, len = 0, n_ch = 0; u64 base = 0; bool fits = true; };
@@ -387,11 +387,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 // (registers 8..15 of the shared block are the rows 16..31: block pair NAB - 1)
+                // (no branch around the add -- a diagonal outside [0, K) adds zero to one of eight classes)
                 const int t = 16 * ((q == 0 && j >= 8) ? NAB - 1 : q) + pb - ((j & 3) + 8 * (j >> 2));
-                if (t >= 0 && t <= K - 1) {
-                    const int tc = t < K - 1 - t ? t : K - 1 - t;
-                    atomicAdd(reinterpret_cast<unsigned long long*>(cs_b + 2 * tc), (unsigned long long)(u32)acc[q][j]);
-                }
+                const bool ok = t >= 0 && t <= K - 1;
+                const int tt = ok ? t : (t & 7);
+                const int tc = tt < K - 1 - tt ? tt : K - 1 - tt;
+                atomicAdd(reinterpret_cast<unsigned long long*>(cs_b + 2 * tc), ok ? (unsigned long long)(u32)acc[q][j] : 0ull);
                 acc[q][j] = 0.f;
             }
         }
@@ -413,85 +414,61 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     u32 n_marked = 0;                             // reads this wave marked (wave-uniform); their total, in queue[512], tells the sweep how many waves to field
     // word-domain accumulators of the fallback path (tiles with invalid bytes, the final partial tile)
     struct FbAcc { u64 n = 0, s0 = 0, s1 = 0, x0 = 0, x1 = 0, fw = 0; };
+    // (into one of sixteen partial summaries, each on a line of its own in the queue block -- the launch's last block adds them
+    // up, at the end of the kernel: the blocks of a small batch all get here within microseconds, and 3-5 atomics each on the ONE
+    // line of the summary were served one after the other)
     auto emit_sums = [&](u64 n, u64 r0, u64 r1, u64 h0, u64 h1, u64 f) {   // wave-uniform values, one set of atomics
         if (lane == 0) {
+            unsigned long long* const S = queue + KMX_Q_SLOTS + (blockIdx.x & 15u) * 16u;
+            atomicAdd(S + 0, (unsigned long long)n);
+            atomicAdd(S + 1, (unsigned long long)r0);
+            if constexpr (K > 32) atomicAdd(S + 2, (unsigned long long)r1);
+            if (want_hash) {
+                atomicXor(S + 3, (unsigned long long)h0);
+                if constexpr (K > 32) atomicXor(S + 4, (unsigned long long)h1);
+            }
             if constexpr (K <= 32) {
-                kmx_summary* o = static_cast<kmx_summary*>(out);
-                atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
-                atomicAdd((unsigned long long*)&o->sum_canon, (unsigned long long)r0);
-                if (want_hash) atomicXor((unsigned long long*)&o->xor_hash, (unsigned long long)h0);
-                if (sumfw_on) atomicAdd((unsigned long long*)&o->sum_fw, (unsigned long long)f);
-            } else {
-                kmx_summary2* o = static_cast<kmx_summary2*>(out);
-                atomicAdd((unsigned long long*)&o->n_valid, (unsigned long long)n);
-                atomicAdd((unsigned long long*)&o->sum_lo, (unsigned long long)r0);
-                atomicAdd((unsigned long long*)&o->sum_hi, (unsigned long long)r1);
-                if (want_hash) {
-                    atomicXor((unsigned long long*)&o->xor_lo, (unsigned long long)h0);
-                    atomicXor((unsigned long long*)&o->xor_hi, (unsigned long long)h1);
-                }
+                if (sumfw_on) atomicAdd(S + 5, (unsigned long long)f);
             }
         }
     };
     constexpr bool FB_FLUSH = K <= 32;   // (two-word k-mers: the per-tile sums then live in scratch, 0.46 -> 0.37 of the roofline at k=63)
     FbAcc fb_all;                                             // !FB_FLUSH: summed over the whole run of the wave
-    auto fallback_read_acc = [&](u64 read, FbAcc& fb) {
-        const uint8_t* s = bases + lead + read * (u64)L;
+    // (`pieces` > 1: the read's windows in `pieces` equal runs, this lane rolls run `piece` -- the final partial tile, below)
+    // (always_inline: called from two places, the body is past hipcc's threshold in the widest variants -- as a CALL its closure and the
+    // accumulators live in scratch: tests/test_kernel_resources.py)
+    auto fallback_read_acc = [&](u64 read, FbAcc& fb, u32 piece = 0, u32 pieces = 1) __attribute__((always_inline)) {
+        // first byte (packed input: first base) and length of what this lane rolls
+        u64 at = (u64)lead + read * (u64)L;
+        u32 len = L;
         if constexpr (RAGGED) {
             const u64 o0 = offsets[read], o1 = ends[read];
             if (read_too_long(o1 - o0, queue + KMX_TOOLONG_FROM_QUEUE)) return;   // (not scanned; kmx_ctx_synchronize reports it)
-            if constexpr (K <= 32) {
-                roll_read<false>(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, u64 fw, u64 rc) {
-                    const u64 canon = fw < rc ? fw : rc;
-                    fb.n += 1;
-                    fb.s0 += canon;
-                    fb.x0 ^= lex_hash(canon, (u32)K);
-                    fb.fw += fw;
-                });
-            } else {
-                roll_read2<false>(bases + o0, (u32)(o1 - o0), (u32)K, [&](u32, U128 fw, U128 rc) {
-                    const U128 c = lt128(fw, rc) ? fw : rc;
-                    const U128 h = lex_hash128(c, (u32)K);
-                    fb.n += 1;
-                    fb.s0 += c.lo;
-                    fb.s1 += c.hi;
-                    fb.x0 ^= h.lo;
-                    fb.x1 ^= h.hi;
-                });
-            }
-        } else if constexpr (PACKED) {
-            static_assert(!PACKED || K <= 32, "packed input: single-word k-mers");
-            roll_read_packed(reinterpret_cast<const u64*>(bases), read * (u64)L, L, (u32)K, [&](u32, u64 fw, u64 rc) {
-                const u64 canon = fw < rc ? fw : rc;
-                fb.n += 1;
-                fb.s0 += canon;
-                fb.x0 ^= lex_hash(canon, (u32)K);
-                fb.fw += fw;
-            });
-        } else if constexpr (SEG && K <= 32) {
-            const u64 i = read / seg.J;
-            const u32 j = (u32)(read - i * seg.J);
-            roll_read<false>(bases + i * (u64)seg.L + seg_pos(j), L - (j >= seg.J1 ? 1u : 0u), (u32)K, [&](u32, u64 fw, u64 rc) {
-                const u64 canon = fw < rc ? fw : rc;
-                fb.n += 1;
-                fb.s0 += canon;
-                fb.x0 ^= lex_hash(canon, (u32)K);
-                fb.fw += fw;
-            });
+            at = o0;
+            len = (u32)(o1 - o0);
         } else if constexpr (SEG) {
             const u64 i = read / seg.J;
             const u32 j = (u32)(read - i * seg.J);
-            roll_read2<false>(bases + i * (u64)seg.L + seg_pos(j), L - (j >= seg.J1 ? 1u : 0u), (u32)K, [&](u32, U128 fw, U128 rc) {
-                const U128 c = lt128(fw, rc) ? fw : rc;
-                const U128 h = lex_hash128(c, (u32)K);
+            at = i * (u64)seg.L + seg_pos(j);
+            len = L - (j >= seg.J1 ? 1u : 0u);
+        }
+        if (pieces > 1u) {
+            const u32 wins = len >= (u32)K ? len - (u32)K + 1u : 0u, run = (wins + pieces - 1u) / pieces, first = piece * run;
+            if (first >= wins) return;
+            at += first;
+            len = (wins - first < run ? wins - first : run) + (u32)K - 1u;
+        }
+        if constexpr (PACKED) {
+            static_assert(!PACKED || K <= 32, "packed input: single-word k-mers");
+            roll_read_packed(reinterpret_cast<const u64*>(bases), at, len, (u32)K, [&](u32, u64 fw, u64 rc) {
+                const u64 canon = fw < rc ? fw : rc;
                 fb.n += 1;
-                fb.s0 += c.lo;
-                fb.s1 += c.hi;
-                fb.x0 ^= h.lo;
-                fb.x1 ^= h.hi;
+                fb.s0 += canon;
+                fb.x0 ^= lex_hash(canon, (u32)K);
+                fb.fw += fw;
             });
         } else if constexpr (K <= 32) {
-            roll_read<false>(s, L, (u32)K, [&](u32, u64 fw, u64 rc) {
+            roll_read<false>(bases + at, len, (u32)K, [&](u32, u64 fw, u64 rc) {
                 const u64 canon = fw < rc ? fw : rc;
                 fb.n += 1;
                 fb.s0 += canon;
@@ -499,7 +476,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                 fb.fw += fw;
             });
         } else {
-            roll_read2<false>(s, L, (u32)K, [&](u32, U128 fw, U128 rc) {
+            roll_read2<false>(bases + at, len, (u32)K, [&](u32, U128 fw, U128 rc) {
                 const U128 c = lt128(fw, rc) ? fw : rc;
                 const U128 h = lex_hash128(c, (u32)K);
                 fb.n += 1;
@@ -510,14 +487,14 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             });
         }
     };
-    // one tile (or the final partial one) on the per-lane path; `mine`: this lane has a read
-    auto fallback_read = [&](u64 read, bool mine) {
+    // one tile (or a part of the final partial one) on the per-lane path; `mine`: this lane has something to roll
+    auto fallback_read = [&](u64 read, bool mine, u32 piece = 0, u32 pieces = 1) __attribute__((always_inline)) {
         if constexpr (FB_FLUSH) {
             FbAcc fb;
-            if (mine) fallback_read_acc(read, fb);
+            if (mine) fallback_read_acc(read, fb, piece, pieces);
             emit_sums(wave_sum(fb.n), wave_sum(fb.s0), wave_sum(fb.s1), wave_xor(fb.x0), wave_xor(fb.x1), wave_sum(fb.fw));
         } else {
-            if (mine) fallback_read_acc(read, fb_all);
+            if (mine) fallback_read_acc(read, fb_all, piece, pieces);
         }
     };
 
@@ -609,6 +586,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     // three co-resident blocks of 8 CUs (old and young waves alike), so heads drain at equal rates.
     // (Handing each head a contiguous region instead changed nothing: 2.50 vs 2.55 ms compute-free, equal in the full kernel.)
     constexpr u32 NQ = 32;
+    const u64 n_static = (u64)gridDim.x * 4u;           // the tiles the waves own without a ticket: wave w starts with tile w (below); head q owns the tiles == q (mod NQ) past them
     // (a grid of fewer than 256 blocks -- a small batch -- spreads over all 32 heads too: crowded on gridDim / 8 of them, most waves found their
     // head drained at once and walked the others in step, one round trip per head: 1e4 reads took longer than 1e5)
     u32 qid = ((blockIdx.x & 255u) * NQ) / (gridDim.x < 256u ? gridDim.x : 256u);
@@ -629,7 +607,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             // (the low word: a head hands out fewer than 2^32 tickets; lanes 32..63 look at the heads again -- same answer, no branch)
             const u32 ln = lane_now() & (NQ - 1u);
             const u32 c = __hip_atomic_load(reinterpret_cast<const u32*>(queue) + ln * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u32 live = (u32)__ballot((u64)c * NQ + ln < n_full);
+            const u32 live = (u32)__ballot((u64)c * NQ + ln + n_static < n_full);
             if (live == 0u) break;
             // (the nearest live head counted from a place that differs from wave to wave: the waves that fail together do not all fall on one head)
             const u32 at = (qid + (u32)wave_id) & (NQ - 1u);
@@ -638,18 +616,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             unsigned long long v = 0;
             if (lane_now() == 0u) v = atomicAdd(queue + qid * 16u, 1ull);               // heads are 128 bytes apart
             const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
-            const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
+            const u64 t = (((u64)hi << 32) | lo) * NQ + qid + n_static;
             if (t < n_full) return t;
         }
         heads_left = 0u;
         return ~0ull;
-    };
-    auto take_now = [&]() -> u64 {   // a ticket from the wave's own head, synchronously: the first two tiles
-        unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(queue + qid * 16u, 1ull);
-        const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
-        const u64 t = (((u64)hi << 32) | lo) * NQ + qid;
-        return t < n_full ? t : dequeue();
     };
     // The ticket for tile t+2 is requested in iteration t right behind phase A -- after the wave has taken its rows and asked for
     // the first rows of tile t+1 -- and looked at when the iteration ends: phases B-D later.  (Requested at the very end of the
@@ -685,7 +656,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             asm volatile("" : : "v"(pend_hi));      // (the use that keeps the pair together: no instruction)
         }
         const u32 lo = __builtin_amdgcn_readfirstlane((u32)pend);
-        const u64 t = (u64)lo * NQ + pend_qid;
+        const u64 t = (u64)lo * NQ + pend_qid + n_static;
         if (t < n_full) return t;
         rot = false;
         qid = (pend_qid + 1u) & (NQ - 1u);   // that head is drained: move on, synchronously (rare)
@@ -1165,11 +1136,15 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     };
 
     // Pipeline order 1: [A of tile t] [issue loads of tile t+1] [B,C,D of tile t]
-    tile = uniform_u64(take_now());
-    next_tile = uniform_u64(take_now());
+    // A wave's FIRST tile is its own number -- no ticket -- and the ticket for its second is in flight while the first tile's rows
+    // are (round 6: two synchronous device atomics used to open every launch, ~2 us before the first byte was asked for).  The
+    // heads hand out the tiles from n_static on.
+    tile = wave_id < n_full ? wave_id : ~0ull;
+    ticket_issue();
     if constexpr (RAGGED) {
+        if (tile < n_full) meta_issue(tile);
+        next_tile = uniform_u64(ticket_take());
         if (tile < n_full) {
-            meta_issue(tile);
             meta_finish(cur_m);
             issue_loads_ragged(cur_m);
         }
@@ -1177,9 +1152,12 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     } else {
         if constexpr (SEG) {
             if (tile < n_full) seg_geom(tile, cur_g);
-            if (next_tile < n_full) seg_geom(next_tile, nx_g);
         }
         if (tile < n_full) issue_loads(tile);
+        next_tile = uniform_u64(ticket_take());
+        if constexpr (SEG) {
+            if (next_tile < n_full) seg_geom(next_tile, nx_g);
+        }
     }
     while (tile < n_full) {
         if constexpr (SEG) seg_lane(cur_g);
@@ -1297,9 +1275,18 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         }
     }
 
-    // ---- final partial tile: per-lane rolling
+    // ---- final partial tile: per-lane rolling.  (Round 6: every read in TAIL runs of windows, a lane per run, over as many waves
+    // as that takes -- one wave rolling up to 63 whole reads was the last thing a small batch waited for: 25 of the 41 us of a
+    // launch on 1e5 reads, profiles/r06_small_batches.txt.  A run of a 150-base read at k = 31: 45 bases.)
     const u32 rem = (u32)(n_reads & 63u);
-    if (rem != 0u && wave_id == 0) fallback_read(n_full * 64u + lane, lane < rem);
+    if (rem != 0u) {
+        constexpr u32 TAIL = 8;
+        const u32 items = rem * TAIL, n_lanes = gridDim.x * 256u;
+        for (u32 it0 = (u32)wave_id * 64u; it0 < items; it0 += n_lanes) {     // (wave-uniform bounds)
+            const u32 it = it0 + lane_now();
+            fallback_read(n_full * 64u + it / TAIL, it < items, it % TAIL, TAIL);
+        }
+    }
 
     // ---- combine the bit-sliced counters into word-domain results (once per wave; wave-uniform branch)
     // Number of set bits of canonical bit (t,b) over all k-mers of the wave:
@@ -1320,9 +1307,11 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             const u32 qidx = 32u * g + p;
             const u32 pcq = TOT[64u * g + lane];           // per-plane totals of this half's set
             if constexpr (K <= 32 && !RAGGED) {
-                u64 wf, wr;
-                plane_weights(qidx >> 1, L, (u32)K, wf, wr);
-                fwall += (u64)pcq * (wf << (qidx & 1u));
+                if (sumfw_on) {     // (two 64-bit divisions per plane: only for the caller who asked for the sum)
+                    u64 wf, wr;
+                    plane_weights(qidx >> 1, L, (u32)K, wf, wr);
+                    fwall += (u64)pcq * (wf << (qidx & 1u));
+                }
             }
             tot[g] = pcq + __shfl_xor(pcq, 32, WAVE);      // lanes p and p+32 hold the same plane of the two sets
             if constexpr (SEG) {
@@ -1357,26 +1346,47 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         u64 s0 = 0, s1 = 0, x0 = 0, x1 = 0;
-        for (u32 pid = lane; pid < 2u * (u32)K; pid += 64u) {
-            const u32 t = pid >> 1, bb = pid & 1u, t2 = (u32)K - 1u - t;
-            const u32 tc = t < t2 ? t : t2;
-            u64 cc = CS[2u * tc + bb];                      // C[t][b] + C[K-1-t][b]; the middle class holds C[mid][b] once
-            if (t == t2) cc += cc;
-            u64 tq = 0;
-            if constexpr (RAGGED) {
-                // every plane from t2 up (bases past a read's end are zero) minus the last t bases of every read
-                for (u32 i = t2; i <= L - 1u; ++i) tq += PL[2u * i + bb];
-                for (u32 i = (u32)K - 1u - t; i + 2u <= (u32)K; ++i) tq -= QE[2u * i + bb];
-            } else {
-                for (u32 i = t2; i <= L - 1u - t; ++i) tq += PL[2u * i + bb];
-                if constexpr (SEG) tq -= (PL + PLANES)[2u * (W - 1u + t2) + bb];   // window W-1 of the short segments
+        // Tq[t][b] is a window of plane totals that slides one base down as t goes up: Tq[0] = the planes K-1 .. L-1, and
+        //   Tq[t+1] - Tq[t] = PL[K-2-t] - PL[L-1-t]          (ragged: PL[K-2-t] - QE[K-2-t], the read ends instead of the frame's end)
+        // -- a sum the lanes of a half-wave share and a running sum over them.  (Round 6.  Until then every
+        // lane walked its window: up to L-K+1 dependent LDS reads, 8 us at the end of every launch whatever its size -- a quarter of
+        // what a batch of 1e5 reads took: profiles/r06_small_batches.txt.)
+        // (lane = (bit b, t mod 32): the scan runs within a half-wave, on DPP alone)
+        const u32 bb = lane >> 5;
+        u64 tq0 = 0;
+        for (u32 i = (u32)(K - 1) + (lane & 31u); i + 1u <= L; i += 32u) tq0 += PL[2u * i + bb];
+        tq0 = half_sum(tq0);
+        u64 carry = 0;                                      // the scan's total over this half-wave, passes before this one
+        for (u32 t0 = 0; t0 < (u32)K; t0 += 32u) {
+            const u32 t = t0 + (lane & 31u), t2 = (u32)K - 1u - t;
+            const bool on = t < (u32)K;
+            u64 dlt = 0;
+            if (on && t + 2u <= (u32)K) {
+                const u32 i = (u32)K - 2u - t;
+                dlt = PL[2u * i + bb];
+                if constexpr (RAGGED) dlt -= QE[2u * i + bb];
+                else dlt -= PL[2u * (L - 1u - t) + bb];
             }
-            const u64 cnt = cc + (nk - mc) - tq;
-            const u32 sh = 2u * (t & 31u) + bb;
-            if (t < 32u) s0 += cnt << sh; else s1 += cnt << sh;
-            if (want_hash && (cnt & 1ull)) {
-                const u32 hb = 2u * t2 + bb;
-                if (hb < 64u) x0 ^= 1ull << hb; else x1 ^= 1ull << (hb - 64u);
+            const u64 inc = half_scan_sum(dlt);
+            u64 tq = tq0 + carry + (inc - dlt);
+            if constexpr (K > 32) {
+                const u32 ilo = (u32)inc, ihi = (u32)(inc >> 32);
+                const u64 e0 = ((u64)(u32)__builtin_amdgcn_readlane((int)ihi, 31) << 32) | (u32)__builtin_amdgcn_readlane((int)ilo, 31);
+                const u64 e1 = ((u64)(u32)__builtin_amdgcn_readlane((int)ihi, 63) << 32) | (u32)__builtin_amdgcn_readlane((int)ilo, 63);
+                carry += bb ? e1 : e0;
+            }
+            if (on) {
+                const u32 tc = t < t2 ? t : t2;
+                u64 cc = CS[2u * tc + bb];                      // C[t][b] + C[K-1-t][b]; the middle class holds C[mid][b] once
+                if (t == t2) cc += cc;
+                if constexpr (SEG) tq -= (PL + PLANES)[2u * (W - 1u + t2) + bb];   // window W-1 of the short segments
+                const u64 cnt = cc + (nk - mc) - tq;
+                const u32 sh = 2u * (t & 31u) + bb;
+                if (t < 32u) s0 += cnt << sh; else s1 += cnt << sh;
+                if (want_hash && (cnt & 1ull)) {
+                    const u32 hb = 2u * t2 + bb;
+                    if (hb < 64u) x0 ^= 1ull << hb; else x1 ^= 1ull << (hb - 64u);
+                }
             }
         }
         bs_s0 = wave_sum(s0);
@@ -1426,7 +1436,56 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
             v[i] = (i == 3u || i == 4u) ? (a ^ b ^ c ^ d) : (a + b + c + d);
         }
         if (v[0] != 0ull) emit_sums(v[0], v[1], v[2], v[3], v[4], v[5]);   // (no k-mer: nothing to add -- every word is zero then)
-        if (v[6] != 0ull && lane == 0) atomicAdd(queue + 512, (unsigned long long)v[6]);
+        if (v[6] != 0ull && lane == 0) atomicAdd(queue + KMX_Q_MARKED, (unsigned long long)v[6]);
+        // ---- the last block to hand in closes the launch (kmx_device.h, "the context's queue block")
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        u32 before = 0;
+        if (lane == 0) before = (u32)atomicAdd(queue + KMX_Q_DONE, 1ull);
+        before = __builtin_amdgcn_readfirstlane(before);
+        if (before + 1u == gridDim.x) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const u32 ln = lane_now();
+            u64 part[6];
+#pragma unroll
+            for (u32 i = 0; i < 6u; ++i) {      // lane s < 16 takes partial summary s -- and leaves zeros
+                part[i] = 0;
+                if (ln < 16u) part[i] = atomicExch(queue + KMX_Q_SLOTS + ln * 16u + i, 0ull);
+            }
+            u64 marked = 0;
+            if (ln == 0u) marked = atomicExch(queue + KMX_Q_MARKED, 0ull);
+            marked = wave_sum(marked);
+            const u64 f_n = wave_sum(part[0]), f_s0 = wave_sum(part[1]), f_s1 = wave_sum(part[2]);
+            const u64 f_x0 = wave_xor(part[3]), f_x1 = wave_xor(part[4]), f_fw = wave_sum(part[5]);
+            if (ln < 32u) queue[ln * 16u] = 0ull;          // the ticket heads
+            if (ln == 0u) {
+                queue[KMX_Q_DONE] = 0ull;
+                queue[KMX_Q_MARKED_OUT] = marked;
+                u64 wds[5];
+                if constexpr (K <= 32) { wds[0] = f_n; wds[1] = f_s0; wds[2] = f_x0; wds[3] = f_fw; wds[4] = 0; }
+                else { wds[0] = f_n; wds[1] = f_s0; wds[2] = f_s1; wds[3] = f_x0; wds[4] = f_x1; }
+                constexpr u32 NWD = K <= 32 ? 4u : 5u;     // kmx_summary / kmx_summary2
+                constexpr u32 XOR0 = K <= 32 ? 2u : 3u, XOR1 = K <= 32 ? 2u : 4u;
+                unsigned long long* const o = static_cast<unsigned long long*>(out);
+                if ((want_sumfw & KMX_BS_STORE) != 0u) {
+#pragma unroll
+                    for (u32 i = 0; i < NWD; ++i) o[i] = wds[i];
+                } else {
+#pragma unroll
+                    for (u32 i = 0; i < NWD; ++i) {
+                        if (i == XOR0 || i == XOR1) atomicXor(o + i, (unsigned long long)wds[i]);
+                        else atomicAdd(o + i, (unsigned long long)wds[i]);
+                    }
+                }
+                if ((want_sumfw & KMX_BS_PUBLISH) != 0u) {
+                    unsigned long long* const host = reinterpret_cast<unsigned long long*>(queue[KMX_Q_HOST]);
+                    host[1] = marked;
+#pragma unroll
+                    for (u32 i = 0; i < 5u; ++i) host[2u + i] = wds[i];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: the words above before the token
+                    __hip_atomic_store(host, (unsigned long long)(want_sumfw >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
     }
 }
 
@@ -1491,7 +1550,8 @@ static hipError_t launch_bs(const uint8_t* bases, u64 n_reads, u32 L, u32 want_h
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, stream, bases, n_reads, L, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
     if constexpr (!PACKED) {
         // the windows with an invalid byte, out again (none on clean input: the waves return at once)
-        return launch_sweep_flagged(bases, n_reads, L, (u32)K, want_hash, want_sumfw, out, queue, n_cu, stream, offsets, lead, ends, seg, RAGGED, SEG);
+        if ((want_sumfw & KMX_BS_NO_SWEEP) == 0u)
+            return launch_sweep_flagged(bases, n_reads, L, (u32)K, want_hash, want_sumfw & KMX_BS_SUMFW, out, queue, n_cu, stream, offsets, lead, ends, seg, RAGGED, SEG);
     }
     return hipGetLastError();
 }

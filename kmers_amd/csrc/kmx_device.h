@@ -168,15 +168,57 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
     return mx(mx(a, b), mx(c, d));
 }
 
-__device__ __forceinline__ u64 wave_sum(u64 v) {
+// Wave-wide sum / xor of a 64-bit value, the same in every lane (scalar).  Within a row of 16 lanes through DPP (no LDS round trip),
+// the four rows through v_readlane.  (Round 6: six ds_bpermute pairs each, one behind the other, used to make up most of a scan's
+// epilogue -- a dozen reductions, ~0.3 us apiece: profiles/r06_small_batches.txt.)  Every caller is at a wave-uniform point.
+#define KMX_DPP64(v, ctrl)                                                                                         \
+    (((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)((v) >> 32), (ctrl), 0xF, 0xF, true) << 32) |          \
+     (u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ u64 wave_lanes_0_16_32_48(u64 v, bool add) {
+    const u32 lo = (u32)v, hi = (u32)(v >> 32);
+    u64 r = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    for (int l = 0; l < 64; l += 16) {
+        const u64 x = ((u64)(u32)__builtin_amdgcn_readlane((int)hi, l) << 32) | (u32)__builtin_amdgcn_readlane((int)lo, l);
+        r = add ? r + x : r ^ x;
+    }
+    return r;
+}
+__device__ __forceinline__ u64 wave_sum(u64 v) {
+    v += KMX_DPP64(v, 0xB1 /* quad_perm:[1,0,3,2] */);
+    v += KMX_DPP64(v, 0x4E /* quad_perm:[2,3,0,1] */);
+    v += KMX_DPP64(v, 0x124 /* row_ror:4 */);
+    v += KMX_DPP64(v, 0x128 /* row_ror:8 */);
+    return wave_lanes_0_16_32_48(v, true);
 }
 __device__ __forceinline__ u64 wave_xor(u64 v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, WAVE);
-    return v;
+    v ^= KMX_DPP64(v, 0xB1);
+    v ^= KMX_DPP64(v, 0x4E);
+    v ^= KMX_DPP64(v, 0x124);
+    v ^= KMX_DPP64(v, 0x128);
+    return wave_lanes_0_16_32_48(v, false);
+}
+
+// Inclusive running sum of a 64-bit value within each half-wave (lanes 0..31 and 32..63 apart), and the total of the lane's
+// half-wave in each of its lanes: DPP again (row_shr, then lane 15 of rows 0 / 2 broadcast into rows 1 / 3).
+__device__ __forceinline__ u64 half_scan_sum(u64 v) {
+    v += KMX_DPP64(v, 0x111 /* row_shr:1 */);
+    v += KMX_DPP64(v, 0x112 /* row_shr:2 */);
+    v += KMX_DPP64(v, 0x114 /* row_shr:4 */);
+    v += KMX_DPP64(v, 0x118 /* row_shr:8 */);
+    const u64 prev_row = ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x142 /* row_bcast:15 */, 0xA, 0xF, false) << 32) |
+                         (u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x142, 0xA /* rows 1 and 3 */, 0xF, false);
+    return v + prev_row;
+}
+__device__ __forceinline__ u64 half_sum(u64 v) {
+    v += KMX_DPP64(v, 0xB1);
+    v += KMX_DPP64(v, 0x4E);
+    v += KMX_DPP64(v, 0x124);
+    v += KMX_DPP64(v, 0x128);
+    const u32 lo = (u32)v, hi = (u32)(v >> 32);
+    auto at = [&](int l) { return ((u64)(u32)__builtin_amdgcn_readlane((int)hi, l) << 32) | (u32)__builtin_amdgcn_readlane((int)lo, l); };
+    const u64 h0 = at(0) + at(16), h1 = at(32) + at(48);
+    return (threadIdx.x & 32u) ? h1 : h0;
 }
 
 // A read of 2^31 bases or more (the iterator's positions are i32, canonical_kmer_iterator.rs:15; kmx.h "Limits") is not
@@ -188,6 +230,24 @@ __device__ __forceinline__ bool read_too_long(u64 len, unsigned long long* flag)
     if (flag) *flag = 1ull;   // (a plain store of one constant: every writer agrees)
     return true;
 }
+
+// ---- the context's queue block (`queue` = d_scratch + 16, u64 words; kmx_internal.h), as the bit-sliced scan uses it (round 6):
+//   [q * 16], q < 32   the ticket heads, 128 bytes apart
+//   [512]              reads marked so far (running count of the launch);  [513] the uniform / ragged gate;  [515] the mask array
+//   [516]              the marked reads of the LAST bit-sliced launch, for its sweep (overwritten, never cleared)
+//   [517]              the context's pinned host words as the device sees them (written once, kmx_ctx_create)
+//   [544..559]         a quiet line (stand-in source of loads that must not fault)
+//   [560]              blocks of the launch that have handed in their sums
+//   [576 + 16 s + i]   partial summary s (s < 16: block b adds into s = b & 15), word i < 6
+// The scan CLOSES its own launch: the last block to hand in adds the sixteen partial summaries up, writes the result, and puts
+// the heads, [512], [560] and the partials back to zero -- so a caller that knows only such launches ran since its last clear
+// need not clear again (two fill kernels and their gaps: 11 us of a small batch's 70, profiles/r06_small_batches.txt).
+constexpr u32 KMX_Q_MARKED = 512, KMX_Q_MARKED_OUT = 516, KMX_Q_HOST = 517, KMX_Q_DONE = 560, KMX_Q_SLOTS = 576;
+// `want_sumfw` of scan_bitsliced_kernel / launch_bs carries the launch's mode: bit 0 = the sum of the forward words is wanted;
+// STORE = the last block stores the summary (the caller did not zero `out`; default: adds to it); PUBLISH = ... and leaves
+// {token, marked reads, the summary's words} in the pinned host words, the token (bits 8..31) last; NO_SWEEP = launch_bs does
+// not enqueue the sweep (the caller does, when it has seen the count)
+constexpr u32 KMX_BS_SUMFW = 1u, KMX_BS_STORE = 2u, KMX_BS_PUBLISH = 4u, KMX_BS_NO_SWEEP = 8u;
 
 // accumulators of one reduce pass, per lane
 struct Acc {

@@ -14,7 +14,10 @@ struct kmx_ctx {
     bool owns_stream;
     int n_cu;
     unsigned long long* h_pinned;   // one pinned host word: the sticky flag read back by kmx_ctx_synchronize on the context's own stream
-    unsigned long long* d_scratch;  // 8 KiB: [0] first_bad, [2..3] fastx totals, [4] length range, [16..] tile-queue heads
+    unsigned long long* d_scratch;  // 8 KiB: [0] first_bad, [2..3] fastx totals, [4] length range, [16..] the queue block (kmx_device.h: ticket heads, marks, partial summaries)
+    unsigned long long* h_pub;      // eight pinned host words the bit-sliced scan's last block can leave {token, marked reads, summary} in (kmx_canonical_reduce_host)
+    uint32_t pub_token;             // the token of the last such launch (24 bits)
+    bool queue_clean;               // the heads and [512] of the queue block are zero: only self-closing launches (kmx_device.h) ran since the last clear
     void* d_big;                    // grow-only work buffer of the partitioned histogram (bucket-id streams)
     size_t big_bytes;
     size_t big_limit;               // kmx_ctx_set_work_buffer_limit: 0 = automatic (an eighth of the device memory, at most half of what is free)

@@ -32,7 +32,9 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
                                                             const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends,
                                                             const BsSeg seg) {
     u64* const masks = reinterpret_cast<u64*>(queue[515]);
-    const u64 n_marked = queue[512];                   // how many reads the scan marked (zeroed by the caller with the heads)
+    // how many reads the scan marked: the bit-sliced scan's last block leaves its count in [516] (and [512] at zero for the next launch,
+    // kmx_device.h); the word-domain scan's histogram sinks count in [512], which their caller clears with the heads
+    const u64 n_marked = queue[HIST ? KMX_Q_MARKED : KMX_Q_MARKED_OUT];
     if (masks == nullptr || n_marked == 0) return;
     // A sweep costs the same for 5 reads as for 64: as many waves as fill their sweeps (~48 reads each), not as many as were launched
     // -- 0.1 % of 2e7 reads dirty: 33 us with every wave of the grid sweeping 5 reads, 16 us with a quarter of them
@@ -410,6 +412,16 @@ hipError_t launch_sweep_flagged(const uint8_t* bases, u64 n_reads, u32 L, u32 k,
     }
     if (big) return launch_sweep_v<16, false, false>(v1, grid, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
     return launch_sweep_v<10, false, false>(v1, grid, stream, bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg);
+}
+
+// The sweep behind a scan of uniform reads (L <= 256, single-word k) that was launched WITHOUT one (KMX_BS_NO_SWEEP:
+// kmx_canonical_reduce_host enqueues it only when the scan's count of marked reads, which it has seen, is not zero).
+hipError_t launch_sweep_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, bool want_hash, bool want_sumfw, kmx_summary* out,
+                                unsigned long long* queue, int n_cu, hipStream_t stream) {
+    const u32 lead = (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);   // (as launch_bs: streamed from the aligned address below)
+    const BsSeg seg{0, 0, 0, 0, 0};
+    return launch_sweep_flagged(bases - lead, n_reads, L, k, want_hash ? 1u : 0u, want_sumfw ? 1u : 0u, out, queue, n_cu, stream, nullptr, lead,
+                                nullptr, seg, false, false);
 }
 
 // Behind a word-domain scan whose sink marks dirty reads (the bucket histograms): what the windows with an invalid byte added to the

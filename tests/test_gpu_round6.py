@@ -365,3 +365,106 @@ def test_histogram_with_dirty_reads(ctx, orc, b, k, L, hk, ragged):
     assert np.array_equal(g.cpu().numpy().view(np.uint64), o)
     ctx.histogram(dev, n, L, k, hasher, hk, b, offsets=d_off, counts=g)
     assert np.array_equal(g.cpu().numpy().view(np.uint64), 2 * o)
+
+
+# ------------------------------------------------------------------ kmx_canonical_reduce_host, and the scan that closes its own launch
+# (round 6: the last block stores the summary, puts the queue block back, and can leave the answer in pinned host words)
+
+HOST_CASES = [  # (k, L, n): the one-launch path (uniform, L <= 256, 13 <= k <= 31), partial last tiles of every size class, tiny batches
+    (31, 150, 64 * 300 + 17), (31, 150, 64 * 40), (31, 150, 63), (31, 150, 1), (31, 150, 65), (21, 100, 64 * 100 + 32), (13, 36, 1000),
+    (17, 250, 64 * 50 + 63), (27, 161, 4000), (31, 256, 777),
+    # ... and what leaves it: k below the bit-sliced domain, reads above a frame (segments)
+    (9, 150, 3000), (12, 100, 64 * 20 + 5), (31, 300, 2000), (21, 1000, 500),
+]
+
+
+@pytest.mark.parametrize("k,L,n", HOST_CASES)
+@pytest.mark.parametrize("share", [0.0, 0.05])
+def test_reduce_host(ctx, orc, k, L, n, share):
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(7 * k + L + n)
+    host = ctx.gen_reads(n * L, first_byte=k + L).cpu().numpy().copy()
+    if share:
+        _dirty(host, n, np.arange(n, dtype=np.int64) * L, np.full(n, L), rng, share)
+        host[(n - 1) * L + L - 1] = ord("N")
+    d = ctx.to_device(host)
+    for flags in (0, _lib.REDUCE_SUM_FW):
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        g = ctx.canonical_reduce_host(d, n, L, k, _lib.HASH_LEX, k, flags)
+        _check1(g, o, with_fw=bool(flags))
+        if not flags:
+            assert g.sum_fw == 0
+        g2 = ctx.canonical_reduce(d, n, L, k, _lib.HASH_LEX, k, flags)
+        _check1(g2, o, with_fw=bool(flags))
+    # another hasher: a second kernel rewrites the fold -- the call must take the long way and still be right
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=min(k + 1, 32))
+    g = ctx.canonical_reduce_host(d, n, L, k, _lib.HASH_LEX, min(k + 1, 32), 0)
+    _check1(g, o, with_fw=False)
+
+
+def test_reduce_host_behind_offsets(ctx, orc):
+    """reads behind an offsets array (uniform ones through the device-side gate, trimmed ones on the ragged scan): the long way"""
+    from kmers_amd import _lib
+
+    k, L, n = 31, 150, 64 * 120 + 9
+    rng = np.random.default_rng(5)
+    for trimmed in (False, True):
+        lens = np.full(n, L, dtype=np.int64)
+        if trimmed:
+            sel = rng.random(n) < 0.05
+            lens[sel] = rng.integers(20, L, size=int(sel.sum()))
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        host = ctx.gen_reads(int(offs[-1]), first_byte=3).cpu().numpy().copy()
+        host[int(offs[5]) + 7] = ord("N")
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k, offsets=offs)
+        g = ctx.canonical_reduce_host(ctx.to_device(host), n, L, k, _lib.HASH_LEX, k, 0, offsets=ctx.to_device(offs))
+        _check1(g, o, with_fw=False)
+
+
+def test_queue_block_survives_mixed_calls(ctx, orc):
+    """The bit-sliced scan leaves the queue block as it found it and kmx_canonical_reduce stops clearing it; every other user of
+    the ticket heads (histogram, materialise, the word-domain scan, the ragged scans, two-word k) clears for itself and leaves its
+    tickets behind.  Any order of calls must give the answers of a fresh context."""
+    from kmers_amd import _lib
+
+    k, L, n = 31, 150, 64 * 90 + 11
+    host = ctx.gen_reads(n * L, first_byte=11).cpu().numpy().copy()
+    host[100 * L + 5] = ord("N")
+    d = ctx.to_device(host)
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+    o9 = orc.canonical_reduce(host, n, L, 9, hasher_k=9)
+    o2 = orc.canonical_reduce2(host, n, L, 63, with_hash=True)
+    offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    d_offs = ctx.to_device(offs)
+    steps = [
+        lambda: _check1(ctx.canonical_reduce_host(d, n, L, k, _lib.HASH_LEX, k, 0), o, False),
+        lambda: _check1(ctx.canonical_reduce(d, n, L, k, _lib.HASH_LEX, k, 0), o, False),
+        lambda: ctx.histogram(d, n, L, k, _lib.HASH_LEX, k, 16),
+        lambda: _check1(ctx.canonical_reduce(d, n, L, 9, _lib.HASH_LEX, 9, 0), o9, False),     # the word-domain scan
+        lambda: ctx.canonical_windows(d, 2000, L, k, want=("canon",)),
+        lambda: _check2(ctx.canonical_reduce2(d, n, L, 63, with_hash=True), o2),
+        lambda: _check1(ctx.canonical_reduce_host(d, n, L, k, _lib.HASH_LEX, k, 0, offsets=d_offs), o, False),   # the gated pair
+    ]
+    rng = np.random.default_rng(99)
+    for _ in range(6):
+        for i in rng.permutation(len(steps)):
+            steps[i]()
+            steps[0]()
+            steps[1]()
+
+
+def test_reduce_host_many_in_a_row(ctx, orc):
+    """the token in the pinned words: a thousand calls of alternating sizes, every answer checked against the first of its size"""
+    from kmers_amd import _lib
+
+    k, L = 31, 150
+    sizes = [64 * 3 + 1, 5000, 64 * 700]
+    host = ctx.gen_reads(max(sizes) * L, first_byte=1).cpu().numpy().copy()
+    d = ctx.to_device(host)
+    want = {}
+    for n in sizes:
+        want[n] = orc.canonical_reduce(host[: n * L], n, L, k, hasher_k=k)
+    for i in range(1000):
+        n = sizes[i % 3]
+        _check1(ctx.canonical_reduce_host(d, n, L, k, _lib.HASH_LEX, k, 0), want[n], False)

@@ -1,10 +1,7 @@
 #!/bin/bash
-# scratch: the GPU session of the moment
-mkdir -p gpurun_out/r6ab
 R=$GRAFT_REPO_ROOT
-for rep in 1 2; do
-  (cd $R/tools/_variants/r5tree && python3 bench.py --config 4 --no-cpu-baseline --no-traffic --steps 5 --warmup 2 --sustain-steps 20 2>/dev/null | python3 $R/tools/bench_line.py "[r5 hist20]")
-  for v in default hsync hnomark hsyncnomark; do
-  python3 tools/bench_variant.py $v --config 4 --no-cpu-baseline --no-traffic --steps 5 --warmup 2 --sustain-steps 20 2>/dev/null | python3 tools/bench_line.py "[$v hist20]"
-  done
-done 2>&1 | tee $R/gpurun_out/r6ab/ab_hist2.txt
+mkdir -p $R/gpurun_out/r6sb
+timeout 2400 python3 -m pytest tests -m gpu -x -q > gpurun_out/r6sb/pytest_full.txt 2>&1
+tail -5 gpurun_out/r6sb/pytest_full.txt
+python3 tools/bench_small_batches.py > gpurun_out/r6sb/small6.txt 2>&1
+python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 300 > gpurun_out/r6sb/bench6.json 2> /dev/null

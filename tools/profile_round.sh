@@ -32,7 +32,7 @@ python3 bench.py --config 4 --dist-single --no-cpu-baseline --steps 5 --warmup 2
 KMX_BENCH_TEST_SHARED_GPU=1 python3 bench.py --gpus 2 --reads-per-gpu 20000000 --steps 5 --warmup 2 --sustain-steps 0 --no-traffic --cpu-baseline-seconds 8 > $out/bench_2ranks_shared_gpu.json 2> /dev/null
 KMX_BENCH_TEST_SHARED_GPU=1 python3 bench.py --gpus 2 --config 4 --reads-per-gpu 20000000 --steps 3 --warmup 1 --sustain-steps 0 --no-traffic --cpu-baseline-seconds 8 > $out/bench_2ranks_shared_gpu_hist20.json 2> /dev/null
 python3 bench.py --packed --no-cpu-baseline --no-traffic > $out/bench_packed.json 2> /dev/null
-for k in 13 17 21 25 27 29 31 33 41 47 51 55 63; do python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 200 -k $k 2>/dev/null | python3 tools/bench_line.py "k=$k"; done > $out/k_sweep.txt
+for k in 9 11 12 13 17 21 25 27 29 31 33 41 47 51 55 63; do python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 200 -k $k 2>/dev/null | python3 tools/bench_line.py "k=$k"; done > $out/k_sweep.txt
 for spec in "36 400000000" "50 300000000" "62 240000000" "75 200000000" "100 150000000" "112 130000000" "125 120000000" "150 100000000" "161 93000000" "170 88000000" "200 75000000" "208 72000000" "216 69000000" "224 66000000" "250 60000000" "256 58000000" "300 50000000" "1000 15000000" "10000 1500000"; do set -- $spec
   python3 bench.py --no-cpu-baseline --no-traffic --sustain-steps 100 --read-len $1 --reads-per-gpu $2 2>/dev/null | python3 tools/bench_line.py "L=$1"; done > $out/len_sweep.txt
 # two-word k on the long frames (round 4), and the settle-steps cross-check of the headline (30 = the default, 0 beside it)
