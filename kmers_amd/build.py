@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libkmx.so")
 # (the slowest translation units first: the pool starts them in this order, and the build is as long as its longest tail)
-SOURCES = ["kmx_sweep.hip", "kmx_hist.hip", "kmx_hist32.hip", "kmx_bitslice.hip", "kmx_scan.hip", "kmx_bitslice_k21.hip", "kmx_bitslice_k13_17.hip", "kmx_bitslice_k18_23.hip",
+SOURCES = ["kmx_sweep.hip", "kmx_hist.hip", "kmx_hist32.hip", "kmx_bitslice.hip", "kmx_scan.hip", "kmx_bitslice_k21.hip", "kmx_bitslice_k9_12.hip", "kmx_bitslice_k13_17.hip", "kmx_bitslice_k18_23.hip",
            "kmx_bitslice_k24_27.hip", "kmx_bitslice_k28_30.hip", "kmx_bitslice_k33_39.hip", "kmx_bitslice_k41_47.hip", "kmx_bitslice_k49_55.hip",
            "kmx_bitslice_k57_61.hip", "kmx_bitslice_k34_40.hip", "kmx_bitslice_k42_48.hip", "kmx_bitslice_k50_56.hip", "kmx_bitslice_k58_64.hip",
            "kmx_bitslice_ragged_k13_16.hip", "kmx_bitslice_ragged_k17_20.hip", "kmx_bitslice_ragged_k21_24.hip", "kmx_bitslice_ragged_k25_28.hip",

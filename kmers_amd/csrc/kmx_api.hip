@@ -145,7 +145,7 @@ hipError_t queue_clear(kmx_ctx* ctx, size_t bytes) {
 int prepare_dirty_flags(kmx_ctx* ctx, uint64_t n_reads, uint32_t k, bool any_k = false) {
     const uint64_t n_tiles = n_reads >> 6;
     uint8_t* buf = nullptr;
-    if (n_tiles && (any_k || (k >= 13 && k <= 31) || (k >= 33 && k <= 64))) {   // the k with a bit-sliced kernel (any_k: the word-domain scan's histogram sinks mark too)
+    if (n_tiles && (any_k || (k >= 9 && k <= 31) || (k >= 33 && k <= 64))) {   // the k with a bit-sliced kernel (any_k: the word-domain scan's histogram sinks mark too)
         if (8u * n_tiles > ctx->flags_bytes) {   // one 64-bit read mask per tile
             if (ctx->d_flags) {
                 (void)hipStreamSynchronize(ctx->stream);

@@ -114,6 +114,6 @@ hipError_t launch_scan_bitsliced2(const uint8_t* bases, u64 n_reads, u32 L, u32 
 
 // segments a uniform read of L bases is cut into by the bit-sliced scan (1: none, it fits a frame): what the caller sizes the
 // dirty-read masks from
-u64 bitsliced_segments_per_read(u32 L, u32 k) { return (L > 256u && k >= 13u && k <= 64u && k != 32u) ? bs_seg_plan(L, k).J : 1u; }
+u64 bitsliced_segments_per_read(u32 L, u32 k) { return (L > 256u && k >= 9u && k <= 64u && k != 32u) ? bs_seg_plan(L, k).J : 1u; }
 
 }  // namespace kmx

@@ -122,7 +122,7 @@ __device__ __forceinline__ bs_v8i fp4_operand_a(u32 m) {
 constexpr int bs_plane_dwords(int NW) { return 32 * NW + 16; }
 // rows of the next tile requested LATE (between pass 1 and pass 2 of phase D): see the kernel, "rows of the prefetch requested late"
 template <int K, int NW, int WPL, bool PACKED, bool RAGGED, bool SEG> constexpr int bs_late() {
-    return PACKED ? 0 : NW == 10 ? ((K > 32 || RAGGED || SEG) ? 5 : WPL > 4 ? (K <= 17 ? 0 : 1) : 0) : NW < 10 ? (K > 32 ? 0 : 3) : NW == 13 ? ((K <= 32 && !SEG) ? 3 : 7) : 8;
+    return PACKED ? 0 : NW == 10 ? ((K > 32 || RAGGED || SEG) ? 5 : WPL > 4 ? (K <= 17 ? 0 : 1) : 0) : NW < 10 ? (K > 32 ? 0 : 3) : (NW == 13 || NW == 11) ? ((K <= 32 && !SEG) ? 3 : 7) : 8;
 }
 // PARK (round 6): phase A leaves every chunk's validation word in LDS beside its packed word, and a tile with an invalid byte
 // looks its reads up there (30 instructions) instead of validating the tile a second time from w[] (150).  The second dword per
@@ -1630,6 +1630,10 @@ static hipError_t launch_bs_any(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
             // 161..208 bp (round 3): the 13-word frame -- 13 instead of 16 transposes per half-wave, 52 instead of 64 prefetch
             // registers (4 waves/SIMD), four fifths of the plane area
             const u32 mis13 = (reinterpret_cast<uintptr_t>(bases) & 15u) ? 1u : 0u;
+            // 161..176 bp (round 6): the 11-word frame -- reads of 161 bases filled 77 % of the 13-word frame's 208
+            // (0.70 of the roofline between 0.77 at 150 and 0.76 at 200 bases: profiles/r05_len_sweep.txt)
+            if (4u * L + mis13 <= 64u * 11u && W <= 160u)
+                return launch_bs<K, 11, 5, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
             if (4u * L + mis13 <= 64u * 13u) {
                 if (W <= 160u) return launch_bs<K, 13, 5, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
                 if (W <= 192u) return launch_bs<K, 13, 6, PACKED>(bases, n_reads, L, want_hash, want_sumfw, out, queue, n_cu, stream);
@@ -1731,7 +1735,7 @@ static hipError_t launch_bs_ragged_any(const uint8_t* bases, const u64* offsets,
     }
 // k with a bit-sliced kernel (u64 k-mers), ASCII and packed (SeqVector) input: 13..31
 #define KMX_BS_FOR_EACH_K(X) \
-    X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+    X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
 KMX_BS_FOR_EACH_K(KMX_BS_DECLARE_K)
 KMX_BS2_FOR_EACH_K(KMX_BS2_DECLARE_K)
 KMX_BSR_FOR_EACH_K(KMX_BSR_DECLARE_K)

@@ -468,3 +468,38 @@ def test_reduce_host_many_in_a_row(ctx, orc):
     for i in range(1000):
         n = sizes[i % 3]
         _check1(ctx.canonical_reduce_host(d, n, L, k, _lib.HASH_LEX, k, 0), want[n], False)
+
+
+# ------------------------------------------------------------------ the 11-word frame (uniform reads of 161..176 bases, round 6)
+@pytest.mark.parametrize("k", [13, 16, 17, 21, 24, 27, 31])
+@pytest.mark.parametrize("L", [161, 168, 175, 176])
+def test_frame_of_11_words(ctx, orc, k, L):
+    """both ends of the frame's range, every k family; W <= 160 takes the frame, k = 13..16 at 173..176 bases leave it (13-word frame);
+    from an unaligned base (one more chunk per tile: 176 bases then leave the frame too); clean and with invalid bytes"""
+    import torch
+    from kmers_amd import _lib
+
+    n = 64 * 150 + 9
+    rng = np.random.default_rng(31 * k + L)
+    host = ctx.gen_reads(n * L, first_byte=k + L).cpu().numpy().copy()
+    for dirty in (False, True):
+        if dirty:
+            _dirty(host, n, np.arange(n, dtype=np.int64) * L, np.full(n, L), rng, 0.03)
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        for lead in (0, 5):
+            big = torch.empty(n * L + 16, dtype=torch.uint8, device="cuda")
+            big[lead : lead + n * L] = torch.from_numpy(host).cuda()
+            g = ctx.canonical_reduce(big[lead : lead + n * L], n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+            _check1(g, o)
+
+
+def test_frame_of_11_words_at_size(ctx, orc):
+    """every wave scans many tiles (the fold of the fp32 accumulators, the ticket heads running dry): 3e6 reads of 170 bases"""
+    from kmers_amd import _lib
+
+    k, L, n = 31, 170, 3_000_000 + 21
+    host = ctx.gen_reads(n * L, first_byte=9).cpu().numpy().copy()
+    host[12345 * L + 7] = ord("N")
+    o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+    g = ctx.canonical_reduce(ctx.to_device(host), n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+    _check1(g, o)
