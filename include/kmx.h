@@ -150,7 +150,7 @@ int kmx_canonical_reduce(kmx_ctx *ctx, const kmx_reads *reads, uint32_t k, uint3
 
 /* The same call with its answer in HOST memory when it returns (round 6): what a caller that reduces one small
  * batch at a time -- the reference's iterator over one read set, canonical_kmer_iterator.rs:42-116 -- pays is
- * the launch and the wait, not the bytes.  Uniform reads of up to 256 bases, k in [13,31], hasher NONE or
+ * the launch and the wait, not the bytes.  Uniform reads of up to 256 bases, k in [9,31], hasher NONE or
  * LEX(hasher_k == k): ONE kernel launch whose last block writes the summary to pinned host words this call
  * watches (1e5 reads of 150 bases: ~25 us against ~70 us for kmx_canonical_reduce + kmx_memcpy_d2h); a batch
  * with invalid bytes adds the sweep and a copy.  Every other input: kmx_canonical_reduce + the copy.
