@@ -23,7 +23,7 @@ LIB = os.path.join(HERE, "libkmx.so")
 SOURCES = ["kmx_sweep.hip", "kmx_hist.hip", "kmx_hist32.hip", "kmx_bitslice.hip", "kmx_scan.hip", "kmx_bitslice_k21.hip", "kmx_bitslice_k9_12.hip", "kmx_bitslice_k13_17.hip", "kmx_bitslice_k18_23.hip",
            "kmx_bitslice_k24_27.hip", "kmx_bitslice_k28_30.hip", "kmx_bitslice_k33_39.hip", "kmx_bitslice_k41_47.hip", "kmx_bitslice_k49_55.hip",
            "kmx_bitslice_k57_61.hip", "kmx_bitslice_k34_40.hip", "kmx_bitslice_k42_48.hip", "kmx_bitslice_k50_56.hip", "kmx_bitslice_k58_64.hip",
-           "kmx_bitslice_ragged_k13_16.hip", "kmx_bitslice_ragged_k17_20.hip", "kmx_bitslice_ragged_k21_24.hip", "kmx_bitslice_ragged_k25_28.hip",
+           "kmx_bitslice_ragged_k9_12.hip", "kmx_bitslice_ragged_k13_16.hip", "kmx_bitslice_ragged_k17_20.hip", "kmx_bitslice_ragged_k21_24.hip", "kmx_bitslice_ragged_k25_28.hip",
            "kmx_bitslice_ragged_k29_31.hip", "kmx_bitslice_ragged2_k33_36.hip", "kmx_bitslice_ragged2_k37_40.hip", "kmx_bitslice_ragged2_k41_44.hip", "kmx_bitslice_ragged2_k45_48.hip", "kmx_bitslice_ragged2_k49_52.hip", "kmx_bitslice_ragged2_k53_56.hip", "kmx_bitslice_ragged2_k57_60.hip", "kmx_bitslice_ragged2_k61_64.hip", "kmx_generic.hip", "kmx_segments.hip", "kmx_elem.hip", "kmx_seqvec.hip", "kmx_minimizers.hip", "kmx_fastx.hip", "kmx_comm.hip", "kmx_api.hip"]
 HEADERS = [os.path.join(CSRC, "kmx_device.h"), os.path.join(CSRC, "kmx_hist_part.h"), os.path.join(CSRC, "kmx_bitslice_kernel.h"), os.path.join(CSRC, "kmx_internal.h"), os.path.join(CSRC, "kmx_scan_kernel.h"),
            os.path.join(HERE, "..", "include", "kmx.h")]

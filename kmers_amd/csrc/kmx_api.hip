@@ -527,7 +527,7 @@ static int reduce_impl(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_
         const uint32_t Lh = reads->read_len ? reads->read_len : 160u;
         // (only where BOTH bit-sliced launchers take the call: the ragged one needs a 16-byte aligned base -- with a misaligned
         // base the uniform scan used to be enqueued behind the gate and the generic kernel then counted the batch a second time)
-        if (reads->d_offsets && !want_sumfw && k >= 13 && k <= 31 && Lh >= k && Lh <= 256 && reads->read_len <= 256 &&
+        if (reads->d_offsets && !want_sumfw && k >= 9 && k <= 31 && Lh >= k && Lh <= 256 && reads->read_len <= 256 &&
             (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
             uint32_t* gate = reinterpret_cast<uint32_t*>(ctx->d_scratch + 16 + 513);
             KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 1, 1, ctx->stream));
@@ -555,7 +555,7 @@ static int reduce_impl(kmx_ctx* ctx, const kmx_reads* reads, uint32_t k, uint32_
                 KMX_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gate), 0, 2, ctx->stream));
             }
         }
-        if (!handled && reads->d_offsets && reads->read_len > 256 && k >= 13 && k <= 31 &&
+        if (!handled && reads->d_offsets && reads->read_len > 256 && k >= 9 && k <= 31 &&
             (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
             // Long ragged reads (a length bound above the frames: PacBio / ONT reads, contigs), round 4: cut into overlapping
             // segments on the device (kmx_segments.hip) and scanned by the ragged bit-sliced kernel as reads of their own.  Two

@@ -1706,9 +1706,9 @@ static hipError_t launch_bs_ragged_any(const uint8_t* bases, const u64* offsets,
                                      unsigned long long* queue, int n_cu, hipStream_t stream, u32 want_sumfw, const u64* ends) { \
         return launch_bs_ragged_any<K>(bases, offsets, n_reads, Lf, want_hash, out, queue, n_cu, stream, want_sumfw, ends);  \
     }
-// k with a bit-sliced kernel for ragged reads: 13..31, like the uniform kernel
+// k with a bit-sliced kernel for ragged reads: 9..31, like the uniform kernel
 #define KMX_BSR_FOR_EACH_K(X) \
-    X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+    X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
 // ... and two-word k (33..64; round 4): ONE instantiation each, the 10-word frame at four windows per lane -- a two-word k leaves
 // at most 128 windows in 160 bases; the window blocks past W are skipped at run time
 #define KMX_BSR2_DECLARE_K(K) \

@@ -503,3 +503,47 @@ def test_frame_of_11_words_at_size(ctx, orc):
     o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
     g = ctx.canonical_reduce(ctx.to_device(host), n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
     _check1(g, o)
+
+
+# ------------------------------------------------------------------ k = 9..12 on the bit-sliced scan (round 6; the word-domain scan before)
+@pytest.mark.parametrize("k", [9, 10, 11, 12])
+def test_small_k_on_the_bitsliced_scan(ctx, orc, k):
+    """every frame (reads of 36 .. 256 bases), segments of longer reads, reads behind offsets (with a bound, without, trimmed, a bound
+    above the frames: segments cut on the device), invalid bytes everywhere, the forward sum"""
+    from kmers_amd import _lib
+
+    rng = np.random.default_rng(k)
+    for L in (36, 80, 100, 128, 150, 170, 200, 256, 300, 1000):
+        n = 64 * 60 + 7 if L <= 256 else 900
+        host = ctx.gen_reads(n * L, first_byte=k + L).cpu().numpy().copy()
+        _dirty(host, n, np.arange(n, dtype=np.int64) * L, np.full(n, L), rng, 0.03)
+        o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+        g = ctx.canonical_reduce(ctx.to_device(host), n, L, k, _lib.HASH_LEX, k, _lib.REDUCE_SUM_FW)
+        _check1(g, o)
+        g = ctx.canonical_reduce_host(ctx.to_device(host), n, L, k, _lib.HASH_LEX, k, 0)
+        _check1(g, o, with_fw=False)
+    n = 64 * 80 + 3
+    for bound, lo, hi in ((150, 20, 151), (0, 5, 161), (250, 100, 251), (100, 0, 101), (2000, 200, 2001)):
+        lens = rng.integers(lo, hi, n)
+        lens[::3] = hi - 1
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        host = ctx.gen_reads(int(offs[-1]), first_byte=k).cpu().numpy().copy()
+        _dirty(host, n, offs[:-1].astype(np.int64), lens, rng, 0.03)
+        o = orc.canonical_reduce(host, n, bound, k, hasher_k=k, offsets=offs)
+        for flags in (0, _lib.REDUCE_SUM_FW):
+            g = ctx.canonical_reduce(ctx.to_device(host), n, bound, k, _lib.HASH_LEX, k, flags, offsets=ctx.to_device(offs))
+            _check1(g, o, with_fw=bool(flags))
+
+
+def test_small_k_packed(ctx, orc):
+    """SeqVector input (2-bit packed): k = 9..12 take the bit-sliced scan too"""
+    from kmers_amd import _lib
+
+    for k in (9, 12):
+        for L in (100, 150):
+            n = 64 * 50 + 11
+            host = ctx.gen_reads(n * L, first_byte=k).cpu().numpy().copy()
+            o = orc.canonical_reduce(host, n, L, k, hasher_k=k)
+            words = ctx.seqvec_from_bytes(ctx.to_device(host))
+            g = ctx.seqvec_canonical_reduce(words, n, L, k, _lib.HASH_LEX, k)
+            _check1(g, o, with_fw=False)
