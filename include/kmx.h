@@ -215,7 +215,8 @@ int kmx_hash_words(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint32_t hash
  * DefaultHasher::new() / BuildHasherDefault: key0 = key1 = 0; RandomState: its pair of random keys, which the caller holds.
  * The algorithm lives in Rust's standard library, not in the crate: restated from the SipHash paper (Aumasson, Bernstein 2012);
  * the restatement reproduces the paper's SipHash-2-4 test vectors through the same round function (tests/test_oracle_golden.py),
- * and no reference value for 1-3 exists in the crate (its two tests check properties): parity is pinned to that extent. */
+ * its 1-3 instance the first row of Rust's own SipHasher13 test table (library/core/tests/hash/sip.rs); no reference value for
+ * 1-3 exists in the crate itself (its two tests check properties): parity is pinned to that extent. */
 int kmx_hash_words_sip13(kmx_ctx *ctx, const uint64_t *d_in, uint64_t n, uint64_t key0, uint64_t key1, uint64_t *d_out);
 
 /* CanonicalKmer::get_word_equivalency (canonical_kmer.rs:152-161): out[i] in KMX_{NO,IDENTITY,TWIN}_MATCH */
