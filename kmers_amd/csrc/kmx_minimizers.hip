@@ -15,6 +15,8 @@
 //     written by consecutive threads.
 #include "kmx_device.h"
 
+#include <type_traits>
+
 namespace kmx {
 
 __device__ __forceinline__ u64 mmr_field(const u32* __restrict__ a, u32 bitoff, u32 nbits /* <= 56 */) {
@@ -22,6 +24,12 @@ __device__ __forceinline__ u64 mmr_field(const u32* __restrict__ a, u32 bitoff, 
     const u64 lo = (u64)a[q] | ((u64)a[q + 1u] << 32);
     const u64 v = sh ? ((lo >> sh) | ((u64)a[q + 2u] << (64u - sh))) : lo;
     return v & ((1ull << nbits) - 1ull);
+}
+
+// ... and a field of at most 25 bits: two dwords, one funnel shift
+__device__ __forceinline__ u32 mmr_field32(const u32* __restrict__ a, u32 bitoff, u32 nbits /* <= 25 */) {
+    const u32 q = bitoff >> 5, sh = bitoff & 31u;
+    return __builtin_amdgcn_alignbit(a[q + 1u], a[q], sh) & ((1u << nbits) - 1u);
 }
 
 // how the reads of a batch lie: read R of the kernel's index space = piece (R % J) of read R / J (J = 1: the reads themselves)
@@ -34,12 +42,16 @@ struct MmrGeom {
 };
 
 // MODE 0: identity hasher, 1: LexHasher(hk == w), 2: LexHasher(any hk).  RAGGED: reads behind offsets (J == 1).
-template <int THREADS, int RB, int MODE, bool RAGGED>
+// K32 (round 6): hash and position fit ONE dword (hash bits + 8 <= 32: l-mers of up to 12 bases) -- the keys are u32, a radix-4 pass is
+// four dword reads, a v_min3_u32 and a v_min_u32 where 64-bit keys cost three compares and six selects, and a field is two dwords and
+// one funnel shift: the kernel is bound by VALU issue (profiles/r06_pmc_minimizers.txt), k = 21 / w = 11 3.3 -> see there.
+template <int THREADS, int RB, int MODE, bool RAGGED, bool K32 = false>
 __global__ void __launch_bounds__(THREADS)
 minimizers_reads_kernel(const uint8_t* __restrict__ bases, u64 total_bytes, const MmrGeom geo, u32 Lmax, u32 k, u32 w, u32 hk,
                         u64* __restrict__ out_word, u32* __restrict__ out_pos, unsigned long long* __restrict__ first_bad) {
     static_assert(THREADS == 16 * RB, "16 threads per read");   // (and a piece is at most 256 bases = 16 + 2 dwords: two per thread)
-    extern __shared__ __attribute__((aligned(16))) u64 hs[];   // keys [2][RB][NLS], then FW [RB][ND], RV [RB][ND] (u32), then the reads' geometry
+    using key_t = std::conditional_t<K32, u32, u64>;
+    extern __shared__ __attribute__((aligned(16))) u64 hs[];   // keys [2][RB][NLS] (8 bytes each reserved, K32 uses half), then FW [RB][ND], RV [RB][ND] (u32), then the reads' geometry
     const u32 NLS = Lmax - w + 1u, span = k - w + 1u;
     const u32 ND = ((2u * Lmax + 31u) >> 5) + 2u;               // dwords of a staged read (+2: the field reads look ahead)
     u32* FW = reinterpret_cast<u32*>(hs + 2u * RB * NLS);
@@ -62,7 +74,7 @@ minimizers_reads_kernel(const uint8_t* __restrict__ bases, u64 total_bytes, cons
             q.len = (u32)(o1 - o0 > (u64)Lmax ? 0u : o1 - o0);        // (a read above the bound: the caller took another kernel)
             q.slot = geo.win_offsets[R];
         } else {
-            const u64 rd = R / geo.J;
+            const u64 rd = geo.J == 1u ? R : R / geo.J;      // (whole reads: no 64-bit division per thread and iteration)
             const u32 j = (u32)(R - rd * geo.J);
             q.sp = bases + rd * (u64)geo.L + (u64)j * geo.T;
             const u32 left = geo.L - j * geo.T;                         // bases from the piece's first
@@ -92,8 +104,8 @@ minimizers_reads_kernel(const uint8_t* __restrict__ bases, u64 total_bytes, cons
     request(cur);
     for (u64 r0 = (u64)blockIdx.x * RB; r0 < n_pieces; r0 += (u64)gridDim.x * RB) {
         const u32 nr = (u32)(n_pieces - r0 < RB ? n_pieces - r0 : RB);
-        u64* A = hs;
-        u64* B = hs + RB * NLS;
+        key_t* A = reinterpret_cast<key_t*>(hs);
+        key_t* B = reinterpret_cast<key_t*>(hs + RB * NLS);
         const uint8_t* const sp = cur.sp;
         const u32 len = cur.len;
         if (j16 == 0u) {
@@ -154,13 +166,23 @@ minimizers_reads_kernel(const uint8_t* __restrict__ bases, u64 total_bytes, cons
         const u32 NL = len >= w ? len - w + 1u : 0u;             // l-mers of the piece
         if (r < nr) {
             for (u32 p = j16; p < NL; p += 16u) {
-                u64 h;
-                if (MODE == 1) h = mmr_field(RV + r * ND, 2u * (len - p - w), 2u * w);
-                else {
-                    const u64 lm = mmr_field(FW + r * ND, 2u * p, 2u * w);
-                    h = MODE == 0 ? lm : lex_hash(lm, hk);
+                if constexpr (K32) {
+                    u32 h;
+                    if (MODE == 1) h = mmr_field32(RV + r * ND, 2u * (len - p - w), 2u * w);
+                    else {
+                        const u32 lm = mmr_field32(FW + r * ND, 2u * p, 2u * w);
+                        h = MODE == 0 ? lm : revgroups32(lm) >> (32u - 2u * hk);      // (= lex_hash on a value of one dword)
+                    }
+                    A[r * NLS + p] = (h << 8) | p;
+                } else {
+                    u64 h;
+                    if (MODE == 1) h = mmr_field(RV + r * ND, 2u * (len - p - w), 2u * w);
+                    else {
+                        const u64 lm = mmr_field(FW + r * ND, 2u * p, 2u * w);
+                        h = MODE == 0 ? lm : lex_hash(lm, hk);
+                    }
+                    A[r * NLS + p] = (h << 8) | p;
                 }
-                A[r * NLS + p] = (h << 8) | p;
             }
         }
         __syncthreads();
@@ -170,43 +192,72 @@ minimizers_reads_kernel(const uint8_t* __restrict__ bases, u64 total_bytes, cons
         while (4u * lenw <= span) {
             if (r < nr) {
                 for (u32 p = j16; p < NL; p += 16u) {
-                    const u64* const ap = A + r * NLS + p;
-                    u64 m = ap[0];
-                    const u64 b = p + lenw < NL ? ap[lenw] : m, c = p + 2u * lenw < NL ? ap[2u * lenw] : m, d = p + 3u * lenw < NL ? ap[3u * lenw] : m;
+                    // (past the piece's last key: that key once more -- a minimum does not mind, and one v_min_u32 on the index is a third of
+                    // a compare and two selects on a 64-bit key)
+                    const key_t* const ap = A + r * NLS + p;
+                    const u32 room = NL - 1u - p;
+                    key_t m = ap[0];
+                    const key_t b = ap[lenw < room ? lenw : room], c = ap[2u * lenw < room ? 2u * lenw : room], d = ap[3u * lenw < room ? 3u * lenw : room];
                     m = m < b ? m : b;
-                    const u64 m2 = c < d ? c : d;
+                    const key_t m2 = c < d ? c : d;
                     B[r * NLS + p] = m < m2 ? m : m2;
                 }
             }
             __syncthreads();
-            u64* t = A; A = B; B = t;
+            key_t* t = A; A = B; B = t;
             lenw *= 4u;
         }
         if (2u * lenw <= span) {
             if (r < nr) {
                 for (u32 p = j16; p < NL; p += 16u) {
-                    const u64 a = A[r * NLS + p];
-                    const u64 b = p + lenw < NL ? A[r * NLS + p + lenw] : a;
+                    const key_t a = A[r * NLS + p];
+                    const u32 room = NL - 1u - p;
+                    const key_t b = A[r * NLS + p + (lenw < room ? lenw : room)];
                     B[r * NLS + p] = a < b ? a : b;
                 }
             }
             __syncthreads();
-            u64* t = A; A = B; B = t;
+            key_t* t = A; A = B; B = t;
             lenw *= 2u;
         }
         const u32 second = span - lenw;      // the window [i, i+span) = [i, i+lenw) u [i+second, i+second+lenw)
         const u32 total = CUM[RB];
-        for (u32 e = threadIdx.x; e < total; e += THREADS) {
+        bool done = false;
+        if constexpr (!RAGGED) {
+            if (geo.J == 1u) {
+                // reads of ONE length, whole: k-mer e of the block is k-mer e % Wk of its read e / Wk (a multiply instead of a search through
+                // CUM), and the block's slots are one run from a wave-uniform first slot -- the stores take a 32-bit index (round 6: the
+                // kernel is bound by VALU issue, 289 instructions per read: profiles/r06_pmc_minimizers.txt)
+                const u32 Wk = geo.L - k + 1u, magic = Wk > 1u ? (u32)(0x100000000ull / Wk) + 1u : 0u;   // e < 16 x 256: e / Wk = umulhi(e, magic) (Wk = 1: e itself)
+                u64* const ow = out_word + r0 * (u64)Wk;
+                u32* const op = out_pos + r0 * (u64)Wk;
+                for (u32 e = threadIdx.x; e < total; e += THREADS) {
+                    const u32 rr = Wk > 1u ? __umulhi(e, magic) : e, i = e - rr * Wk;
+                    const key_t a = A[rr * NLS + i], b = A[rr * NLS + i + second];
+                    const key_t key = a < b ? a : b;
+                    const u32 pos = (u32)(key & 0xFFu);
+                    u64 word;
+                    if constexpr (K32) word = MODE == 0 ? (u64)(key >> 8) : MODE == 1 ? (u64)(revgroups32((u32)(key >> 8)) >> (32u - 2u * w)) : (u64)mmr_field32(FW + rr * ND, 2u * pos, 2u * w);
+                    else word = MODE == 0 ? (u64)(key >> 8) : MODE == 1 ? lex_hash((u64)(key >> 8), w) : mmr_field(FW + rr * ND, 2u * pos, 2u * w);
+                    __builtin_nontemporal_store(word, &ow[e]);
+                    __builtin_nontemporal_store(pos, &op[e]);
+                }
+                done = true;
+            }
+        }
+        for (u32 e = threadIdx.x; !done && e < total; e += THREADS) {
             u32 rr = 0;      // the piece that holds k-mer e of the block (CUM is non-decreasing: four halvings)
 #pragma unroll
             for (u32 step = RB / 2u; step != 0u; step >>= 1) rr += e >= CUM[rr + step] ? step : 0u;
             const u32 i = e - CUM[rr];
-            const u64 a = A[rr * NLS + i], b = A[rr * NLS + i + second];
-            const u64 key = a < b ? a : b;
+            const key_t a = A[rr * NLS + i], b = A[rr * NLS + i + second];
+            const key_t key = a < b ? a : b;
             const u32 pos = (u32)(key & 0xFFu);
             const u64 slot = SLOT[rr] + i;
             // the l-mer itself: the key's hash IS it (identity), or it with its bases reversed (LexHasher(w) on w bases)
-            const u64 word = MODE == 0 ? key >> 8 : MODE == 1 ? lex_hash(key >> 8, w) : mmr_field(FW + rr * ND, 2u * pos, 2u * w);
+            u64 word;
+            if constexpr (K32) word = MODE == 0 ? (u64)(key >> 8) : MODE == 1 ? (u64)(revgroups32((u32)(key >> 8)) >> (32u - 2u * w)) : (u64)mmr_field32(FW + rr * ND, 2u * pos, 2u * w);
+            else word = MODE == 0 ? (u64)(key >> 8) : MODE == 1 ? lex_hash((u64)(key >> 8), w) : mmr_field(FW + rr * ND, 2u * pos, 2u * w);
             __builtin_nontemporal_store(word, &out_word[slot]);
             __builtin_nontemporal_store(pos + PBASE[rr], &out_pos[slot]);
         }
@@ -281,9 +332,10 @@ hipError_t launch_minimizers_reads(const uint8_t* bases, u64 total_bytes, const 
         const u32 NLS = Lmax - w + 1u, ND = ((2u * Lmax + 31u) >> 5) + 2u;
         const size_t lds = (size_t)2u * RB * NLS * 8u + (size_t)(2u * RB * ND + ((RB * ND) & 1u)) * 4u + (size_t)RB * 8u + (size_t)(3u * RB + 1u) * 4u + 16u;
         const int mode = hasher != KMX_HASH_LEX ? 0 : (hk == w ? 1 : 2);
+        const bool k32 = hash_bits + 8u <= 32u && 2u * w + 8u <= 32u;   // hash and position in one dword (and the l-mer itself in 24 bits)
 #define KMX_MMR_LAUNCH(M, RG)                                                                                                          \
     do {                                                                                                                               \
-        auto kern = minimizers_reads_kernel<256, RB, M, RG>;                                                                           \
+        auto kern = k32 ? minimizers_reads_kernel<256, RB, M, RG, true> : minimizers_reads_kernel<256, RB, M, RG, false>;              \
         if (lds > 64u * 1024u) {                                                                                                       \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                                             \

@@ -14,6 +14,8 @@
 // CanonicalKmer::append_base, canonical_kmer.rs:90-94).
 #include "kmx_device.h"
 
+#include <type_traits>
+
 // (the per-window stores of the sliding-minimum kernel carry the nt hint (+2 ... +6 %: profiles/r03_nt_stores.txt)
 namespace kmx {
 
@@ -204,23 +206,30 @@ __device__ __forceinline__ u64 lds_field(const u32* __restrict__ a, u32 bitoff, 
     const u64 v = sh ? ((lo >> sh) | ((u64)a[q + 2u] << (64u - sh))) : lo;
     return v & ((1ull << nbits) - 1ull);
 }
-template <int THREADS, int RB, int MODE>
+// ... and a field of at most 25 bits: two dwords, one funnel shift
+__device__ __forceinline__ u32 lds_field32(const u32* __restrict__ a, u32 bitoff, u32 nbits /* <= 25 */) {
+    const u32 q = bitoff >> 5, sh = bitoff & 31u;
+    return __builtin_amdgcn_alignbit(a[q + 1u], a[q], sh) & ((1u << nbits) - 1u);
+}
+// K32 (round 6): hash and position fit one dword (hash bits + 8 <= 32, l-mers of up to 12 bases): u32 keys -- see kmx_minimizers.hip
+template <int THREADS, int RB, int MODE, bool K32 = false>
 __global__ void __launch_bounds__(THREADS)
 seqvec_minimizers_slide_kernel(const u64* __restrict__ words, u64 n_reads, u32 L, u32 k, u32 w, u32 hk,
                                u64* __restrict__ out_word, u32* __restrict__ out_pos) {
     static_assert(THREADS == 16 * RB, "16 threads per read");
-    extern __shared__ __attribute__((aligned(16))) u64 hs[];   // keys [2][RB][NL], then FW [RB][ND], RV [RB][ND] (u32)
+    using key_t = std::conditional_t<K32, u32, u64>;
+    extern __shared__ __attribute__((aligned(16))) u64 hs[];   // keys [2][RB][NL] (8 bytes each reserved, K32 uses half), then FW [RB][ND], RV [RB][ND] (u32)
     const u32 NL = L - w + 1u, W = L - k + 1u, span = k - w + 1u;
     const u32 ND = ((2u * L + 31u) >> 5) + 2u;                  // dwords of a staged read (+2: the field reads look ahead)
     u32* FW = reinterpret_cast<u32*>(hs + 2u * RB * NL);
     u32* RV = FW + RB * ND;
     const u64 n_words = (n_reads * (u64)L + 31u) >> 5;
     const u32 r = threadIdx.x >> 4, j16 = threadIdx.x & 15u;
-    const u32 recipW = ((1u << 24) + W - 1u) / W;               // e / W for e < RB*W <= 2^12 (e * W < 2^24)
+    const u32 recipW = W > 1u ? (u32)(0x100000000ull / W) + 1u : 0u;   // e / W = umulhi(e, recipW) for e < RB * W <= 2^12 (W = 1: e itself)
     for (u64 r0 = (u64)blockIdx.x * RB; r0 < n_reads; r0 += (u64)gridDim.x * RB) {
         const u32 nr = (u32)(n_reads - r0 < RB ? n_reads - r0 : RB);
-        u64* A = hs;
-        u64* B = hs + RB * NL;
+        key_t* A = reinterpret_cast<key_t*>(hs);
+        key_t* B = reinterpret_cast<key_t*>(hs + RB * NL);
         // the read, realigned: dword d = its bits [32d, 32d+32) (whatever follows the read in the vector comes along: never looked at)
         if (r < nr) {
             const u64 bit0 = 2u * (r0 + r) * (u64)L;
@@ -247,37 +256,71 @@ seqvec_minimizers_slide_kernel(const u64* __restrict__ words, u64 n_reads, u32 L
         if (MODE == 1) __syncthreads();
         if (r < nr) {
             for (u32 p = j16; p < NL; p += 16u) {
-                u64 h;
-                if (MODE == 1) h = lds_field(RV + r * ND, 2u * (L - p - w), 2u * w);
-                else {
-                    const u64 lm = lds_field(FW + r * ND, 2u * p, 2u * w);
-                    h = MODE == 0 ? lm : lex_hash(lm, hk);
+                if constexpr (K32) {
+                    u32 h;
+                    if (MODE == 1) h = lds_field32(RV + r * ND, 2u * (L - p - w), 2u * w);
+                    else {
+                        const u32 lm = lds_field32(FW + r * ND, 2u * p, 2u * w);
+                        h = MODE == 0 ? lm : revgroups32(lm) >> (32u - 2u * hk);      // (= lex_hash on a value of one dword)
+                    }
+                    A[r * NL + p] = (h << 8) | p;
+                } else {
+                    u64 h;
+                    if (MODE == 1) h = lds_field(RV + r * ND, 2u * (L - p - w), 2u * w);
+                    else {
+                        const u64 lm = lds_field(FW + r * ND, 2u * p, 2u * w);
+                        h = MODE == 0 ? lm : lex_hash(lm, hk);
+                    }
+                    A[r * NL + p] = (h << 8) | p;
                 }
-                A[r * NL + p] = (h << 8) | p;
             }
         }
         __syncthreads();
+        // minima over len consecutive keys: len x 4 per pass while that fits the span (two passes at span = 17 where doubling took four:
+        // half the LDS writes and block barriers), then one doubling if there is room.  Past the read's last key: that key once more --
+        // a minimum does not mind, and one v_min_u32 on the index is a third of a compare and two selects on a 64-bit key.  (Round 6,
+        // as kmx_minimizers.hip: the kernel is bound by VALU issue, profiles/r06_pmc_minimizers.txt.)
         u32 len = 1;
-        while (2u * len <= span) {
+        while (4u * len <= span) {
             if (r < nr) {
                 for (u32 p = j16; p < NL; p += 16u) {
-                    const u64 a = A[r * NL + p];
-                    const u64 b = p + len < NL ? A[r * NL + p + len] : a;
+                    const key_t* const ap = A + r * NL + p;
+                    const u32 room = NL - 1u - p;
+                    key_t m = ap[0];
+                    const key_t b = ap[len < room ? len : room], c = ap[2u * len < room ? 2u * len : room], d = ap[3u * len < room ? 3u * len : room];
+                    m = m < b ? m : b;
+                    const key_t m2 = c < d ? c : d;
+                    B[r * NL + p] = m < m2 ? m : m2;
+                }
+            }
+            __syncthreads();
+            key_t* t = A; A = B; B = t;
+            len *= 4u;
+        }
+        if (2u * len <= span) {
+            if (r < nr) {
+                for (u32 p = j16; p < NL; p += 16u) {
+                    const u32 room = NL - 1u - p;
+                    const key_t a = A[r * NL + p];
+                    const key_t b = A[r * NL + p + (len < room ? len : room)];
                     B[r * NL + p] = a < b ? a : b;
                 }
             }
             __syncthreads();
-            u64* t = A; A = B; B = t;
+            key_t* t = A; A = B; B = t;
             len *= 2u;
         }
         const u32 second = span - len;      // the window [i, i+span) = [i, i+len) u [i+second, i+second+len)
+        // (the block's slots are one run from a wave-uniform first slot: the stores take a 32-bit index)
+        u64* const ow = out_word + r0 * (u64)W;
+        u32* const op = out_pos + r0 * (u64)W;
         for (u32 e = threadIdx.x; e < nr * W; e += THREADS) {
-            const u32 rr = (u32)(((u64)e * recipW) >> 24), i = e - rr * W;
-            const u64 a = A[rr * NL + i], b = A[rr * NL + i + second];
+            const u32 rr = W > 1u ? __umulhi(e, recipW) : e, i = e - rr * W;
+            const key_t a = A[rr * NL + i], b = A[rr * NL + i + second];
             const u32 pos = (u32)((a < b ? a : b) & 0xFFu);
-            const u64 slot = (r0 + rr) * (u64)W + i;
-            __builtin_nontemporal_store(lds_field(FW + rr * ND, 2u * pos, 2u * w), &out_word[slot]);
-            __builtin_nontemporal_store(pos, &out_pos[slot]);
+            const u64 lmer = K32 ? (u64)lds_field32(FW + rr * ND, 2u * pos, 2u * w) : lds_field(FW + rr * ND, 2u * pos, 2u * w);
+            __builtin_nontemporal_store(lmer, &ow[e]);
+            __builtin_nontemporal_store(pos, &op[e]);
         }
         __syncthreads();
     }
@@ -333,9 +376,10 @@ hipError_t launch_seqvec_minimizers(const u64* words, u64 n_reads, u32 L, u32 k,
         const u32 ND = ((2u * L + 31u) >> 5) + 2u;
         const size_t lds = (size_t)2u * RB * NL * 8u + (size_t)2u * RB * ND * 4u;
         const int mode = hasher != KMX_HASH_LEX ? 0 : (hk == w ? 1 : 2);
-        auto k0 = seqvec_minimizers_slide_kernel<256, RB, 0>;
-        auto k1 = seqvec_minimizers_slide_kernel<256, RB, 1>;
-        auto k2 = seqvec_minimizers_slide_kernel<256, RB, 2>;
+        const bool k32 = hash_bits + 8u <= 32u && 2u * w + 8u <= 32u;   // hash and position in one dword (and the l-mer itself in 24 bits)
+        auto k0 = k32 ? seqvec_minimizers_slide_kernel<256, RB, 0, true> : seqvec_minimizers_slide_kernel<256, RB, 0, false>;
+        auto k1 = k32 ? seqvec_minimizers_slide_kernel<256, RB, 1, true> : seqvec_minimizers_slide_kernel<256, RB, 1, false>;
+        auto k2 = k32 ? seqvec_minimizers_slide_kernel<256, RB, 2, true> : seqvec_minimizers_slide_kernel<256, RB, 2, false>;
         auto kern = mode == 0 ? k0 : mode == 1 ? k1 : k2;
         if (lds > 64u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
