@@ -69,7 +69,7 @@ for trace_dir, needle, label, bench in (("trace", "scan_bitsliced_kernel<31, 10,
         r = b["roofline"]
         out.append(f"* **{label}** `{st['kernel']}`: n={st['n']} full-size launches, avg {st['avg_ms']:.3f} ms, median {st['median_ms']:.3f}, "
                    f"min {st['min_ms']:.3f}, max {st['max_ms']:.3f} (kernel-trace timestamps, warm-ups included); same run, HIP events in bench.py over "
-                   f"the 20 timed steps: avg {r['avg_kernel_ms']:.3f} ms (scan + the idle rolling kernel) -> {r['achieved']:.0f} GB/s algorithmic = "
+                   f"the 20 timed steps: avg {r['avg_kernel_ms']:.3f} ms (scan + the idle sweep) -> {r['achieved']:.0f} GB/s algorithmic = "
                    f"**{100 * r['frac']:.1f} %** of 8 TB/s, {100 * r['frac_of_same_run_stream_read']:.1f} % of the same-run read stream ({r['same_run_stream_read_GBps']:.0f} GB/s).")
 h = full_launch_stats("trace_hist20", "SinkHistPart")
 if h:
