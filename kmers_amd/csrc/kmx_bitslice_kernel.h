@@ -1,4 +1,4 @@
-// kmx_bitslice_kernel.h -- K1b: bit-sliced canonical k-mer scan (the headline kernel: every k from 13 to 64).
+// kmx_bitslice_kernel.h -- K1b: bit-sliced canonical k-mer scan (the headline kernel: every k from 9 to 64).
 //
 // Why: on gfx950 only the simplest VALU ops (v_and/or/xor/not, v_lshrrev, v_add_u32, v_bitop3_b32)
 // issue at 32 lanes/clk; v_alignbit, v_perm, v_cmp*, v_cndmask, carry adds, 64-bit ops and v_bcnt
@@ -128,7 +128,7 @@ template <int K, int NW, int WPL, bool PACKED, bool RAGGED, bool SEG> constexpr 
 // looks its reads up there (30 instructions) instead of validating the tile a second time from w[] (150).  The second dword per
 // chunk is LDS time, though, and the variants that are short of it pay on CLEAN input: interleaved with round 5's build on one box the
 // headline <31,10,4> and k = 13 lost nothing, k = 21 (five windows per lane, a late row) 0.6 %, the two-word k = 63 2 %, the 7- / 13- /
-// 16-word frames 2-3 % (profiles/r06_ab_r5_r6.txt).  So: the uniform 10-word frame without late rows -- k = 13..17 and 22..31 on
+// 16-word frames 2-3 % (profiles/r06_ab_r5_r6.txt).  So: the uniform 10-word frame without late rows -- k = 9..17 and 22..31 on
 // 150-base reads, the metric's shape -- parks; every other variant finds its dirty reads the round-5 way.
 template <int K, int NW, int WPL, bool PACKED, bool RAGGED, bool SEG> constexpr bool bs_park() {
     return !PACKED && !RAGGED && !SEG && NW == 10 && K <= 32 && bs_late<K, NW, WPL, PACKED, RAGGED, SEG>() == 0;
