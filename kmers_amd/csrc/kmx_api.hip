@@ -652,7 +652,9 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
     DeviceGuard g(ctx->device);
     if (!reads->d_offsets && !d_win_offsets) {   // uniform layout: fast word-domain kernel
         bool handled = false;
-        KMX_HIP(ctx, queue_clear(ctx, 32 * 128));
+        // (the window sinks mark the reads of a tile with an invalid byte and the sweep behind the passes zeroes their spoiled slots: round 6)
+        KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));
+        if (int st = prepare_dirty_flags(ctx, reads->n_reads, k, k >= 2u /* (k = 1: no sweep behind the passes, so no marks) */)) return st;
         KMX_HIP(ctx, kmx::launch_windows_uniform(reads->d_bases, reads->n_reads, reads->read_len, k, d_fw, d_rc, d_canon,
                                                  d_flags, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;
@@ -670,7 +672,8 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
                 const uint64_t *starts = nullptr, *ends = nullptr, *wins = nullptr;
                 uint64_t n_seg = 0;
                 KMX_HIP(ctx, kmx::launch_uniform_segments_plan(reads->n_reads, L, k, T, scratch, &starts, &ends, &wins, &n_seg, ctx->stream));
-                KMX_HIP(ctx, queue_clear(ctx, 32 * 128));
+                KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));
+                if (int st = prepare_dirty_flags(ctx, n_seg, k, k >= 2u /* (k = 1: no sweep behind the passes, so no marks) */)) return st;
                 KMX_HIP(ctx, kmx::launch_windows_ragged(reads->d_bases, starts, wins, n_seg, 256u, k, d_fw, d_rc, d_canon, d_flags, ctx->d_scratch + 16, ctx->n_cu,
                                                         ctx->stream, &handled, ends));
                 if (handled) return KMX_OK;
@@ -687,7 +690,8 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
         if (st == 0) {
             if (n_seg == 0) return KMX_OK;      // no read holds a window
             bool handled = false;
-            KMX_HIP(ctx, queue_clear(ctx, 32 * 128));
+            KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));
+            if (int st2 = prepare_dirty_flags(ctx, n_seg, k, k >= 2u /* (k = 1: no sweep behind the passes, so no marks) */)) return st2;
             KMX_HIP(ctx, kmx::launch_windows_ragged(reads->d_bases, starts, wins, n_seg, 256u, k, d_fw, d_rc, d_canon, d_flags, ctx->d_scratch + 16, ctx->n_cu,
                                                     ctx->stream, &handled, ends));
             if (handled) return KMX_OK;
@@ -695,7 +699,8 @@ int kmx_canonical_windows(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t* 
     }
     if (reads->d_offsets && d_win_offsets) {     // ragged reads: the tiled word-domain kernel (read_len = optional length bound)
         bool handled = false;
-        KMX_HIP(ctx, queue_clear(ctx, 32 * 128));
+        KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));
+        if (int st = prepare_dirty_flags(ctx, reads->n_reads, k, k >= 2u /* (k = 1: no sweep behind the passes, so no marks) */)) return st;
         KMX_HIP(ctx, kmx::launch_windows_ragged(reads->d_bases, reads->d_offsets, d_win_offsets, reads->n_reads, reads->read_len, k,
                                                 d_fw, d_rc, d_canon, d_flags, ctx->d_scratch + 16, ctx->n_cu, ctx->stream, &handled));
         if (handled) return KMX_OK;

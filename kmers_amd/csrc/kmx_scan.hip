@@ -92,6 +92,11 @@ struct WindowsParams {
 template <bool ALIGNED, bool RG = false>
 struct SinkWindowsT {
     static_assert(!RG || ALIGNED, "the ragged ring is a mode of the line-aligned sink");
+    // (round 6) a tile with an invalid byte: fast path + marks (kmx_scan_kernel.h, SinkMarksDirty) -- launch_windows_* ends with the
+    // sweep that writes the spoiled windows' slots as the iterator leaves them, zeros (kmx_sweep.hip, ZERO); rolled per lane such a
+    // tile cost 6 tiles' worth, and 2 % dirty reads the materialise 37 % (profiles/r06_windows_dirty.txt)
+    static constexpr bool kMarksDirty = true;
+    static constexpr bool kMarksCoarse = true;     // (all reads of a dirty tile: kmx_scan_kernel.h, SinkMarksCoarse)
     static constexpr u32 PITCH = 17;                        // u64 per lane row (16 + 1 pad: conflict-free both ways)
     static constexpr u32 PLANE = 64u * PITCH * 2u;          // dwords of one staged u64 array of a wave
     // staging sized by what the caller asked for (with all three u64 planes a block holds 108 KB = one block per CU and one
@@ -399,6 +404,8 @@ struct FlagsParams {
     u32 magic;       // floor(2^32 / W) + 1: b / W = umulhi(b, magic) for b < 2^16
 };
 struct SinkFlags {
+    static constexpr bool kMarksDirty = true;   // (as SinkWindowsT: the sweep behind the passes zeroes the spoiled windows' flags)
+    static constexpr bool kMarksCoarse = true;
     static constexpr u32 NB = 8, BP = 9;        // mask dwords per read (W <= 256); LDS pitch (the ninth stays zero)
     static constexpr u32 kLdsDwordsPerWave = 0;
     static constexpr bool kRagged = false;
@@ -506,10 +513,23 @@ hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
     return dispatch<SinkReduce<false>>(bases, n_reads, L, k, p, queue, n_cu, stream, NoPre(), offsets);
 }
 
+hipError_t launch_sweep_windows(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags,
+                                const u64* win_offsets, unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets,
+                                const u64* ends);
+
+static hipError_t windows_uniform_passes(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon,
+                                         uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream);
+// (the passes, then the sweep over the reads they marked: every pass marks the same reads, the masks are consumed once)
 hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon,
                                   uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream, bool* handled) {
     *handled = scan_domain(bases, n_reads, L, k);
     if (!*handled) return hipSuccess;
+    if (hipError_t e = windows_uniform_passes(bases, n_reads, L, k, fw, rc, canon, flags, queue, n_cu, stream)) return e;
+    if (k < 2u) return hipSuccess;     // (k = 1: the sinks' scan does not mark)
+    return launch_sweep_windows(bases, n_reads, L, k, fw, rc, canon, flags, nullptr, queue, n_cu, stream, nullptr, nullptr);
+}
+static hipError_t windows_uniform_passes(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon,
+                                         uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream) {
     const WindowsParams p{fw, rc, canon, flags, nullptr};
     const u32 W = L - k + 1u;
     if (SinkWindowsT<true>::wants_aligned(p, W)) return dispatch<SinkWindowsT<true>>(bases, n_reads, L, k, p, queue, n_cu, stream);
@@ -542,11 +562,21 @@ hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 
 }
 
 // ragged reads: win_offsets[r] = slot of window 0 of read r (n_reads+1 entries); L = optional bound of the read lengths
+static hipError_t windows_ragged_passes(const uint8_t* bases, const u64* offsets, const u64* win_offsets, u64 n_reads, u32 L, u32 k,
+                                        u64* fw, u64* rc, u64* canon, uint8_t* flags, unsigned long long* queue, int n_cu,
+                                        hipStream_t stream, const u64* ends);
 hipError_t launch_windows_ragged(const uint8_t* bases, const u64* offsets, const u64* win_offsets, u64 n_reads, u32 L, u32 k,
                                  u64* fw, u64* rc, u64* canon, uint8_t* flags, unsigned long long* queue, int n_cu,
                                  hipStream_t stream, bool* handled, const u64* ends) {
     *handled = offsets && win_offsets && scan_domain_ragged(bases, L, k);
     if (!*handled) return hipSuccess;
+    if (hipError_t e = windows_ragged_passes(bases, offsets, win_offsets, n_reads, L, k, fw, rc, canon, flags, queue, n_cu, stream, ends)) return e;
+    if (k < 2u) return hipSuccess;
+    return launch_sweep_windows(bases, n_reads, L, k, fw, rc, canon, flags, win_offsets, queue, n_cu, stream, offsets, ends);
+}
+static hipError_t windows_ragged_passes(const uint8_t* bases, const u64* offsets, const u64* win_offsets, u64 n_reads, u32 L, u32 k,
+                                        u64* fw, u64* rc, u64* canon, uint8_t* flags, unsigned long long* queue, int n_cu,
+                                        hipStream_t stream, const u64* ends) {
     const WindowsParams p{fw, rc, canon, flags, win_offsets};
     // one u64 array, no flags (the usual call: the canonical words): whole lines through the ring, each read shifted by its own first slot
     const int n_arr = (fw ? 1 : 0) + (rc ? 1 : 0) + (canon ? 1 : 0);

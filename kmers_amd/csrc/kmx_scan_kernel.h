@@ -60,8 +60,37 @@ template <typename S> struct SinkAliasPacked<S, decltype((void)S::kAliasPacked)>
 // the reads that touch a bad chunk are marked in the array behind queue[515] exactly as the bit-sliced scan marks them; what the
 // windows with an invalid byte added is subtracted by sweep_flagged_kernel (kmx_sweep.hip).  The bucket histograms: a rolled tile
 // cost 2-3 tiles, and with an N in 2 % of the reads 73 % of the tiles rolled (+62 %: profiles/r05_dirty_bench.txt).
+// The reads of a tile that touch a chunk with an invalid byte (a sink that marks, below): the tile's chunks once more (they are in the L2),
+// one ballot per row; every lane keeps the two rows' ballots its read's chunks lie in (a chunk shared by two reads marks both: the sweep
+// looks at the bytes).  NOT inlined: the line-aligned window sinks run at 249-255 registers, and inline this block's temporaries were 40
+// registers spilled in their window loop (round 6) -- as a call it costs the tiles that take it, and nobody else.
+template <int NW>
+__device__ __attribute__((noinline)) u64 mark_dirty_rows(const uint4* __restrict__ tb, u32 chunks, u32 rd_off, u32 rd_len) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 c0 = rd_off >> 4, c1 = rd_len ? (rd_off + rd_len - 1u) >> 4 : c0, q0 = c0 >> 6, b0 = c0 & 63u;
+    u64 lo = 0, hi = 0;
+#pragma unroll 1
+    for (int it = 0; it < NW; ++it) {
+        const u32 c = it * 64u + lane;
+        uint4 wv = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+        if (c < chunks) wv = tb[c];
+        u32 rb = 0;
+        (void)encode16(wv, rb);
+        const u64 row = __ballot(chunk_has_invalid(rb));
+        lo = q0 == (u32)it ? row : lo;
+        hi = q0 + 1u == (u32)it ? row : hi;
+    }
+    const u64 bits = b0 ? ((lo >> b0) | (hi << (64u - b0))) : lo;
+    return __ballot(rd_len != 0u && (bits & ((1ull << (c1 - c0 + 1u)) - 1ull)) != 0ull);
+}
+
 template <typename S, typename = void> struct SinkMarksDirty { static constexpr bool value = false; };
 template <typename S> struct SinkMarksDirty<S, decltype((void)S::kMarksDirty)> { static constexpr bool value = S::kMarksDirty; };
+// ... and a sink that marks COARSELY (static constexpr bool kMarksCoarse): every read of a dirty tile -- one store of a constant, nothing
+// computed -- and leaves it to the sweep to look at the bytes.  The line-aligned window sinks: at 249-255 registers they have none to
+// spare for finding the reads (inline or as a call, the block cost the CLEAN materialise 15-18 %: profiles/r06_windows_dirty.txt).
+template <typename S, typename = void> struct SinkMarksCoarse { static constexpr bool value = false; };
+template <typename S> struct SinkMarksCoarse<S, decltype((void)S::kMarksCoarse)> { static constexpr bool value = S::kMarksCoarse; };
 template <typename S, int NW> constexpr int sink_waves() { return NW <= 10 ? SinkWaves<S>::value : SinkWavesBig<S>::value; }
 template <int NW, int V, int DW, typename Sink, typename Params, bool RAGGED = false>
 __global__ void __launch_bounds__(256, (sink_waves<Sink, NW>()))
@@ -197,7 +226,7 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         return dequeue();
     };
     constexpr bool MARK = SinkMarksDirty<Sink>::value;
-    [[maybe_unused]] u64* const dirty_masks = MARK ? reinterpret_cast<u64*>(queue[515]) : nullptr;
+    [[maybe_unused]] u64* const dirty_masks = (MARK && !SinkMarksCoarse<Sink>::value) ? reinterpret_cast<u64*>(queue[515]) : nullptr;
     [[maybe_unused]] u32 n_marked = 0;
     u64 next_tile = dequeue();
     constexpr bool PF = SinkPrefetch<Sink>::value && !RAGGED && NW <= 10;   // (the 16-word frame: 80 more registers do not fit two waves)
@@ -308,27 +337,27 @@ scan_uniform_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         bool roll_tile = !tile_fits || __any(chunk_has_invalid(bad));
-        if constexpr (MARK) {
+        if constexpr (MARK && SinkMarksCoarse<Sink>::value) {
+            // (nothing of this is carried across the tile loop -- no pointer, no counter: the mask array's address is read here, and
+            // what the sweep is told is "many", by a plain store that every marking wave agrees on; it fields all its waves then)
+            if (roll_tile && tile_fits) {
+                const unsigned long long dq = queue[515];
+                u64* const dmk = reinterpret_cast<u64*>(((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(dq >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((u32)dq));
+                if (dmk != nullptr) {
+                    if (lane == 0) {      // (all 64: a read without a window costs the sweep nothing)
+                        dmk[tile] = ~0ull;
+                        queue[512] = 1ull << 40;
+                    }
+                    roll_tile = false;
+                }
+            }
+        } else if constexpr (MARK) {
             if (roll_tile && tile_fits && dirty_masks != nullptr) {
                 // which reads touch a chunk with an invalid byte?  The tile's chunks once more (they are in the L2), one ballot per row;
                 // every lane keeps the two rows' ballots its read's chunks lie in (a chunk shared by two reads marks both: the sweep looks
                 // at the bytes)
                 const u32 rd_off = posF - 16u, rd_len = RAGGED ? my_len : L;     // the read's bytes, relative to the tile's aligned start
-                const u32 c0 = rd_off >> 4, c1 = rd_len ? (rd_off + rd_len - 1u) >> 4 : c0, q0 = c0 >> 6, b0 = c0 & 63u;
-                u64 lo = 0, hi = 0;
-#pragma unroll
-                for (int it = 0; it < NW; ++it) {
-                    const u32 c = it * 64u + lane;
-                    uint4 wv = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
-                    if (c < chunks) wv = tb[c];
-                    u32 rb = 0;
-                    (void)encode16(wv, rb);
-                    const u64 row = __ballot(chunk_has_invalid(rb));
-                    lo = q0 == (u32)it ? row : lo;
-                    hi = q0 + 1u == (u32)it ? row : hi;
-                }
-                const u64 bits = b0 ? ((lo >> b0) | (hi << (64u - b0))) : lo;
-                const u64 dm = __ballot(rd_len != 0u && (bits & ((1ull << (c1 - c0 + 1u)) - 1ull)) != 0ull);
+                const u64 dm = mark_dirty_rows<NW>(tb, chunks, rd_off, rd_len);
                 if (lane == 0 && dm != 0ull) dirty_masks[tile] = dm;
                 n_marked += (u32)__builtin_popcountll(dm);
                 roll_tile = false;

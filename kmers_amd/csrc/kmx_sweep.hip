@@ -26,15 +26,24 @@ template <int NW, int V1> constexpr int sweep_pitch() {     // dwords of a lane'
 }
 // HIST: the windows are taken out of a bucket histogram instead of a summary (the word-domain scan's histogram sinks mark their dirty
 // reads the same way: kmx_scan_kernel.h, SinkMarksDirty) -- `out` = the counters, want_hash = the hasher, want_sumfw = hasher_k | log2_buckets << 8.
-template <int NW, int V1, bool RAGGED, bool SEG, bool HIST = false>
-__global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, u32 want_hash,
-                                                            u32 want_sumfw, void* __restrict__ out, unsigned long long* __restrict__ queue,
-                                                            const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends,
-                                                            const BsSeg seg) {
+// MODE 2 (ZERO, round 6): behind a MATERIALISE pass (kmx_canonical_windows: the word-domain scan's window sinks mark their dirty reads too and
+// take the fast path on a dirty tile instead of rolling it per lane -- 2 % dirty reads cost the materialise 37 %): the slots of the windows
+// that hold an invalid byte are written as the reference's iterator leaves them -- words 0, flags 0 (kmx.h) -- in every array asked for.
+struct SweepZero {
+    u64 *fw, *rc, *canon;
+    uint8_t* flags;
+    const u64* win_offsets;      // ragged: slot of window 0 of read r; nullptr: r (L - k + 1)
+};
+template <int NW, int V1, bool RAGGED, bool SEG, int MODE>
+__device__ __forceinline__ void sweep_body(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, u32 want_hash,
+                                           u32 want_sumfw, void* __restrict__ out, unsigned long long* __restrict__ queue,
+                                           const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends,
+                                           const BsSeg& seg, const SweepZero& zo) {
+    constexpr bool HIST = MODE == 1, ZERO = MODE == 2;
     u64* const masks = reinterpret_cast<u64*>(queue[515]);
     // how many reads the scan marked: the bit-sliced scan's last block leaves its count in [516] (and [512] at zero for the next launch,
     // kmx_device.h); the word-domain scan's histogram sinks count in [512], which their caller clears with the heads
-    const u64 n_marked = queue[HIST ? KMX_Q_MARKED : KMX_Q_MARKED_OUT];
+    const u64 n_marked = queue[(HIST || ZERO) ? KMX_Q_MARKED : KMX_Q_MARKED_OUT];
     if (masks == nullptr || n_marked == 0) return;
     // A sweep costs the same for 5 reads as for 64: as many waves as fill their sweeps (~48 reads each), not as many as were launched
     // -- 0.1 % of 2e7 reads dirty: 33 us with every wave of the grid sweeping 5 reads, 16 us with a quarter of them
@@ -84,8 +93,10 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
         // ---- this lane's read
         const uint8_t* sp = bases;
         u32 len = 0;
+        [[maybe_unused]] u64 slot0 = 0;      // ZERO: the lane's read's first output slot
         if (lane < n_aside) {
             const u64 read = aside[lane];
+            if constexpr (ZERO) slot0 = zo.win_offsets ? zo.win_offsets[read] : read * (u64)(L - k + 1u);
             sp = bases + lead + read * (u64)L;
             len = L;
             if constexpr (SEG) {     // segment `read` of a long uniform read (scan_bitsliced_kernel<.., SEG>)
@@ -176,7 +187,7 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
         }
         a_n += ng;
         // ---- the row: the packed words, and the complemented, group-reversed ones delayed by cg groups
-        {
+        if constexpr (!ZERO) {
             u32 R[NW + 1];
 #pragma unroll
             for (int m = 0; m < NW; ++m) {
@@ -212,6 +223,20 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
             for (int j = 0; j < NB; ++j) {
                 const u32 lo = 32u * j, e = a + 32u;
                 wb[j] &= lo >= e ? ~0u : (lo + 32u <= e ? 0u : ~0u << (e - lo));
+            }
+            if constexpr (ZERO) {
+                // the spoiled windows' slots, one store per array and window (k of them per invalid byte: 2 % of the reads with an N are
+                // 0.6 windows per read of the batch)
+                u32 bits = wv;
+                while (bits != 0u) {
+                    const u64 slot = slot0 + a + (u32)__builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    if (zo.fw) zo.fw[slot] = 0ull;
+                    if (zo.rc) zo.rc[slot] = 0ull;
+                    if (zo.canon) zo.canon[slot] = 0ull;
+                    if (zo.flags) zo.flags[slot] = 0;
+                }
+                continue;
             }
             // the packed stream from base a; the rc stream from the group where window a + 31 starts (window a + j: 31 - j groups on)
             u32 F2[NWW], G2[NWW];
@@ -354,7 +379,7 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
         }
     }
     __syncthreads();
-    if (HIST || threadIdx.x != 0) return;
+    if (HIST || ZERO || threadIdx.x != 0) return;
     const u64 n = part[0][0] + part[1][0] + part[2][0] + part[3][0];
     if (n == 0) return;   // nothing to take out: no atomics
     const u64 s0 = part[0][1] + part[1][1] + part[2][1] + part[3][1], s1 = part[0][2] + part[1][2] + part[2][2] + part[3][2];
@@ -376,6 +401,21 @@ __global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __res
             atomicXor((unsigned long long*)&o->xor_hi, (unsigned long long)x1);
         }
     }
+}
+
+template <int NW, int V1, bool RAGGED, bool SEG, bool HIST = false>
+__global__ void __launch_bounds__(256) sweep_flagged_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, u32 want_hash,
+                                                            u32 want_sumfw, void* __restrict__ out, unsigned long long* __restrict__ queue,
+                                                            const u64* __restrict__ offsets, u32 lead, const u64* __restrict__ ends,
+                                                            const BsSeg seg) {
+    sweep_body<NW, V1, RAGGED, SEG, HIST ? 1 : 0>(bases, n_reads, L, k, want_hash, want_sumfw, out, queue, offsets, lead, ends, seg, SweepZero{});
+}
+// (V1 = 0: a window's words are not formed)
+template <int NW, bool RAGGED>
+__global__ void __launch_bounds__(256) sweep_zero_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k,
+                                                         unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead,
+                                                         const u64* __restrict__ ends, const SweepZero zo) {
+    sweep_body<NW, 0, RAGGED, false, 2>(bases, n_reads, L, k, 0u, 0u, nullptr, queue, offsets, lead, ends, BsSeg{0, 0, 0, 0, 0}, zo);
 }
 
 template <int NW, bool RAGGED, bool SEG>
@@ -422,6 +462,37 @@ hipError_t launch_sweep_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k,
     const BsSeg seg{0, 0, 0, 0, 0};
     return launch_sweep_flagged(bases - lead, n_reads, L, k, want_hash ? 1u : 0u, want_sumfw ? 1u : 0u, out, queue, n_cu, stream, nullptr, lead,
                                 nullptr, seg, false, false);
+}
+
+// Behind the materialise passes (kmx_scan.hip, launch_windows_*): uniform reads (L <= 256; offsets == nullptr) or reads behind offsets
+// (L = their bound, 0: none; `ends`: nullptr = offsets + 1), k <= 31.  Any of the four arrays may be nullptr.
+hipError_t launch_sweep_windows(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags,
+                                const u64* win_offsets, unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets,
+                                const u64* ends) {
+    if (k < 2u || k > 31u) return hipErrorInvalidValue;
+    u32 lead = 0;
+    if (!offsets) {
+        lead = (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
+        bases -= lead;
+    } else if (!ends) {
+        ends = offsets + 1;
+    }
+    u64 grid1 = (u64)n_cu * 2u;
+    const u64 need1 = ((n_reads >> 6) + 255u) / 256u;
+    if (grid1 > need1) grid1 = need1;
+    const dim3 grid((unsigned)(grid1 ? grid1 : 1));
+    const bool big = L > 160u || (offsets && L == 0u);
+    const u32 Lf = offsets ? (big ? 256u : 160u) : L;
+    if (Lf < k || Lf > 256u) return hipErrorInvalidValue;
+    const SweepZero zo{fw, rc, canon, flags, win_offsets};
+    if (offsets) {
+        if (big) hipLaunchKernelGGL((sweep_zero_kernel<16, true>), grid, dim3(256), 0, stream, bases, n_reads, Lf, k, queue, offsets, lead, ends, zo);
+        else hipLaunchKernelGGL((sweep_zero_kernel<10, true>), grid, dim3(256), 0, stream, bases, n_reads, Lf, k, queue, offsets, lead, ends, zo);
+    } else {
+        if (big) hipLaunchKernelGGL((sweep_zero_kernel<16, false>), grid, dim3(256), 0, stream, bases, n_reads, Lf, k, queue, offsets, lead, ends, zo);
+        else hipLaunchKernelGGL((sweep_zero_kernel<10, false>), grid, dim3(256), 0, stream, bases, n_reads, Lf, k, queue, offsets, lead, ends, zo);
+    }
+    return hipGetLastError();
 }
 
 // Behind a word-domain scan whose sink marks dirty reads (the bucket histograms): what the windows with an invalid byte added to the

@@ -547,3 +547,48 @@ def test_small_k_packed(ctx, orc):
             words = ctx.seqvec_from_bytes(ctx.to_device(host))
             g = ctx.seqvec_canonical_reduce(words, n, L, k, _lib.HASH_LEX, k)
             _check1(g, o, with_fw=False)
+
+
+# ------------------------------------------------------------------ materialise on reads with invalid bytes (round 6)
+# The window sinks take the fast path on a tile with an invalid byte -- every read of it is marked, one store -- and the ZERO form of
+# the sweep writes the spoiled windows' slots as the iterator leaves them: words 0, flags 0 (kmx.h; canonical_kmer_iterator.rs:50-66).
+@pytest.mark.parametrize("k,L", [(31, 150), (21, 100), (13, 250), (9, 36), (2, 150), (31, 300)])
+@pytest.mark.parametrize("want", [("canon",), ("fw", "rc", "canon", "flags"), ("flags",), ("fw", "flags")])
+def test_windows_on_dirty_reads_at_size(ctx, orc, k, L, want):
+    n = 64 * 700 + 13
+    rng = np.random.default_rng(17 * k + L + len(want))
+    host = ctx.gen_reads(n * L, first_byte=k).cpu().numpy().copy()
+    _dirty(host, n, np.arange(n, dtype=np.int64) * L, np.full(n, L), rng, 0.03)
+    host[(n - 1) * L + L - 1] = ord("N")
+    host[5 * L] = ord("n")
+    exp = dict(zip(("fw", "rc", "canon", "flags"), orc.canonical_windows(host, n, L, k)))
+    outs = ctx.canonical_windows(ctx.to_device(host), n, L, k, want=want)
+    for name in want:
+        got = outs[name].cpu().numpy()
+        got = got.view(np.uint64) if name != "flags" else got
+        assert np.array_equal(got, exp[name]), name
+    # ... and the mask array is all zero again: a clean call behind it gives clean answers
+    clean = ctx.gen_reads(n * L, first_byte=k).cpu().numpy().copy()
+    exp_c = orc.canonical_windows(clean, n, L, k)[2]
+    got_c = ctx.canonical_windows(ctx.to_device(clean), n, L, k, want=("canon",))["canon"].cpu().numpy().view(np.uint64)
+    assert np.array_equal(got_c, exp_c)
+
+
+@pytest.mark.parametrize("bound", [150, 0, 250, 1000])
+def test_windows_on_dirty_ragged_reads(ctx, orc, bound):
+    k, n = 31, 64 * 300 + 9
+    rng = np.random.default_rng(bound + 1)
+    hi = bound if bound else 160
+    lens = rng.integers(max(hi // 3, 1), hi + 1, n)
+    lens[::5] = hi
+    lens[7] = 0
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    host = ctx.gen_reads(int(offs[-1]), first_byte=bound).cpu().numpy().copy()
+    _dirty(host, n, offs[:-1].astype(np.int64), lens, rng, 0.04)
+    exp = dict(zip(("fw", "rc", "canon", "flags"), orc.canonical_windows(host, n, bound, k, offsets=offs)))
+    for want in (("canon",), ("fw", "rc", "canon", "flags")):
+        outs = ctx.canonical_windows(ctx.to_device(host), n, bound, k, offsets=ctx.to_device(offs), host_offsets=offs, want=want)
+        for name in want:
+            got = outs[name].cpu().numpy()
+            got = got.view(np.uint64) if name != "flags" else got
+            assert np.array_equal(got, exp[name]), (name, want)
