@@ -332,10 +332,63 @@ __device__ __forceinline__ void sweep_body(const uint8_t* __restrict__ bases, u6
     // reads spent more time waiting for masks than sweeping)
     u64 m0 = 0, m1 = 0, m2 = 0, m3 = 0, t = 0;   // m0: the masks being taken apart, of the tiles t (this lane's) -- m1..m3: of the groups n_waves, 2 n_waves, 3 n_waves on
     u32 left = 0;
+    // ZERO: the window sinks mark COARSELY -- every read of a tile that holds an invalid byte (kmx_scan_kernel.h, SinkMarksCoarse) -- and a sweep
+    // of 64 reads costs ~12 us: with an N in 2 % of the reads 73 % of the tiles are dirty, one sweep each, 0.7 ms per 1e7 reads.  So the wave first
+    // looks at such a tile as the scan would have (its chunks in rows of 64, coalesced, one ballot per row) and keeps the reads that touch a chunk
+    // with an invalid byte: ~1.5 us per tile, and one sweep per 64 DIRTY reads.  A tile whose chunks cannot be taken whole (the batch's last bytes,
+    // a span outside the frame, an unaligned base) stays marked as it is: the per-read path is safe anywhere.
+    [[maybe_unused]] auto lane64 = [&](u64 v, u32 l) -> u64 {
+        return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), (int)l) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, (int)l);
+    };
+    [[maybe_unused]] auto refine = [&](u64 mi, u64 ti) -> u64 {
+        u64 todo = __ballot(mi != 0ull);
+        while (todo != 0ull) {
+            const u32 src = (u32)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const u64 T = lane64(ti, src);
+            u64 o0, o1;
+            if constexpr (RAGGED) {
+                o0 = offsets[T * 64u + lane];
+                o1 = ends[T * 64u + lane];
+            } else {
+                o0 = (u64)lead + (T * 64u + lane) * (u64)L;
+                o1 = o0 + L;
+            }
+            const u64 first = lane64(o0, 0u), last = lane64(o1, 63u);
+            const u64 base_al = first & ~15ull, n_ch = (last - base_al + 15u) >> 4;
+            const bool whole = n_ch <= 64u * (u64)NW && bases + base_al + 16u * n_ch <= buf_end && (reinterpret_cast<uintptr_t>(bases) & 15u) == 0u &&
+                               !__any(o1 - o0 > 16u * (u64)NW);
+            if (!whole) continue;
+            const u32 rd_off = (u32)(o0 - base_al), rd_len = (u32)(o1 - o0);
+            const u32 c0 = rd_off >> 4, c1 = rd_len ? (rd_off + rd_len - 1u) >> 4 : c0, q0 = c0 >> 6, b0 = c0 & 63u;
+            const uint4* __restrict__ tb = reinterpret_cast<const uint4*>(bases + base_al);
+            uint4 wv[NW];
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const u32 c = (u32)it * 64u + lane;
+                wv[it] = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+                if (c < (u32)n_ch) wv[it] = tb[c];
+            }
+            u64 lo = 0, hi = 0;
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                u32 rb = 0;
+                (void)encode16(wv[it], rb);
+                const u64 rowb = __ballot(chunk_has_invalid(rb));
+                lo = q0 == (u32)it ? rowb : lo;
+                hi = q0 + 1u == (u32)it ? rowb : hi;
+            }
+            const u64 bits = b0 ? ((lo >> b0) | (hi << (64u - b0))) : lo;
+            const u64 dm = __ballot(rd_len != 0u && (bits & ((1ull << (c1 - c0 + 1u)) - 1ull)) != 0ull);
+            if (lane == src) mi = dm;
+        }
+        return mi;
+    };
     auto fetch = [&](u64 gi) -> u64 {
         const u64 ti = gi * 64u + lane;
         u64 mi = (gi < n_groups && ti < n_full) ? masks[ti] : 0ull;
         if (mi != 0ull) masks[ti] = 0ull;
+        if constexpr (ZERO) mi = refine(mi, ti);
         return mi;
     };
     for (bool more = true; more;) {
