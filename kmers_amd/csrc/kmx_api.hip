@@ -79,9 +79,9 @@ hipError_t launch_histogram_generic(const kmx_reads* r, u32 k, u32 hasher, u32 h
 hipError_t launch_reduce2_generic(const kmx_reads* r, u32 k, u32 with_hash, kmx_summary2* out, int n_cu, hipStream_t st, unsigned long long* too_long,
                                   const u32* gate);
 hipError_t launch_windows2_tiled(const kmx_reads* r, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu, hipStream_t st,
-                                 bool* handled);
+                                 bool* handled, unsigned long long* queue);
 hipError_t launch_windows2_tiled_ragged(const kmx_reads* r, const u64* win_offsets, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu,
-                                        hipStream_t st, bool* handled, unsigned long long* too_long, const u64* ends = nullptr);
+                                        hipStream_t st, bool* handled, unsigned long long* too_long, const u64* ends, unsigned long long* queue);
 hipError_t launch_windows2_generic(const kmx_reads* r, const u64* win_off, u32 k, u64* fw, u64* rc, u64* canon,
                                    uint8_t* flags, int n_cu, hipStream_t st, unsigned long long* too_long);
 // kmx_elem.hip
@@ -789,8 +789,12 @@ int kmx_canonical_windows2(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t*
     if (reads->n_reads == 0) return KMX_OK;
     DeviceGuard g(ctx->device);
     bool handled = false;   // uniform reads of up to 256 bases in the dense layout (slot r*W + p): the tiled kernel (kmx_generic.hip)
-    if (!reads->d_offsets && !d_win_offsets)   // (a caller's win_offsets for uniform reads are honoured by the lane-per-read kernel, as kmx_canonical_windows does)
-        KMX_HIP(ctx, kmx::launch_windows2_tiled(reads, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled));
+    if (!reads->d_offsets && !d_win_offsets) {   // (a caller's win_offsets for uniform reads are honoured by the lane-per-read kernel, as kmx_canonical_windows does)
+        // (a tile with an invalid byte stays on the tiled path: its reads are marked, the sweep behind the passes zeroes the spoiled slots -- round 6)
+        KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));
+        if (int st = prepare_dirty_flags(ctx, reads->n_reads, k, true)) return st;
+        KMX_HIP(ctx, kmx::launch_windows2_tiled(reads, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled, ctx->d_scratch + 16));
+    }
     if (!handled && !reads->d_offsets && !d_win_offsets && reads->read_len > 256 && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u &&
         reads->n_reads < (1ull << 40) && (uint64_t)reads->read_len * reads->n_reads < (1ull << 62)) {
         // uniform reads longer than a frame (round 4): planned as segments on the device, as kmx_canonical_windows does
@@ -805,7 +809,9 @@ int kmx_canonical_windows2(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t*
             segs.d_offsets = starts;
             segs.n_reads = n_seg;
             segs.read_len = 256u;
-            KMX_HIP(ctx, kmx::launch_windows2_tiled_ragged(&segs, wins, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled, ctx->d_scratch + 8, ends));
+            KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));
+            if (int stf = prepare_dirty_flags(ctx, segs.n_reads, k, true)) return stf;
+            KMX_HIP(ctx, kmx::launch_windows2_tiled_ragged(&segs, wins, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled, ctx->d_scratch + 8, ends, ctx->d_scratch + 16));
         }
     }
     if (!handled && reads->d_offsets && d_win_offsets && reads->read_len > 256 && (reinterpret_cast<uintptr_t>(reads->d_bases) & 15u) == 0u) {
@@ -820,12 +826,17 @@ int kmx_canonical_windows2(kmx_ctx* ctx, const kmx_reads* reads, const uint64_t*
             segs.d_offsets = starts;
             segs.n_reads = n_seg;
             segs.read_len = 256u;
-            KMX_HIP(ctx, kmx::launch_windows2_tiled_ragged(&segs, wins, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled, ctx->d_scratch + 8, ends));
+            KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));
+            if (int stf = prepare_dirty_flags(ctx, segs.n_reads, k, true)) return stf;
+            KMX_HIP(ctx, kmx::launch_windows2_tiled_ragged(&segs, wins, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled, ctx->d_scratch + 8, ends, ctx->d_scratch + 16));
         }
     }
-    if (!handled && reads->d_offsets && d_win_offsets)   // ragged reads (round 4): tiled too; read_len = optional length bound
+    if (!handled && reads->d_offsets && d_win_offsets) {   // ragged reads (round 4): tiled too; read_len = optional length bound
+        KMX_HIP(ctx, queue_clear(ctx, 32 * 128 + 16));
+        if (int stf = prepare_dirty_flags(ctx, reads->n_reads, k, true)) return stf;
         KMX_HIP(ctx, kmx::launch_windows2_tiled_ragged(reads, d_win_offsets, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, &handled,
-                                                       ctx->d_scratch + 8));
+                                                       ctx->d_scratch + 8, nullptr, ctx->d_scratch + 16));
+    }
     if (handled) return KMX_OK;
     KMX_HIP(ctx, kmx::launch_windows2_generic(reads, d_win_offsets, k, d_fw2, d_rc2, d_canon2, d_flags, ctx->n_cu, ctx->stream, ctx->d_scratch + 8));
     return KMX_OK;

@@ -191,7 +191,10 @@ template <int NW, bool STAGE, bool RAGGED = false>
 __global__ void __launch_bounds__(256)
 windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, Win2Out out, u32 lead,
                       const u64* __restrict__ offsets, const u64* __restrict__ win_offsets, unsigned long long* __restrict__ too_long,
-                      const u64* __restrict__ ends_arg) {
+                      const u64* __restrict__ ends_arg, unsigned long long* __restrict__ queue) {
+    // `queue` (round 6; nullptr: none): the context's queue block.  A tile with an invalid byte then stays on the tiled path -- all its reads
+    // marked, one store, as the single-word window sinks do (kmx_scan_kernel.h, SinkMarksCoarse) -- and the ZERO sweep behind the passes
+    // (kmx_sweep.hip) writes the spoiled windows' slots as the iterator leaves them; without it such a tile takes the per-read path.
     // `lead`: `bases` is the 16-byte aligned address at or below the first read, which starts `lead` bytes in
     // RAGGED: read r = bases[offsets[r], ends[r]); ends_arg == nullptr: back to back (ends = offsets + 1); a separate array serves
     // reads that overlap in memory -- the segments a long uniform read is planned as (kmx_segments.hip)
@@ -279,7 +282,20 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const u64 read = t * 64u + lane;
-        if (!fits || __any(chunk_has_invalid(bad))) {   // (wave-uniform) exact iterator semantics, one lane per read
+        bool per_read = !fits;
+        if (!per_read && __any(chunk_has_invalid(bad))) {
+            const unsigned long long dq = queue ? queue[515] : 0ull;
+            u64* const dmk = reinterpret_cast<u64*>(((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(dq >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((u32)dq));
+            if (dmk != nullptr) {
+                if (lane == 0) {
+                    dmk[t] = ~0ull;
+                    queue[512] = 1ull << 40;      // ("many": a plain store every marking wave agrees on)
+                }
+            } else {
+                per_read = true;
+            }
+        }
+        if (per_read) {   // (wave-uniform) exact iterator semantics, one lane per read
             windows2_one_read(RAGGED ? bases + my_off : bases + lead + read * (u64)L, my_len, k, slot0, out);
         } else {
             // rolling windows: f[j] = F[i + j], h[j] = H[Q - i - 1 + j], j = 0..4
@@ -420,10 +436,13 @@ windows2_tiled_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
     }
 }
 
+hipError_t launch_sweep_windows(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags,
+                                const u64* win_offsets, unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets,
+                                const u64* ends, bool two_words);
 template <int NW, bool RAGGED = false>
 static hipError_t launch_windows2_tiled_nw(const uint8_t* bases, u64 n_reads, u32 L, u32 k, const Win2Out& out, int n_cu, hipStream_t st,
                                            const u64* offsets = nullptr, const u64* win_offsets = nullptr, unsigned long long* too_long = nullptr,
-                                           const u64* ends = nullptr) {
+                                           const u64* ends = nullptr, unsigned long long* queue = nullptr) {
     const u32 lead = RAGGED ? 0u : (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
     const u32 chunks = 4u * L + ((RAGGED || lead != 0u) ? 1u : 0u);
     const u32 ldsw = (chunks + 1u + (u32)NW + 8u + 3u) & ~3u;
@@ -441,19 +460,22 @@ static hipError_t launch_windows2_tiled_nw(const uint8_t* bases, u64 n_reads, u3
         if (!arr[a]) continue;
         Win2Out o1{nullptr, nullptr, nullptr, first ? out.flags : nullptr};
         (a == 0 ? o1.fw : a == 1 ? o1.rc : o1.canon) = arr[a];
-        hipLaunchKernelGGL((windows2_tiled_kernel<NW, true, RAGGED>), dim3((unsigned)grid), dim3(256), lds_bytes, st, bases - lead, n_reads, L, k, o1, lead, offsets, win_offsets, too_long, ends);
+        hipLaunchKernelGGL((windows2_tiled_kernel<NW, true, RAGGED>), dim3((unsigned)grid), dim3(256), lds_bytes, st, bases - lead, n_reads, L, k, o1, lead, offsets, win_offsets, too_long, ends, queue);
         first = false;
     }
     if (first) {   // flags only
         const size_t lds0 = (size_t)ldsw * 4u * 4u;
-        hipLaunchKernelGGL((windows2_tiled_kernel<NW, false, RAGGED>), dim3((unsigned)grid), dim3(256), lds0, st, bases - lead, n_reads, L, k, out, lead, offsets, win_offsets, too_long, ends);
+        hipLaunchKernelGGL((windows2_tiled_kernel<NW, false, RAGGED>), dim3((unsigned)grid), dim3(256), lds0, st, bases - lead, n_reads, L, k, out, lead, offsets, win_offsets, too_long, ends, queue);
     }
-    return hipGetLastError();
+    if (hipError_t e = hipGetLastError()) return e;
+    // the reads the passes marked (every pass marks the same ones): the spoiled windows' slots, zeroed
+    if (queue) return launch_sweep_windows(bases, n_reads, RAGGED ? (L > 160u ? 256u : 160u) : L, k, out.fw, out.rc, out.canon, out.flags, win_offsets, queue, n_cu, st, offsets, ends, true);
+    return hipSuccess;
 }
 
 // uniform reads of k..256 bases, k in 33..64; *handled = false: the caller takes the lane-per-read kernel
 hipError_t launch_windows2_tiled(const kmx_reads* r, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu, hipStream_t st,
-                                 bool* handled) {
+                                 bool* handled, unsigned long long* queue) {
     *handled = false;
     const u32 L = r->read_len;
     if (r->d_offsets || k < 33 || k > 64 || L < k || L > 256 || r->n_reads < 64u) return hipSuccess;
@@ -464,14 +486,14 @@ hipError_t launch_windows2_tiled(const kmx_reads* r, u32 k, u64* fw, u64* rc, u6
     if (r->n_reads * (u64)L >= (1ull << 62)) return hipSuccess;
     *handled = true;
     const Win2Out out{fw, rc, canon, flags};
-    if (L <= 160) return launch_windows2_tiled_nw<10>(r->d_bases, r->n_reads, L, k, out, n_cu, st);
-    return launch_windows2_tiled_nw<16>(r->d_bases, r->n_reads, L, k, out, n_cu, st);
+    if (L <= 160) return launch_windows2_tiled_nw<10>(r->d_bases, r->n_reads, L, k, out, n_cu, st, nullptr, nullptr, nullptr, nullptr, queue);
+    return launch_windows2_tiled_nw<16>(r->d_bases, r->n_reads, L, k, out, n_cu, st, nullptr, nullptr, nullptr, nullptr, queue);
 }
 
 // ragged reads (offsets + win_offsets), k in 33..64, 16-byte aligned bases; read_len = optional length bound (0: unknown -> the
 // 256-base frame); tiles with a longer read take the per-read path inside the kernel
 hipError_t launch_windows2_tiled_ragged(const kmx_reads* r, const u64* win_offsets, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags, int n_cu,
-                                        hipStream_t st, bool* handled, unsigned long long* too_long, const u64* ends) {
+                                        hipStream_t st, bool* handled, unsigned long long* too_long, const u64* ends, unsigned long long* queue) {
     *handled = false;
     if (!r->d_offsets || !win_offsets || k < 33 || k > 64 || r->n_reads < 64u || r->read_len > 256) return hipSuccess;
     if (reinterpret_cast<uintptr_t>(r->d_bases) & 15u) return hipSuccess;
@@ -480,8 +502,8 @@ hipError_t launch_windows2_tiled_ragged(const kmx_reads* r, const u64* win_offse
     if (L < k + 15u) L = k + 15u;
     *handled = true;
     const Win2Out out{fw, rc, canon, flags};
-    if (L <= 160) return launch_windows2_tiled_nw<10, true>(r->d_bases, r->n_reads, L, k, out, n_cu, st, r->d_offsets, win_offsets, too_long, ends);
-    return launch_windows2_tiled_nw<16, true>(r->d_bases, r->n_reads, L, k, out, n_cu, st, r->d_offsets, win_offsets, too_long, ends);
+    if (L <= 160) return launch_windows2_tiled_nw<10, true>(r->d_bases, r->n_reads, L, k, out, n_cu, st, r->d_offsets, win_offsets, too_long, ends, queue);
+    return launch_windows2_tiled_nw<16, true>(r->d_bases, r->n_reads, L, k, out, n_cu, st, r->d_offsets, win_offsets, too_long, ends, queue);
 }
 
 __global__ void __launch_bounds__(256)

@@ -515,7 +515,7 @@ hipError_t launch_scan_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k, 
 
 hipError_t launch_sweep_windows(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags,
                                 const u64* win_offsets, unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets,
-                                const u64* ends);
+                                const u64* ends, bool two_words);
 
 static hipError_t windows_uniform_passes(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon,
                                          uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream);
@@ -526,7 +526,7 @@ hipError_t launch_windows_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 
     if (!*handled) return hipSuccess;
     if (hipError_t e = windows_uniform_passes(bases, n_reads, L, k, fw, rc, canon, flags, queue, n_cu, stream)) return e;
     if (k < 2u) return hipSuccess;     // (k = 1: the sinks' scan does not mark)
-    return launch_sweep_windows(bases, n_reads, L, k, fw, rc, canon, flags, nullptr, queue, n_cu, stream, nullptr, nullptr);
+    return launch_sweep_windows(bases, n_reads, L, k, fw, rc, canon, flags, nullptr, queue, n_cu, stream, nullptr, nullptr, false);
 }
 static hipError_t windows_uniform_passes(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon,
                                          uint8_t* flags, unsigned long long* queue, int n_cu, hipStream_t stream) {
@@ -572,7 +572,7 @@ hipError_t launch_windows_ragged(const uint8_t* bases, const u64* offsets, const
     if (!*handled) return hipSuccess;
     if (hipError_t e = windows_ragged_passes(bases, offsets, win_offsets, n_reads, L, k, fw, rc, canon, flags, queue, n_cu, stream, ends)) return e;
     if (k < 2u) return hipSuccess;
-    return launch_sweep_windows(bases, n_reads, L, k, fw, rc, canon, flags, win_offsets, queue, n_cu, stream, offsets, ends);
+    return launch_sweep_windows(bases, n_reads, L, k, fw, rc, canon, flags, win_offsets, queue, n_cu, stream, offsets, ends, false);
 }
 static hipError_t windows_ragged_passes(const uint8_t* bases, const u64* offsets, const u64* win_offsets, u64 n_reads, u32 L, u32 k,
                                         u64* fw, u64* rc, u64* canon, uint8_t* flags, unsigned long long* queue, int n_cu,

@@ -33,6 +33,7 @@ struct SweepZero {
     u64 *fw, *rc, *canon;
     uint8_t* flags;
     const u64* win_offsets;      // ragged: slot of window 0 of read r; nullptr: r (L - k + 1)
+    u32 two;                     // [u64;2] k-mers (kmx_canonical_windows2): two words per slot
 };
 template <int NW, int V1, bool RAGGED, bool SEG, int MODE>
 __device__ __forceinline__ void sweep_body(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32 k, u32 want_hash,
@@ -231,9 +232,15 @@ __device__ __forceinline__ void sweep_body(const uint8_t* __restrict__ bases, u6
                 while (bits != 0u) {
                     const u64 slot = slot0 + a + (u32)__builtin_ctz(bits);
                     bits &= bits - 1u;
-                    if (zo.fw) zo.fw[slot] = 0ull;
-                    if (zo.rc) zo.rc[slot] = 0ull;
-                    if (zo.canon) zo.canon[slot] = 0ull;
+                    if (zo.two) {
+                        if (zo.fw) zo.fw[2u * slot] = zo.fw[2u * slot + 1u] = 0ull;
+                        if (zo.rc) zo.rc[2u * slot] = zo.rc[2u * slot + 1u] = 0ull;
+                        if (zo.canon) zo.canon[2u * slot] = zo.canon[2u * slot + 1u] = 0ull;
+                    } else {
+                        if (zo.fw) zo.fw[slot] = 0ull;
+                        if (zo.rc) zo.rc[slot] = 0ull;
+                        if (zo.canon) zo.canon[slot] = 0ull;
+                    }
                     if (zo.flags) zo.flags[slot] = 0;
                 }
                 continue;
@@ -518,11 +525,12 @@ hipError_t launch_sweep_uniform(const uint8_t* bases, u64 n_reads, u32 L, u32 k,
 }
 
 // Behind the materialise passes (kmx_scan.hip, launch_windows_*): uniform reads (L <= 256; offsets == nullptr) or reads behind offsets
-// (L = their bound, 0: none; `ends`: nullptr = offsets + 1), k <= 31.  Any of the four arrays may be nullptr.
+// (L = their bound, 0: none; `ends`: nullptr = offsets + 1), k <= 31 -- or, two_words, the [u64;2] k-mers of kmx_canonical_windows2
+// (k = 33..64, two words per slot).  Any of the four arrays may be nullptr.
 hipError_t launch_sweep_windows(const uint8_t* bases, u64 n_reads, u32 L, u32 k, u64* fw, u64* rc, u64* canon, uint8_t* flags,
                                 const u64* win_offsets, unsigned long long* queue, int n_cu, hipStream_t stream, const u64* offsets,
-                                const u64* ends) {
-    if (k < 2u || k > 31u) return hipErrorInvalidValue;
+                                const u64* ends, bool two_words) {
+    if (two_words ? (k < 33u || k > 64u) : (k < 2u || k > 31u)) return hipErrorInvalidValue;
     u32 lead = 0;
     if (!offsets) {
         lead = (u32)(reinterpret_cast<uintptr_t>(bases) & 15u);
@@ -537,7 +545,7 @@ hipError_t launch_sweep_windows(const uint8_t* bases, u64 n_reads, u32 L, u32 k,
     const bool big = L > 160u || (offsets && L == 0u);
     const u32 Lf = offsets ? (big ? 256u : 160u) : L;
     if (Lf < k || Lf > 256u) return hipErrorInvalidValue;
-    const SweepZero zo{fw, rc, canon, flags, win_offsets};
+    const SweepZero zo{fw, rc, canon, flags, win_offsets, two_words ? 1u : 0u};
     if (offsets) {
         if (big) hipLaunchKernelGGL((sweep_zero_kernel<16, true>), grid, dim3(256), 0, stream, bases, n_reads, Lf, k, queue, offsets, lead, ends, zo);
         else hipLaunchKernelGGL((sweep_zero_kernel<10, true>), grid, dim3(256), 0, stream, bases, n_reads, Lf, k, queue, offsets, lead, ends, zo);

@@ -592,3 +592,30 @@ def test_windows_on_dirty_ragged_reads(ctx, orc, bound):
             got = outs[name].cpu().numpy()
             got = got.view(np.uint64) if name != "flags" else got
             assert np.array_equal(got, exp[name]), (name, want)
+
+
+@pytest.mark.parametrize("k,L", [(33, 150), (63, 150), (64, 250), (47, 100)])
+def test_windows2_on_dirty_reads_at_size(ctx, orc, k, L):
+    """[u64;2] materialise: a tile with an invalid byte stays on the tiled path, the ZERO sweep writes the spoiled slots (two words each)"""
+    n = 64 * 500 + 21
+    rng = np.random.default_rng(k + L)
+    host = ctx.gen_reads(n * L, first_byte=k).cpu().numpy().copy()
+    _dirty(host, n, np.arange(n, dtype=np.int64) * L, np.full(n, L), rng, 0.03)
+    host[(n - 1) * L + L - 1] = ord("N")
+    fw, rc, canon, flags = orc.canonical_windows2(host, n, L, k)
+    outs = ctx.canonical_windows2(ctx.to_device(host), n, L, k)
+    for name, exp in (("fw", fw), ("rc", rc), ("canon", canon)):
+        assert np.array_equal(outs[name].cpu().numpy().view(np.uint64).reshape(-1, 2), exp), name
+    assert np.array_equal(outs["flags"].cpu().numpy(), flags)
+    # ragged: the same reads behind offsets, some trimmed
+    lens = np.full(n, L, dtype=np.int64)
+    sel = rng.random(n) < 0.1
+    lens[sel] = rng.integers(k // 2, L, size=int(sel.sum()))
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    hostr = np.concatenate([host[i * L : i * L + lens[i]] for i in range(0, n, 1)]) if n <= 40000 else None
+    if hostr is not None:
+        fw, rc, canon, flags = orc.canonical_windows2(hostr, n, L, k, offsets=offs)
+        outs = ctx.canonical_windows2(ctx.to_device(hostr), n, L, k, offsets=ctx.to_device(offs), host_offsets=offs)
+        for name, exp in (("fw", fw), ("rc", rc), ("canon", canon)):
+            assert np.array_equal(outs[name].cpu().numpy().view(np.uint64).reshape(-1, 2), exp), name
+        assert np.array_equal(outs["flags"].cpu().numpy(), flags)
