@@ -122,7 +122,7 @@ __device__ __forceinline__ bs_v8i fp4_operand_a(u32 m) {
 constexpr int bs_plane_dwords(int NW) { return 32 * NW + 16; }
 // rows of the next tile requested LATE (between pass 1 and pass 2 of phase D): see the kernel, "rows of the prefetch requested late"
 template <int K, int NW, int WPL, bool PACKED, bool RAGGED, bool SEG> constexpr int bs_late() {
-    return PACKED ? 0 : NW == 10 ? ((K > 32 || RAGGED || SEG) ? 5 : WPL > 4 ? (K <= 17 ? 0 : 1) : 0) : NW < 10 ? (K > 32 ? 0 : 3) : (NW == 13 || NW == 11) ? ((K <= 32 && !SEG) ? 3 : 7) : 8;
+    return PACKED ? 0 : NW == 10 ? ((K > 32 || RAGGED || SEG) ? 5 : WPL > 4 ? (K <= 17 ? 0 : 1) : 0) : NW < 10 ? (K > 32 ? 0 : 3) : NW == 13 ? ((K <= 32 && !SEG) ? 3 : 7) : NW == 11 ? (SEG ? 6 : 3) : 8;
 }
 // PARK (round 6): phase A leaves every chunk's validation word in LDS beside its packed word, and a tile with an invalid byte
 // looks its reads up there (30 instructions) instead of validating the tile a second time from w[] (150).  The second dword per
@@ -187,7 +187,7 @@ scan_bitsliced_kernel(const uint8_t* __restrict__ bases, u64 n_reads, u32 L, u32
                       void* __restrict__ out /* kmx_summary (K<=32) or kmx_summary2 (K>32) */,
                       unsigned long long* __restrict__ queue, const u64* __restrict__ offsets, u32 lead,
                       const u64* __restrict__ ends, const BsSeg seg) {
-    static_assert(!SEG || (!PACKED && !RAGGED && (NW == 10 || NW == 13)), "segments of long uniform reads: ASCII, the 10- and the 13-word frame");
+    static_assert(!SEG || (!PACKED && !RAGGED && (NW == 10 || NW == 11 || NW == 13)), "segments of long uniform reads: ASCII, the 10-, the 11- and the 13-word frame");
     // `ends` (RAGGED with offsets): read r = bases[offsets[r], ends[r]) -- offsets + 1 for reads stored back to back, an array of
     // its own for the overlapping SEGMENTS a batch of long ragged reads was cut into (kmx_segments.hip, round 4).
     // `lead` (uniform ASCII input whose first byte is not 16-byte aligned): `bases` is the aligned address below it and
@@ -1572,7 +1572,10 @@ static inline BsSegPlan bs_seg_plan(u32 L, u32 k) {
     // the 10-word frame's 0.43 at two waves; at three it spills inside the loop) -- profiles/r05_seg2_frames.txt, r05_seg2_3waves.txt.
     const u32 t_max = (k > 32u && k <= 49u) ? t10 : t13;
     const u32 J = (wr + t_max - 1u) / t_max, T = (wr + J - 1u) / J;
-    return BsSegPlan{J, J - (J * T - wr), T, (T <= t10) ? 10u : 13u};
+    // (round 6) single-word k: segments of up to 176 bases take the 11-word frame -- reads of 257..~320 bases (2 x 300 runs) are two segments of
+    // ~165 bases, three quarters of the 13-word frame's 208 (0.64 of the roofline at 300 bases: profiles/r06_len_sweep.txt)
+    const u32 nw = T <= t10 ? 10u : (k <= 31u && T + k - 1u <= 176u - 1u && T <= 160u) ? 11u : 13u;
+    return BsSegPlan{J, J - (J * T - wr), T, nw};
 }
 template <int K>
 static hipError_t launch_bs_seg(const uint8_t* bases, u64 n_reads, u32 L, u32 want_hash, u32 want_sumfw, void* out,
@@ -1583,6 +1586,7 @@ static hipError_t launch_bs_seg(const uint8_t* bases, u64 n_reads, u32 L, u32 wa
     const u64 n_seg = n_reads * pl.J;
     const u32 Lf = pl.T + (u32)K - 1u;
     if constexpr (K <= 31) {
+        if (pl.NW == 11u) return launch_bs<K, 11, 5, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
         if (pl.NW == 13u) return launch_bs<K, 13, 6, false, false, true>(bases, n_seg, Lf, want_hash, want_sumfw, out, queue, n_cu, stream, nullptr, nullptr, seg);
     } else if constexpr (K > 49) {
         // Two-word k from 50 up in the 13-word frame (round 5; bs_seg_plan says why the smaller ones stay in the 10-word frame): of a
