@@ -349,9 +349,10 @@ inline uint64_t hash_one(const SipHasher13State& st, const Kmer& km, Context& ct
 // Batch form of the streaming loop (what the GPU is for): summary over many reads resident on the device.
 inline kmx_summary canonical_reduce(Context& ctx, const kmx_reads& reads, uint32_t k, uint32_t hasher = KMX_HASH_NONE,
                                     uint32_t hasher_k = 0, uint32_t flags = 0) {
-    DeviceBuffer<kmx_summary> out(ctx, 1);
-    ctx.check(kmx_canonical_reduce(ctx.get(), &reads, k, hasher, hasher_k, flags, out.data()), "canonical_reduce");
-    return out.download()[0];
+    // (the summary straight into host memory: one kernel launch for clean uniform reads, no device allocation, no copy -- kmx.h, round 6)
+    kmx_summary out{};
+    ctx.check(kmx_canonical_reduce_host(ctx.get(), &reads, k, hasher, hasher_k, flags, &out), "canonical_reduce");
+    return out;
 }
 
 // FASTA / FASTQ ingestion (build-defined, the reference has no parser): a file image -> the reads
